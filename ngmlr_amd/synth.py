@@ -1,0 +1,256 @@
+"""Seeded synthetic tile generator for the convex-gap alignment hot path.
+
+A *tile* is exactly one ``IAlignment::SingleAlign`` call of the reference
+(``/root/reference/src/IAlignment.h:227-232``): a NUL-free reference window
+``ref`` (W chars), a read segment ``qry`` (H chars) and one ``CorridorLine``
+(offset, length) per read row.  The corridor constructors below restate the
+host-side formulas of the reference's only caller so that synthetic tiles have the
+shapes the real pipeline produces (float32 arithmetic with C truncation, done with
+numpy float32 so the integers come out identical):
+
+* ``corridor_anchors``   -- getCorridorEndpointsWithAnchors, src/AlignmentBuffer.cpp:129-197
+* ``corridor_endpoints`` -- getCorridorEndpoints,            src/AlignmentBuffer.cpp:107-127
+* ``corridor_linear``    -- getCorridorLinear,               src/AlignmentBuffer.cpp:68-82
+* ``corridor_full``      -- getCorridorFull,                 src/AlignmentBuffer.cpp:84-105
+* ``estimate_corridor``  -- estimateCorridor + clamp,        src/AlignmentBuffer.cpp:1454-1467,265-266
+
+GRCh38 and pbsim are not available offline, so reads are drawn from a seeded uniform
+ACGT reference with a PacBio-like (ins:del:sub = 6:3:1) or ONT-like (4:4:2) error
+model.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+F32 = np.float32
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_CODE = np.zeros(256, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _CODE[_c] = _i
+
+
+@dataclass
+class Tile:
+    ref: bytes
+    qry: bytes
+    row_offset: np.ndarray  # int32[H]
+    row_length: np.ndarray  # int32[H]
+    ext_qstart: int = 0
+    ext_qend: int = 0
+    tag: str = ""
+
+    @property
+    def H(self) -> int:
+        return len(self.qry)
+
+    @property
+    def W(self) -> int:
+        return len(self.ref)
+
+    @property
+    def cells(self) -> int:
+        """Sum of corridor row lengths = bytes of the reference's directionMatrix."""
+        return int(self.row_length.astype(np.int64).sum())
+
+    def algorithmic_bytes(self) -> int:
+        """B ~= C + 6H + 2W (direction byte per cell + sequences,
+        row offsets, backtrack reads, ops)."""
+        return self.cells + 6 * self.H + 2 * self.W
+
+
+# --------------------------------------------------------------------------- corridors
+
+def _trunc_i32(a: np.ndarray) -> np.ndarray:
+    return np.trunc(a).astype(np.int64).astype(np.int32)
+
+
+def corridor_anchors(H: int, W: int, mult: int = 1, scatter_left: float = 0.0,
+                     scatter_right: float = 0.0) -> Tuple[np.ndarray, np.ndarray]:
+    """src/AlignmentBuffer.cpp:140-192 with the anchor scatter given directly
+    (max positive / negative deviation of anchors from the k-line)."""
+    k = F32(H) * F32(1.0) / F32(W)
+    left = F32(scatter_left)
+    right = F32(scatter_right)
+    left = F32(left + F32(128))
+    right = F32(right + F32(128))
+    left = F32(left + F32(F32(left + right) * F32(0.1)))
+    right = F32(right + F32(F32(left + right) * F32(0.1)))
+    left = F32(left * F32(mult))
+    right = F32(right * F32(mult))
+    width = int(np.trunc(F32(left + right)))
+    i = np.arange(H, dtype=np.int64).astype(F32)
+    off = _trunc_i32((i - F32(0)) / k - right)
+    return off, np.full(H, width, dtype=np.int32)
+
+
+def corridor_endpoints(H: int, W: int, corridor: int, realign: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """src/AlignmentBuffer.cpp:110-124; ``corridor`` is corridor*corridorMultiplier."""
+    width = corridor // (1 if realign else 4)
+    k = F32(H) * F32(1.0) / F32(W)
+    d = F32(width) / F32(2.0)
+    i = np.arange(H, dtype=np.int64).astype(F32)
+    off = _trunc_i32((i - d) / k)
+    return off, np.full(H, width, dtype=np.int32)
+
+
+def corridor_linear(H: int, width: int) -> Tuple[np.ndarray, np.ndarray]:
+    """src/AlignmentBuffer.cpp:77-80 (short reads)."""
+    off = (np.arange(H, dtype=np.int64) - width // 2).astype(np.int32)
+    return off, np.full(H, width, dtype=np.int32)
+
+
+def corridor_full(H: int, W: int) -> Tuple[np.ndarray, np.ndarray]:
+    """src/AlignmentBuffer.cpp:93-103: every row spans the whole window plus 20%."""
+    off = int(W * -0.2)
+    length = W + int(W * 0.2)
+    return np.full(H, off, dtype=np.int32), np.full(H, length, dtype=np.int32)
+
+
+def estimate_corridor(H: int, Wspan: int, refSeqLen: int) -> int:
+    """src/AlignmentBuffer.cpp:1454-1467 then the 2*refSeqLen clamp of :265-266."""
+    c = max(int(F32(abs(H - Wspan)) * F32(2.1)), int(F32(H) * F32(0.2)))
+    c = min(8192, c)
+    return min(c, refSeqLen * 2)
+
+
+# --------------------------------------------------------------------------- sequences
+
+def random_ref(rng: np.random.Generator, n: int, n_frac: float = 0.0, x_frac: float = 0.0) -> np.ndarray:
+    """Uniform ACGT with optional 'N' / 'x' (the two extra symbols the reference's
+    decoder emits, src/SequenceProvider.cpp:91-105, :501)."""
+    s = _ACGT[rng.integers(0, 4, size=n)]
+    if n_frac > 0:
+        s = np.where(rng.random(n) < n_frac, np.uint8(ord("N")), s)
+    if x_frac > 0:
+        s = np.where(rng.random(n) < x_frac, np.uint8(ord("x")), s)
+    return s.astype(np.uint8)
+
+
+def mutate(rng: np.random.Generator, ref: np.ndarray, err: float,
+           ratio: Sequence[float] = (6, 3, 1), n_frac: float = 0.0) -> np.ndarray:
+    """Read = ref with `err` errors per base split ins:del:sub = ratio."""
+    tot = float(sum(ratio))
+    p_ins, p_del, p_sub = (err * r / tot for r in ratio)
+    n = len(ref)
+    u = rng.random(n)
+    keep = u >= p_del                      # deletions drop the ref base
+    sub = (u >= p_del) & (u < p_del + p_sub)
+    base = ref.copy()
+    shift = rng.integers(1, 4, size=n)
+    is_acgt = np.isin(base, _ACGT)
+    # substitution: rotate within ACGT so the base always changes
+    code = _CODE[base].astype(np.int64)
+    subbed = _ACGT[(code + shift) % 4]
+    base = np.where(sub & is_acgt, subbed, base)
+    n_ins = rng.random(n) < p_ins
+    out_len = int(keep.sum() + n_ins.sum())
+    out = np.empty(out_len, dtype=np.uint8)
+    # positions: each kept base emits itself, each insertion flag emits one random base before it
+    emit_counts = keep.astype(np.int64) + n_ins.astype(np.int64)
+    starts = np.cumsum(emit_counts) - emit_counts
+    ins_pos = starts[n_ins]
+    out[ins_pos] = _ACGT[rng.integers(0, 4, size=len(ins_pos))]
+    base_pos = (starts + n_ins.astype(np.int64))[keep]
+    out[base_pos] = base[keep]
+    if n_frac > 0:
+        out = np.where(rng.random(out_len) < n_frac, np.uint8(ord("N")), out)
+    return out
+
+
+def revcomp(s: np.ndarray) -> np.ndarray:
+    comp = np.arange(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    return comp[s[::-1]]
+
+
+# --------------------------------------------------------------------------- tiles
+
+def make_tile(rng: np.random.Generator, W: int, err: float = 0.15,
+              ratio: Sequence[float] = (6, 3, 1), corridor: str = "anchors", mult: int = 1,
+              scatter: float = 0.0, width: Optional[int] = None, n_frac: float = 0.0,
+              x_frac: float = 0.0, realign: bool = False, ref_pad: int = 0,
+              tag: str = "") -> Tile:
+    """One tile: reference window of W bases (the read covers all but `ref_pad`
+    bases on each side), read = mutated copy, corridor by name."""
+    ref = random_ref(rng, W, n_frac=n_frac, x_frac=x_frac)
+    qry = mutate(rng, ref[ref_pad:W - ref_pad] if ref_pad else ref, err, ratio)
+    if len(qry) == 0:
+        qry = ref[:1].copy()
+    H = len(qry)
+    if corridor == "anchors":
+        sl = float(rng.random() * scatter)
+        sr = float(rng.random() * scatter)
+        off, ln = corridor_anchors(H, W, mult=mult, scatter_left=sl, scatter_right=sr)
+    elif corridor == "endpoints":
+        c = width if width is not None else estimate_corridor(H, W, W)
+        off, ln = corridor_endpoints(H, W, c * mult, realign=realign)
+    elif corridor == "linear":
+        w = width if width is not None else 256 + 2 * int(F32(0.15) * F32(H))
+        off, ln = corridor_linear(H, w * mult)
+    elif corridor == "full":
+        off, ln = corridor_full(H, W)
+    else:
+        raise ValueError(corridor)
+    return Tile(ref=ref.tobytes(), qry=qry.tobytes(), row_offset=off, row_length=ln, tag=tag or corridor)
+
+
+def workload_pacbio(n_tiles: int, seed: int = 7, read_len: int = 10000, err: float = 0.15,
+                    scatter: float = 25.0) -> List[Tile]:
+    """Config C2: PacBio-like 10 kb reads, 15 % error (6:3:1), anchors corridor.
+    With ~25 bp of anchor scatter the width lands at the 309-369 the reference
+    shows on such reads."""
+    rng = np.random.default_rng(seed)
+    tiles = []
+    for i in range(n_tiles):
+        W = int(read_len * (0.9 + 0.2 * rng.random()))
+        tiles.append(make_tile(rng, W, err=err, ratio=(6, 3, 1), corridor="anchors",
+                               scatter=scatter, tag="pacbio"))
+    return tiles
+
+
+def workload_ont(n_tiles: int, seed: int = 11, max_len: int = 20000, err: float = 0.25) -> List[Tile]:
+    """Config C3: ONT-like reads (4:4:2), tile mix median ~1.3 kb up to 20 kb,
+    width 309-463, 10 % of tiles at corridor multiplier 2 (retries)."""
+    rng = np.random.default_rng(seed)
+    tiles = []
+    for i in range(n_tiles):
+        W = int(min(max_len, max(200, rng.lognormal(mean=np.log(1300.0), sigma=1.0))))
+        mult = 2 if rng.random() < 0.10 else 1
+        tiles.append(make_tile(rng, W, err=err, ratio=(4, 4, 2), corridor="anchors",
+                               scatter=60.0, mult=mult, tag="ont"))
+    return tiles
+
+
+def workload_ultralong_sv(n_tiles: int, seed: int = 13, read_len: int = 100000) -> List[Tile]:
+    """Config C5: 100 kb tiles at widths {309, 2048, 8192} plus full-matrix
+    inversion tiles (500-5000 bp)."""
+    rng = np.random.default_rng(seed)
+    tiles = []
+    for i in range(n_tiles):
+        kind = i % 4
+        if kind == 3:
+            W = int(rng.integers(500, 5000))
+            tiles.append(make_tile(rng, W, err=0.2, ratio=(4, 4, 2), corridor="full", tag="sv-full"))
+        else:
+            width = (309, 2048, 8192)[kind]
+            if width == 309:
+                tiles.append(make_tile(rng, read_len, err=0.2, ratio=(4, 4, 2), corridor="anchors", tag="ul-309"))
+            else:
+                tiles.append(make_tile(rng, read_len, err=0.2, ratio=(4, 4, 2), corridor="endpoints",
+                                       width=width, realign=True, tag="ul-%d" % width))
+    return tiles
+
+
+def workload_short(n_tiles: int, seed: int = 17) -> List[Tile]:
+    """Short reads (<= 256 bp) through getCorridorLinear (src/AlignmentBuffer.cpp:2576-2594)."""
+    rng = np.random.default_rng(seed)
+    tiles = []
+    for i in range(n_tiles):
+        L = int(rng.integers(50, 257))
+        pad = (256 + 2 * int(F32(0.15) * F32(L))) // 2
+        tiles.append(make_tile(rng, L + 2 * pad, err=0.08, corridor="linear", ref_pad=pad, tag="short"))
+    return tiles

@@ -1,0 +1,126 @@
+"""ctypes loader for the CPU checkers under oracle/ (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module; the product package ``ngmlr_amd`` never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_SO = os.path.join(HERE, "libcvx_oracle_port.so")
+REF_SO = os.path.join(HERE, "_ref", "libcvx_oracle_ref.so")
+
+DEFAULT_PARAMS = (2.0, -5.0, -5.0, -5.0, -1.0, 0.15)  # src/IConfig.h:50-55
+
+
+class OracleOut(C.Structure):
+    _fields_ = [("ret", C.c_int32), ("score", C.c_float), ("position_offset", C.c_int32),
+                ("qstart", C.c_int32), ("qend", C.c_int32), ("nm", C.c_int32),
+                ("identity", C.c_float), ("alignment_length", C.c_int32),
+                ("cigar_op_count", C.c_int32), ("sv_type", C.c_int32),
+                ("first_ref", C.c_int32), ("first_read", C.c_int32),
+                ("last_ref", C.c_int32), ("last_read", C.c_int32),
+                ("nm_count", C.c_int32), ("cigar_len", C.c_int32), ("md_len", C.c_int32)]
+
+
+def build(which: str = "all") -> None:
+    """Compile the checkers (gcc/g++ only).  `ref` is skipped when /root/reference is absent."""
+    subprocess.run(["make", "-s", "-C", HERE, which], check=True)
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+class Oracle:
+    """One aligner instance of either checker.  kind: 'port' | 'reference'."""
+
+    def __init__(self, kind: str = "port", params=DEFAULT_PARAMS):
+        path = PORT_SO if kind == "port" else REF_SO
+        if not os.path.exists(path):
+            if kind == "port":
+                build("port")
+            else:
+                raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+        self.lib.oracle_create.restype = C.c_void_p
+        self.lib.oracle_create.argtypes = [C.POINTER(C.c_float)]
+        self.lib.oracle_destroy.argtypes = [C.c_void_p]
+        self.lib.oracle_kind.restype = C.c_char_p
+        self.lib.oracle_align.restype = C.c_int
+        self.lib.oracle_align.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p,
+                                          C.c_int32, C.c_int32, C.c_int32, C.POINTER(OracleOut),
+                                          C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32]
+        self.kind = self.lib.oracle_kind().decode()
+        assert self.kind == kind, (self.kind, kind)
+        p = (C.c_float * 6)(*params)
+        self.h = C.c_void_p(self.lib.oracle_create(p))
+        if kind == "port":
+            self.lib.oracle_port_set_spec_fill.argtypes = [C.c_void_p, C.c_int]
+            self.lib.oracle_port_last_fwd.argtypes = [C.c_void_p]
+
+    def close(self):
+        if self.h:
+            self.lib.oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_spec_fill(self, on: bool) -> None:
+        self.lib.oracle_port_set_spec_fill(self.h, int(on))
+
+    def last_fwd(self):
+        a = (C.c_int32 * 5)()
+        self.lib.oracle_port_last_fwd(a)
+        return dict(best_x=a[0], best_y=a[1], ref_position=a[2], qstart=a[3], qend=a[4])
+
+    def align(self, tile, want_nm: bool = True) -> dict:
+        H = len(tile.qry)
+        off = np.ascontiguousarray(tile.row_offset, dtype=np.int32)
+        ln = np.ascontiguousarray(tile.row_length, dtype=np.int32)
+        assert len(off) == H and len(ln) == H
+        cap = 4 * H + 4 * len(tile.ref) + 256
+        cig = C.create_string_buffer(cap)
+        md = C.create_string_buffer(cap)
+        nm_cap = 2 * (H + 1) + len(tile.ref) + 16
+        nm = np.zeros((nm_cap, 3), dtype=np.int32)
+        out = OracleOut()
+        rc = self.lib.oracle_align(self.h, tile.ref, tile.qry, off.ctypes.data, ln.ctypes.data, H,
+                                   tile.ext_qstart, tile.ext_qend, C.byref(out), cig, md, cap,
+                                   nm.ctypes.data if want_nm else None, nm_cap)
+        d = {k: getattr(out, k) for k, _ in OracleOut._fields_}
+        d["rc"] = rc
+        d["score_bits"] = int(np.float32(out.score).view(np.uint32))
+        d["cigar"] = cig.value.decode()
+        d["md"] = md.value.decode()
+        d["nm_per_position"] = nm[:out.nm_count].copy()
+        return d
+
+
+COMPARE_KEYS = ("ret", "score_bits", "position_offset", "qstart", "qend", "nm", "alignment_length",
+                "cigar_op_count", "sv_type", "first_ref", "first_read", "last_ref", "last_read",
+                "cigar", "md")
+
+
+def same_alignment(a: dict, b: dict, keys=COMPARE_KEYS) -> Optional[str]:
+    """None if equal on every field the reference's caller can observe, else the first difference."""
+    if a["ret"] < 0 and b["ret"] < 0:
+        return None  # both invalid: the caller only sees -1 / Score -1
+    for k in keys:
+        if a[k] != b[k]:
+            return "%s: %r != %r" % (k, a[k] if len(str(a[k])) < 80 else str(a[k])[:80], b[k] if len(str(b[k])) < 80 else str(b[k])[:80])
+    if np.float32(a["identity"]).view(np.uint32) != np.float32(b["identity"]).view(np.uint32):
+        return "identity"
+    if a["nm_per_position"].shape != b["nm_per_position"].shape or not np.array_equal(a["nm_per_position"], b["nm_per_position"]):
+        return "nm_per_position"
+    return None
