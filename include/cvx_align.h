@@ -1,0 +1,180 @@
+/*
+ * cvx_align.h -- C ABI of the MI355X-native convex-gap banded Smith-Waterman
+ * aligner (libcvxalign.so).  This is the drop-in boundary for ngmlr's hot path:
+ * everything ngmlr's IAlignment plugin surface needs for
+ *
+ *     Convex::ConvexAlignFast::SingleAlign(mode, CorridorLine*, corridorHeight,
+ *                                          refSeq, qrySeq, Align&, externalQStart,
+ *                                          externalQEnd, extData)
+ *     (reference src/IAlignment.h:227-232, src/ConvexAlignFast.cpp:452-559)
+ *
+ * expressed as plain C: opaque handle, plain pointers and sizes, int return codes,
+ * no C++ types and no exceptions across the boundary.  A "tile" below is exactly
+ * one such SingleAlign call; the library takes thousands of them per launch.
+ *
+ * Entry point                 replaces (reference file:line)
+ * --------------------------- -----------------------------------------------------
+ * cvx_create / cvx_destroy    ConvexAlignFast ctor/dtor      src/ConvexAlignFast.cpp:29-64
+ *                             (pfCreateAlignment(gpu_id)     src/IAlignment.h:249-250)
+ * cvx_align_batch             N x SingleAlign steps 1-4      src/ConvexAlignFast.cpp:463-487
+ *                             = AlignmentMatrixFast::prepare src/AlignmentMatrixFast.cpp:30-60
+ *                             + fwdFillMatrixSSESimple       src/ConvexAlignFast.cpp:914-1287
+ *                             + revBacktrack / validPath     src/ConvexAlignFast.cpp:335-432
+ *                             (the BatchAlign slot the reference leaves unimplemented,
+ *                              src/ConvexAlignFast.cpp:441-450)
+ * cvx_batch_* (staged form)   the same, with inputs resident in HBM between calls
+ * cvx_format_alignment        convertCigar + N-clip flags    src/ConvexAlignFast.cpp:112-333,493-528
+ *
+ * The binding a maintainer adds on the ngmlr side is in INTEGRATION.md
+ * (ngmlr_amd/csrc/convex_align_hip.{h,cpp}: an IAlignment subclass over this ABI).
+ *
+ * There is no CPU fallback: every compute entry point fails with CVX_ERR_NO_DEVICE
+ * when no gfx950 device is usable.
+ */
+#ifndef CVX_ALIGN_H
+#define CVX_ALIGN_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVX_ABI_VERSION 1
+
+/* return codes */
+enum {
+	CVX_OK = 0,
+	CVX_ERR_NO_DEVICE = -1,      /* no HIP device / wrong device id */
+	CVX_ERR_PARAMS = -2,         /* scoring parameters outside the proven-equivalent regime */
+	CVX_ERR_ARG = -3,            /* NULL pointer, negative size, height != strlen(qry) ... */
+	CVX_ERR_OOM = -4,            /* device or host allocation failed */
+	CVX_ERR_HIP = -5,            /* a HIP call failed; see cvx_last_error() */
+	CVX_ERR_CAPACITY = -6        /* caller's ops arena too small; *ops_used holds the need */
+};
+
+/* per-tile status in cvx_result.status */
+enum {
+	CVX_TILE_OK = 0,             /* valid alignment (reference: return value >= 0) */
+	CVX_TILE_INVALID_ROW0 = 1,   /* best cell in read row 0          (:338) */
+	CVX_TILE_INVALID_EDGE = 2,   /* path touched outer 10% of corridor (validPath) */
+	CVX_TILE_INVALID_LENGTH = 3, /* consumed read length != H         (:424-428) */
+	CVX_TILE_TOO_LARGE = 4,      /* > maxMatrixSizeMB (AlignmentMatrixFast.cpp:45,55-57) */
+	CVX_TILE_EMPTY = 5,          /* H == 0 or no cell inside [0,W) */
+	CVX_TILE_UNSUPPORTED = -1    /* corridor shape no device kernel covers (loud, never silent) */
+};
+
+/* operation codes inside the ops arena: (length << 4) | op, forward order.
+ * Same numbering as the reference's directionMatrix (src/AlignmentMatrixFast.h:15-24). */
+enum { CVX_OP_I = 1, CVX_OP_D = 2, CVX_OP_EQ = 7, CVX_OP_X = 8 };
+
+/* Scoring, ctor order of ConvexAlignFast (src/ConvexAlignFast.cpp:29-43):
+ * match > 0, the rest < 0 except gap_decay >= 0.  Defaults: 2,-5,-5,-5,-1,0.15
+ * (src/IConfig.h:50-55). */
+typedef struct {
+	float match;
+	float mismatch;
+	float gap_open;      /* gap_open_read == gap_open_ref in the reference */
+	float gap_extend;    /* --gap-extend-max */
+	float gap_extend_min;
+	float gap_decay;
+} cvx_params;
+
+/* One SingleAlign call.  ref/qry need not be NUL-terminated (lengths are explicit;
+ * the reference takes strlen).  Row y of the corridor covers reference columns
+ * [row_offset[y], row_offset[y]+row_length[y]) clipped to [0, ref_len); the two
+ * arrays are read with a byte stride so that &CorridorLine[0].offset /
+ * &CorridorLine[0].length with stride sizeof(CorridorLine)=16 can be passed
+ * directly (src/IAlignment.h:29-33). */
+typedef struct {
+	const char *ref;
+	const char *qry;
+	const int32_t *row_offset;
+	const int32_t *row_length;
+	int32_t ref_len;
+	int32_t qry_len;          /* = corridor height; every caller passes them equal */
+	int32_t row_stride_bytes; /* 4 for packed int32 arrays, 16 for CorridorLine[] */
+	int32_t reserved;
+} cvx_tile;
+
+/* What the forward fill + backtrack leave behind (FwdResults, src/ConvexAlignFast.h:69-77). */
+typedef struct {
+	float score;            /* curr_max of the fill (Align::Score when status == 0) */
+	int32_t status;         /* CVX_TILE_* */
+	int32_t best_ref_index; /* argmax cell, first in (y,x) order */
+	int32_t best_read_index;
+	int32_t ref_position;   /* Align::PositionOffset */
+	int32_t qstart;         /* leading soft clip (without externalQStart) */
+	int32_t qend;           /* trailing soft clip (without externalQEnd) */
+	int32_t n_ops;
+	uint64_t ops_begin;     /* index of the first op in the ops arena */
+	uint64_t cells;         /* sum of row_length = bytes of the reference's directionMatrix */
+} cvx_result;
+
+typedef struct cvx_context *cvx_handle;
+typedef struct cvx_batch_s *cvx_batch;
+
+/* Timing of the last cvx_batch_run, measured with HIP events on the library's stream. */
+typedef struct {
+	float plan_ms;      /* corridor analysis kernel + plan readback */
+	float fill_ms;      /* all forward-fill launches */
+	float backtrack_ms; /* backtrack + ops compaction */
+	float total_ms;     /* first launch -> last kernel done */
+	uint64_t cells;     /* corridor cells (sum of row_length) in the batch */
+	uint64_t active_cells; /* cells inside [0,W): what the fill really computes */
+	uint64_t dir_bytes; /* bytes of direction codes written to HBM */
+	int32_t n_fill_launches;
+	int32_t n_tiles_fast; /* tiles taken by the single-wave ring kernels */
+} cvx_timing;
+
+const char *cvx_last_error(void);
+int cvx_abi_version(void);
+int cvx_device_count(void);
+
+/* max_matrix_mb: IConfig::maxMatrixSizeMB (src/IConfig.h:47), 0 -> 10000. */
+int cvx_create(int device_id, const cvx_params *params, uint64_t max_matrix_mb, cvx_handle *out);
+void cvx_destroy(cvx_handle h);
+
+/* Synchronous convenience form: upload, run, download.  ops_arena receives the
+ * run-length ops of all valid tiles back to back; ops_used is set even on
+ * CVX_ERR_CAPACITY so the caller can retry. */
+int cvx_align_batch(cvx_handle h, int32_t n_tiles, const cvx_tile *tiles, cvx_result *results,
+		uint32_t *ops_arena, uint64_t ops_capacity, uint64_t *ops_used);
+
+/* Staged form: inputs stay resident in HBM, run may be repeated (bench / pipelining). */
+int cvx_batch_upload(cvx_handle h, int32_t n_tiles, const cvx_tile *tiles, cvx_batch *out);
+int cvx_batch_run(cvx_handle h, cvx_batch b);            /* enqueue + wait */
+int cvx_batch_timing(cvx_batch b, cvx_timing *t);
+int cvx_batch_ops_total(cvx_batch b, uint64_t *n_ops);
+int cvx_batch_download(cvx_handle h, cvx_batch b, cvx_result *results,
+		uint32_t *ops_arena, uint64_t ops_capacity, uint64_t *ops_used);
+void cvx_batch_free(cvx_handle h, cvx_batch b);
+
+/* Host-side text stage (convertCigar, src/ConvexAlignFast.cpp:112-333, and the
+ * N-clip flags of :493-528).  Pure host code, no device needed. */
+typedef struct {
+	int32_t ret;              /* SingleAlign return value: QStart + sum(M) + sum(I) + QEnd, or -1 */
+	float score;              /* Align::Score (-1.0f when ret < 0) */
+	int32_t position_offset;
+	int32_t qstart, qend;     /* including externalQStart / externalQEnd */
+	int32_t nm;
+	float identity;
+	int32_t alignment_length;
+	int32_t cigar_op_count;
+	int32_t sv_type;
+	int32_t first_ref, first_read, last_ref, last_read;
+	int32_t nm_count;         /* PositionNM triples written */
+	int32_t cigar_len, md_len;/* full lengths (text is truncated to the given capacity) */
+} cvx_alignment_text;
+
+int cvx_format_alignment(const cvx_result *r, const uint32_t *ops_arena,
+		const char *ref, int32_t ref_len, int32_t qry_len,
+		int32_t ext_qstart, int32_t ext_qend,
+		char *cigar, int32_t cigar_cap, char *md, int32_t md_cap,
+		int32_t *nm_triples, int32_t nm_cap, cvx_alignment_text *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

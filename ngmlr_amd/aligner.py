@@ -1,0 +1,158 @@
+"""Host-side mirror of the reference's aligner surface for the convex-gap hot path.
+
+``ConvexAlignHip`` plays the role of ``Convex::ConvexAlignFast`` behind ngmlr's
+``IAlignment`` interface (reference src/IAlignment.h:211-247): constructed with the
+same six scoring floats (src/AlignmentBuffer.h:345-363), ``single_align`` has the
+argument meaning and error behaviour of the corridor ``SingleAlign`` overload
+(returns -1 and Score -1.0 for "no valid alignment"), and ``batch_align`` is the
+``BatchAlign`` slot the reference leaves unimplemented (src/ConvexAlignFast.cpp:441-450).
+All compute goes through the C ABI of include/cvx_align.h; the C++ twin of this class
+(the actual drop-in) is ngmlr_amd/csrc/convex_align_hip.{h,cpp}.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+
+DEFAULT_SCORING = dict(match=2.0, mismatch=-5.0, gap_open=-5.0, gap_extend=-5.0,
+                       gap_extend_min=-1.0, gap_decay=0.15)  # src/IConfig.h:50-55
+
+
+class ConvexAlignHip:
+    def __init__(self, device: int = 0, max_matrix_mb: int = 10000, **scoring):
+        self.lib = capi.load()
+        sc = dict(DEFAULT_SCORING)
+        sc.update(scoring)
+        self.params = capi.CvxParams(sc["match"], sc["mismatch"], sc["gap_open"], sc["gap_extend"],
+                                     sc["gap_extend_min"], sc["gap_decay"])
+        self.h = C.c_void_p()
+        capi.check(self.lib.cvx_create(device, C.byref(self.params), max_matrix_mb, C.byref(self.h)))
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.cvx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # IAlignment::GetAlignBatchSize(): the reference's convex aligner answers 0
+    # ("no batching"); this backend takes any batch.
+    def get_align_batch_size(self) -> int:
+        return 1 << 20
+
+    # ------------------------------------------------------------------ staged API
+    def _pack(self, tiles: Sequence):
+        n = len(tiles)
+        arr = (capi.CvxTile * max(n, 1))()
+        keep = []
+        for i, t in enumerate(tiles):
+            off = np.ascontiguousarray(t.row_offset, dtype=np.int32)
+            ln = np.ascontiguousarray(t.row_length, dtype=np.int32)
+            keep.append((off, ln, t.ref, t.qry))
+            arr[i].ref = t.ref
+            arr[i].qry = t.qry
+            arr[i].row_offset = off.ctypes.data
+            arr[i].row_length = ln.ctypes.data
+            arr[i].ref_len = len(t.ref)
+            arr[i].qry_len = len(t.qry)
+            arr[i].row_stride_bytes = 4
+        return arr, keep
+
+    def upload(self, tiles: Sequence) -> "DeviceBatch":
+        arr, keep = self._pack(tiles)
+        b = C.c_void_p()
+        capi.check(self.lib.cvx_batch_upload(self.h, len(tiles), arr, C.byref(b)))
+        return DeviceBatch(self, b, list(tiles))
+
+    # ------------------------------------------------------------------ reference-shaped API
+    def batch_align(self, tiles: Sequence, want_nm: bool = True) -> List[dict]:
+        """N x SingleAlign: returns one Align-like dict per tile (keys as oracle/pyoracle)."""
+        batch = self.upload(tiles)
+        try:
+            batch.run()
+            return batch.alignments(want_nm=want_nm)
+        finally:
+            batch.free()
+
+    def single_align(self, tile, want_nm: bool = True) -> dict:
+        return self.batch_align([tile], want_nm=want_nm)[0]
+
+
+class DeviceBatch:
+    """Tiles resident in HBM; run() may be repeated (bench) before download."""
+
+    def __init__(self, aligner: ConvexAlignHip, handle, tiles):
+        self.al = aligner
+        self.b = handle
+        self.tiles = tiles
+        self.results = None
+        self.ops = None
+
+    def run(self) -> capi.CvxTiming:
+        capi.check(self.al.lib.cvx_batch_run(self.al.h, self.b))
+        t = capi.CvxTiming()
+        capi.check(self.al.lib.cvx_batch_timing(self.b, C.byref(t)))
+        return t
+
+    def download(self):
+        n = len(self.tiles)
+        total = C.c_uint64()
+        capi.check(self.al.lib.cvx_batch_ops_total(self.b, C.byref(total)))
+        res = (capi.CvxResult * max(n, 1))()
+        ops = np.zeros(max(int(total.value), 1), dtype=np.uint32)
+        used = C.c_uint64()
+        capi.check(self.al.lib.cvx_batch_download(self.al.h, self.b, res, ops.ctypes.data,
+                                                  len(ops), C.byref(used)))
+        self.results = res
+        self.ops = ops
+        return res, ops
+
+    def alignments(self, want_nm: bool = True) -> List[dict]:
+        if self.results is None:
+            self.download()
+        return [format_alignment(self.al.lib, self.results[i], self.ops, t, want_nm)
+                for i, t in enumerate(self.tiles)]
+
+    def free(self) -> None:
+        if self.b:
+            self.al.lib.cvx_batch_free(self.al.h, self.b)
+            self.b = None
+
+
+def format_alignment(lib, res: capi.CvxResult, ops: np.ndarray, tile, want_nm: bool = True) -> dict:
+    """Host text stage (cvx_format_alignment) -> dict with the Align fields."""
+    H, W = len(tile.qry), len(tile.ref)
+    cap = 4 * H + 64
+    txt = capi.CvxAlignmentText()
+    for _ in range(3):
+        cig = C.create_string_buffer(cap)
+        md = C.create_string_buffer(cap)
+        nm_cap = 2 * (H + 1) + W + 16
+        nm = np.zeros((nm_cap, 3), dtype=np.int32)
+        capi.check(lib.cvx_format_alignment(C.byref(res), ops.ctypes.data, tile.ref, W, H,
+                                            tile.ext_qstart, tile.ext_qend, cig, cap, md, cap,
+                                            nm.ctypes.data if want_nm else None, nm_cap, C.byref(txt)))
+        if txt.cigar_len < cap and txt.md_len < cap:
+            break
+        cap = max(txt.cigar_len, txt.md_len) + 64
+    d = {k: getattr(txt, k) for k, _ in capi.CvxAlignmentText._fields_}
+    d["score_bits"] = int(np.float32(txt.score).view(np.uint32))
+    d["cigar"] = cig.value.decode()
+    d["md"] = md.value.decode()
+    n = min(txt.alignment_length, nm_cap) if (txt.ret >= 0 and want_nm) else 0
+    d["nm_per_position"] = nm[:n].copy()
+    d["nm_count"] = n
+    d["status"] = res.status
+    d["fwd_score_bits"] = int(np.float32(res.score).view(np.uint32))
+    d["best_x"] = res.best_ref_index
+    d["best_y"] = res.best_read_index
+    d["rc"] = 0
+    return d

@@ -1,0 +1,104 @@
+"""ctypes binding of include/cvx_align.h (libcvxalign.so).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C ngmlr_amd/csrc``.
+Loading fails loudly when it is missing: there is no Python or CPU fallback for the
+compute entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcvxalign.so")
+
+CVX_OK = 0
+ERR_NAMES = {0: "CVX_OK", -1: "CVX_ERR_NO_DEVICE", -2: "CVX_ERR_PARAMS", -3: "CVX_ERR_ARG",
+             -4: "CVX_ERR_OOM", -5: "CVX_ERR_HIP", -6: "CVX_ERR_CAPACITY"}
+TILE_STATUS = {0: "ok", 1: "invalid-row0", 2: "invalid-edge", 3: "invalid-length", 4: "too-large",
+               5: "empty", -1: "unsupported"}
+
+EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_create", "cvx_destroy",
+           "cvx_align_batch", "cvx_batch_upload", "cvx_batch_run", "cvx_batch_timing",
+           "cvx_batch_ops_total", "cvx_batch_download", "cvx_batch_free", "cvx_format_alignment")
+
+
+class CvxParams(C.Structure):
+    _fields_ = [("match", C.c_float), ("mismatch", C.c_float), ("gap_open", C.c_float),
+                ("gap_extend", C.c_float), ("gap_extend_min", C.c_float), ("gap_decay", C.c_float)]
+
+
+class CvxTile(C.Structure):
+    _fields_ = [("ref", C.c_char_p), ("qry", C.c_char_p), ("row_offset", C.c_void_p),
+                ("row_length", C.c_void_p), ("ref_len", C.c_int32), ("qry_len", C.c_int32),
+                ("row_stride_bytes", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CvxResult(C.Structure):
+    _fields_ = [("score", C.c_float), ("status", C.c_int32), ("best_ref_index", C.c_int32),
+                ("best_read_index", C.c_int32), ("ref_position", C.c_int32), ("qstart", C.c_int32),
+                ("qend", C.c_int32), ("n_ops", C.c_int32), ("ops_begin", C.c_uint64),
+                ("cells", C.c_uint64)]
+
+
+class CvxTiming(C.Structure):
+    _fields_ = [("plan_ms", C.c_float), ("fill_ms", C.c_float), ("backtrack_ms", C.c_float),
+                ("total_ms", C.c_float), ("cells", C.c_uint64), ("active_cells", C.c_uint64),
+                ("dir_bytes", C.c_uint64), ("n_fill_launches", C.c_int32), ("n_tiles_fast", C.c_int32)]
+
+
+class CvxAlignmentText(C.Structure):
+    _fields_ = [("ret", C.c_int32), ("score", C.c_float), ("position_offset", C.c_int32),
+                ("qstart", C.c_int32), ("qend", C.c_int32), ("nm", C.c_int32), ("identity", C.c_float),
+                ("alignment_length", C.c_int32), ("cigar_op_count", C.c_int32), ("sv_type", C.c_int32),
+                ("first_ref", C.c_int32), ("first_read", C.c_int32), ("last_ref", C.c_int32),
+                ("last_read", C.c_int32), ("nm_count", C.c_int32), ("cigar_len", C.c_int32),
+                ("md_len", C.c_int32)]
+
+
+class CvxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, str(code)), msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libcvxalign.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the HIP path has no fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.cvx_last_error.restype = C.c_char_p
+    lib.cvx_abi_version.restype = C.c_int
+    lib.cvx_device_count.restype = C.c_int
+    lib.cvx_create.argtypes = [C.c_int, C.POINTER(CvxParams), C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.cvx_destroy.argtypes = [C.c_void_p]
+    lib.cvx_destroy.restype = None
+    lib.cvx_align_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CvxTile), C.POINTER(CvxResult),
+                                    C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.cvx_batch_upload.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CvxTile), C.POINTER(C.c_void_p)]
+    lib.cvx_batch_run.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cvx_batch_timing.argtypes = [C.c_void_p, C.POINTER(CvxTiming)]
+    lib.cvx_batch_ops_total.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.cvx_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CvxResult), C.c_void_p,
+                                       C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.cvx_batch_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cvx_batch_free.restype = None
+    lib.cvx_format_alignment.argtypes = [C.POINTER(CvxResult), C.c_void_p, C.c_char_p, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
+                                         C.c_char_p, C.c_int32, C.c_void_p, C.c_int32,
+                                         C.POINTER(CvxAlignmentText)]
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != CVX_OK:
+        raise CvxError(rc, load().cvx_last_error().decode(errors="replace"))

@@ -1,0 +1,25 @@
+/* cvx_launch.h -- host-callable launchers of the gfx950 kernels (cvx_kernels.hip). */
+#ifndef CVX_LAUNCH_H
+#define CVX_LAUNCH_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "cvx_types.h"
+
+namespace cvx {
+
+struct RowDesc {
+	int32_t off, len;
+};
+
+/* (m, nw) pairs that exist: m in {1,2,3,4,5,6,8} with nw = 1; m = 4 with nw in {2,4,8,16}. */
+hipError_t launch_fill(int m, int nw, bool wrap, const FillArgs &a, int grid, hipStream_t st);
+hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles,
+		unsigned long long max_matrix_mb, hipStream_t st);
+hipError_t launch_backtrack(const BacktrackArgs &a, hipStream_t st);
+hipError_t launch_compact(const int32_t *regions, const TileRun *trun, const TileOut *tout,
+		const uint64_t *dst_off, uint32_t *dense, int n_tiles, hipStream_t st);
+
+}  // namespace cvx
+#endif

@@ -1,0 +1,492 @@
+/*
+ * cvx_runtime.cpp -- host side of libcvxalign.so: the C ABI of include/cvx_align.h
+ * over the gfx950 kernels of cvx_kernels.hip.
+ *
+ * One cvx_context = one device + one HIP stream (ngmlr creates one aligner per worker
+ * thread, reference src/CS.cpp:418; contexts are independent, a context is not
+ * re-entrant -- same contract as the reference's ConvexAlignFast instances).
+ *
+ * cvx_batch_run():
+ *   plan_kernel -> (readback, host assigns kernel class / arena offsets) ->
+ *   fill_ring_kernel per class -> backtrack_kernel -> (readback n_ops) -> compact_ops_kernel
+ *
+ * There is no CPU compute path in this file: without a device every entry point
+ * returns CVX_ERR_NO_DEVICE.
+ */
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cvx_align.h"
+#include "cvx_launch.h"
+#include "cvx_types.h"
+
+using namespace cvx;
+
+namespace {
+
+thread_local std::string g_err;
+
+void set_err(const char *fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_err = buf;
+}
+
+#define HIP_TRY(expr)                                                              \
+	do {                                                                           \
+		hipError_t e_ = (expr);                                                    \
+		if (e_ != hipSuccess) {                                                    \
+			set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return (e_ == hipErrorOutOfMemory) ? CVX_ERR_OOM : CVX_ERR_HIP;        \
+		}                                                                          \
+	} while (0)
+
+struct KernelClass {
+	int m, nw;
+	int ring() const { return 64 * m * nw; }
+};
+
+/* smallest ring first */
+const KernelClass kClasses[] = {
+	{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}, {8, 1}, {4, 4}, {4, 8}, {4, 16},
+};
+const int kNumClasses = (int) (sizeof(kClasses) / sizeof(kClasses[0]));
+
+template <typename T>
+struct DevBuf {
+	T *p = nullptr;
+	size_t cap = 0; /* elements */
+	int ensure(size_t n) {
+		if (n <= cap) return CVX_OK;
+		if (p) { (void) hipFree(p); p = nullptr; cap = 0; }
+		size_t want = n + n / 8 + 64;
+		hipError_t e = hipMalloc((void **) &p, want * sizeof(T));
+		if (e != hipSuccess) {
+			set_err("hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
+			p = nullptr;
+			return CVX_ERR_OOM;
+		}
+		cap = want;
+		return CVX_OK;
+	}
+	void release() {
+		if (p) (void) hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+};
+
+}  // namespace
+
+struct cvx_context {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	ScoreParams sp;
+	uint64_t max_matrix_mb = 10000;
+	int num_cus = 256;
+};
+
+struct cvx_batch_s {
+	int n = 0;
+	std::vector<TileIn> tin;
+	std::vector<TilePlan> plan;
+	std::vector<TileRun> trun;
+	std::vector<TileOut> tout;
+	std::vector<uint64_t> dst_off;
+	std::vector<int32_t> lists;
+	uint64_t ops_total = 0;
+	bool ran = false;
+
+	DevBuf<uint8_t> d_seq;
+	DevBuf<RowDesc> d_rows;
+	DevBuf<TileIn> d_tin;
+	DevBuf<TilePlan> d_plan;
+	DevBuf<TileRun> d_trun;
+	DevBuf<TileOut> d_tout;
+	DevBuf<uint32_t> d_dirs;
+	DevBuf<int32_t> d_regions;
+	DevBuf<int32_t> d_lists;
+	DevBuf<int32_t> d_heads;
+	DevBuf<uint64_t> d_dstoff;
+	DevBuf<uint32_t> d_dense;
+
+	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	cvx_timing timing;
+
+	void release() {
+		d_seq.release(); d_rows.release(); d_tin.release(); d_plan.release(); d_trun.release();
+		d_tout.release(); d_dirs.release(); d_regions.release(); d_lists.release();
+		d_heads.release(); d_dstoff.release(); d_dense.release();
+		for (auto &e : ev) if (e) { (void) hipEventDestroy(e); e = nullptr; }
+	}
+};
+
+extern "C" {
+
+const char *cvx_last_error(void) { return g_err.c_str(); }
+
+int cvx_abi_version(void) { return CVX_ABI_VERSION; }
+
+int cvx_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_handle *out) {
+	if (!p || !out) { set_err("cvx_create: NULL argument"); return CVX_ERR_ARG; }
+	*out = nullptr;
+	/* The device kernels implement the scalar recurrence (reference
+	 * src/ConvexAlignFast.cpp:606-774).  The SSE path the reference actually runs is
+	 * identical to it only while opening a gap directly off the other gap type can
+	 * never win: gap_open + gap_ext_min < mismatch.  Outside
+	 * that regime we refuse rather than compute something the reference would not. */
+	const bool sane = p->match > 0.0f && p->mismatch < 0.0f && p->gap_open < 0.0f &&
+			p->gap_extend < 0.0f && p->gap_extend_min < 0.0f && p->gap_decay >= 0.0f &&
+			p->gap_extend <= p->gap_extend_min &&
+			(p->gap_open + p->gap_extend_min) < p->mismatch - 0.25f;
+	if (!sane) {
+		set_err("cvx_create: scoring (%g,%g,%g,%g,%g,%g) outside the supported regime "
+				"(need match>0, penalties<0, gap_extend<=gap_extend_min, "
+				"gap_open+gap_extend_min < mismatch-0.25)",
+				p->match, p->mismatch, p->gap_open, p->gap_extend, p->gap_extend_min, p->gap_decay);
+		return CVX_ERR_PARAMS;
+	}
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		set_err("cvx_create: no HIP device available (the HIP path has no CPU fallback)");
+		return CVX_ERR_NO_DEVICE;
+	}
+	if (device_id < 0 || device_id >= ndev) {
+		set_err("cvx_create: device %d out of range (%d devices)", device_id, ndev);
+		return CVX_ERR_NO_DEVICE;
+	}
+	HIP_TRY(hipSetDevice(device_id));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		set_err("cvx_create: device %d is %s; this library carries gfx950 code only", device_id, prop.gcnArchName);
+		return CVX_ERR_NO_DEVICE;
+	}
+	cvx_context *c = new (std::nothrow) cvx_context();
+	if (!c) return CVX_ERR_OOM;
+	c->device = device_id;
+	c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	c->sp.mat = p->match; c->sp.mis = p->mismatch; c->sp.go = p->gap_open;
+	c->sp.ge = p->gap_extend; c->sp.gem = p->gap_extend_min; c->sp.decay = p->gap_decay;
+	c->max_matrix_mb = max_matrix_mb ? max_matrix_mb : 10000;
+	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	if (e != hipSuccess) {
+		set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
+		delete c;
+		return CVX_ERR_HIP;
+	}
+	*out = c;
+	return CVX_OK;
+}
+
+void cvx_destroy(cvx_handle h) {
+	if (!h) return;
+	(void) hipSetDevice(h->device);
+	if (h->stream) (void) hipStreamDestroy(h->stream);
+	delete h;
+}
+
+int cvx_batch_upload(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_batch *out) {
+	if (!h || !out || n < 0 || (n > 0 && !tiles)) { set_err("cvx_batch_upload: bad argument"); return CVX_ERR_ARG; }
+	*out = nullptr;
+	HIP_TRY(hipSetDevice(h->device));
+
+	uint64_t seq_bytes = 0, n_rows = 0;
+	int64_t max_hw = 0;
+	for (int i = 0; i < n; ++i) {
+		const cvx_tile &t = tiles[i];
+		if (t.ref_len < 0 || t.qry_len < 0 || (t.ref_len > 0 && !t.ref) || (t.qry_len > 0 && !t.qry) ||
+				(t.qry_len > 0 && (!t.row_offset || !t.row_length)) || (t.row_stride_bytes & 3) || t.row_stride_bytes < 4) {
+			set_err("cvx_batch_upload: tile %d malformed", i);
+			return CVX_ERR_ARG;
+		}
+		seq_bytes += (uint64_t) t.ref_len + (uint64_t) t.qry_len;
+		n_rows += (uint64_t) t.qry_len;
+		max_hw = std::max<int64_t>(max_hw, (int64_t) t.ref_len + t.qry_len);
+	}
+	const uint64_t pad = (uint64_t) max_hw + kRingMax + 256;
+	const uint64_t seq_total = seq_bytes + 2 * pad + 64;
+	if (seq_total >= 0xFFFF0000ull) {
+		set_err("cvx_batch_upload: %llu sequence bytes exceed one batch (4 GiB); split the batch",
+				(unsigned long long) seq_total);
+		return CVX_ERR_ARG;
+	}
+
+	cvx_batch_s *b = new (std::nothrow) cvx_batch_s();
+	if (!b) return CVX_ERR_OOM;
+	b->n = n;
+	memset(&b->timing, 0, sizeof(b->timing));
+	int rc = CVX_OK;
+	try {
+		b->tin.resize((size_t) n);
+		std::vector<uint8_t> hseq((size_t) seq_total, (uint8_t) 0);
+		std::vector<RowDesc> hrows((size_t) std::max<uint64_t>(n_rows, 1));
+		uint64_t so = pad, ro = 0;
+		for (int i = 0; i < n; ++i) {
+			const cvx_tile &t = tiles[i];
+			TileIn &ti = b->tin[(size_t) i];
+			ti.ref_off = (uint32_t) so;
+			if (t.ref_len) memcpy(&hseq[(size_t) so], t.ref, (size_t) t.ref_len);
+			so += (uint64_t) t.ref_len;
+			ti.qry_off = (uint32_t) so;
+			if (t.qry_len) memcpy(&hseq[(size_t) so], t.qry, (size_t) t.qry_len);
+			so += (uint64_t) t.qry_len;
+			ti.W = t.ref_len;
+			ti.H = t.qry_len;
+			ti.row_off = ro;
+			ti.reserved = 0;
+			const char *po = (const char *) t.row_offset;
+			const char *pl = (const char *) t.row_length;
+			for (int y = 0; y < t.qry_len; ++y) {
+				RowDesc rd;
+				memcpy(&rd.off, po + (size_t) y * (size_t) t.row_stride_bytes, 4);
+				memcpy(&rd.len, pl + (size_t) y * (size_t) t.row_stride_bytes, 4);
+				hrows[(size_t) ro++] = rd;
+			}
+		}
+		if ((rc = b->d_seq.ensure((size_t) seq_total)) == CVX_OK &&
+				(rc = b->d_rows.ensure(hrows.size())) == CVX_OK &&
+				(rc = b->d_tin.ensure((size_t) std::max(n, 1))) == CVX_OK &&
+				(rc = b->d_plan.ensure((size_t) std::max(n, 1))) == CVX_OK &&
+				(rc = b->d_trun.ensure((size_t) std::max(n, 1))) == CVX_OK &&
+				(rc = b->d_tout.ensure((size_t) std::max(n, 1))) == CVX_OK &&
+				(rc = b->d_dstoff.ensure((size_t) std::max(n, 1))) == CVX_OK &&
+				(rc = b->d_lists.ensure((size_t) std::max(n, 1))) == CVX_OK &&
+				(rc = b->d_heads.ensure(64)) == CVX_OK) {
+			hipError_t e = hipMemcpy(b->d_seq.p, hseq.data(), (size_t) seq_total, hipMemcpyHostToDevice);
+			if (e == hipSuccess && n_rows) e = hipMemcpy(b->d_rows.p, hrows.data(), (size_t) n_rows * sizeof(RowDesc), hipMemcpyHostToDevice);
+			if (e == hipSuccess && n) e = hipMemcpy(b->d_tin.p, b->tin.data(), (size_t) n * sizeof(TileIn), hipMemcpyHostToDevice);
+			for (auto &ev : b->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+			if (e != hipSuccess) { set_err("upload copy failed: %s", hipGetErrorString(e)); rc = CVX_ERR_HIP; }
+		}
+	} catch (const std::bad_alloc &) {
+		set_err("cvx_batch_upload: host allocation failed");
+		rc = CVX_ERR_OOM;
+	}
+	if (rc != CVX_OK) { b->release(); delete b; return rc; }
+	*out = b;
+	return CVX_OK;
+}
+
+static float ev_ms(hipEvent_t a, hipEvent_t b) {
+	float ms = 0.0f;
+	if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.0f;
+	return ms;
+}
+
+int cvx_batch_run(cvx_handle h, cvx_batch b) {
+	if (!h || !b) { set_err("cvx_batch_run: NULL argument"); return CVX_ERR_ARG; }
+	HIP_TRY(hipSetDevice(h->device));
+	const int n = b->n;
+	hipStream_t st = h->stream;
+	b->ran = false;
+	b->ops_total = 0;
+	memset(&b->timing, 0, sizeof(b->timing));
+	if (n == 0) { b->ran = true; return CVX_OK; }
+
+	HIP_TRY(hipEventRecord(b->ev[0], st));
+	HIP_TRY(launch_plan(b->d_rows.p, b->d_tin.p, b->d_plan.p, n, h->max_matrix_mb, st));
+	b->plan.resize((size_t) n);
+	HIP_TRY(hipMemcpyAsync(b->plan.data(), b->d_plan.p, (size_t) n * sizeof(TilePlan), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+
+	/* ---- host planning: kernel class, arena offsets, work lists */
+	b->trun.assign((size_t) n, TileRun());
+	b->tout.assign((size_t) n, TileOut());
+	std::vector<std::vector<int32_t>> cls((size_t) kNumClasses * 2);
+	uint64_t dir_dwords = 0, ops_ints = 0, cells = 0, active = 0;
+	int n_fast = 0;
+	for (int i = 0; i < n; ++i) {
+		const TilePlan &p = b->plan[(size_t) i];
+		TileRun &r = b->trun[(size_t) i];
+		TileOut &o = b->tout[(size_t) i];
+		memset(&r, 0, sizeof(r));
+		memset(&o, 0, sizeof(o));
+		o.score = -1.0f;
+		cells += p.cells;
+		r.skip = 1;
+		if (p.flags & kPlanTooLarge) { o.status = CVX_TILE_TOO_LARGE; continue; }
+		if (p.flags & kPlanEmpty) { o.status = CVX_TILE_EMPTY; continue; }
+		int k = -1;
+		if (!(p.flags & kPlanIrregular)) {
+			for (int c = 0; c < kNumClasses; ++c) if (kClasses[c].ring() >= p.need) { k = c; break; }
+		}
+		if (k < 0) { o.status = CVX_TILE_UNSUPPORTED; continue; }
+		r.skip = 0;
+		r.ring = kClasses[k].ring();
+		r.r0 = p.r0;
+		r.nsteps = p.rend - p.r0;
+		r.dir_off = dir_dwords;
+		dir_dwords += (uint64_t) ((r.nsteps + 15) / 16) * (uint64_t) r.ring;
+		r.ops_cap = b->tin[(size_t) i].H + b->tin[(size_t) i].W + 8;
+		r.ops_off = ops_ints;
+		ops_ints += (uint64_t) r.ops_cap;
+		active += p.active;
+		if (kClasses[k].nw == 1) n_fast++;
+		cls[(size_t) k * 2 + ((p.flags & kPlanWrap16) ? 1 : 0)].push_back(i);
+	}
+	int rc;
+	if ((rc = b->d_dirs.ensure((size_t) dir_dwords + 64)) != CVX_OK) return rc;
+	if ((rc = b->d_regions.ensure((size_t) ops_ints + 64)) != CVX_OK) return rc;
+
+	b->lists.clear();
+	std::vector<int> seg_begin(cls.size(), 0);
+	for (size_t c = 0; c < cls.size(); ++c) {
+		auto &v = cls[c];
+		/* longest processing time first: the persistent waves pull from the front */
+		std::sort(v.begin(), v.end(), [&](int32_t x, int32_t y) {
+			const uint64_t ax = b->plan[(size_t) x].active, ay = b->plan[(size_t) y].active;
+			return ax != ay ? ax > ay : x < y;
+		});
+		seg_begin[c] = (int) b->lists.size();
+		b->lists.insert(b->lists.end(), v.begin(), v.end());
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_trun.p, b->trun.data(), (size_t) n * sizeof(TileRun), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(b->d_tout.p, b->tout.data(), (size_t) n * sizeof(TileOut), hipMemcpyHostToDevice, st));
+	if (!b->lists.empty())
+		HIP_TRY(hipMemcpyAsync(b->d_lists.p, b->lists.data(), b->lists.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync(b->d_heads.p, 0, 64 * sizeof(int32_t), st));
+	HIP_TRY(hipEventRecord(b->ev[1], st));
+
+	/* ---- forward fill, one launch per populated kernel class */
+	int launches = 0;
+	for (size_t c = 0; c < cls.size(); ++c) {
+		if (cls[c].empty()) continue;
+		const KernelClass &kc = kClasses[c / 2];
+		FillArgs a;
+		a.seq = b->d_seq.p;
+		a.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
+		a.tin = b->d_tin.p;
+		a.trun = b->d_trun.p;
+		a.tout = b->d_tout.p;
+		a.dirs = b->d_dirs.p;
+		a.list = b->d_lists.p + seg_begin[c];
+		a.list_n = (int) cls[c].size();
+		a.queue_head = b->d_heads.p + c;
+		a.sp = h->sp;
+		const int per_cu = kc.nw == 1 ? 32 : std::max(1, 16 / kc.nw);
+		const int grid = std::min(a.list_n, h->num_cus * per_cu);
+		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, a, grid, st));
+		launches++;
+	}
+	HIP_TRY(hipEventRecord(b->ev[2], st));
+
+	/* ---- backtrack + ops compaction */
+	BacktrackArgs ba;
+	ba.seq = b->d_seq.p;
+	ba.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
+	ba.tin = b->d_tin.p;
+	ba.trun = b->d_trun.p;
+	ba.tout = b->d_tout.p;
+	ba.dirs = b->d_dirs.p;
+	ba.ops = b->d_regions.p;
+	ba.n_tiles = n;
+	HIP_TRY(launch_backtrack(ba, st));
+	HIP_TRY(hipMemcpyAsync(b->tout.data(), b->d_tout.p, (size_t) n * sizeof(TileOut), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	b->dst_off.assign((size_t) n, 0);
+	uint64_t total = 0;
+	for (int i = 0; i < n; ++i) {
+		b->dst_off[(size_t) i] = total;
+		if (b->tout[(size_t) i].status == 0) total += (uint64_t) b->tout[(size_t) i].n_ops;
+	}
+	b->ops_total = total;
+	if ((rc = b->d_dense.ensure((size_t) total + 64)) != CVX_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(b->d_dstoff.p, b->dst_off.data(), (size_t) n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+	HIP_TRY(launch_compact(b->d_regions.p, b->d_trun.p, b->d_tout.p, b->d_dstoff.p, b->d_dense.p, n, st));
+	HIP_TRY(hipEventRecord(b->ev[3], st));
+	HIP_TRY(hipStreamSynchronize(st));
+
+	b->timing.plan_ms = ev_ms(b->ev[0], b->ev[1]);
+	b->timing.fill_ms = ev_ms(b->ev[1], b->ev[2]);
+	b->timing.backtrack_ms = ev_ms(b->ev[2], b->ev[3]);
+	b->timing.total_ms = ev_ms(b->ev[0], b->ev[3]);
+	b->timing.cells = cells;
+	b->timing.active_cells = active;
+	b->timing.dir_bytes = dir_dwords * 4;
+	b->timing.n_fill_launches = launches;
+	b->timing.n_tiles_fast = n_fast;
+	b->ran = true;
+	return CVX_OK;
+}
+
+int cvx_batch_timing(cvx_batch b, cvx_timing *t) {
+	if (!b || !t) { set_err("cvx_batch_timing: NULL argument"); return CVX_ERR_ARG; }
+	*t = b->timing;
+	return CVX_OK;
+}
+
+int cvx_batch_ops_total(cvx_batch b, uint64_t *n_ops) {
+	if (!b || !n_ops || !b->ran) { set_err("cvx_batch_ops_total: batch not run"); return CVX_ERR_ARG; }
+	*n_ops = b->ops_total;
+	return CVX_OK;
+}
+
+int cvx_batch_download(cvx_handle h, cvx_batch b, cvx_result *results, uint32_t *ops_arena,
+		uint64_t ops_capacity, uint64_t *ops_used) {
+	if (!h || !b || !b->ran || (b->n > 0 && !results)) { set_err("cvx_batch_download: bad argument / batch not run"); return CVX_ERR_ARG; }
+	HIP_TRY(hipSetDevice(h->device));
+	if (ops_used) *ops_used = b->ops_total;
+	for (int i = 0; i < b->n; ++i) {
+		const TileOut &o = b->tout[(size_t) i];
+		cvx_result &r = results[i];
+		memset(&r, 0, sizeof(r));
+		r.score = o.score;
+		r.status = o.status;
+		r.best_ref_index = o.best_x;
+		r.best_read_index = o.best_y;
+		r.ref_position = o.ref_position;
+		r.qstart = o.qstart;
+		r.qend = o.qend;
+		r.n_ops = o.status == 0 ? o.n_ops : 0;
+		r.ops_begin = b->dst_off[(size_t) i];
+		r.cells = b->plan[(size_t) i].cells;
+	}
+	if (b->ops_total > ops_capacity) {
+		set_err("cvx_batch_download: ops arena too small (%llu needed, %llu given)",
+				(unsigned long long) b->ops_total, (unsigned long long) ops_capacity);
+		return CVX_ERR_CAPACITY;
+	}
+	if (b->ops_total) {
+		if (!ops_arena) { set_err("cvx_batch_download: NULL ops arena"); return CVX_ERR_ARG; }
+		HIP_TRY(hipMemcpy(ops_arena, b->d_dense.p, (size_t) b->ops_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	}
+	return CVX_OK;
+}
+
+void cvx_batch_free(cvx_handle h, cvx_batch b) {
+	if (!b) return;
+	if (h) (void) hipSetDevice(h->device);
+	b->release();
+	delete b;
+}
+
+int cvx_align_batch(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_result *results,
+		uint32_t *ops_arena, uint64_t ops_capacity, uint64_t *ops_used) {
+	cvx_batch b = nullptr;
+	int rc = cvx_batch_upload(h, n, tiles, &b);
+	if (rc != CVX_OK) return rc;
+	rc = cvx_batch_run(h, b);
+	if (rc == CVX_OK) rc = cvx_batch_download(h, b, results, ops_arena, ops_capacity, ops_used);
+	cvx_batch_free(h, b);
+	return rc;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,119 @@
+/*
+ * cvx_types.h -- structures shared by the gfx950 kernels (cvx_kernels.hip) and the
+ * host runtime (cvx_runtime.cpp).  Internal; the public boundary is include/cvx_align.h.
+ *
+ * HBM layout of one uploaded batch (all arenas are single hipMalloc blocks):
+ *
+ *   seq   : bytes.  [pad][tile0 ref][tile0 qry][tile1 ref]... [pad]; a tile addresses
+ *           its sequences by 32-bit byte offsets, so one batch holds < 4 GiB of bases.
+ *           The pads (>= max(H+W)+RING_MAX) keep the speculative reference-character
+ *           loads of idle ring slots inside the allocation.
+ *   rows  : int2 (offset, length) per read row = the caller's CorridorLine[] without
+ *           the 8 bytes of offsetInMatrix (reference src/IAlignment.h:29-33).
+ *   dirs  : 2-bit backtracking codes, anti-diagonal-major (see below).
+ *   ops   : per-tile regions the backtrack writes run-length ops into, then a dense
+ *           arena the host downloads.
+ *
+ * Direction matrix layout.  The reference keeps 1 byte per corridor cell, row-major
+ * (directionMatrix, src/AlignmentMatrixFast.h:261).  The device fill walks the
+ * corridor by anti-diagonals r = x + y, holding read row y in ring slot (y mod N);
+ * slot s of step t = r - r0 stores its 2-bit code at
+ *
+ *      dword  dir_off + (t >> 4) * N + s ,  bits [2*(t&15), 2*(t&15)+1]
+ *
+ * so a wave writes N contiguous dwords every 16 steps (fully coalesced) and the
+ * backtrack finds cell (x, y) at t = x + y - r0, s = y mod N.  Codes: 0 stop /
+ * outside, 1 insertion (up), 2 deletion (left), 3 diagonal (EQ or X, re-derived from
+ * the sequences).  Only the *layout* differs from the reference; the algorithmic
+ * byte count used for the roofline stays 1 byte per cell.
+ */
+#ifndef CVX_TYPES_H
+#define CVX_TYPES_H
+
+#include <stdint.h>
+
+namespace cvx {
+
+struct RowDesc2 { int32_t x, y; };  /* (offset, length); same layout as HIP's int2 */
+
+/* A finished row's slot is handed to row y+N only at a 4-step group boundary, so
+ * row y+N-1 must not start earlier than 3 steps after row y ended. */
+static const int kSwitchMargin = 3;
+static const int kRingMax = 4096;      /* largest ring any fill kernel provides */
+
+struct ScoreParams {
+	float mat, mis, go, ge, gem, decay;
+};
+
+struct TileIn {            /* written by the host at upload */
+	uint32_t ref_off;      /* byte offset of ref[0] in the seq arena */
+	uint32_t qry_off;      /* byte offset of qry[0] */
+	int32_t W, H;
+	uint64_t row_off;      /* index of row 0 in the rows arena (int2 units) */
+	uint64_t reserved;
+};
+
+enum PlanFlags {
+	kPlanIrregular = 1,    /* row start/end anti-diagonals not monotone: no ring kernel */
+	kPlanEmpty = 2,        /* no cell inside [0,W) */
+	kPlanTooLarge = 4,     /* exceeds maxMatrixSizeMB */
+	kPlanWrap16 = 8        /* a row or column can carry a gap run past SHRT_MAX */
+};
+
+struct TilePlan {          /* written by plan_kernel, read back by the host */
+	int32_t r0;            /* first anti-diagonal with a cell */
+	int32_t rend;          /* one past the last */
+	int32_t need;          /* ring slots needed */
+	int32_t flags;
+	uint64_t cells;        /* sum of row_length (reference matrixSize) */
+	uint64_t active;       /* cells inside [0,W) */
+};
+
+struct TileRun {           /* written by the host after planning */
+	uint64_t dir_off;      /* dword offset in the dirs arena */
+	uint64_t ops_off;      /* int offset of this tile's ops region */
+	int32_t ring;          /* N */
+	int32_t ops_cap;
+	int32_t r0;
+	int32_t nsteps;
+	int32_t skip;          /* != 0: tile not computed (status preset in TileOut) */
+	int32_t pad;
+};
+
+struct TileOut {
+	float score;
+	int32_t status;
+	int32_t best_x, best_y;
+	int32_t ref_position, qstart, qend;
+	int32_t n_ops;
+	int32_t ops_first;     /* index of the first op inside the tile's region */
+	int32_t pad;
+};
+
+struct FillArgs {
+	const uint8_t *seq;
+	const RowDesc2 *rows;
+	const TileIn *tin;
+	const TileRun *trun;
+	TileOut *tout;
+	uint32_t *dirs;
+	const int32_t *list;   /* tile indices of this kernel class, largest first */
+	int32_t list_n;
+	int32_t *queue_head;   /* work-queue cursor (zeroed before launch) */
+	ScoreParams sp;
+};
+
+struct BacktrackArgs {
+	const uint8_t *seq;
+	const RowDesc2 *rows;
+	const TileIn *tin;
+	const TileRun *trun;
+	TileOut *tout;
+	const uint32_t *dirs;
+	int32_t *ops;          /* region arena */
+	int32_t n_tiles;
+};
+
+}  // namespace cvx
+
+#endif

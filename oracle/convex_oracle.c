@@ -503,6 +503,13 @@ void oracle_port_set_spec_fill(void *h, int on) { ((oracle_t *) h)->use_spec_fil
 
 /* Port-only: forward results of the last call (for kernel-level parity checks). */
 static __thread int g_last_best_x, g_last_best_y, g_last_ref_position, g_last_qstart, g_last_qend;
+static __thread int *g_last_ops; static __thread int g_last_nops;
+/* Port-only: run-length ops (len<<4|op, forward order, clips excluded) of the last valid call. */
+int oracle_port_last_ops(int32_t *out, int32_t cap) {
+	int n = g_last_nops < cap ? g_last_nops : cap;
+	if (out && n > 0) memcpy(out, g_last_ops, sizeof(int) * (size_t) n);
+	return g_last_nops;
+}
 void oracle_port_last_fwd(int32_t out[5]) {
 	out[0] = g_last_best_x; out[1] = g_last_best_y; out[2] = g_last_ref_position;
 	out[3] = g_last_qstart; out[4] = g_last_qend;
@@ -556,7 +563,12 @@ int oracle_align(void *h, const char *ref, const char *qry,
 		g_last_best_x = f.best_ref_index; g_last_best_y = f.best_read_index;
 		g_last_ref_position = f.ref_position; g_last_qstart = f.qstart; g_last_qend = f.qend;
 		if (hard) rc = -1;
+		g_last_nops = 0;
 		if (valid) {
+			int nops = (bc_len - 1) - (f.alignment_offset + 1);
+			g_last_ops = (int *) realloc(g_last_ops, sizeof(int) * (size_t) (nops > 0 ? nops : 1));
+			memcpy(g_last_ops, bc + f.alignment_offset + 1, sizeof(int) * (size_t) (nops > 0 ? nops : 0));
+			g_last_nops = nops;
 			text_t t;
 			t.cigar_cap = m.H * 4 + 64;
 			t.cigar = (char *) malloc((size_t) t.cigar_cap + 64);

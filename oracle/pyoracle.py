@@ -64,6 +64,8 @@ class Oracle:
         if kind == "port":
             self.lib.oracle_port_set_spec_fill.argtypes = [C.c_void_p, C.c_int]
             self.lib.oracle_port_last_fwd.argtypes = [C.c_void_p]
+            self.lib.oracle_port_last_ops.argtypes = [C.c_void_p, C.c_int32]
+            self.lib.oracle_port_last_ops.restype = C.c_int
 
     def close(self):
         if self.h:
@@ -83,6 +85,12 @@ class Oracle:
         a = (C.c_int32 * 5)()
         self.lib.oracle_port_last_fwd(a)
         return dict(best_x=a[0], best_y=a[1], ref_position=a[2], qstart=a[3], qend=a[4])
+
+    def last_ops(self) -> np.ndarray:
+        n = self.lib.oracle_port_last_ops(None, 0)
+        a = np.zeros(max(n, 1), dtype=np.int32)
+        self.lib.oracle_port_last_ops(a.ctypes.data, n)
+        return a[:n].astype(np.uint32)
 
     def align(self, tile, want_nm: bool = True) -> dict:
         H = len(tile.qry)
