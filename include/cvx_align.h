@@ -128,6 +128,19 @@ typedef struct {
 	int32_t n_tiles_fast; /* tiles taken by the single-wave ring kernels */
 } cvx_timing;
 
+/* One forward-fill launch of the last cvx_batch_run (HIP-event timed on the stream). */
+typedef struct {
+	int32_t slots_per_lane;  /* M */
+	int32_t waves;           /* NW: waves cooperating on one tile */
+	int32_t wrap16;          /* int16 gap-run wrap emulation compiled in */
+	int32_t n_tiles;
+	float ms;                /* kernel duration */
+	uint64_t cells;          /* sum of row_length over the launch's tiles */
+	uint64_t active_cells;   /* cells inside [0,W) */
+	uint64_t alg_bytes;      /* algorithmic bytes: sum over tiles of C + 6H + 2W */
+	uint64_t read_bases;     /* sum of qry_len */
+} cvx_launch_info;
+
 const char *cvx_last_error(void);
 int cvx_abi_version(void);
 int cvx_device_count(void);
@@ -147,6 +160,8 @@ int cvx_batch_upload(cvx_handle h, int32_t n_tiles, const cvx_tile *tiles, cvx_b
 int cvx_batch_run(cvx_handle h, cvx_batch b);            /* enqueue + wait */
 int cvx_batch_timing(cvx_batch b, cvx_timing *t);
 int cvx_batch_ops_total(cvx_batch b, uint64_t *n_ops);
+/* i in [0, timing.n_fill_launches) */
+int cvx_batch_launch_info(cvx_batch b, int32_t i, cvx_launch_info *info);
 int cvx_batch_download(cvx_handle h, cvx_batch b, cvx_result *results,
 		uint32_t *ops_arena, uint64_t ops_capacity, uint64_t *ops_used);
 void cvx_batch_free(cvx_handle h, cvx_batch b);

@@ -74,7 +74,7 @@ class ConvexAlignHip:
 
     # ------------------------------------------------------------------ reference-shaped API
     def batch_align(self, tiles: Sequence, want_nm: bool = True) -> List[dict]:
-        """N x SingleAlign: returns one Align-like dict per tile (keys as oracle/pyoracle)."""
+        """N x SingleAlign: returns one Align-like dict per tile (keys = the Align fields)."""
         batch = self.upload(tiles)
         try:
             batch.run()
@@ -101,6 +101,16 @@ class DeviceBatch:
         t = capi.CvxTiming()
         capi.check(self.al.lib.cvx_batch_timing(self.b, C.byref(t)))
         return t
+
+    def launches(self) -> list:
+        t = capi.CvxTiming()
+        capi.check(self.al.lib.cvx_batch_timing(self.b, C.byref(t)))
+        out = []
+        for i in range(t.n_fill_launches):
+            li = capi.CvxLaunchInfo()
+            capi.check(self.al.lib.cvx_batch_launch_info(self.b, i, C.byref(li)))
+            out.append({k: getattr(li, k) for k, _ in capi.CvxLaunchInfo._fields_})
+        return out
 
     def download(self):
         n = len(self.tiles)

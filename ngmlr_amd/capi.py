@@ -20,7 +20,7 @@ TILE_STATUS = {0: "ok", 1: "invalid-row0", 2: "invalid-edge", 3: "invalid-length
 
 EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_create", "cvx_destroy",
            "cvx_align_batch", "cvx_batch_upload", "cvx_batch_run", "cvx_batch_timing",
-           "cvx_batch_ops_total", "cvx_batch_download", "cvx_batch_free", "cvx_format_alignment")
+           "cvx_batch_ops_total", "cvx_batch_launch_info", "cvx_batch_download", "cvx_batch_free", "cvx_format_alignment")
 
 
 class CvxParams(C.Structure):
@@ -45,6 +45,12 @@ class CvxTiming(C.Structure):
     _fields_ = [("plan_ms", C.c_float), ("fill_ms", C.c_float), ("backtrack_ms", C.c_float),
                 ("total_ms", C.c_float), ("cells", C.c_uint64), ("active_cells", C.c_uint64),
                 ("dir_bytes", C.c_uint64), ("n_fill_launches", C.c_int32), ("n_tiles_fast", C.c_int32)]
+
+
+class CvxLaunchInfo(C.Structure):
+    _fields_ = [("slots_per_lane", C.c_int32), ("waves", C.c_int32), ("wrap16", C.c_int32),
+                ("n_tiles", C.c_int32), ("ms", C.c_float), ("cells", C.c_uint64),
+                ("active_cells", C.c_uint64), ("alg_bytes", C.c_uint64), ("read_bases", C.c_uint64)]
 
 
 class CvxAlignmentText(C.Structure):
@@ -86,6 +92,7 @@ def load() -> C.CDLL:
     lib.cvx_batch_upload.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CvxTile), C.POINTER(C.c_void_p)]
     lib.cvx_batch_run.argtypes = [C.c_void_p, C.c_void_p]
     lib.cvx_batch_timing.argtypes = [C.c_void_p, C.POINTER(CvxTiming)]
+    lib.cvx_batch_launch_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CvxLaunchInfo)]
     lib.cvx_batch_ops_total.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.cvx_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CvxResult), C.c_void_p,
                                        C.c_uint64, C.POINTER(C.c_uint64)]

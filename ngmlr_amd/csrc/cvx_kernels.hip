@@ -66,12 +66,12 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 	const int H = ti.H, W = ti.W;
 
 	__shared__ unsigned long long s_cells, s_active;
-	__shared__ int s_need, s_flags, s_maxlen;
-	if (threadIdx.x == 0) { s_cells = 0; s_active = 0; s_need = 1; s_flags = 0; s_maxlen = 0; }
+	__shared__ int s_need, s_flags, s_maxlen, s_rend;
+	if (threadIdx.x == 0) { s_cells = 0; s_active = 0; s_need = 1; s_flags = 0; s_maxlen = 0; s_rend = -0x7fffffff; }
 	__syncthreads();
 
 	unsigned long long cells = 0, active = 0;
-	int need = 1, flags = 0, maxlen = 0;
+	int need = 1, flags = 0, maxlen = 0, rendmax = -0x7fffffff;
 	for (int y = threadIdx.x; y < H; y += blockDim.x) {
 		const int2 ol = r[y];
 		int gs, ge;
@@ -79,10 +79,11 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 		cells += (unsigned long long) (long long) ol.y;
 		active += (unsigned long long) (ge - gs);
 		if (ol.y > maxlen) maxlen = ol.y;
+		if (ge > rendmax) rendmax = ge;
 		if (y > 0) {
 			int pgs, pge;
 			row_span(r[y - 1], W, y - 1, pgs, pge);
-			if (gs <= pgs || ge < pge) flags |= kPlanIrregular;
+			if (gs <= pgs) flags |= kPlanIrregular;  /* ring schedule needs increasing row starts */
 		}
 		/* first row y' > y that starts at or after ge + margin (gs is increasing) */
 		const int lim = ge + kSwitchMargin;
@@ -101,6 +102,7 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 	atomicMax(&s_need, need);
 	atomicOr(&s_flags, flags);
 	atomicMax(&s_maxlen, maxlen);
+	atomicMax(&s_rend, rendmax);
 	__syncthreads();
 
 	if (threadIdx.x == 0) {
@@ -114,8 +116,7 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 			int gs, ge;
 			row_span(r[0], W, 0, gs, ge);
 			r0 = gs;
-			row_span(r[H - 1], W, H - 1, gs, ge);
-			rend = ge;
+			rend = s_rend;
 		}
 		if (H <= 0 || s_active == 0) f |= kPlanEmpty;
 		/* src/AlignmentMatrixFast.cpp:45: (ulong)(matrixSize / 1000.0f / 1000.0f) < maxMatrixSizeMB */
@@ -306,13 +307,15 @@ fill_ring_kernel(const FillArgs a) {
 						if (mx > s.best[j]) { s.best[j] = mx; s.best_r[j] = r; }
 						s.dacc[j] |= code << sh;
 					}
-					s.cnt[j] += 1;
 					if (s.cnt[j] == s.len[j]) {
-						/* row finished: the slot is "outside the corridor" from now on
-						 * (empty element, src/AlignmentMatrixFast.h:49-53) */
+						/* first step after the row's last cell.  The slot below (processed
+						 * earlier in this step) has just consumed that last cell as its "up"
+						 * and keeps its score as next step's "diag"; from now on this slot is
+						 * outside the corridor (empty element, src/AlignmentMatrixFast.h:49-53). */
 						s.S[j] = 0.0f; s.drun[j] = 0; s.irun[j] = 0;
 						s.V[j] = go; s.Hc[j] = go;
 					}
+					s.cnt[j] += 1;
 				}
 				r += 1;
 			}
@@ -320,7 +323,7 @@ fill_ring_kernel(const FillArgs a) {
 			/* hand finished slots to their next row (y + N) */
 #pragma unroll
 			for (int j = 0; j < M; ++j) {
-				if (s.cnt[j] >= s.len[j] && s.y[j] < H) {
+				if (s.cnt[j] > s.len[j] && s.y[j] < H) {   /* ended AND already reset */
 					if (s.best_r[j] >= r - s.cnt[j]) s.best_y[j] = s.y[j];
 					s.y[j] += N;
 					bind_row(j, r);

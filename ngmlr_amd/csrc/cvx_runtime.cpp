@@ -122,6 +122,8 @@ struct cvx_batch_s {
 	DevBuf<uint32_t> d_dense;
 
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	std::vector<hipEvent_t> lev;          /* 2 events per fill launch */
+	std::vector<cvx_launch_info> launches;
 	cvx_timing timing;
 
 	void release() {
@@ -129,6 +131,8 @@ struct cvx_batch_s {
 		d_tout.release(); d_dirs.release(); d_regions.release(); d_lists.release();
 		d_heads.release(); d_dstoff.release(); d_dense.release();
 		for (auto &e : ev) if (e) { (void) hipEventDestroy(e); e = nullptr; }
+		for (auto &e : lev) if (e) (void) hipEventDestroy(e);
+		lev.clear();
 	}
 };
 
@@ -367,9 +371,27 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 
 	/* ---- forward fill, one launch per populated kernel class */
 	int launches = 0;
+	b->launches.clear();
 	for (size_t c = 0; c < cls.size(); ++c) {
 		if (cls[c].empty()) continue;
 		const KernelClass &kc = kClasses[c / 2];
+		while (b->lev.size() < (size_t) (launches + 1) * 2) {
+			hipEvent_t e;
+			HIP_TRY(hipEventCreate(&e));
+			b->lev.push_back(e);
+		}
+		cvx_launch_info li;
+		memset(&li, 0, sizeof(li));
+		li.slots_per_lane = kc.m; li.waves = kc.nw; li.wrap16 = (int) (c & 1); li.n_tiles = (int) cls[c].size();
+		for (int32_t ti : cls[c]) {
+			const TilePlan &p = b->plan[(size_t) ti];
+			const TileIn &in = b->tin[(size_t) ti];
+			li.cells += p.cells; li.active_cells += p.active;
+			li.alg_bytes += p.cells + 6ull * (uint64_t) in.H + 2ull * (uint64_t) in.W;
+			li.read_bases += (uint64_t) in.H;
+		}
+		b->launches.push_back(li);
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2], st));
 		FillArgs a;
 		a.seq = b->d_seq.p;
 		a.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
@@ -384,6 +406,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		const int per_cu = kc.nw == 1 ? 32 : std::max(1, 16 / kc.nw);
 		const int grid = std::min(a.list_n, h->num_cus * per_cu);
 		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, a, grid, st));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2 + 1], st));
 		launches++;
 	}
 	HIP_TRY(hipEventRecord(b->ev[2], st));
@@ -414,6 +437,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	HIP_TRY(hipEventRecord(b->ev[3], st));
 	HIP_TRY(hipStreamSynchronize(st));
 
+	for (int i = 0; i < launches; ++i) b->launches[(size_t) i].ms = ev_ms(b->lev[(size_t) i * 2], b->lev[(size_t) i * 2 + 1]);
 	b->timing.plan_ms = ev_ms(b->ev[0], b->ev[1]);
 	b->timing.fill_ms = ev_ms(b->ev[1], b->ev[2]);
 	b->timing.backtrack_ms = ev_ms(b->ev[2], b->ev[3]);
@@ -430,6 +454,12 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 int cvx_batch_timing(cvx_batch b, cvx_timing *t) {
 	if (!b || !t) { set_err("cvx_batch_timing: NULL argument"); return CVX_ERR_ARG; }
 	*t = b->timing;
+	return CVX_OK;
+}
+
+int cvx_batch_launch_info(cvx_batch b, int32_t i, cvx_launch_info *info) {
+	if (!b || !info || !b->ran || i < 0 || (size_t) i >= b->launches.size()) { set_err("cvx_batch_launch_info: bad index"); return CVX_ERR_ARG; }
+	*info = b->launches[(size_t) i];
 	return CVX_OK;
 }
 

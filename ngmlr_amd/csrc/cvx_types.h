@@ -36,9 +36,10 @@ namespace cvx {
 
 struct RowDesc2 { int32_t x, y; };  /* (offset, length); same layout as HIP's int2 */
 
-/* A finished row's slot is handed to row y+N only at a 4-step group boundary, so
- * row y+N-1 must not start earlier than 3 steps after row y ended. */
-static const int kSwitchMargin = 3;
+/* A finished row's slot is cleared one step after its last cell (the row below still
+ * reads that cell) and handed to row y+N at the next 4-step group boundary, so row
+ * y+N-1 must not start earlier than 4 steps after row y ended. */
+static const int kSwitchMargin = 4;
 static const int kRingMax = 4096;      /* largest ring any fill kernel provides */
 
 struct ScoreParams {

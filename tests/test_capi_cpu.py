@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol include/*.h
+declares, and refuses to compute without a device (no silent fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "cvx_align.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cvx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(built):
+    from ngmlr_amd import capi
+    lib = capi.load()
+    names = declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(capi.EXPORTS)
+    assert lib.cvx_abi_version() == 1
+
+
+def test_library_carries_gfx950_code_object(built):
+    from ngmlr_amd import capi
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-S", capi.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert ".hip_fatbin" in out
+    strs = subprocess.run(["strings", "-n", "6", capi.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert "gfx950" in strs
+    assert "fill_ring_kernel" in strs
+
+
+def test_product_does_not_link_the_oracle(built):
+    from ngmlr_amd import capi
+    out = subprocess.run(["ldd", capi.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert "oracle" not in out
+    nm = subprocess.run(["nm", "-D", capi.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert "oracle_align" not in nm
+    for root, _, files in os.walk(os.path.join(ROOT, "ngmlr_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+                assert not re.search(r"#include\s*[<\"][^>\"]*oracle", txt), f
+                assert "dlopen" not in txt and "libcvx_oracle" not in txt, f
+
+
+def test_no_device_is_a_loud_error(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ngmlr_amd import capi
+    from ngmlr_amd.aligner import ConvexAlignHip
+    with pytest.raises(capi.CvxError) as e:
+        ConvexAlignHip()
+    assert e.value.code == -1 and "no CPU fallback" in str(e.value)
+
+
+def test_scoring_outside_proven_regime_is_refused(built):
+    """gap_open + gap_ext_min must stay below mismatch -- checked before
+    any device is touched."""
+    from ngmlr_amd import capi
+    lib = capi.load()
+    h = C.c_void_p()
+    for bad in [(2, -10, -5, -5, -1, 0.15), (2, -5, -5, -5, 1, 0.15), (-2, -5, -5, -5, -1, 0.15), (2, -5, -5, -1, -5, 0.15)]:
+        p = capi.CvxParams(*bad)
+        assert lib.cvx_create(0, C.byref(p), 0, C.byref(h)) == -2, bad
+    assert b"supported regime" in lib.cvx_last_error()

@@ -1,0 +1,101 @@
+"""GPU (-m gpu): behaviour of the C ABI itself -- statuses, capacities, staged reuse."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_statuses(hip_aligner, port_oracle):
+    from ngmlr_amd import synth
+    rng = np.random.default_rng(8)
+    ok = synth.make_tile(rng, 500, corridor="anchors")
+    # best cell in row 0 -> invalid (reference src/ConvexAlignFast.cpp:338)
+    row0 = synth.Tile(b"ACGTACGTAC", b"A" + b"T" * 0, *synth.corridor_linear(1, 30), tag="row0")
+    # decreasing offsets: not a shape any reference caller builds -> loud "unsupported"
+    H = 120
+    weird = synth.Tile(synth.random_ref(rng, 400).tobytes(), synth.random_ref(rng, H).tobytes(),
+                       (300 - 2 * np.arange(H)).astype(np.int32), np.full(H, 60, np.int32), tag="decreasing")
+    empty = synth.Tile(b"ACGT" * 10, b"ACGT" * 5, np.full(20, 100, np.int32), np.full(20, 30, np.int32), tag="outside")
+    got = hip_aligner.batch_align([ok, row0, weird, empty])
+    assert got[0]["status"] == 0 and got[0]["ret"] == ok.H
+    assert got[1]["status"] == 1 and got[1]["ret"] == -1 and got[1]["score"] == -1.0
+    assert got[2]["status"] == -1 and got[2]["ret"] == -1
+    assert got[3]["status"] == 5 and got[3]["ret"] == -1
+    assert port_oracle.align(row0)["ret"] == -1 and port_oracle.align(empty)["ret"] == -1
+
+
+def test_too_large_matrix_is_rejected_like_the_reference(built):
+    """maxMatrixSizeMB (src/AlignmentMatrixFast.cpp:45,55-57), here lowered to 1 MB."""
+    from ngmlr_amd import synth
+    from ngmlr_amd.aligner import ConvexAlignHip
+    al = ConvexAlignHip(device=0, max_matrix_mb=1)
+    rng = np.random.default_rng(1)
+    small = synth.make_tile(rng, 1000, corridor="anchors")     # 0.3 MB
+    big = synth.make_tile(rng, 8000, corridor="anchors")       # 2.5 MB
+    got = al.batch_align([small, big])
+    assert got[0]["status"] == 0 and got[1]["status"] == 4 and got[1]["ret"] == -1
+    al.close()
+
+
+def test_capacity_error_and_retry(hip_aligner):
+    from ngmlr_amd import capi, synth
+    lib = capi.load()
+    tiles = synth.workload_ont(8, seed=3, max_len=1200)
+    batch = hip_aligner.upload(tiles)
+    batch.run()
+    total = C.c_uint64()
+    capi.check(lib.cvx_batch_ops_total(batch.b, C.byref(total)))
+    assert total.value > 8
+    res = (capi.CvxResult * 8)()
+    small = np.zeros(4, dtype=np.uint32)
+    used = C.c_uint64()
+    rc = lib.cvx_batch_download(hip_aligner.h, batch.b, res, small.ctypes.data, 4, C.byref(used))
+    assert rc == -6 and used.value == total.value
+    ops = np.zeros(int(used.value), dtype=np.uint32)
+    assert lib.cvx_batch_download(hip_aligner.h, batch.b, res, ops.ctypes.data, len(ops), C.byref(used)) == 0
+    assert sum(r.n_ops for r in res) == total.value
+    batch.free()
+
+
+def test_staged_batch_can_be_rerun(hip_aligner):
+    from ngmlr_amd import synth
+    from oracle.pyoracle import same_alignment
+    tiles = synth.workload_ont(16, seed=6, max_len=2500)
+    batch = hip_aligner.upload(tiles)
+    batch.run()
+    a = batch.alignments(want_nm=False)
+    batch.results = None
+    t = batch.run()
+    b = batch.alignments(want_nm=False)
+    assert t.n_fill_launches >= 1 and t.fill_ms > 0 and t.cells == sum(x.cells for x in tiles)
+    for x, y in zip(a, b):
+        assert same_alignment(x, y, keys=("ret", "score_bits", "cigar", "md")) is None
+    batch.free()
+
+
+def test_corridorline_stride_is_accepted(hip_aligner, port_oracle):
+    """The C++ shim passes &CorridorLine[0].offset with stride 16 (src/IAlignment.h:29-33)."""
+    from ngmlr_amd import capi, synth
+    from ngmlr_amd.aligner import format_alignment
+    from oracle.pyoracle import same_alignment
+    lib = capi.load()
+    rng = np.random.default_rng(12)
+    t = synth.make_tile(rng, 700, corridor="anchors", scatter=40)
+    lines = np.zeros((t.H, 4), dtype=np.int32)       # {int offset; int length; unsigned long offsetInMatrix}
+    lines[:, 0] = t.row_offset
+    lines[:, 1] = t.row_length
+    tile = capi.CvxTile()
+    tile.ref, tile.qry = t.ref, t.qry
+    tile.row_offset = lines.ctypes.data
+    tile.row_length = lines.ctypes.data + 4
+    tile.ref_len, tile.qry_len, tile.row_stride_bytes = t.W, t.H, 16
+    res = (capi.CvxResult * 1)()
+    ops = np.zeros(t.H + t.W + 8, dtype=np.uint32)
+    used = C.c_uint64()
+    capi.check(lib.cvx_align_batch(hip_aligner.h, 1, C.byref(tile), res, ops.ctypes.data, len(ops), C.byref(used)))
+    got = format_alignment(lib, res[0], ops, t)
+    assert same_alignment(port_oracle.align(t), got) is None

@@ -1,0 +1,171 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (libcvxalign.so), against the CPU
+oracle -- bit-exact on score bits, CIGAR, MD, offsets, clips, NM and the per-position
+mismatch profile -- plus the golden tiles recorded from the reference binary, the edge
+cases, and size-independent properties at BASELINE.json's full sizes."""
+import re
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import same_alignment
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(hip_aligner, port_oracle, tiles, need_valid=True):
+    got = hip_aligner.batch_align(tiles)
+    bad = []
+    n_valid = 0
+    for t, g in zip(tiles, got):
+        want = port_oracle.align(t)
+        d = same_alignment(want, g)
+        if d is None and want["ret"] >= 0:
+            f = port_oracle.last_fwd()
+            if (f["best_x"], f["best_y"]) != (g["best_x"], g["best_y"]):
+                d = "argmax cell"
+        assert g["status"] != -1, "tile %s fell outside every device kernel" % t.tag
+        n_valid += want["ret"] >= 0
+        if d:
+            bad.append((t.tag, t.H, t.W, int(t.row_length[0]), d))
+    assert not bad, bad[:5]
+    if need_valid:
+        assert n_valid > 0
+    return got
+
+
+def test_native_library_is_the_one_running(hip_aligner):
+    """The driver records loaded .so files; make the dependence explicit as well."""
+    maps = open("/proc/self/maps").read()
+    assert "libcvxalign.so" in maps and "libamdhip64" in maps
+
+
+@pytest.mark.parametrize("name", ["ref_test_2.npz", "ref_test_4.npz", "ref_test_3.npz"])
+def test_golden_tiles_from_reference_pipeline(hip_aligner, name):
+    pairs = util.load_golden(name)
+    got = hip_aligner.batch_align([t for t, _ in pairs])
+    for (t, exp), g in zip(pairs, got):
+        assert util.golden_diff(exp, g) is None, (t.tag, util.golden_diff(exp, g))
+
+
+def test_zoo_all_corridor_kinds(hip_aligner, port_oracle):
+    _check(hip_aligner, port_oracle, util.tile_zoo(seed=31, n=240, max_w=3000))
+
+
+def test_edge_cases(hip_aligner, port_oracle):
+    _check(hip_aligner, port_oracle, util.edge_tiles())
+
+
+def test_ont_mix_with_retries(hip_aligner, port_oracle):
+    from ngmlr_amd import synth
+    _check(hip_aligner, port_oracle, synth.workload_ont(150, seed=77, max_len=8000))
+
+
+def test_short_reads(hip_aligner, port_oracle):
+    from ngmlr_amd import synth
+    _check(hip_aligner, port_oracle, synth.workload_short(200, seed=5))
+
+
+def test_every_ring_class(hip_aligner, port_oracle):
+    """Corridor widths chosen to land in each fill kernel class (ring 64 ... 4096),
+    including the lock-stepped multi-wave classes."""
+    from ngmlr_amd import synth
+    rng = np.random.default_rng(1234)
+    tiles = []
+    for width in (40, 100, 200, 340, 369, 420, 560, 700, 900, 1500, 2048, 3500, 7000):
+        W = max(1200, width + 300)
+        t = synth.make_tile(rng, W, err=0.15, corridor="endpoints", width=width, realign=True, tag="w%d" % width)
+        tiles.append(t)
+    for W in (150, 400, 1100, 2400, 3900):
+        tiles.append(synth.make_tile(rng, W, err=0.2, ratio=(4, 4, 2), corridor="full", tag="full%d" % W))
+    hip = _check(hip_aligner, port_oracle, tiles, need_valid=True)
+    batch = hip_aligner.upload(tiles)
+    batch.run()
+    rings = sorted({(li["slots_per_lane"], li["waves"]) for li in batch.launches()})
+    batch.free()
+    assert len(rings) >= 8 and any(nw > 1 for _, nw in rings), rings
+
+
+def test_full_size_pacbio_tiles_bit_exact(hip_aligner, port_oracle):
+    """configs[1] shape: 10 kb reads, width 309-369 (a handful: the oracle needs ~50 ms each)."""
+    from ngmlr_amd import synth
+    _check(hip_aligner, port_oracle, synth.workload_pacbio(12, seed=2024, read_len=10000))
+
+
+def _cigar_consumes(cigar):
+    q = r = 0
+    for n, op in re.findall(r"(\d+)([MIDS])", cigar):
+        n = int(n)
+        if op in "MIS":
+            q += n
+        if op in "MD":
+            r += n
+    return q, r
+
+
+def _rescore(tile, g, sp=(2.0, -5.0, -5.0, -5.0, -1.0, 0.15)):
+    """Score of the reported path under the convex gap model, accumulated in float32 in path
+    order exactly as the DP does (so it must equal Align::Score bit for bit)."""
+    mat, mis, go, ge, gem, dec = (np.float32(v) for v in sp)
+    s = np.float32(0)
+    x = g["position_offset"]
+    y = g["qstart"] - tile.ext_qstart
+    md_ops = []
+    for n, op in re.findall(r"(\d+)([MIDS])", g["cigar"]):
+        n = int(n)
+        if op == "S":
+            continue
+        if op == "M":
+            for _ in range(n):
+                s = np.float32(s + (mat if tile.ref[x] == tile.qry[y] else mis))
+                x += 1; y += 1
+        else:
+            for k in range(n):
+                pen = go if k == 0 else np.float32(min(gem, np.float32(ge + np.float32(np.float32(k) * dec))))
+                s = np.float32(s + pen)
+                if op == "I":
+                    y += 1
+                else:
+                    x += 1
+    return s
+
+
+def test_properties_at_full_size(hip_aligner):
+    """No oracle here (too slow at this count): size-independent properties on 10 kb and
+    20 kb tiles.  CIGAR consumes exactly the read; reference span stays in the window;
+    re-scoring the reported path reproduces Score bit for bit; NM/MD agree with the path;
+    results do not depend on batch order or batch composition (idempotence)."""
+    from ngmlr_amd import synth
+    tiles = synth.workload_pacbio(96, seed=11, read_len=10000) + synth.workload_ont(64, seed=12, max_len=20000)
+    got = hip_aligner.batch_align(tiles, want_nm=False)
+    n_valid = 0
+    for t, g in zip(tiles, got):
+        assert g["status"] in (0, 1, 2, 3)
+        if g["ret"] < 0:
+            continue
+        n_valid += 1
+        q, r = _cigar_consumes(g["cigar"])
+        assert q == t.H == g["ret"]
+        assert 0 <= g["position_offset"] and g["position_offset"] + r <= t.W
+        assert g["last_ref"] == r and g["last_read"] - g["first_read"] == q - g["qstart"] - g["qend"]
+        assert np.float32(_rescore(t, g)).view(np.uint32) == g["score_bits"], t.tag
+        md_mism = len(re.findall(r"[A-Zx]", re.sub(r"\^[A-Zx]+", "", g["md"])))
+        ins = sum(int(n) for n, op in re.findall(r"(\d+)([ID])", g["cigar"]))
+        assert g["nm"] == md_mism + ins
+    assert n_valid >= 0.9 * len(tiles)
+    perm = np.random.default_rng(0).permutation(len(tiles))
+    again = hip_aligner.batch_align([tiles[i] for i in perm], want_nm=False)
+    for k, i in enumerate(perm):
+        assert same_alignment(got[i], again[k], keys=("ret", "score_bits", "cigar", "md", "position_offset")) is None
+    solo = hip_aligner.single_align(tiles[5], want_nm=False)
+    assert same_alignment(got[5], solo, keys=("ret", "score_bits", "cigar", "md")) is None
+
+
+def test_ultralong_tile(hip_aligner, port_oracle):
+    """configs[4] shape: one 100 kb tile (direction matrix > 30 MB in the reference) and a
+    wide-corridor tile through the multi-wave kernel."""
+    from ngmlr_amd import synth
+    rng = np.random.default_rng(4)
+    tiles = [synth.make_tile(rng, 100000, err=0.2, ratio=(4, 4, 2), corridor="anchors", tag="ul100k"),
+             synth.make_tile(rng, 30000, err=0.2, ratio=(4, 4, 2), corridor="endpoints", width=2048, realign=True, tag="ul-w2048")]
+    _check(hip_aligner, port_oracle, tiles)

@@ -1,0 +1,75 @@
+"""CPU: the product's host text stage (cvx_format_alignment: CIGAR, MD, NM, identity,
+per-position mismatch profile, N-clip flags) against the oracle and the recorded
+reference outputs, fed with the oracle's run-length ops."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import same_alignment
+from tests import util
+
+
+def _format_from_oracle(port_oracle, tile):
+    from ngmlr_amd import capi
+    from ngmlr_amd.aligner import format_alignment
+    want = port_oracle.align(tile)
+    if want["ret"] < 0:
+        return want, None
+    f = port_oracle.last_fwd()
+    ops = port_oracle.last_ops()
+    r = capi.CvxResult()
+    r.score = want["score"]
+    r.status = 0
+    r.ref_position, r.qstart, r.qend = f["ref_position"], f["qstart"], f["qend"]
+    r.n_ops, r.ops_begin = len(ops), 0
+    return want, format_alignment(capi.load(), r, ops if len(ops) else np.zeros(1, np.uint32), tile)
+
+
+def test_format_matches_oracle_on_zoo(port_oracle):
+    n = 0
+    for t in util.tile_zoo(seed=21, n=120) + util.edge_tiles():
+        want, got = _format_from_oracle(port_oracle, t)
+        if got is None:
+            continue
+        assert same_alignment(want, got) is None, (t.tag, same_alignment(want, got))
+        n += 1
+    assert n > 60
+
+
+@pytest.mark.parametrize("name", ["ref_test_2.npz", "ref_test_4.npz", "ref_test_3.npz"])
+def test_format_matches_recorded_reference(port_oracle, name):
+    for t, exp in util.load_golden(name):
+        want, got = _format_from_oracle(port_oracle, t)
+        if got is not None:
+            assert util.golden_diff(exp, got) is None, t.tag
+
+
+def test_invalid_tile_formats_as_minus_one(built):
+    from ngmlr_amd import capi
+    lib = capi.load()
+    r = capi.CvxResult()
+    r.status = 2
+    r.score = 123.0
+    txt = capi.CvxAlignmentText()
+    cig = C.create_string_buffer(16)
+    md = C.create_string_buffer(16)
+    assert lib.cvx_format_alignment(C.byref(r), None, b"ACGT", 4, 4, 0, 0, cig, 16, md, 16, None, 0, C.byref(txt)) == 0
+    assert txt.ret == -1 and txt.score == -1.0 and cig.value == b""
+
+
+def test_text_truncation_reports_full_length(port_oracle):
+    from ngmlr_amd import capi
+    t = util.tile_zoo(seed=3, n=1, max_w=900)[0]
+    want = port_oracle.align(t)
+    assert want["ret"] >= 0
+    f, ops = port_oracle.last_fwd(), port_oracle.last_ops()
+    r = capi.CvxResult()
+    r.status = 0; r.ref_position, r.qstart, r.qend = f["ref_position"], f["qstart"], f["qend"]
+    r.n_ops, r.ops_begin = len(ops), 0
+    txt = capi.CvxAlignmentText()
+    cig = C.create_string_buffer(8)
+    md = C.create_string_buffer(8)
+    assert capi.load().cvx_format_alignment(C.byref(r), ops.ctypes.data, t.ref, t.W, t.H, t.ext_qstart, t.ext_qend, cig, 8, md, 8, None, 0, C.byref(txt)) == 0
+    assert txt.cigar_len == len(want["cigar"]) and txt.md_len == len(want["md"])
+    assert cig.value == want["cigar"][:7].encode()

@@ -1,0 +1,110 @@
+"""Shared helpers for the tests: golden-fixture loading and a seeded tile zoo."""
+import os
+
+import numpy as np
+
+from ngmlr_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+FIELD_NAMES = ("position_offset", "qstart", "qend", "nm", "alignment_length", "cigar_op_count", "sv_type",
+               "first_ref", "first_read", "last_ref", "last_read")
+
+
+def load_golden(name):
+    """-> list of (Tile, expected dict) recorded from the unmodified reference binary
+    (tools/make_golden.sh) on its own test data."""
+    z = np.load(os.path.join(GOLDEN, name))
+    out = []
+    for i in range(int(z["n"])):
+        p = "t%d_" % i
+        meta = z[p + "meta"]
+        t = synth.Tile(ref=z[p + "ref"].tobytes(), qry=z[p + "qry"].tobytes(),
+                       row_offset=z[p + "off"].astype(np.int32), row_length=z[p + "len"].astype(np.int32),
+                       ext_qstart=int(meta[0]), ext_qend=int(meta[1]), tag="%s#%d" % (name, i))
+        exp = {"ret": int(meta[2]), "score_bits": int(z[p + "bits"][0]), "identity_bits": int(z[p + "bits"][1]),
+               "cigar": z[p + "cigar"].tobytes().decode(), "md": z[p + "md"].tobytes().decode(),
+               "nm_per_position": z[p + "nm"].astype(np.int32)}
+        for k, v in zip(FIELD_NAMES, z[p + "fields"]):
+            exp[k] = int(v)
+        exp["identity"] = float(np.uint32(exp["identity_bits"]).view(np.float32))
+        out.append((t, exp))
+    return out
+
+
+def golden_diff(exp, got):
+    """None if `got` (oracle or HIP dict) equals the recorded reference output."""
+    if exp["ret"] < 0:
+        return None if got["ret"] < 0 else "ret: reference -1, got %d" % got["ret"]
+    for k in ("ret", "score_bits", "cigar", "md") + FIELD_NAMES:
+        if exp[k] != got[k]:
+            return "%s: %r != %r" % (k, str(exp[k])[:60], str(got[k])[:60])
+    if int(np.float32(got["identity"]).view(np.uint32)) != exp["identity_bits"]:
+        return "identity"
+    a, b = exp["nm_per_position"], got["nm_per_position"]
+    if a.shape != b.shape or not np.array_equal(a, b):
+        return "nm_per_position"
+    return None
+
+
+def tile_zoo(seed=123, n=60, max_w=2500):
+    """Seeded mix over every corridor constructor, error model and the odd symbols."""
+    rng = np.random.default_rng(seed)
+    tiles = []
+    kinds = ["anchors", "endpoints", "linear", "full", "anchors", "endpoints"]
+    for i in range(n):
+        kind = kinds[i % len(kinds)]
+        W = int(rng.integers(20, max_w))
+        if kind == "full":
+            W = min(W, 700)
+        err = float(rng.choice([0.02, 0.1, 0.15, 0.3, 0.45]))
+        ratio = [(6, 3, 1), (4, 4, 2), (1, 1, 1)][i % 3]
+        t = synth.make_tile(rng, W, err=err, ratio=ratio, corridor=kind, scatter=float(rng.choice([0, 30, 120])),
+                            mult=int(rng.integers(1, 4)), n_frac=0.01 if i % 4 == 0 else 0.0,
+                            x_frac=0.01 if i % 7 == 0 else 0.0, realign=bool(i % 2))
+        if i % 5 == 0:
+            t.ext_qstart = int(rng.integers(0, 300))
+            t.ext_qend = int(rng.integers(0, 300))
+        tiles.append(t)
+    return tiles
+
+
+def edge_tiles():
+    """Edge cases the reference's recurrence meets in the field."""
+    rng = np.random.default_rng(99)
+    out = []
+    # tiny reads and windows
+    for H, W in ((1, 1), (1, 40), (2, 3), (5, 300), (17, 17), (40, 2)):
+        ref = synth.random_ref(rng, W)
+        qry = synth.random_ref(rng, H)
+        off, ln = synth.corridor_linear(H, 30)
+        out.append(synth.Tile(ref.tobytes(), qry.tobytes(), off, ln, tag="tiny%dx%d" % (H, W)))
+    # identical sequences (pure diagonal), all-mismatch (score 0 everywhere), poly-A
+    r = synth.random_ref(rng, 400)
+    off, ln = synth.corridor_anchors(400, 400)
+    out.append(synth.Tile(r.tobytes(), r.tobytes(), off, ln, tag="identical"))
+    out.append(synth.Tile(b"A" * 300, b"C" * 300, *synth.corridor_anchors(300, 300), tag="all-mismatch"))
+    out.append(synth.Tile(b"A" * 500, b"A" * 450, *synth.corridor_anchors(450, 500), tag="poly-a"))
+    # N == N is a match, 'x' never matches
+    out.append(synth.Tile(b"ACGTNNNNNNNNACGTACGT" * 10, b"ACGTNNNNNNNNACGTACGT" * 10, *synth.corridor_anchors(200, 200), tag="n-match"))
+    out.append(synth.Tile(b"ACGTxxxxxxxxACGTACGT" * 10, b"ACGTNNNNNNNNACGTACGT" * 10, *synth.corridor_anchors(200, 200), tag="x-never"))
+    # long deletion / insertion (convex gap decay saturates at run 27)
+    a = synth.random_ref(rng, 900)
+    out.append(synth.Tile(a.tobytes(), np.concatenate([a[:400], a[480:]]).tobytes(), *synth.corridor_anchors(820, 900), tag="del80"))
+    out.append(synth.Tile(np.concatenate([a[:400], a[480:]]).tobytes(), a.tobytes(), *synth.corridor_anchors(900, 820), tag="ins80"))
+    # corridor too narrow for the true path -> validPath rejects (ret -1)
+    b = synth.random_ref(rng, 1200)
+    out.append(synth.Tile(b.tobytes(), np.concatenate([b[:300], b[700:]]).tobytes(), *synth.corridor_linear(800, 64), tag="narrow"))
+    # corridor hanging over both ends of the window, ragged clipping
+    c = synth.random_ref(rng, 300)
+    H = 260
+    off = (np.arange(H) * 2 - 200).astype(np.int32)
+    out.append(synth.Tile(c.tobytes(), synth.mutate(rng, c, 0.1)[:H].tobytes().ljust(H, b"A"), off, np.full(H, 250, np.int32), tag="overhang"))
+    # row lengths that differ row to row (ragged corridor, still monotone)
+    d = synth.random_ref(rng, 600)
+    q = synth.mutate(rng, d, 0.1)
+    H = len(q)
+    off = (np.arange(H) - 100).astype(np.int32)
+    ln = (200 + (np.arange(H) % 7) * 3).astype(np.int32)
+    out.append(synth.Tile(d.tobytes(), q.tobytes(), off, ln, tag="ragged"))
+    return out
