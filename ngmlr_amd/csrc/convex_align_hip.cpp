@@ -1,0 +1,173 @@
+/*
+ * convex_align_hip.cpp -- see convex_align_hip.h.  Host-only C++; all device work is
+ * behind include/cvx_align.h.  No CPU alignment path exists here: if the device
+ * library reports an error the call throws, exactly like a hard error in the reference.
+ */
+#include "convex_align_hip.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace Convex {
+
+ConvexAlignHip::ConvexAlignHip(int const stdOutMode, float const match, float const mismatch,
+		float const gapOpen, float const gapExtend, float const gapExtendMin, float const gapDecay,
+		int const deviceId) : handle(0) {
+	(void) stdOutMode;
+	cvx_params p;
+	p.match = match; p.mismatch = mismatch; p.gap_open = gapOpen;
+	p.gap_extend = gapExtend; p.gap_extend_min = gapExtendMin; p.gap_decay = gapDecay;
+	if (cvx_create(deviceId, &p, 0, &handle) != CVX_OK) {
+		fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
+		throw "ConvexAlignHip: no usable MI355X / unsupported scoring";
+	}
+}
+
+ConvexAlignHip::~ConvexAlignHip() {
+	cvx_destroy(handle);
+	handle = 0;
+}
+
+/* the reference's convex aligners answer 0 to both (src/ConvexAlignFast.cpp:434-439) */
+int ConvexAlignHip::GetScoreBatchSize() const { return 0; }
+int ConvexAlignHip::GetAlignBatchSize() const { return 0; }
+
+int ConvexAlignHip::BatchScore(int const, int const, char const * const * const,
+		char const * const * const, float * const, void *) {
+	throw "Not implemented";
+}
+
+int ConvexAlignHip::BatchAlign(int const, int const, char const * const * const,
+		char const * const * const, Align * const, void *) {
+	throw "Not implemented";   /* no corridor in this signature; use AlignTiles() */
+}
+
+int ConvexAlignHip::SingleAlign(int const, int const, char const * const, char const * const,
+		Align &, void *) {
+	fprintf(stderr, "SingleAlign not implemented");
+	throw "Not implemented";
+}
+
+int ConvexAlignHip::SingleAlign(int const mode, CorridorLine * corridor, int const corridorHeight,
+		char const * const refSeq, char const * const qrySeq, Align & result,
+		int const externalQStart, int const externalQEnd, void * extData) {
+	(void) mode; (void) extData;
+	Tile t;
+	t.corridor = corridor; t.corridorHeight = corridorHeight;
+	t.refSeq = refSeq; t.qrySeq = qrySeq; t.result = &result;
+	t.externalQStart = externalQStart; t.externalQEnd = externalQEnd; t.ret = -1;
+	AlignTiles(&t, 1);
+	return t.ret;
+}
+
+void ConvexAlignHip::AlignTiles(Tile * tiles, int n) {
+	if (n <= 0) return;
+	packed.resize((size_t) n);
+	results.resize((size_t) n);
+	uint64_t ops_need = 0;
+	for (int i = 0; i < n; ++i) {
+		Tile & t = tiles[i];
+		Align & a = *t.result;
+		a.svType = 0;               /* the reference reads it as a debug id, then clears it */
+		a.Score = -1.0f;
+		t.ret = -1;
+		cvx_tile & c = packed[(size_t) i];
+		c.ref = t.refSeq;
+		c.qry = t.qrySeq;
+		c.ref_len = (int32_t) strlen(t.refSeq);
+		c.qry_len = (int32_t) strlen(t.qrySeq);
+		if (t.corridorHeight != c.qry_len) {
+			/* every reference caller passes corridorHeight == strlen(qry); anything else
+			 * indexes the corridor out of bounds in the reference itself */
+			fprintf(stderr, "ConvexAlignHip: corridorHeight %d != read length %d\n", t.corridorHeight, c.qry_len);
+			throw 1;
+		}
+		c.row_offset = &t.corridor[0].offset;
+		c.row_length = &t.corridor[0].length;
+		c.row_stride_bytes = (int32_t) sizeof(CorridorLine);
+		c.reserved = 0;
+		/* caller-visible side effect of AlignmentMatrixFast::prepare (src/AlignmentMatrixFast.cpp:39-44) */
+		unsigned long acc = 0;
+		for (int y = 0; y < t.corridorHeight; ++y) {
+			t.corridor[y].offsetInMatrix = acc;
+			acc += (unsigned long) (long) t.corridor[y].length;
+		}
+		ops_need += (uint64_t) c.ref_len + (uint64_t) c.qry_len + 8;
+	}
+	if (ops.size() < ops_need) ops.resize((size_t) ops_need);
+	uint64_t used = 0;
+	int rc = cvx_align_batch(handle, n, packed.data(), results.data(), ops.data(), ops.size(), &used);
+	if (rc != CVX_OK) {
+		fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
+		throw 1;
+	}
+	for (int i = 0; i < n; ++i) {
+		if (results[(size_t) i].status == CVX_TILE_UNSUPPORTED) {
+			fprintf(stderr, "ConvexAlignHip: corridor shape not covered by any device kernel\n");
+			throw 1;
+		}
+		finish(tiles[i], results[(size_t) i], packed[(size_t) i].ref_len, packed[(size_t) i].qry_len);
+	}
+}
+
+/* convertCigar + flags into the caller's Align (src/ConvexAlignFast.cpp:488-539) */
+void ConvexAlignHip::finish(Tile & t, cvx_result const & r, int refLen, int qryLen) {
+	Align & a = *t.result;
+	if (r.status != CVX_TILE_OK) {
+		if (r.status == CVX_TILE_TOO_LARGE) {
+			fprintf(stderr, "Warning: Couldn't allocate alignment matrix. Required memory (%llu) > max matrix size\n\n",
+					(unsigned long long) (r.cells / 1000000ull));
+		} else if (a.pBuffer2 != 0) {
+			a.pBuffer2[0] = '\0';
+		}
+		a.Score = -1.0f;
+		t.ret = -1;
+		return;
+	}
+	cvx_alignment_text txt;
+	for (;;) {
+		int rc = cvx_format_alignment(&r, ops.data(), t.refSeq, refLen, qryLen, t.externalQStart,
+				t.externalQEnd, a.pBuffer1, a.maxBufferLength, a.pBuffer2, a.maxMdBufferLength,
+				(int32_t *) a.nmPerPosition, a.nmPerPostionLength, &txt);
+		if (rc != CVX_OK) throw 1;
+		bool again = false;
+		if (txt.md_len >= a.maxMdBufferLength) {       /* checkMdBufferLength: grow with new[] */
+			int cap = a.maxMdBufferLength > 0 ? a.maxMdBufferLength : 64;
+			while (cap <= txt.md_len) cap *= 2;
+			delete[] a.pBuffer2;
+			a.pBuffer2 = new char[cap];
+			a.maxMdBufferLength = cap;
+			again = true;
+		}
+		if (txt.nm_count > a.nmPerPostionLength) {      /* addPosition: grow with new[] */
+			int cap = a.nmPerPostionLength > 0 ? a.nmPerPostionLength : 64;
+			while (cap < txt.nm_count) cap *= 2;
+			delete[] a.nmPerPosition;
+			a.nmPerPosition = new PositionNM[cap];
+			a.nmPerPostionLength = cap;
+			again = true;
+		}
+		if (!again) break;
+	}
+	if (txt.cigar_len > a.maxBufferLength) {
+		fprintf(stderr, "CIGAR/MD buffer not long enough (%d %d > %d %d). Please report this!\n",
+				txt.cigar_len, txt.md_len, a.maxBufferLength, a.maxMdBufferLength);
+		throw 1;
+	}
+	a.QStart = txt.qstart;
+	a.QEnd = txt.qend;
+	a.firstPosition.refPosition = txt.first_ref;
+	a.firstPosition.readPosition = txt.first_read;
+	a.lastPosition.refPosition = txt.last_ref;
+	a.lastPosition.readPosition = txt.last_read;
+	a.Identity = txt.identity;
+	a.NM = txt.nm;
+	a.alignmentLength = txt.alignment_length;
+	a.cigarOpCount = txt.cigar_op_count;
+	a.PositionOffset = txt.position_offset;
+	a.Score = txt.score;
+	a.svType = txt.sv_type;
+	t.ret = txt.ret;
+}
+
+}  // namespace Convex

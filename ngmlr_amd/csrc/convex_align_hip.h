@@ -1,0 +1,72 @@
+/*
+ * convex_align_hip.h -- the drop-in: an IAlignment implementation that runs ngmlr's
+ * convex-gap alignment on an MI355X through the C ABI of include/cvx_align.h.
+ *
+ * It takes the place of Convex::ConvexAlignFast at the one construction site
+ * (reference src/AlignmentBuffer.h:355-363) and keeps its contract:
+ *   - same constructor arguments (stdOutMode + six scoring floats), plus a device id;
+ *   - SingleAlign(mode, CorridorLine*, ...) has the same argument meaning, side effects
+ *     (offsetInMatrix written into the caller's lines, pBuffer2 / nmPerPosition possibly
+ *     re-allocated with new[], align.svType consumed as read id then reset) and the same
+ *     error convention: -1 / Score -1.0f for "no valid alignment", `throw 1` for hard
+ *     errors (reference src/ConvexAlignFast.cpp:452-559);
+ *   - BatchScore / corridor-less SingleAlign throw like the reference's do.
+ * Extra: AlignTiles() -- many corridor alignments in one launch (the shape the
+ * reference's BatchAlign slot lacks a corridor argument for).
+ */
+#ifndef CONVEX_ALIGN_HIP_H
+#define CONVEX_ALIGN_HIP_H
+
+#include <stdint.h>
+#include <vector>
+
+#include "ngmlr_abi.h"
+#include "cvx_align.h"
+
+namespace Convex {
+
+class ConvexAlignHip: public IAlignment {
+public:
+	ConvexAlignHip(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
+			float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId = 0);
+	virtual ~ConvexAlignHip();
+
+	virtual int GetScoreBatchSize() const;
+	virtual int GetAlignBatchSize() const;
+
+	virtual int BatchScore(int const mode, int const batchSize, char const * const * const refSeqList,
+			char const * const * const qrySeqList, float * const results, void * extData);
+	virtual int BatchAlign(int const mode, int const batchSize, char const * const * const refSeqList,
+			char const * const * const qrySeqList, Align * const results, void * extData);
+	virtual int SingleAlign(int const mode, int const corridor, char const * const refSeq,
+			char const * const qrySeq, Align & result, void * extData);
+	virtual int SingleAlign(int const mode, CorridorLine * corridor, int const corridorHeight,
+			char const * const refSeq, char const * const qrySeq, Align & result,
+			int const externalQStart, int const externalQEnd, void * extData);
+
+	/* One request of AlignTiles(): exactly the arguments of the corridor SingleAlign. */
+	struct Tile {
+		CorridorLine * corridor;
+		int corridorHeight;
+		char const * refSeq;
+		char const * qrySeq;
+		Align * result;
+		int externalQStart;
+		int externalQEnd;
+		int ret;               /* out: what SingleAlign would have returned */
+	};
+	/* n independent corridor alignments in one device launch. */
+	void AlignTiles(Tile * tiles, int n);
+
+private:
+	cvx_handle handle;
+	std::vector<cvx_tile> packed;
+	std::vector<cvx_result> results;
+	std::vector<uint32_t> ops;
+
+	void finish(Tile & t, cvx_result const & r, int refLen, int qryLen);
+};
+
+}  // namespace Convex
+
+#endif

@@ -1,0 +1,53 @@
+"""GPU (-m gpu): the C++ IAlignment drop-in (Convex::ConvexAlignHip) driven like
+AlignmentBuffer::computeAlignment drives the reference aligner, on tiles whose expected
+Align contents come from the CPU oracle and from the recorded reference pipeline."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def write_records(path, pairs):
+    """Same record layout as tools/ref_recorder/recording_aligner.h."""
+    with open(path, "wb") as f:
+        for t, e in pairs:
+            f.write(struct.pack("<6i", 0x43565854, t.W, t.H, t.H, t.ext_qstart, t.ext_qend))
+            f.write(t.ref); f.write(t.qry)
+            f.write(np.ascontiguousarray(t.row_offset, dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(t.row_length, dtype="<i4").tobytes())
+            f.write(struct.pack("<iI", e["ret"], e["score_bits"]))
+            if e["ret"] >= 0:
+                f.write(struct.pack("<11i", *[e[k] for k in util.FIELD_NAMES]))
+                f.write(struct.pack("<I", int(np.float32(e["identity"]).view(np.uint32))))
+                c, m = e["cigar"].encode(), e["md"].encode()
+                nm = np.ascontiguousarray(e["nm_per_position"], dtype="<i4")
+            else:
+                f.write(struct.pack("<11i", *([0] * 11)))
+                f.write(struct.pack("<I", 0))
+                c, m, nm = b"", b"", np.zeros((0, 3), dtype="<i4")
+            f.write(struct.pack("<2i", len(c), len(m)))
+            f.write(c); f.write(m)
+            f.write(struct.pack("<i", len(nm)))
+            f.write(nm.tobytes())
+
+
+@pytest.mark.parametrize("mode", ["single", "batch"])
+def test_cpp_shim_matches_oracle(built, port_oracle, tmp_path, mode):
+    exe = os.path.join(ROOT, "ngmlr_amd", "shim_test")
+    assert os.path.exists(exe), "shim_test not built"
+    tiles = util.tile_zoo(seed=77, n=80, max_w=2500) + util.edge_tiles()
+    pairs = [(t, port_oracle.align(t)) for t in tiles]
+    pairs += util.load_golden("ref_test_2.npz") + util.load_golden("ref_test_4.npz")
+    rec = str(tmp_path / "tiles.bin")
+    write_records(rec, pairs)
+    cmd = [exe, rec] + (["batch"] if mode == "batch" else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr[-2000:]
+    assert "0 mismatches" in res.stdout
