@@ -21,7 +21,9 @@
  * slots, one DPP wave_ror:1 for the lane boundary) and "diag" is the up value the
  * slot saw one step earlier.  Row state never touches LDS or HBM; the only HBM
  * traffic is one reference character per cell (L1/L2 resident) in, and the 2-bit
- * direction codes out, N contiguous dwords per 16 steps.
+ * direction codes out (two bit-plane words per slot per 32 steps, 2N dwords).
+ * The recurrence's priority chain runs on 64-bit lane masks in SGPRs (SALU), so the
+ * VALU only sees the float adds/max/compares and a few selects per cell.
  *
  * Floating point: scores are IEEE binary32, every * and + rounded separately as in
  * the reference's scalar and SSE code (compile with -ffp-contract=off).
@@ -132,40 +134,41 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 
 /* ------------------------------------------------------------------ fill */
 
-template <int M, int NW, bool WRAP>
-struct Ring {
-	static constexpr int N = 64 * M * NW;
+typedef unsigned long long u64;
 
-	/* per-slot state, all in VGPRs (static indexing only) */
-	float S[M];      /* score of the slot's latest cell (0 while the row is idle) */
-	float Hc[M];     /* left candidate that cell offers to the next column          */
-	float V[M];      /* up candidate it offers to the next row                      */
-	float dg[M];     /* diagonal score for the slot's next cell                     */
-	int drun[M];     /* deletion run of the latest cell (0 unless direction D)      */
-	int irun[M];     /* insertion run (0 unless direction I)                        */
-	int cnt[M];      /* next column index inside the row (negative: not started)    */
-	int len[M];      /* row length after clipping to [0,W)                          */
-	int qch[M];      /* read character of the row                                   */
-	int y[M];        /* read row held by the slot                                   */
-	unsigned xa[M];  /* seq-arena offset of the reference character for the group   */
-	unsigned dacc[M];/* 2-bit direction codes of the current 16-step block          */
-	float best[M];
-	int best_r[M], best_y[M];
-};
+/* per-lane predicate <-> wave-uniform 64-bit lane mask (SGPR pair) */
+CVX_DEV u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+CVX_DEV bool lanes(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+/* mask of lane i <- mask of lane (i-1) mod 64 : the SALU twin of wave_ror:1 */
+CVX_DEV u64 rot1_m(u64 m) { return (m << 1) | (m >> 63); }
+/* acc = (acc << 1) | (lane's bit of m): one v_addc_co_u32 with the mask as carry-in.
+ * m must come from SALU mask logic (it does: planes are s_or_b64 results). */
+CVX_DEV unsigned shl1_in(unsigned acc, u64 m) {
+	asm volatile("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(acc) : "s"(m) : "vcc");
+	return acc;
+}
+
+template <bool WRAP> struct RunT { typedef float type; };
+template <> struct RunT<true> { typedef int type; };
 
 template <int M, int NW, bool WRAP>
 __global__ void __launch_bounds__(64 * NW)
 fill_ring_kernel(const FillArgs a) {
 	constexpr int N = 64 * M * NW;
+	typedef typename RunT<WRAP>::type run_t;   /* gap run: float (exact small ints) or int16-emulating int */
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = tid >> 6;
-	const float mat = a.sp.mat, mis = a.sp.mis, go = a.sp.go;
+	const float go = a.sp.go;
 	const float gext = a.sp.ge, gem = a.sp.gem, decay = a.sp.decay;
+	/* keep match / mismatch in VGPRs: v_cndmask cannot take two SGPR values plus a mask */
+	float vmat = a.sp.mat, vmis = a.sp.mis;
+	asm volatile("" : "+v"(vmat), "+v"(vmis));
 
 	__shared__ int s_tile;
 	__shared__ float s_xf[2][NW > 1 ? NW : 1][2];
-	__shared__ int s_xi[2][NW > 1 ? NW : 1];
+	__shared__ run_t s_xi[2][NW > 1 ? NW : 1];
+	__shared__ int s_xm[2][NW > 1 ? NW : 1];
 	__shared__ float s_rbest[NW > 1 ? NW : 1];
 	__shared__ int s_ry[NW > 1 ? NW : 1], s_rx[NW > 1 ? NW : 1];
 
@@ -190,156 +193,192 @@ fill_ring_kernel(const FillArgs a) {
 		const int H = ti.H, W = ti.W;
 		uint32_t *dirs = a.dirs + tr.dir_off;
 
-		Ring<M, NW, WRAP> s;
+		/* per-slot state in VGPRs (static indexing only).  A slot that is not inside its
+		 * row's range holds the reference's empty element (score 0, run 0, STOP:
+		 * src/AlignmentMatrixFast.h:49-53), i.e. S = 0, runs = 0, V = Hc = gap_open;
+		 * the update below produces exactly that for inactive lanes by itself. */
+		float S[M];        /* score of the slot's latest cell                            */
+		float Hc[M];       /* left candidate that cell offers to the next column         */
+		float V[M];        /* up candidate it offers to the next row                     */
+		float dg[M];       /* diagonal score for the slot's next cell                    */
+		run_t drun[M];     /* deletion run of the latest cell (0 unless direction D)     */
+		run_t irun[M];     /* insertion run (0 unless direction I)                       */
+		int cnt[M];        /* next column index inside the row (negative: not started)   */
+		int len[M];        /* row length after clipping to [0,W)                         */
+		int qch[M];        /* read character of the row                                  */
+		int y[M];          /* read row held by the slot                                  */
+		unsigned xa[M];    /* seq-arena offset of the next reference dword to prefetch   */
+		unsigned cwn[M];   /* reference characters of the NEXT 4-step group              */
+		float best[M];
+		int best_r[M], best_y[M];
+		unsigned accA[M], accB[M];   /* direction bit-planes of the current 32-step block */
+		/* per-slot lane masks in SGPRs */
+		u64 mD[M];         /* latest cell is a deletion (run > 0)  */
+		u64 mI[M];         /* latest cell is an insertion          */
 
-		/* (re)bind slot j to its row s.y[j]; rnext = index of the next step */
+		/* (re)bind slot j to its row y[j]; rnext = index of the next step.  Leaves the
+		 * reference characters of the group starting at rnext in cwn[j]. */
 		auto bind_row = [&](int j, int rnext) {
-			const int yy = s.y[j];
+			const int yy = y[j];
 			if (yy < H) {
 				const int2 ol = rows[yy];
 				long long lo = ol.x > 0 ? ol.x : 0;
 				long long hi = (long long) ol.x + (long long) ol.y;
 				if (hi > W) hi = W;
 				if (hi < lo) hi = lo;
-				s.cnt[j] = rnext - (yy + (int) lo);
-				s.len[j] = (int) (hi - lo);
-				s.qch[j] = seq[ti.qry_off + (unsigned) yy];
-				s.xa[j] = ti.ref_off + (unsigned) (rnext - yy);
+				cnt[j] = rnext - (yy + (int) lo);
+				len[j] = (int) (hi - lo);
+				qch[j] = seq[ti.qry_off + (unsigned) yy];
+				xa[j] = ti.ref_off + (unsigned) (rnext - yy);
 			} else {
-				s.cnt[j] = -(1 << 30);
-				s.len[j] = 0;
-				s.qch[j] = 0;
-				s.xa[j] = ti.ref_off;
+				cnt[j] = -(1 << 30);
+				len[j] = 0;
+				qch[j] = 0;
+				xa[j] = ti.ref_off;
 			}
+			cwn[j] = *reinterpret_cast<const unsigned *>(seq + xa[j]);
+			xa[j] += 4u;
 		};
 
 #pragma unroll
 		for (int j = 0; j < M; ++j) {
-			s.y[j] = tid * M + j;
-			s.S[j] = 0.0f; s.Hc[j] = go; s.V[j] = go; s.dg[j] = 0.0f;
-			s.drun[j] = 0; s.irun[j] = 0; s.dacc[j] = 0u;
-			s.best[j] = -1.0f; s.best_r[j] = 0; s.best_y[j] = 0;
+			y[j] = tid * M + j;
+			S[j] = 0.0f; Hc[j] = go; V[j] = go; dg[j] = 0.0f;
+			drun[j] = 0; irun[j] = 0;
+			best[j] = -1.0f; best_r[j] = 0; best_y[j] = 0;
+			accA[j] = accB[j] = 0u;
+			mD[j] = 0; mI[j] = 0;
 			bind_row(j, tr.r0);
 		}
 
 		const int ngroups = (tr.nsteps + 3) >> 2;
 		int r = tr.r0;
 		for (int g = 0; g < ngroups; ++g) {
-			/* one unaligned dword = the 4 reference characters of this group */
+			/* this group's reference characters were fetched one group ago */
 			unsigned cw[M];
 #pragma unroll
 			for (int j = 0; j < M; ++j) {
-				cw[j] = *reinterpret_cast<const unsigned *>(seq + s.xa[j]);
-				s.xa[j] += 4u;
+				cw[j] = cwn[j];
+				cwn[j] = *reinterpret_cast<const unsigned *>(seq + xa[j]);
+				xa[j] += 4u;
 			}
-			const int shbase = (g & 3) * 8;
 
 #pragma unroll
 			for (int i = 0; i < 4; ++i) {
-				/* the lane boundary: previous lane's last slot, values of step r-1 */
-				float uV0 = rot1_f(s.V[M - 1]);
-				float uS0 = rot1_f(s.S[M - 1]);
-				int uI0 = rot1_i(s.irun[M - 1]);
+				/* lane boundary: previous lane's last slot, values of step r-1 */
+				float uV0 = rot1_f(V[M - 1]);
+				float uS0 = rot1_f(S[M - 1]);
+				run_t uI0;
+				if (WRAP) uI0 = (run_t) rot1_i((int) irun[M - 1]);
+				else uI0 = (run_t) rot1_f((float) irun[M - 1]);
+				u64 mIu0 = rot1_m(mI[M - 1]);
 				if (NW > 1) {
 					const int par = (r & 1);
 					if (lane == 63) {
-						s_xf[par][wave][0] = s.V[M - 1];
-						s_xf[par][wave][1] = s.S[M - 1];
-						s_xi[par][wave] = s.irun[M - 1];
+						s_xf[par][wave][0] = V[M - 1];
+						s_xf[par][wave][1] = S[M - 1];
+						s_xi[par][wave] = irun[M - 1];
+						s_xm[par][wave] = (int) (mI[M - 1] >> 63);
 					}
 					__syncthreads();
+					const int pw = (wave + NW - 1) % NW;
 					if (lane == 0) {
-						const int pw = (wave + NW - 1) % NW;
 						uV0 = s_xf[par][pw][0];
 						uS0 = s_xf[par][pw][1];
 						uI0 = s_xi[par][pw];
 					}
+					const int bit = __builtin_amdgcn_readfirstlane(s_xm[par][pw]);
+					mIu0 = (mIu0 & ~1ull) | (u64) (bit & 1);
 				}
-				const int sh = shbase + 2 * i;
 
+				/* descending j: slot j reads slot j-1 before slot j-1 is advanced */
 #pragma unroll
 				for (int j = M - 1; j >= 0; --j) {
-					const float uV = (j > 0) ? s.V[j > 0 ? j - 1 : 0] : uV0;
-					const float uS = (j > 0) ? s.S[j > 0 ? j - 1 : 0] : uS0;
-					const int uI = (j > 0) ? s.irun[j > 0 ? j - 1 : 0] : uI0;
+					const float uV = (j > 0) ? V[j > 0 ? j - 1 : 0] : uV0;
+					const float uS = (j > 0) ? S[j > 0 ? j - 1 : 0] : uS0;
+					const run_t uI = (j > 0) ? irun[j > 0 ? j - 1 : 0] : uI0;
+					const u64 mIu = (j > 0) ? mI[j > 0 ? j - 1 : 0] : mIu0;
 
 					const int refc = (int) ((cw[j] >> (8 * i)) & 0xffu);
-					const bool eq = (refc == s.qch[j]);
-					const float diag_cell = s.dg[j] + (eq ? mat : mis);
+					const bool eq = (refc == qch[j]);
+					const float diag_cell = dg[j] + (eq ? vmat : vmis);
 					const float up_cell = uV;
-					const float left_cell = s.Hc[j];
-					const float mx = fmaxf(fmaxf(fmaxf(left_cell, 0.0f), diag_cell), up_cell);
+					const float left_cell = Hc[j];
+					const float mx = fmaxf(fmaxf(fmaxf(left_cell, diag_cell), up_cell), 0.0f);
 
-					const bool eL = (mx == left_cell);
-					const bool eU = (mx == up_cell);
-					const bool eG = (mx == diag_cell);
-					const bool isDl = s.drun[j] > 0;
-					const bool isIu = uI > 0;
+					const u64 eL = ballot(mx == left_cell);
+					const u64 eU = ballot(mx == up_cell);
+					const u64 eG = ballot(mx == diag_cell);
+					const u64 act = ballot((unsigned) cnt[j] < (unsigned) len[j]);
+					const u64 isDl = WRAP ? ballot(drun[j] > 0) : mD[j];
+					const u64 isIu = WRAP ? ballot(uI > 0) : mIu;
 					/* priority: del-extend > ins-extend > diag > del-open > ins-open > stop
-					 * (src/ConvexAlignFast.cpp:703-738) */
-					const bool c2 = isIu && eU;
-					const bool newD = eL && (isDl || !(c2 || eG));
-					const bool newI = !newD && eU && (isIu || !eG);
-					const bool newG = !newD && !newI && eG;
-					int nd, ni;
+					 * (src/ConvexAlignFast.cpp:703-738), on lane masks; nothing fires on a
+					 * lane that is outside its row */
+					const u64 c2 = isIu & eU;
+					const u64 nD = eL & (isDl | ~(c2 | eG)) & act;
+					const u64 nI = ~nD & eU & (isIu | ~eG) & act;
+					const u64 nG = eG & ~nD & ~nI & act;
+
+					/* outside the row the new "cell" is the empty element: score 0 */
+					const float sc = lanes(act) ? mx : 0.0f;
+					run_t nd, ni;
+					float runf;
 					if (WRAP) {
 						/* indelRun is a short in the reference (src/AlignmentMatrixFast.h:43) */
-						nd = newD ? (isDl ? (int) (short) (s.drun[j] + 1) : 1) : 0;
-						ni = newI ? (isIu ? (int) (short) (uI + 1) : 1) : 0;
+						nd = lanes(nD) ? (lanes(isDl) ? (run_t) (short) ((int) drun[j] + 1) : (run_t) 1) : (run_t) 0;
+						ni = lanes(nI) ? (lanes(isIu) ? (run_t) (short) ((int) uI + 1) : (run_t) 1) : (run_t) 0;
+						runf = (float) (lanes(nD) ? nd : ni);
 					} else {
-						nd = newD ? s.drun[j] + 1 : 0;
-						ni = newI ? uI + 1 : 0;
+						nd = lanes(nD) ? (run_t) (drun[j] + 1) : (run_t) 0;
+						ni = lanes(nI) ? (run_t) (uI + 1) : (run_t) 0;
+						runf = (float) nd + (float) ni;   /* one of them is 0: exact */
 					}
-					const unsigned code = newD ? 2u : (newI ? 1u : (newG ? 3u : 0u));
+					const float pen = fminf(gem, gext + runf * decay);
+					const float E = (sc == 0.0f) ? 0.0f : sc + pen;   /* :669-675 */
+					const float O = sc + go;
+					const u64 better = ballot(mx > best[j]) & act;
 
-					const bool act = (unsigned) s.cnt[j] < (unsigned) s.len[j];
-					s.dg[j] = uS;
-					if (act) {
-						const int run = WRAP ? (newD ? nd : ni) : (nd | ni);
-						const float pen = fminf(gem, gext + (float) run * decay);
-						const float E = (mx == 0.0f) ? 0.0f : mx + pen;
-						const float O = mx + go;
-						s.S[j] = mx;
-						s.drun[j] = nd;
-						s.irun[j] = ni;
-						s.V[j] = newI ? E : O;
-						s.Hc[j] = newD ? E : O;
-						if (mx > s.best[j]) { s.best[j] = mx; s.best_r[j] = r; }
-						s.dacc[j] |= code << sh;
-					}
-					if (s.cnt[j] == s.len[j]) {
-						/* first step after the row's last cell.  The slot below (processed
-						 * earlier in this step) has just consumed that last cell as its "up"
-						 * and keeps its score as next step's "diag"; from now on this slot is
-						 * outside the corridor (empty element, src/AlignmentMatrixFast.h:49-53). */
-						s.S[j] = 0.0f; s.drun[j] = 0; s.irun[j] = 0;
-						s.V[j] = go; s.Hc[j] = go;
-					}
-					s.cnt[j] += 1;
+					dg[j] = uS;
+					S[j] = sc;
+					drun[j] = nd;
+					irun[j] = ni;
+					V[j] = lanes(nI) ? E : O;
+					Hc[j] = lanes(nD) ? E : O;
+					best[j] = lanes(better) ? mx : best[j];
+					best_r[j] = lanes(better) ? r : best_r[j];
+					mD[j] = nD;
+					mI[j] = nI;
+					cnt[j] += 1;
+					accA[j] = shl1_in(accA[j], nI | nG);   /* code bit 0: I or diagonal */
+					accB[j] = shl1_in(accB[j], nD | nG);   /* code bit 1: D or diagonal */
 				}
 				r += 1;
 			}
 
-			/* hand finished slots to their next row (y + N) */
+			/* hand finished slots to their next row (y + N): a row's last cell is consumed
+			 * by the row below one step after it was computed, so wait for cnt > len */
 #pragma unroll
 			for (int j = 0; j < M; ++j) {
-				if (s.cnt[j] > s.len[j] && s.y[j] < H) {   /* ended AND already reset */
-					if (s.best_r[j] >= r - s.cnt[j]) s.best_y[j] = s.y[j];
-					s.y[j] += N;
+				if (cnt[j] > len[j] && y[j] < H) {
+					if (best_r[j] >= r - cnt[j]) best_y[j] = y[j];
+					y[j] += N;
 					bind_row(j, r);
 				}
 			}
 
-			if ((g & 3) == 3) {
-				uint32_t *d = dirs + (size_t) (g >> 2) * N + (size_t) tid * M;
+			if ((g & 7) == 7) {
+				uint32_t *d = dirs + ((size_t) (g >> 3) * N + (size_t) tid * M) * 2;
 #pragma unroll
-				for (int j = 0; j < M; ++j) { d[j] = s.dacc[j]; s.dacc[j] = 0u; }
+				for (int j = 0; j < M; ++j) { d[2 * j] = accA[j]; d[2 * j + 1] = accB[j]; }
 			}
 		}
-		if ((ngroups & 3) != 0) {
-			uint32_t *d = dirs + (size_t) (ngroups >> 2) * N + (size_t) tid * M;
+		if ((ngroups & 7) != 0) {
+			/* partial last block: left-align so that step (t & 31) sits at bit 31 - (t & 31) */
+			const int sh = 32 - 4 * (ngroups & 7);
+			uint32_t *d = dirs + ((size_t) (ngroups >> 3) * N + (size_t) tid * M) * 2;
 #pragma unroll
-			for (int j = 0; j < M; ++j) d[j] = s.dacc[j];
+			for (int j = 0; j < M; ++j) { d[2 * j] = accA[j] << sh; d[2 * j + 1] = accB[j] << sh; }
 		}
 
 		/* argmax with the reference's tie-break: first strict maximum in (y, x) order
@@ -348,10 +387,10 @@ fill_ring_kernel(const FillArgs a) {
 		int by = 0x7fffffff, bx = 0x7fffffff;
 #pragma unroll
 		for (int j = 0; j < M; ++j) {
-			if (s.y[j] < H && s.best_r[j] >= r - s.cnt[j]) s.best_y[j] = s.y[j];
-			const float v = s.best[j];
-			const int vy = s.best_y[j];
-			const int vx = s.best_r[j] - s.best_y[j];
+			if (y[j] < H && best_r[j] >= r - cnt[j]) best_y[j] = y[j];
+			const float v = best[j];
+			const int vy = best_y[j];
+			const int vx = best_r[j] - best_y[j];
 			if (v > -1.0f) {
 				if (v > b || (v == b && (vy < by || (vy == by && vx < bx)))) { b = v; by = vy; bx = vx; }
 			}
@@ -391,17 +430,26 @@ fill_ring_kernel(const FillArgs a) {
 
 /* validPath, src/AlignmentMatrixFast.cpp:213-220: float arithmetic, int truncation,
  * no contraction. */
-CVX_DEV bool valid_path(const int2 ol, int x) {
-	const int width = ol.y;
-	const int minC = (int) ((float) ol.x + 0.1f * (float) width);
+CVX_DEV bool valid_path(const int off, const int width, int x) {
+	const int minC = (int) ((float) off + 0.1f * (float) width);
 	const int maxC = (int) ((float) (minC + width) - 0.1f * (float) width);
 	return x > minC && x < maxC;
 }
 
+/*
+ * One wave per tile, run-skipping walk.  The path is a chain of runs (diagonal runs
+ * broken by short gaps); instead of one dependent load per cell, the 64 lanes probe the
+ * next 64 cells along the current direction at once (lane i looks at the i-th cell
+ * back), a ballot finds how far the run goes, and the walk jumps to its end.  A 10-kb
+ * PacBio tile is ~3 000 probes instead of ~20 000 dependent steps.  Every probe is four
+ * coalesced loads (corridor rows, plane words, both sequences).  The walk state is
+ * wave-uniform; lane 0 writes the run-length ops.
+ */
 __global__ void __launch_bounds__(64)
 backtrack_kernel(const BacktrackArgs a) {
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	const int t = blockIdx.x;
 	if (t >= a.n_tiles) return;
+	const int lane = threadIdx.x;
 	const TileRun tr = a.trun[t];
 	if (tr.skip) return;
 	const TileIn ti = a.tin[t];
@@ -410,13 +458,13 @@ backtrack_kernel(const BacktrackArgs a) {
 	const int H = ti.H;
 	const int N = tr.ring;
 	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off;
-	const uint32_t *dirs = a.dirs + tr.dir_off;
+	const uint2 *dirs = reinterpret_cast<const uint2 *>(a.dirs + tr.dir_off);
 	const uint8_t *ref = a.seq + ti.ref_off;
 	const uint8_t *qry = a.seq + ti.qry_off;
 	int *ops = a.ops + tr.ops_off;
 
 	/* src/ConvexAlignFast.cpp:338 */
-	if (o.best_y <= 0) { o.status = 1; a.tout[t] = o; return; }
+	if (o.best_y <= 0) { if (lane == 0) { o.status = 1; a.tout[t] = o; } return; }
 
 	const int qend = (H - o.best_y) - 1;
 	int idx = tr.ops_cap - 1;
@@ -424,37 +472,75 @@ backtrack_kernel(const BacktrackArgs a) {
 	int elem_len = qend;
 	int consumed = qend;
 	int x = o.best_x, y = o.best_y;
+	int s = y % N;         /* ring slot of row y */
 	int status = 0;
-	for (;;) {
-		/* getDirection, src/AlignmentMatrixFast.cpp:185-195 */
-		if (y < 0 || x < 0) break;
-		const int2 ol = rows[y];
-		if (x < ol.x || x >= ol.x + ol.y) break;
-		const int tt = x + y - tr.r0;
-		if (tt < 0) break;
-		const uint32_t w = dirs[(size_t) (tt >> 4) * N + (y % N)];
-		const unsigned code = (w >> (2 * (tt & 15))) & 3u;
-		if (code == 0u) break;
-		if (!valid_path(ol, x)) { status = 2; break; }
-		int cur;
-		if (code == 3u) {
-			cur = (ref[x] == qry[y]) ? 7 : 8;
-			x -= 1; y -= 1; consumed += 1;
-		} else if (code == 1u) {
-			cur = 1; y -= 1; consumed += 1;
-		} else {
-			cur = 2; x -= 1;
-		}
+	unsigned want = 3u;    /* direction of the run being followed (first probe: a guess) */
+
+	/* revBacktrack's run-length bookkeeping (src/ConvexAlignFast.cpp:395-403) */
+	auto emit = [&](int cur, int n) {
+		if (n <= 0) return;
 		if (cur == elem) {
-			elem_len += 1;
+			elem_len += n;
 		} else {
-			if (elem != 4) ops[idx--] = (elem_len << 4) | elem;
+			if (elem != 4) { if (lane == 0) ops[idx] = (elem_len << 4) | elem; idx -= 1; }
 			elem = cur;
-			elem_len = 1;
+			elem_len = n;
+		}
+	};
+
+	for (;;) {
+		const int dx = (want != 1u) ? 1 : 0, dy = (want != 2u) ? 1 : 0;
+		const int cx = x - lane * dx, cy = y - lane * dy;
+		const bool inside = (cx >= 0 && cy >= 0);
+		const int lx = cx > 0 ? cx : 0, ly = cy > 0 ? cy : 0;
+		int sl = s - lane * dy;
+		if (sl < 0) sl += N;
+		const int tt = cx + cy - tr.r0;
+		const int ttc = tt > 0 ? tt : 0;
+		const int2 ol = rows[ly];
+		const uint2 w = dirs[(size_t) (ttc >> 5) * N + sl];
+		const int rc = ref[lx], qc = qry[ly];
+		/* getDirection, src/AlignmentMatrixFast.cpp:185-195: outside -> STOP */
+		const bool in_row = inside && tt >= 0 && cx >= ol.x && cx < ol.x + ol.y;
+		const int bit = 31 - (ttc & 31);
+		unsigned code = ((w.x >> bit) & 1u) | (((w.y >> bit) & 1u) << 1);
+		if (!in_row) code = 0u;
+
+		const u64 run = ballot(code == want);
+		const int L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);   /* cells of this run */
+		const u64 low = (L == 64) ? ~0ull : ((1ull << L) - 1ull);
+		/* every visited cell must pass validPath before the move (:368-373) */
+		const u64 vp = ballot(valid_path(ol.x, ol.y, cx));
+		if ((~vp & low) != 0ull) { status = 2; break; }
+
+		if (want == 3u) {
+			const u64 eqm = ballot(rc == qc);
+			int pos = 0;
+			while (pos < L) {
+				const int isq = (int) ((eqm >> pos) & 1ull);
+				const u64 m = (isq ? ~eqm : eqm) >> pos;
+				int rl = (m == 0ull) ? 64 - pos : __builtin_ctzll(m);
+				if (rl > L - pos) rl = L - pos;
+				emit(isq ? 7 : 8, rl);
+				pos += rl;
+			}
+			x -= L; y -= L; consumed += L;
+		} else if (want == 1u) {
+			emit(1, L);
+			y -= L; consumed += L;
+		} else {
+			emit(2, L);
+			x -= L;
+		}
+		if (want != 2u) { s -= L; if (s < 0) s += N; }
+		if (L < 64) {
+			const unsigned nxt = (unsigned) __builtin_amdgcn_readlane((int) code, L);
+			if (nxt == 0u) break;     /* CIGAR_STOP (or outside the matrix) */
+			want = nxt;
 		}
 	}
 	if (status == 0) {
-		if (elem != 4) ops[idx--] = (elem_len << 4) | elem;
+		if (elem != 4) { if (lane == 0) ops[idx] = (elem_len << 4) | elem; idx -= 1; }
 		consumed += (y + 1);
 		o.ref_position = x + 1;
 		o.qstart = y + 1;
@@ -464,7 +550,7 @@ backtrack_kernel(const BacktrackArgs a) {
 		if (H != consumed) status = 3;
 	}
 	o.status = status;
-	a.tout[t] = o;
+	if (lane == 0) a.tout[t] = o;
 }
 
 /* dense[dst_off[t] .. +n_ops) = region of tile t */
@@ -526,7 +612,7 @@ hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, i
 
 hipError_t launch_backtrack(const BacktrackArgs &a, hipStream_t st) {
 	if (a.n_tiles <= 0) return hipSuccess;
-	hipLaunchKernelGGL(backtrack_kernel, dim3((a.n_tiles + 63) / 64), dim3(64), 0, st, a);
+	hipLaunchKernelGGL(backtrack_kernel, dim3(a.n_tiles), dim3(64), 0, st, a);   /* one wave per tile */
 	return hipGetLastError();
 }
 

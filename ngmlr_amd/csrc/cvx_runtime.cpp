@@ -89,9 +89,12 @@ struct DevBuf {
 
 }  // namespace
 
+static const int kAuxStreams = 4;
+
 struct cvx_context {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};  /* concurrent fill classes */
 	ScoreParams sp;
 	uint64_t max_matrix_mb = 10000;
 	int num_cus = 256;
@@ -191,6 +194,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	c->sp.ge = p->gap_extend; c->sp.gem = p->gap_extend_min; c->sp.decay = p->gap_decay;
 	c->max_matrix_mb = max_matrix_mb ? max_matrix_mb : 10000;
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
 	if (e != hipSuccess) {
 		set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
 		delete c;
@@ -204,6 +208,7 @@ void cvx_destroy(cvx_handle h) {
 	if (!h) return;
 	(void) hipSetDevice(h->device);
 	if (h->stream) (void) hipStreamDestroy(h->stream);
+	for (auto &a : h->aux) if (a) (void) hipStreamDestroy(a);
 	delete h;
 }
 
@@ -338,7 +343,8 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		r.r0 = p.r0;
 		r.nsteps = p.rend - p.r0;
 		r.dir_off = dir_dwords;
-		dir_dwords += (uint64_t) ((r.nsteps + 15) / 16) * (uint64_t) r.ring;
+		dir_dwords += (uint64_t) ((r.nsteps + 31) / 32) * (uint64_t) r.ring * 2ull;
+		r.mnw = kClasses[k].m | (kClasses[k].nw << 8);
 		r.ops_cap = b->tin[(size_t) i].H + b->tin[(size_t) i].W + 8;
 		r.ops_off = ops_ints;
 		ops_ints += (uint64_t) r.ops_cap;
@@ -369,10 +375,13 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	HIP_TRY(hipMemsetAsync(b->d_heads.p, 0, 64 * sizeof(int32_t), st));
 	HIP_TRY(hipEventRecord(b->ev[1], st));
 
-	/* ---- forward fill, one launch per populated kernel class */
+	/* ---- forward fill: one launch per populated kernel class, classes run concurrently
+	 * on separate streams (a sparsely populated class would otherwise serialise a whole
+	 * tile latency behind the big one); widest rings first, they have the longest tiles */
 	int launches = 0;
 	b->launches.clear();
-	for (size_t c = 0; c < cls.size(); ++c) {
+	for (int cc = (int) cls.size() - 1; cc >= 0; --cc) {
+		const size_t c = (size_t) cc;
 		if (cls[c].empty()) continue;
 		const KernelClass &kc = kClasses[c / 2];
 		while (b->lev.size() < (size_t) (launches + 1) * 2) {
@@ -391,7 +400,9 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 			li.read_bases += (uint64_t) in.H;
 		}
 		b->launches.push_back(li);
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2], st));
+		hipStream_t ls = h->aux[launches % kAuxStreams];
+		HIP_TRY(hipStreamWaitEvent(ls, b->ev[1], 0));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2], ls));
 		FillArgs a;
 		a.seq = b->d_seq.p;
 		a.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
@@ -405,8 +416,9 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		a.sp = h->sp;
 		const int per_cu = kc.nw == 1 ? 32 : std::max(1, 16 / kc.nw);
 		const int grid = std::min(a.list_n, h->num_cus * per_cu);
-		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, a, grid, st));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2 + 1], st));
+		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, a, grid, ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2 + 1], ls));
+		HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) launches * 2 + 1], 0));
 		launches++;
 	}
 	HIP_TRY(hipEventRecord(b->ev[2], st));

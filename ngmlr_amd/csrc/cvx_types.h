@@ -16,15 +16,18 @@
  *
  * Direction matrix layout.  The reference keeps 1 byte per corridor cell, row-major
  * (directionMatrix, src/AlignmentMatrixFast.h:261).  The device fill walks the
- * corridor by anti-diagonals r = x + y, holding read row y in ring slot (y mod N);
- * slot s of step t = r - r0 stores its 2-bit code at
+ * corridor by anti-diagonals r = x + y, holding read row y in ring slot s = y mod N
+ * (slot s = thread * M + j).  A cell's 2-bit code (0 stop / outside, 1 insertion = up,
+ * 2 deletion = left, 3 diagonal -- EQ or X is re-derived from the sequences) is kept
+ * as two bit-plane words per slot per 32 steps: for step t = r - r0
  *
- *      dword  dir_off + (t >> 4) * N + s ,  bits [2*(t&15), 2*(t&15)+1]
+ *      dword  dir_off + ((t >> 5) * N + s) * 2 + plane ,   bit 31 - (t & 31)
+ *      plane 0 = code bit 0 (I or diagonal), plane 1 = code bit 1 (D or diagonal)
  *
- * so a wave writes N contiguous dwords every 16 steps (fully coalesced) and the
- * backtrack finds cell (x, y) at t = x + y - r0, s = y mod N.  Codes: 0 stop /
- * outside, 1 insertion (up), 2 deletion (left), 3 diagonal (EQ or X, re-derived from
- * the sequences).  Only the *layout* differs from the reference; the algorithmic
+ * The fill shifts the per-step lane masks of the recurrence into the words with one
+ * add-with-carry each; a lane stores its 2*M words every 32 steps (coalesced), and the
+ * backtrack finds both planes of a cell in one 8-byte load, neighbouring path cells in
+ * neighbouring words.  Only the *layout* differs from the reference; the algorithmic
  * byte count used for the roofline stays 1 byte per cell.
  */
 #ifndef CVX_TYPES_H
@@ -78,7 +81,7 @@ struct TileRun {           /* written by the host after planning */
 	int32_t r0;
 	int32_t nsteps;
 	int32_t skip;          /* != 0: tile not computed (status preset in TileOut) */
-	int32_t pad;
+	int32_t mnw;           /* M | NW << 8 of the fill kernel class that owns the tile */
 };
 
 struct TileOut {
