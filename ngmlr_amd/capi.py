@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcvxalign.so")
+LIB_PATH = os.environ.get("CVX_LIB") or os.path.join(HERE, "libcvxalign.so")   # CVX_LIB: A/B builds while tuning
 
 CVX_OK = 0
 ERR_NAMES = {0: "CVX_OK", -1: "CVX_ERR_NO_DEVICE", -2: "CVX_ERR_PARAMS", -3: "CVX_ERR_ARG",

@@ -40,7 +40,7 @@ namespace cvx {
 
 /* lane i <- lane (i-1) mod 64 : DPP wave_ror:1 (GFX9 DPP_WF_RR1 = 0x13C) */
 CVX_DEV int rot1_i(int v) {
-	return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xf, 0xf, false);
+	return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xf, 0xf, true);
 }
 CVX_DEV float rot1_f(float v) {
 	return __int_as_float(rot1_i(__float_as_int(v)));
@@ -151,8 +151,17 @@ CVX_DEV unsigned shl1_in(unsigned acc, u64 m) {
 template <bool WRAP> struct RunT { typedef float type; };
 template <> struct RunT<true> { typedef int type; };
 
+#ifndef CVX_FILL_WAVES_PER_EU
+#define CVX_FILL_WAVES_PER_EU 0
+#endif
+#if CVX_FILL_WAVES_PER_EU > 0
+#define CVX_FILL_OCC __attribute__((amdgpu_waves_per_eu(CVX_FILL_WAVES_PER_EU, CVX_FILL_WAVES_PER_EU)))
+#else
+#define CVX_FILL_OCC
+#endif
+
 template <int M, int NW, bool WRAP>
-__global__ void __launch_bounds__(64 * NW)
+__global__ void __launch_bounds__(64 * NW) CVX_FILL_OCC
 fill_ring_kernel(const FillArgs a) {
 	constexpr int N = 64 * M * NW;
 	typedef typename RunT<WRAP>::type run_t;   /* gap run: float (exact small ints) or int16-emulating int */
@@ -171,6 +180,10 @@ fill_ring_kernel(const FillArgs a) {
 	__shared__ int s_xm[2][NW > 1 ? NW : 1];
 	__shared__ float s_rbest[NW > 1 ? NW : 1];
 	__shared__ int s_ry[NW > 1 ? NW : 1], s_rx[NW > 1 ? NW : 1];
+	/* rarely touched per-slot state lives in LDS to keep VGPRs for occupancy: the read
+	 * row a slot holds and the row of its best cell (both only change at a row switch) */
+	__shared__ int s_y[M][64 * NW];
+	__shared__ int s_besty[M][64 * NW];
 
 	for (;;) {
 		int qi;
@@ -206,11 +219,10 @@ fill_ring_kernel(const FillArgs a) {
 		int cnt[M];        /* next column index inside the row (negative: not started)   */
 		int len[M];        /* row length after clipping to [0,W)                         */
 		int qch[M];        /* read character of the row                                  */
-		int y[M];          /* read row held by the slot                                  */
 		unsigned xa[M];    /* seq-arena offset of the next reference dword to prefetch   */
 		unsigned cwn[M];   /* reference characters of the NEXT 4-step group              */
 		float best[M];
-		int best_r[M], best_y[M];
+		int best_r[M];
 		unsigned accA[M], accB[M];   /* direction bit-planes of the current 32-step block */
 		/* per-slot lane masks in SGPRs */
 		u64 mD[M];         /* latest cell is a deletion (run > 0)  */
@@ -219,7 +231,7 @@ fill_ring_kernel(const FillArgs a) {
 		/* (re)bind slot j to its row y[j]; rnext = index of the next step.  Leaves the
 		 * reference characters of the group starting at rnext in cwn[j]. */
 		auto bind_row = [&](int j, int rnext) {
-			const int yy = y[j];
+			const int yy = s_y[j][tid];
 			if (yy < H) {
 				const int2 ol = rows[yy];
 				long long lo = ol.x > 0 ? ol.x : 0;
@@ -242,10 +254,11 @@ fill_ring_kernel(const FillArgs a) {
 
 #pragma unroll
 		for (int j = 0; j < M; ++j) {
-			y[j] = tid * M + j;
+			s_y[j][tid] = tid * M + j;
+			s_besty[j][tid] = 0;
 			S[j] = 0.0f; Hc[j] = go; V[j] = go; dg[j] = 0.0f;
 			drun[j] = 0; irun[j] = 0;
-			best[j] = -1.0f; best_r[j] = 0; best_y[j] = 0;
+			best[j] = -1.0f; best_r[j] = 0;
 			accA[j] = accB[j] = 0u;
 			mD[j] = 0; mI[j] = 0;
 			bind_row(j, tr.r0);
@@ -261,6 +274,14 @@ fill_ring_kernel(const FillArgs a) {
 				cw[j] = cwn[j];
 				cwn[j] = *reinterpret_cast<const unsigned *>(seq + xa[j]);
 				xa[j] += 4u;
+			}
+			/* flush the previous 32-step block of direction words HERE, right after the
+			 * wait for this group's characters: gfx9 counts loads and stores in one vmcnt,
+			 * so a store issued just before that wait would be waited for in full */
+			if (g != 0 && (g & 7) == 0) {
+				uint32_t *d = dirs + ((size_t) ((g >> 3) - 1) * N + (size_t) tid * M) * 2;
+#pragma unroll
+				for (int j = 0; j < M; ++j) { d[2 * j] = accA[j]; d[2 * j + 1] = accB[j]; }
 			}
 
 #pragma unroll
@@ -360,25 +381,23 @@ fill_ring_kernel(const FillArgs a) {
 			 * by the row below one step after it was computed, so wait for cnt > len */
 #pragma unroll
 			for (int j = 0; j < M; ++j) {
-				if (cnt[j] > len[j] && y[j] < H) {
-					if (best_r[j] >= r - cnt[j]) best_y[j] = y[j];
-					y[j] += N;
+				if (cnt[j] > len[j] && cnt[j] < (1 << 29)) {     /* finished a real row */
+					const int yy = s_y[j][tid];
+					if (best_r[j] >= r - cnt[j]) s_besty[j][tid] = yy;
+					s_y[j][tid] = yy + N;
 					bind_row(j, r);
 				}
 			}
 
-			if ((g & 7) == 7) {
-				uint32_t *d = dirs + ((size_t) (g >> 3) * N + (size_t) tid * M) * 2;
-#pragma unroll
-				for (int j = 0; j < M; ++j) { d[2 * j] = accA[j]; d[2 * j + 1] = accB[j]; }
-			}
 		}
-		if ((ngroups & 7) != 0) {
-			/* partial last block: left-align so that step (t & 31) sits at bit 31 - (t & 31) */
-			const int sh = 32 - 4 * (ngroups & 7);
-			uint32_t *d = dirs + ((size_t) (ngroups >> 3) * N + (size_t) tid * M) * 2;
+		if (ngroups > 0) {
+			/* last block (complete or partial): left-align so that step (t & 31) sits at
+			 * bit 31 - (t & 31) */
+			const int done = ((ngroups - 1) & 7) + 1;     /* groups in the last block */
+			const int sh = 32 - 4 * done;
+			uint32_t *d = dirs + ((size_t) ((ngroups - 1) >> 3) * N + (size_t) tid * M) * 2;
 #pragma unroll
-			for (int j = 0; j < M; ++j) { d[2 * j] = accA[j] << sh; d[2 * j + 1] = accB[j] << sh; }
+			for (int j = 0; j < M; ++j) { d[2 * j] = sh ? accA[j] << sh : accA[j]; d[2 * j + 1] = sh ? accB[j] << sh : accB[j]; }
 		}
 
 		/* argmax with the reference's tie-break: first strict maximum in (y, x) order
@@ -387,10 +406,10 @@ fill_ring_kernel(const FillArgs a) {
 		int by = 0x7fffffff, bx = 0x7fffffff;
 #pragma unroll
 		for (int j = 0; j < M; ++j) {
-			if (y[j] < H && best_r[j] >= r - cnt[j]) best_y[j] = y[j];
+			int vy = s_besty[j][tid];
+			if (s_y[j][tid] < H && best_r[j] >= r - cnt[j]) vy = s_y[j][tid];
 			const float v = best[j];
-			const int vy = best_y[j];
-			const int vx = best_r[j] - best_y[j];
+			const int vx = best_r[j] - vy;
 			if (v > -1.0f) {
 				if (v > b || (v == b && (vy < by || (vy == by && vx < bx)))) { b = v; by = vy; bx = vx; }
 			}

@@ -98,6 +98,7 @@ struct cvx_context {
 	ScoreParams sp;
 	uint64_t max_matrix_mb = 10000;
 	int num_cus = 256;
+	int tune_min_slots = 0;   /* tuning knob (env CVX_TUNE_MIN_M): smallest M*NW a tile may use */
 };
 
 struct cvx_batch_s {
@@ -193,6 +194,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	c->sp.mat = p->match; c->sp.mis = p->mismatch; c->sp.go = p->gap_open;
 	c->sp.ge = p->gap_extend; c->sp.gem = p->gap_extend_min; c->sp.decay = p->gap_decay;
 	c->max_matrix_mb = max_matrix_mb ? max_matrix_mb : 10000;
+	if (const char *e = getenv("CVX_TUNE_MIN_M")) c->tune_min_slots = atoi(e);
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
 	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
 	if (e != hipSuccess) {
@@ -335,7 +337,8 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		if (p.flags & kPlanEmpty) { o.status = CVX_TILE_EMPTY; continue; }
 		int k = -1;
 		if (!(p.flags & kPlanIrregular)) {
-			for (int c = 0; c < kNumClasses; ++c) if (kClasses[c].ring() >= p.need) { k = c; break; }
+			for (int c = 0; c < kNumClasses; ++c)
+				if (kClasses[c].ring() >= p.need && kClasses[c].m * kClasses[c].nw >= h->tune_min_slots) { k = c; break; }
 		}
 		if (k < 0) { o.status = CVX_TILE_UNSUPPORTED; continue; }
 		r.skip = 0;
