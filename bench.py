@@ -85,7 +85,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tiles", type=int, default=2048, help="tiles per GPU per step")
+    ap.add_argument("--tiles", type=int, default=12288, help="tiles per GPU per step (>= 2 full rounds of resident waves)")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,14 +100,15 @@ def main() -> int:
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("CVX_BENCH_FORCE_DIST"):
+        # launched by torch.distributed.run (also with --nproc-per-node 1): one rank per GPU over RCCL
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
-    dev = local_rank if world > 1 else 0
+    dev = local_rank if dist is not None else 0
 
     from ngmlr_amd import synth
     from ngmlr_amd.aligner import ConvexAlignHip

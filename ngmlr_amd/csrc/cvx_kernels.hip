@@ -68,12 +68,12 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 	const int H = ti.H, W = ti.W;
 
 	__shared__ unsigned long long s_cells, s_active;
-	__shared__ int s_need, s_flags, s_maxlen, s_rend;
-	if (threadIdx.x == 0) { s_cells = 0; s_active = 0; s_need = 1; s_flags = 0; s_maxlen = 0; s_rend = -0x7fffffff; }
+	__shared__ int s_need, s_flags, s_maxlen, s_rend, s_r0;
+	if (threadIdx.x == 0) { s_cells = 0; s_active = 0; s_need = 1; s_flags = 0; s_maxlen = 0; s_rend = -0x7fffffff; s_r0 = 0x7fffffff; }
 	__syncthreads();
 
 	unsigned long long cells = 0, active = 0;
-	int need = 1, flags = 0, maxlen = 0, rendmax = -0x7fffffff;
+	int need = 1, flags = 0, maxlen = 0, rendmax = -0x7fffffff, r0min = 0x7fffffff;
 	for (int y = threadIdx.x; y < H; y += blockDim.x) {
 		const int2 ol = r[y];
 		int gs, ge;
@@ -82,6 +82,7 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 		active += (unsigned long long) (ge - gs);
 		if (ol.y > maxlen) maxlen = ol.y;
 		if (ge > rendmax) rendmax = ge;
+		if (gs < r0min) r0min = gs;
 		if (y > 0) {
 			int pgs, pge;
 			row_span(r[y - 1], W, y - 1, pgs, pge);
@@ -105,6 +106,7 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 	atomicOr(&s_flags, flags);
 	atomicMax(&s_maxlen, maxlen);
 	atomicMax(&s_rend, rendmax);
+	atomicMin(&s_r0, r0min);
 	__syncthreads();
 
 	if (threadIdx.x == 0) {
@@ -114,12 +116,7 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 		p.need = s_need;
 		int f = s_flags;
 		int r0 = 0, rend = 0;
-		if (H > 0) {
-			int gs, ge;
-			row_span(r[0], W, 0, gs, ge);
-			r0 = gs;
-			rend = s_rend;
-		}
+		if (H > 0) { r0 = s_r0; rend = s_rend; }   /* first / one-past-last anti-diagonal with a cell */
 		if (H <= 0 || s_active == 0) f |= kPlanEmpty;
 		/* src/AlignmentMatrixFast.cpp:45: (ulong)(matrixSize / 1000.0f / 1000.0f) < maxMatrixSizeMB */
 		const float mb = (float) s_cells / 1000.0f / 1000.0f;

@@ -15,6 +15,9 @@ struct RowDesc {
 
 /* (m, nw) pairs that exist: m in {1,2,3,4,5,6,8} with nw = 1; m = 4 with nw in {2,4,8,16}. */
 hipError_t launch_fill(int m, int nw, bool wrap, const FillArgs &a, int grid, hipStream_t st);
+/* catch-all kernel (cvx_generic.hip): any ring size, state in a global scratch */
+size_t generic_scratch_bytes(int ring);
+hipError_t launch_fill_generic(const FillArgs &a, uint8_t *scratch, const uint64_t *scratch_off, hipStream_t st);
 hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles,
 		unsigned long long max_matrix_mb, hipStream_t st);
 hipError_t launch_backtrack(const BacktrackArgs &a, hipStream_t st);

@@ -99,6 +99,7 @@ struct cvx_context {
 	uint64_t max_matrix_mb = 10000;
 	int num_cus = 256;
 	int tune_min_slots = 0;   /* tuning knob (env CVX_TUNE_MIN_M): smallest M*NW a tile may use */
+	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
 };
 
 struct cvx_batch_s {
@@ -124,6 +125,8 @@ struct cvx_batch_s {
 	DevBuf<int32_t> d_heads;
 	DevBuf<uint64_t> d_dstoff;
 	DevBuf<uint32_t> d_dense;
+	DevBuf<uint8_t> d_gscratch;      /* slot state of tiles taken by the catch-all kernel */
+	DevBuf<uint64_t> d_gscratch_off;
 
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	std::vector<hipEvent_t> lev;          /* 2 events per fill launch */
@@ -133,7 +136,7 @@ struct cvx_batch_s {
 	void release() {
 		d_seq.release(); d_rows.release(); d_tin.release(); d_plan.release(); d_trun.release();
 		d_tout.release(); d_dirs.release(); d_regions.release(); d_lists.release();
-		d_heads.release(); d_dstoff.release(); d_dense.release();
+		d_heads.release(); d_dstoff.release(); d_dense.release(); d_gscratch.release(); d_gscratch_off.release();
 		for (auto &e : ev) if (e) { (void) hipEventDestroy(e); e = nullptr; }
 		for (auto &e : lev) if (e) (void) hipEventDestroy(e);
 		lev.clear();
@@ -195,6 +198,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	c->sp.ge = p->gap_extend; c->sp.gem = p->gap_extend_min; c->sp.decay = p->gap_decay;
 	c->max_matrix_mb = max_matrix_mb ? max_matrix_mb : 10000;
 	if (const char *e = getenv("CVX_TUNE_MIN_M")) c->tune_min_slots = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_FORCE_WRAP16")) c->tune_force_wrap = atoi(e);
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
 	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
 	if (e != hipSuccess) {
@@ -322,6 +326,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	b->trun.assign((size_t) n, TileRun());
 	b->tout.assign((size_t) n, TileOut());
 	std::vector<std::vector<int32_t>> cls((size_t) kNumClasses * 2);
+	std::vector<int32_t> generic;
 	uint64_t dir_dwords = 0, ops_ints = 0, cells = 0, active = 0;
 	int n_fast = 0;
 	for (int i = 0; i < n; ++i) {
@@ -340,7 +345,27 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 			for (int c = 0; c < kNumClasses; ++c)
 				if (kClasses[c].ring() >= p.need && kClasses[c].m * kClasses[c].nw >= h->tune_min_slots) { k = c; break; }
 		}
-		if (k < 0) { o.status = CVX_TILE_UNSUPPORTED; continue; }
+		if (k < 0) {
+			/* catch-all kernel: ring = need (regular, too wide for registers) or one slot per
+			 * row (irregular row starts) */
+			const int64_t want = (p.flags & kPlanIrregular) ? (int64_t) b->tin[(size_t) i].H : (int64_t) p.need;
+			const int64_t ring = ((want > 0 ? want : 1) + 63) / 64 * 64;
+			const uint64_t dd = (uint64_t) ((p.rend - p.r0 + 31) / 32) * (uint64_t) ring * 2ull;
+			if (ring > (1 << 30) || dd > (4ull << 30)) { o.status = CVX_TILE_UNSUPPORTED; continue; }  /* > 16 GiB of codes */
+			r.skip = 0;
+			r.ring = (int32_t) ring;
+			r.r0 = p.r0;
+			r.nsteps = p.rend - p.r0;
+			r.dir_off = dir_dwords;
+			dir_dwords += dd;
+			r.mnw = 0;
+			r.ops_cap = b->tin[(size_t) i].H + b->tin[(size_t) i].W + 8;
+			r.ops_off = ops_ints;
+			ops_ints += (uint64_t) r.ops_cap;
+			active += p.active;
+			generic.push_back(i);
+			continue;
+		}
 		r.skip = 0;
 		r.ring = kClasses[k].ring();
 		r.r0 = p.r0;
@@ -353,7 +378,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		ops_ints += (uint64_t) r.ops_cap;
 		active += p.active;
 		if (kClasses[k].nw == 1) n_fast++;
-		cls[(size_t) k * 2 + ((p.flags & kPlanWrap16) ? 1 : 0)].push_back(i);
+		cls[(size_t) k * 2 + (((p.flags & kPlanWrap16) || h->tune_force_wrap) ? 1 : 0)].push_back(i);
 	}
 	int rc;
 	if ((rc = b->d_dirs.ensure((size_t) dir_dwords + 64)) != CVX_OK) return rc;
@@ -370,6 +395,16 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		});
 		seg_begin[c] = (int) b->lists.size();
 		b->lists.insert(b->lists.end(), v.begin(), v.end());
+	}
+	const int generic_begin = (int) b->lists.size();
+	b->lists.insert(b->lists.end(), generic.begin(), generic.end());
+	std::vector<uint64_t> goff(generic.size() + 1, 0);
+	for (size_t g = 0; g < generic.size(); ++g)
+		goff[g + 1] = goff[g] + (uint64_t) generic_scratch_bytes(b->trun[(size_t) generic[g]].ring);
+	if (!generic.empty()) {
+		if ((rc = b->d_gscratch.ensure((size_t) goff.back() + 256)) != CVX_OK) return rc;
+		if ((rc = b->d_gscratch_off.ensure(goff.size())) != CVX_OK) return rc;
+		HIP_TRY(hipMemcpyAsync(b->d_gscratch_off.p, goff.data(), goff.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
 	}
 	HIP_TRY(hipMemcpyAsync(b->d_trun.p, b->trun.data(), (size_t) n * sizeof(TileRun), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(b->d_tout.p, b->tout.data(), (size_t) n * sizeof(TileOut), hipMemcpyHostToDevice, st));
@@ -420,6 +455,42 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		const int per_cu = kc.nw == 1 ? 32 : std::max(1, 16 / kc.nw);
 		const int grid = std::min(a.list_n, h->num_cus * per_cu);
 		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, a, grid, ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2 + 1], ls));
+		HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) launches * 2 + 1], 0));
+		launches++;
+	}
+	if (!generic.empty()) {
+		while (b->lev.size() < (size_t) (launches + 1) * 2) {
+			hipEvent_t e;
+			HIP_TRY(hipEventCreate(&e));
+			b->lev.push_back(e);
+		}
+		cvx_launch_info li;
+		memset(&li, 0, sizeof(li));
+		li.slots_per_lane = 0; li.waves = 16; li.wrap16 = 1; li.n_tiles = (int) generic.size();
+		for (int32_t ti : generic) {
+			const TilePlan &p = b->plan[(size_t) ti];
+			const TileIn &in = b->tin[(size_t) ti];
+			li.cells += p.cells; li.active_cells += p.active;
+			li.alg_bytes += p.cells + 6ull * (uint64_t) in.H + 2ull * (uint64_t) in.W;
+			li.read_bases += (uint64_t) in.H;
+		}
+		b->launches.push_back(li);
+		hipStream_t ls = h->aux[launches % kAuxStreams];
+		HIP_TRY(hipStreamWaitEvent(ls, b->ev[1], 0));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2], ls));
+		FillArgs a;
+		a.seq = b->d_seq.p;
+		a.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
+		a.tin = b->d_tin.p;
+		a.trun = b->d_trun.p;
+		a.tout = b->d_tout.p;
+		a.dirs = b->d_dirs.p;
+		a.list = b->d_lists.p + generic_begin;
+		a.list_n = (int) generic.size();
+		a.queue_head = b->d_heads.p + 63;
+		a.sp = h->sp;
+		HIP_TRY(launch_fill_generic(a, b->d_gscratch.p, b->d_gscratch_off.p, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2 + 1], ls));
 		HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) launches * 2 + 1], 0));
 		launches++;

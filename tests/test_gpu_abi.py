@@ -15,7 +15,7 @@ def test_statuses(hip_aligner, port_oracle):
     ok = synth.make_tile(rng, 500, corridor="anchors")
     # best cell in row 0 -> invalid (reference src/ConvexAlignFast.cpp:338)
     row0 = synth.Tile(b"ACGTACGTAC", b"A" + b"T" * 0, *synth.corridor_linear(1, 30), tag="row0")
-    # decreasing offsets: not a shape any reference caller builds -> loud "unsupported"
+    # decreasing offsets: not a shape any reference caller builds -> catch-all kernel, still exact
     H = 120
     weird = synth.Tile(synth.random_ref(rng, 400).tobytes(), synth.random_ref(rng, H).tobytes(),
                        (300 - 2 * np.arange(H)).astype(np.int32), np.full(H, 60, np.int32), tag="decreasing")
@@ -23,7 +23,8 @@ def test_statuses(hip_aligner, port_oracle):
     got = hip_aligner.batch_align([ok, row0, weird, empty])
     assert got[0]["status"] == 0 and got[0]["ret"] == ok.H
     assert got[1]["status"] == 1 and got[1]["ret"] == -1 and got[1]["score"] == -1.0
-    assert got[2]["status"] == -1 and got[2]["ret"] == -1
+    from oracle.pyoracle import same_alignment
+    assert got[2]["status"] != -1 and same_alignment(port_oracle.align(weird), got[2]) is None
     assert got[3]["status"] == 5 and got[3]["ret"] == -1
     assert port_oracle.align(row0)["ret"] == -1 and port_oracle.align(empty)["ret"] == -1
 

@@ -72,7 +72,7 @@ def test_every_ring_class(hip_aligner, port_oracle):
     from ngmlr_amd import synth
     rng = np.random.default_rng(1234)
     tiles = []
-    for width in (40, 100, 200, 340, 369, 420, 560, 700, 900, 1500, 2048, 3500, 7000):
+    for width in (40, 100, 200, 340, 369, 420, 560, 700, 900, 1500, 2048, 3500, 7000, 8192, 12000):
         W = max(1200, width + 300)
         t = synth.make_tile(rng, W, err=0.15, corridor="endpoints", width=width, realign=True, tag="w%d" % width)
         tiles.append(t)
@@ -84,6 +84,47 @@ def test_every_ring_class(hip_aligner, port_oracle):
     rings = sorted({(li["slots_per_lane"], li["waves"]) for li in batch.launches()})
     batch.free()
     assert len(rings) >= 8 and any(nw > 1 for _, nw in rings), rings
+
+
+def test_int16_run_kernels(built, port_oracle, monkeypatch):
+    """The WRAP instantiations (indelRun as the reference's short, taken by tiles with H or a
+    row > 32767) must equal the float-run kernels and the oracle wherever no run wraps."""
+    from ngmlr_amd.aligner import ConvexAlignHip
+    monkeypatch.setenv("CVX_TUNE_FORCE_WRAP16", "1")
+    al = ConvexAlignHip(device=0)
+    tiles = util.tile_zoo(seed=41, n=90, max_w=2500) + util.edge_tiles()
+    _check(al, port_oracle, tiles)
+    batch = al.upload(tiles[:20])
+    batch.run()
+    assert all(li["wrap16"] == 1 for li in batch.launches())
+    batch.free()
+    al.close()
+
+
+def test_irregular_corridors_take_the_catch_all_kernel(hip_aligner, port_oracle):
+    """CorridorLine[] shapes no reference caller builds (row starts that do not increase):
+    computed on the device by the catch-all kernel, never on the CPU, still bit-exact."""
+    from ngmlr_amd import synth
+    rng = np.random.default_rng(77)
+    tiles = []
+    for k in range(8):
+        W = int(rng.integers(150, 900))
+        ref = synth.random_ref(rng, W)
+        qry = synth.mutate(rng, ref, 0.12)
+        H = len(qry)
+        base, ln = synth.corridor_anchors(H, W)
+        if k % 4 == 0:
+            off = base + rng.integers(-40, 40, size=H).astype(np.int32)          # jitter
+        elif k % 4 == 1:
+            off = (W - np.arange(H)).astype(np.int32) - 150                       # anti-diagonal band
+        elif k % 4 == 2:
+            off = np.where(np.arange(H) % 50 < 25, base, base - 60).astype(np.int32)   # zigzag
+        else:
+            off = np.full(H, -10, dtype=np.int32)                                 # constant start (gs ties not allowed? still increasing)
+            off[::7] -= 30
+        ln = (ln + rng.integers(0, 30, size=H)).astype(np.int32)
+        tiles.append(synth.Tile(ref.tobytes(), qry.tobytes(), off.astype(np.int32), ln, tag="irregular%d" % k))
+    _check(hip_aligner, port_oracle, tiles, need_valid=False)
 
 
 def test_full_size_pacbio_tiles_bit_exact(hip_aligner, port_oracle):
