@@ -51,3 +51,17 @@ def test_cpp_shim_matches_oracle(built, port_oracle, tmp_path, mode):
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr[-2000:]
     assert "0 mismatches" in res.stdout
+
+
+def test_batching_aligner_many_threads(built, port_oracle, tmp_path):
+    """24 worker threads call the blocking SingleAlign of one shared
+    BatchingAligner; requests coalesce into a few device launches, results stay exact."""
+    exe = os.path.join(ROOT, "ngmlr_amd", "batching_test")
+    assert os.path.exists(exe), "batching_test not built"
+    tiles = util.tile_zoo(seed=91, n=160, max_w=1800)
+    pairs = [(t, port_oracle.align(t)) for t in tiles]
+    rec = str(tmp_path / "tiles.bin")
+    write_records(rec, pairs)
+    res = subprocess.run([exe, rec, "24"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr[-2000:]
+    assert "0 mismatches" in res.stdout
