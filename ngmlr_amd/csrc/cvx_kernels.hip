@@ -148,17 +148,18 @@ CVX_DEV unsigned shl1_in(unsigned acc, u64 m) {
 template <bool WRAP> struct RunT { typedef float type; };
 template <> struct RunT<true> { typedef int type; };
 
+/* Occupancy target.  The M = 3 single-wave kernel (corridors of 310-370 columns, i.e. almost
+ * every PacBio/ONT tile) is measured ~14 % faster at 6 waves/SIMD (80 VGPRs, the few spilled
+ * values are tile constants outside the step loop) than at the 5 the allocator picks by itself;
+ * the other classes keep the default.  CVX_FILL_WAVES_PER_EU overrides for A/B runs. */
 #ifndef CVX_FILL_WAVES_PER_EU
-#define CVX_FILL_WAVES_PER_EU 0
+#define CVX_FILL_WAVES_PER_EU 6
 #endif
-#if CVX_FILL_WAVES_PER_EU > 0
-#define CVX_FILL_OCC __attribute__((amdgpu_waves_per_eu(CVX_FILL_WAVES_PER_EU, CVX_FILL_WAVES_PER_EU)))
-#else
-#define CVX_FILL_OCC
-#endif
+#define CVX_FILL_OCC(M, NW) __attribute__((amdgpu_waves_per_eu( \
+		((M) == 3 && (NW) == 1) ? CVX_FILL_WAVES_PER_EU : 1, ((M) == 3 && (NW) == 1) ? CVX_FILL_WAVES_PER_EU : 8)))
 
 template <int M, int NW, bool WRAP>
-__global__ void __launch_bounds__(64 * NW) CVX_FILL_OCC
+__global__ void __launch_bounds__(64 * NW) CVX_FILL_OCC(M, NW)
 fill_ring_kernel(const FillArgs a) {
 	constexpr int N = 64 * M * NW;
 	typedef typename RunT<WRAP>::type run_t;   /* gap run: float (exact small ints) or int16-emulating int */
