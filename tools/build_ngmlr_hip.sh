@@ -1,0 +1,41 @@
+#!/bin/bash
+# tools/build_ngmlr_hip.sh -- the drop-in, end to end: builds the reference's own ngmlr
+# (its CMake, its sources, in a fresh /tmp copy) with exactly the change INTEGRATION.md
+# describes -- Convex::ConvexAlignHip constructed instead of Convex::ConvexAlignFast at
+# src/AlignmentBuffer.h:355 -- linked against this repository's libcvxalign.so.  The
+# binary lands in oracle/_ref/ngmlr_hip (git-ignored build artefact, travels to the GPU
+# box like the .so files); tests/test_gpu_e2e.py runs it on the reference's test data and
+# compares the SAM with the unmodified reference's output (tests/golden/test_*.sam).
+# Needs /root/reference, cmake, zlib (this container only).  No reference source enters
+# the repository.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REPO="$(dirname "$HERE")"
+make -s -C "$REPO/ngmlr_amd/csrc"
+WORK="$(mktemp -d /tmp/ngmlr_hip.XXXXXX)"
+cp -r /root/reference "$WORK/src_tree"
+T="$WORK/src_tree"
+python3 - "$T" "$REPO" <<'PY'
+import re, sys
+T, REPO = sys.argv[1], sys.argv[2]
+p = T + '/src/AlignmentBuffer.h'
+s = open(p).read()
+s = s.replace('#include "ConvexAlignFast.h"', '#include "ConvexAlignFast.h"\n#include "convex_align_hip.h"', 1)
+pat = re.compile(r'aligner = new Convex::ConvexAlignFast\(', re.S)
+assert len(pat.findall(s)) == 1
+s = pat.sub('aligner = new Convex::ConvexAlignHip(', s)
+open(p, 'w').write(s)
+p = T + '/src/CMakeLists.txt'
+c = open(p).read()
+c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp' % (REPO, REPO, REPO), 1)
+c = c.replace('TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})', 'TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})\nTARGET_LINK_LIBRARIES(ngmlr %s/ngmlr_amd/libcvxalign.so)\nset_target_properties(ngmlr PROPERTIES BUILD_RPATH "\\$ORIGIN/../../ngmlr_amd;/opt/rocm/lib" SKIP_BUILD_RPATH FALSE)' % REPO, 1)
+open(p, 'w').write(c)
+PY
+mkdir -p "$T/build" && cd "$T/build"
+cmake .. -DCMAKE_POLICY_VERSION_MINIMUM=3.5 -DCMAKE_BUILD_TYPE=RELWITHDEBINFO > "$WORK/cmake.log" 2>&1
+make -j8 > "$WORK/make.log" 2>&1 || { tail -30 "$WORK/make.log"; exit 1; }
+BIN=$(ls "$T"/bin/ngmlr-*/ngmlr)
+mkdir -p "$REPO/oracle/_ref"
+cp "$BIN" "$REPO/oracle/_ref/ngmlr_hip"
+echo "built $REPO/oracle/_ref/ngmlr_hip"
+readelf -d "$REPO/oracle/_ref/ngmlr_hip" | grep -E "RPATH|RUNPATH|NEEDED" | head
