@@ -145,6 +145,131 @@ CVX_DEV unsigned shl1_in(unsigned acc, u64 m) {
 	return acc;
 }
 
+/* ------------------------------------------------------------------ backtrack */
+
+/* validPath, src/AlignmentMatrixFast.cpp:213-220: float arithmetic, int truncation,
+ * no contraction. */
+CVX_DEV bool valid_path(const int off, const int width, int x) {
+	const int minC = (int) ((float) off + 0.1f * (float) width);
+	const int maxC = (int) ((float) (minC + width) - 0.1f * (float) width);
+	return x > minC && x < maxC;
+}
+
+/*
+ * revBacktrack (src/ConvexAlignFast.cpp:335-432) by ONE wave, run-skipping.  The path is
+ * a chain of runs (diagonal runs broken by short gaps); instead of one dependent load per
+ * cell, the 64 lanes probe the next 64 cells along the current direction at once (lane i
+ * looks at the i-th cell back), a ballot finds how far the run goes, and the walk jumps to
+ * its end.  A 10-kb PacBio tile is ~3 000 probes instead of ~20 000 dependent steps.
+ * Every probe is four coalesced loads (corridor rows, plane words, both sequences).  The
+ * walk state is wave-uniform; lane 0 writes the run-length ops.  `o` carries the argmax
+ * in (score, best_x, best_y) and returns the FwdResults.
+ */
+CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int r0, const int ops_cap,
+		const int2 *rows, const uint2 *dirs, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
+	/* the argmax may arrive in VGPRs (fused call after a lane reduction): make the walk's
+	 * state provably wave-uniform so that it runs on scalar branches */
+	const int best_x = __builtin_amdgcn_readfirstlane(o.best_x);
+	const int best_y = __builtin_amdgcn_readfirstlane(o.best_y);
+	/* src/ConvexAlignFast.cpp:338 */
+	if (best_y <= 0) { o.status = 1; return; }
+#if defined(CVX_DBG_BT) && CVX_DBG_BT == 2
+	if (best_y > 0) { o.status = 1; return; }
+#endif
+
+	const int qend = (H - best_y) - 1;
+	int idx = ops_cap - 1;
+	int elem = 4;          /* CIGAR_S: the trailing clip is tracked but not stored */
+	int elem_len = qend;
+	int consumed = qend;
+	int x = best_x, y = best_y;
+	int s = y % N;         /* ring slot of row y */
+	int status = 0;
+	unsigned want = 3u;    /* direction of the run being followed (first probe: a guess) */
+
+	/* revBacktrack's run-length bookkeeping (src/ConvexAlignFast.cpp:395-403) */
+	auto emit = [&](int cur, int n) {
+		if (n <= 0) return;
+		if (cur == elem) {
+			elem_len += n;
+		} else {
+			if (elem != 4) { if (lane == 0) ops[idx] = (elem_len << 4) | elem; idx -= 1; }
+			elem = cur;
+			elem_len = n;
+		}
+	};
+
+	/* every probe either consumes a cell or fixes the direction, so x + y + 2 probes always
+	 * suffice; the cap turns corrupted direction data into an invalid tile, never a hang */
+	int budget = 2 * (best_x + best_y) + 8;
+	for (;;) {
+		if (--budget < 0) { status = 3; break; }
+#if defined(CVX_DBG_BT) && CVX_DBG_BT == 3
+		if (budget >= 0) { status = 3; break; }
+#endif
+		const int dx = (want != 1u) ? 1 : 0, dy = (want != 2u) ? 1 : 0;
+		const int cx = x - lane * dx, cy = y - lane * dy;
+		const bool inside = (cx >= 0 && cy >= 0);
+		const int lx = cx > 0 ? cx : 0, ly = cy > 0 ? cy : 0;
+		int sl = s - lane * dy;
+		if (sl < 0) sl += N;
+		const int tt = cx + cy - r0;
+		const int ttc = tt > 0 ? tt : 0;
+		const int2 ol = rows[ly];
+		const uint2 w = dirs[(size_t) (ttc >> 5) * N + sl];
+		const int rc = ref[lx], qc = qry[ly];
+		/* getDirection, src/AlignmentMatrixFast.cpp:185-195: outside -> STOP */
+		const bool in_row = inside && tt >= 0 && cx >= ol.x && cx < ol.x + ol.y;
+		const int bit = 31 - (ttc & 31);
+		unsigned code = ((w.x >> bit) & 1u) | (((w.y >> bit) & 1u) << 1);
+		if (!in_row) code = 0u;
+
+		const u64 run = ballot(code == want);
+		const int L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);   /* cells of this run */
+		const u64 low = (L == 64) ? ~0ull : ((1ull << L) - 1ull);
+		/* every visited cell must pass validPath before the move (:368-373) */
+		const u64 vp = ballot(valid_path(ol.x, ol.y, cx));
+		if ((~vp & low) != 0ull) { status = 2; break; }
+
+		if (want == 3u) {
+			const u64 eqm = ballot(rc == qc);
+			int pos = 0;
+			while (pos < L) {
+				const int isq = (int) ((eqm >> pos) & 1ull);
+				const u64 m = (isq ? ~eqm : eqm) >> pos;
+				int rl = (m == 0ull) ? 64 - pos : __builtin_ctzll(m);
+				if (rl > L - pos) rl = L - pos;
+				emit(isq ? 7 : 8, rl);
+				pos += rl;
+			}
+			x -= L; y -= L; consumed += L;
+		} else if (want == 1u) {
+			emit(1, L);
+			y -= L; consumed += L;
+		} else {
+			emit(2, L);
+			x -= L;
+		}
+		if (want != 2u) { s -= L; if (s < 0) s += N; }
+		if (L < 64) {
+			const unsigned nxt = (unsigned) __builtin_amdgcn_readlane((int) code, L);
+			if (nxt == 0u) break;     /* CIGAR_STOP (or outside the matrix) */
+			want = nxt;
+		}
+	}
+	if (status == 0) {
+		if (elem != 4) { if (lane == 0) ops[idx] = (elem_len << 4) | elem; idx -= 1; }
+		consumed += (y + 1);
+		o.ref_position = x + 1;
+		o.qstart = y + 1;
+		o.qend = qend;
+		o.ops_first = idx + 1;
+		o.n_ops = ops_cap - 1 - idx;
+		if (H != consumed) status = 3;
+	}
+	o.status = status;
+}
+
 template <bool WRAP> struct RunT { typedef float type; };
 template <> struct RunT<true> { typedef int type; };
 
@@ -165,7 +290,7 @@ fill_ring_kernel(const FillArgs a) {
 	typedef typename RunT<WRAP>::type run_t;   /* gap run: float (exact small ints) or int16-emulating int */
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
-	const int wave = tid >> 6;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* provably wave-uniform */
 	const float go = a.sp.go;
 	const float gext = a.sp.ge, gem = a.sp.gem, decay = a.sp.decay;
 	/* keep match / mismatch in VGPRs: v_cndmask cannot take two SGPR values plus a mask */
@@ -431,37 +556,48 @@ fill_ring_kernel(const FillArgs a) {
 				}
 			}
 		}
-		if (tid == 0) {
+		/* backtrack right here, by wave 0, while the other waves of the SIMD keep filling
+		 * their tiles: the walk is a chain of HBM round trips and costs them almost nothing */
+		if (NW > 1) {
+			if (tid == 0) { s_rbest[0] = b; s_ry[0] = by; s_rx[0] = bx; }
+			__syncthreads();       /* also orders every wave's direction stores before the walk */
+			b = s_rbest[0]; by = s_ry[0]; bx = s_rx[0];
+		}
+		/* wave-uniform copies (after the reductions every lane of wave 0 holds the same
+		 * values; telling the compiler keeps the tile loop on scalar branches) */
+		b = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(b)));
+		by = __builtin_amdgcn_readfirstlane(by);
+		bx = __builtin_amdgcn_readfirstlane(bx);
+		if (wave == 0) {
 			TileOut o;
 			o.score = b;
 			o.status = (b > -1.0f) ? 0 : 5;
 			o.best_x = (b > -1.0f) ? bx : 0;
 			o.best_y = (b > -1.0f) ? by : 0;
-			o.ref_position = 0; o.qstart = 0; o.qend = 0; o.n_ops = 0; o.ops_first = 0; o.pad = 0;
-			a.tout[t] = o;
+			o.ref_position = 0; o.qstart = 0; o.qend = 0; o.n_ops = 0; o.ops_first = 0;
+#ifndef CVX_FUSE_BT
+#define CVX_FUSE_BT 0      /* 0: never (default), 1: single-wave tiles, 2: all ring tiles.
+                            * EXPERIMENTAL: the in-kernel walk hangs on gfx950/ROCm 7.2 (the persistent
+                            * tile loop gets restructured as a divergent loop); kept for round 2 */
+#endif
+			const bool fuse = (CVX_FUSE_BT == 2) || (CVX_FUSE_BT == 1 && NW == 1);
+			o.pad = fuse ? 1 : 0;  /* 1 = backtracked here: the stand-alone kernel skips this tile */
+			if (fuse && o.status == 0) {
+				__builtin_amdgcn_s_waitcnt(0);          /* own direction stores have landed */
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#if defined(CVX_DBG_BT) && CVX_DBG_BT == 1
+				if (false)
+#endif
+				backtrack_walk(lane, H, N, tr.r0, tr.ops_cap, rows,
+						reinterpret_cast<const uint2 *>(dirs), seq + ti.ref_off, seq + ti.qry_off,
+						a.ops + tr.ops_off, o);
+			}
+			if (lane == 0) a.tout[t] = o;
 		}
 	}
 }
 
-/* ------------------------------------------------------------------ backtrack */
-
-/* validPath, src/AlignmentMatrixFast.cpp:213-220: float arithmetic, int truncation,
- * no contraction. */
-CVX_DEV bool valid_path(const int off, const int width, int x) {
-	const int minC = (int) ((float) off + 0.1f * (float) width);
-	const int maxC = (int) ((float) (minC + width) - 0.1f * (float) width);
-	return x > minC && x < maxC;
-}
-
-/*
- * One wave per tile, run-skipping walk.  The path is a chain of runs (diagonal runs
- * broken by short gaps); instead of one dependent load per cell, the 64 lanes probe the
- * next 64 cells along the current direction at once (lane i looks at the i-th cell
- * back), a ballot finds how far the run goes, and the walk jumps to its end.  A 10-kb
- * PacBio tile is ~3 000 probes instead of ~20 000 dependent steps.  Every probe is four
- * coalesced loads (corridor rows, plane words, both sequences).  The walk state is
- * wave-uniform; lane 0 writes the run-length ops.
- */
+/* stand-alone form (tiles filled by the catch-all kernel): one wave per tile */
 __global__ void __launch_bounds__(64)
 backtrack_kernel(const BacktrackArgs a) {
 	const int t = blockIdx.x;
@@ -471,104 +607,15 @@ backtrack_kernel(const BacktrackArgs a) {
 	if (tr.skip) return;
 	const TileIn ti = a.tin[t];
 	TileOut o = a.tout[t];
-	if (o.status != 0) return;
-	const int H = ti.H;
-	const int N = tr.ring;
-	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off;
-	const uint2 *dirs = reinterpret_cast<const uint2 *>(a.dirs + tr.dir_off);
-	const uint8_t *ref = a.seq + ti.ref_off;
-	const uint8_t *qry = a.seq + ti.qry_off;
-	int *ops = a.ops + tr.ops_off;
-
-	/* src/ConvexAlignFast.cpp:338 */
-	if (o.best_y <= 0) { if (lane == 0) { o.status = 1; a.tout[t] = o; } return; }
-
-	const int qend = (H - o.best_y) - 1;
-	int idx = tr.ops_cap - 1;
-	int elem = 4;          /* CIGAR_S: the trailing clip is tracked but not stored */
-	int elem_len = qend;
-	int consumed = qend;
-	int x = o.best_x, y = o.best_y;
-	int s = y % N;         /* ring slot of row y */
-	int status = 0;
-	unsigned want = 3u;    /* direction of the run being followed (first probe: a guess) */
-
-	/* revBacktrack's run-length bookkeeping (src/ConvexAlignFast.cpp:395-403) */
-	auto emit = [&](int cur, int n) {
-		if (n <= 0) return;
-		if (cur == elem) {
-			elem_len += n;
-		} else {
-			if (elem != 4) { if (lane == 0) ops[idx] = (elem_len << 4) | elem; idx -= 1; }
-			elem = cur;
-			elem_len = n;
-		}
-	};
-
-	for (;;) {
-		const int dx = (want != 1u) ? 1 : 0, dy = (want != 2u) ? 1 : 0;
-		const int cx = x - lane * dx, cy = y - lane * dy;
-		const bool inside = (cx >= 0 && cy >= 0);
-		const int lx = cx > 0 ? cx : 0, ly = cy > 0 ? cy : 0;
-		int sl = s - lane * dy;
-		if (sl < 0) sl += N;
-		const int tt = cx + cy - tr.r0;
-		const int ttc = tt > 0 ? tt : 0;
-		const int2 ol = rows[ly];
-		const uint2 w = dirs[(size_t) (ttc >> 5) * N + sl];
-		const int rc = ref[lx], qc = qry[ly];
-		/* getDirection, src/AlignmentMatrixFast.cpp:185-195: outside -> STOP */
-		const bool in_row = inside && tt >= 0 && cx >= ol.x && cx < ol.x + ol.y;
-		const int bit = 31 - (ttc & 31);
-		unsigned code = ((w.x >> bit) & 1u) | (((w.y >> bit) & 1u) << 1);
-		if (!in_row) code = 0u;
-
-		const u64 run = ballot(code == want);
-		const int L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);   /* cells of this run */
-		const u64 low = (L == 64) ? ~0ull : ((1ull << L) - 1ull);
-		/* every visited cell must pass validPath before the move (:368-373) */
-		const u64 vp = ballot(valid_path(ol.x, ol.y, cx));
-		if ((~vp & low) != 0ull) { status = 2; break; }
-
-		if (want == 3u) {
-			const u64 eqm = ballot(rc == qc);
-			int pos = 0;
-			while (pos < L) {
-				const int isq = (int) ((eqm >> pos) & 1ull);
-				const u64 m = (isq ? ~eqm : eqm) >> pos;
-				int rl = (m == 0ull) ? 64 - pos : __builtin_ctzll(m);
-				if (rl > L - pos) rl = L - pos;
-				emit(isq ? 7 : 8, rl);
-				pos += rl;
-			}
-			x -= L; y -= L; consumed += L;
-		} else if (want == 1u) {
-			emit(1, L);
-			y -= L; consumed += L;
-		} else {
-			emit(2, L);
-			x -= L;
-		}
-		if (want != 2u) { s -= L; if (s < 0) s += N; }
-		if (L < 64) {
-			const unsigned nxt = (unsigned) __builtin_amdgcn_readlane((int) code, L);
-			if (nxt == 0u) break;     /* CIGAR_STOP (or outside the matrix) */
-			want = nxt;
-		}
-	}
-	if (status == 0) {
-		if (elem != 4) { if (lane == 0) ops[idx] = (elem_len << 4) | elem; idx -= 1; }
-		consumed += (y + 1);
-		o.ref_position = x + 1;
-		o.qstart = y + 1;
-		o.qend = qend;
-		o.ops_first = idx + 1;
-		o.n_ops = tr.ops_cap - 1 - idx;
-		if (H != consumed) status = 3;
-	}
-	o.status = status;
+	if (o.status != 0 || o.pad != 0) return;
+	backtrack_walk(lane, ti.H, tr.ring, tr.r0, tr.ops_cap,
+			reinterpret_cast<const int2 *>(a.rows) + ti.row_off,
+			reinterpret_cast<const uint2 *>(a.dirs + tr.dir_off),
+			a.seq + ti.ref_off, a.seq + ti.qry_off, a.ops + tr.ops_off, o);
+	o.pad = 1;
 	if (lane == 0) a.tout[t] = o;
 }
+
 
 /* dense[dst_off[t] .. +n_ops) = region of tile t */
 __global__ void __launch_bounds__(256)

@@ -451,6 +451,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		a.list = b->d_lists.p + seg_begin[c];
 		a.list_n = (int) cls[c].size();
 		a.queue_head = b->d_heads.p + c;
+		a.ops = b->d_regions.p;
 		a.sp = h->sp;
 		const int per_cu = kc.nw == 1 ? 32 : std::max(1, 16 / kc.nw);
 		const int grid = std::min(a.list_n, h->num_cus * per_cu);
@@ -489,6 +490,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		a.list = b->d_lists.p + generic_begin;
 		a.list_n = (int) generic.size();
 		a.queue_head = b->d_heads.p + 63;
+		a.ops = b->d_regions.p;
 		a.sp = h->sp;
 		HIP_TRY(launch_fill_generic(a, b->d_gscratch.p, b->d_gscratch_off.p, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2 + 1], ls));
@@ -507,7 +509,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	ba.dirs = b->d_dirs.p;
 	ba.ops = b->d_regions.p;
 	ba.n_tiles = n;
-	HIP_TRY(launch_backtrack(ba, st));
+	HIP_TRY(launch_backtrack(ba, st));   /* only tiles the fill kernels did not backtrack in place */
 	HIP_TRY(hipMemcpyAsync(b->tout.data(), b->d_tout.p, (size_t) n * sizeof(TileOut), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	b->dst_off.assign((size_t) n, 0);

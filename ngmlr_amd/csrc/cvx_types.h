@@ -91,7 +91,7 @@ struct TileOut {
 	int32_t ref_position, qstart, qend;
 	int32_t n_ops;
 	int32_t ops_first;     /* index of the first op inside the tile's region */
-	int32_t pad;
+	int32_t pad;           /* 1 once the tile has been backtracked */
 };
 
 struct FillArgs {
@@ -104,6 +104,7 @@ struct FillArgs {
 	const int32_t *list;   /* tile indices of this kernel class, largest first */
 	int32_t list_n;
 	int32_t *queue_head;   /* work-queue cursor (zeroed before launch) */
+	int32_t *ops;          /* per-tile op regions (the fill kernels backtrack their own tiles) */
 	ScoreParams sp;
 };
 
