@@ -24,6 +24,7 @@
  *                              src/ConvexAlignFast.cpp:441-450)
  * cvx_batch_* (staged form)   the same, with inputs resident in HBM between calls
  * cvx_format_alignment        convertCigar + N-clip flags    src/ConvexAlignFast.cpp:112-333,493-528
+ * cvx_score_batch             StrippedSW::BatchScore/SingleScore  src/StrippedSW.cpp:118-203 (next-row f2)
  *
  * The binding a maintainer adds on the ngmlr side is in INTEGRATION.md
  * (ngmlr_amd/csrc/convex_align_hip.{h,cpp}: an IAlignment subclass over this ABI).
@@ -165,6 +166,13 @@ int cvx_batch_launch_info(cvx_batch b, int32_t i, cvx_launch_info *info);
 int cvx_batch_download(cvx_handle h, cvx_batch b, cvx_result *results,
 		uint32_t *ops_arena, uint64_t ops_capacity, uint64_t *ops_used);
 void cvx_batch_free(cvx_handle h, cvx_batch b);
+
+/* Sub-read scoring: what StrippedSW::BatchScore / SingleScore return
+ * (reference src/StrippedSW.cpp:118-203 over ssw.c): refs/qrys are NUL-terminated strings,
+ * scores[i] receives the alignment score (match +1, mismatch -1, N 0, gap 255 per base -- the
+ * reference passes -1 into ssw's uint8_t gap weights) or -1.0f for sequences of 100000
+ * characters or more.  Exact for scores below 32767. */
+int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char *const *qrys, float *scores);
 
 /* Host-side text stage (convertCigar, src/ConvexAlignFast.cpp:112-333, and the
  * N-clip flags of :493-528).  Pure host code, no device needed. */

@@ -86,6 +86,33 @@ class ConvexAlignHip:
         return self.batch_align([tile], want_nm=want_nm)[0]
 
 
+class StrippedSWHip:
+    """Mirror of the reference's StrippedSW for the scoring calls (src/StrippedSW.cpp:118-203):
+    batch_score == BatchScore, single_score == SingleScore; alignment calls are not part of
+    this backend.  GetScoreBatchSize() is 1024 in the reference (src/StrippedSW.h:53-55)."""
+
+    def __init__(self, device: int = 0):
+        self._al = ConvexAlignHip(device=device)
+        self.lib = self._al.lib
+
+    def get_score_batch_size(self) -> int:
+        return 1024
+
+    def batch_score(self, refs: Sequence[bytes], qrys: Sequence[bytes]) -> np.ndarray:
+        n = len(refs)
+        r = (C.c_char_p * max(n, 1))(*refs)
+        q = (C.c_char_p * max(n, 1))(*qrys)
+        out = np.zeros(max(n, 1), dtype=np.float32)
+        capi.check(self.lib.cvx_score_batch(self._al.h, n, r, q, out.ctypes.data))
+        return out[:n]
+
+    def single_score(self, ref: bytes, qry: bytes) -> float:
+        return float(self.batch_score([ref], [qry])[0])
+
+    def close(self) -> None:
+        self._al.close()
+
+
 class DeviceBatch:
     """Tiles resident in HBM; run() may be repeated (bench) before download."""
 

@@ -15,6 +15,14 @@ struct RowDesc {
 
 /* (m, nw) pairs that exist: m in {1,2,3,4,5,6,8} with nw = 1; m = 4 with nw in {2,4,8,16}. */
 hipError_t launch_fill(int m, int nw, bool wrap, const FillArgs &a, int grid, hipStream_t st);
+/* sub-read scoring (cvx_score.hip) */
+struct ScorePair {
+	uint64_t ref_off, qry_off;   /* byte offsets in the sequence buffer (strings keep their NUL) */
+	uint64_t scratch_off;        /* int offset of this pair's two DP rows */
+	int32_t ref_len, qry_len;    /* strlen + 1 */
+};
+hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scratch, float *out, int n, hipStream_t st);
+
 /* catch-all kernel (cvx_generic.hip): any ring size, state in a global scratch */
 size_t generic_scratch_bytes(int ring);
 hipError_t launch_fill_generic(const FillArgs &a, uint8_t *scratch, const uint64_t *scratch_off, hipStream_t st);

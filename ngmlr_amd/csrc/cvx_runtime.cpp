@@ -596,6 +596,45 @@ void cvx_batch_free(cvx_handle h, cvx_batch b) {
 	delete b;
 }
 
+int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char *const *qrys, float *scores) {
+	if (!h || n < 0 || (n > 0 && (!refs || !qrys || !scores))) { set_err("cvx_score_batch: bad argument"); return CVX_ERR_ARG; }
+	if (n == 0) return CVX_OK;
+	HIP_TRY(hipSetDevice(h->device));
+	std::vector<ScorePair> pairs((size_t) n);
+	uint64_t bytes = 0, rows = 0;
+	for (int i = 0; i < n; ++i) {
+		if (!refs[i] || !qrys[i]) { set_err("cvx_score_batch: NULL sequence %d", i); return CVX_ERR_ARG; }
+		const size_t rl = strlen(refs[i]) + 1, ql = strlen(qrys[i]) + 1;
+		ScorePair &p = pairs[(size_t) i];
+		p.ref_off = bytes; bytes += rl;
+		p.qry_off = bytes; bytes += ql;
+		p.ref_len = (int32_t) std::min<size_t>(rl, 0x7fffffff);
+		p.qry_len = (int32_t) std::min<size_t>(ql, 0x7fffffff);
+		p.scratch_off = rows;
+		if (rl < 100000 && ql < 100000) rows += 2 * (uint64_t) rl;
+	}
+	std::vector<uint8_t> hseq((size_t) bytes + 16);
+	for (int i = 0; i < n; ++i) {
+		memcpy(&hseq[(size_t) pairs[(size_t) i].ref_off], refs[i], (size_t) pairs[(size_t) i].ref_len);
+		memcpy(&hseq[(size_t) pairs[(size_t) i].qry_off], qrys[i], (size_t) pairs[(size_t) i].qry_len);
+	}
+	DevBuf<uint8_t> d_seq; DevBuf<ScorePair> d_pairs; DevBuf<int32_t> d_rows; DevBuf<float> d_out;
+	int rc;
+	if ((rc = d_seq.ensure(hseq.size())) != CVX_OK || (rc = d_pairs.ensure((size_t) n)) != CVX_OK ||
+			(rc = d_rows.ensure((size_t) rows + 64)) != CVX_OK || (rc = d_out.ensure((size_t) n)) != CVX_OK) {
+		d_seq.release(); d_pairs.release(); d_rows.release(); d_out.release();
+		return rc;
+	}
+	hipError_t e = hipMemcpyAsync(d_seq.p, hseq.data(), hseq.size(), hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_pairs.p, pairs.data(), (size_t) n * sizeof(ScorePair), hipMemcpyHostToDevice, h->stream);
+	if (e == hipSuccess) e = launch_score(d_seq.p, d_pairs.p, d_rows.p, d_out.p, n, h->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(scores, d_out.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+	d_seq.release(); d_pairs.release(); d_rows.release(); d_out.release();
+	if (e != hipSuccess) { set_err("cvx_score_batch: %s", hipGetErrorString(e)); return CVX_ERR_HIP; }
+	return CVX_OK;
+}
+
 int cvx_align_batch(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_result *results,
 		uint32_t *ops_arena, uint64_t ops_capacity, uint64_t *ops_used) {
 	cvx_batch b = nullptr;

@@ -1,0 +1,38 @@
+/*
+ * stripped_sw_hip.h -- IAlignment implementation of ngmlr's sub-read SCORING calls on the
+ * MI355X.  Takes the place of StrippedSW where ngmlr only scores:
+ * ScoreBuffer's aligner (reference src/CS.cpp:416, src/ScoreBuffer.cpp:124: BatchScore of
+ * up to 1024 (window, sub-read) pairs) and the SingleScore checks
+ * (src/AlignmentBuffer.cpp:1224-1225, :2538, src/ScoreBuffer.cpp:267).  Same return values as
+ * StrippedSW::BatchScore / SingleScore (src/StrippedSW.cpp:118-203); the alignment entry
+ * points throw, as this backend is score-only.
+ */
+#ifndef STRIPPED_SW_HIP_H
+#define STRIPPED_SW_HIP_H
+
+#include "ngmlr_abi.h"
+#include "cvx_align.h"
+
+class StrippedSWHip: public IAlignment {
+public:
+	explicit StrippedSWHip(int const deviceId = 0);
+	virtual ~StrippedSWHip();
+
+	virtual int GetScoreBatchSize() const { return 1024; }   /* src/StrippedSW.h:53-55 */
+	virtual int GetAlignBatchSize() const { return 1024; }
+
+	virtual int BatchScore(int const mode, int const batchSize, char const * const * const refSeqList,
+			char const * const * const qrySeqList, float * const results, void * extData);
+	virtual int SingleScore(int const mode, int const corridor, char const * const refSeq,
+			char const * const qrySeq, float & result, void * extData);
+	virtual int BatchAlign(int const, int const, char const * const * const, char const * const * const,
+			Align * const, void *) { throw "StrippedSWHip: score-only backend"; }
+	virtual int SingleAlign(int const, int const, char const * const, char const * const, Align &, void *) {
+		throw "StrippedSWHip: score-only backend";
+	}
+
+private:
+	cvx_handle handle;
+};
+
+#endif

@@ -132,3 +132,39 @@ def same_alignment(a: dict, b: dict, keys=COMPARE_KEYS) -> Optional[str]:
     if a["nm_per_position"].shape != b["nm_per_position"].shape or not np.array_equal(a["nm_per_position"], b["nm_per_position"]):
         return "nm_per_position"
     return None
+
+
+# ----------------------------------------------------------------- scoring path
+SCORE_PORT_SO = os.path.join(HERE, "libscore_oracle_port.so")
+SCORE_REF_SO = os.path.join(HERE, "_ref", "libscore_oracle_ref.so")
+
+
+def have_score_ref() -> bool:
+    return os.path.exists(SCORE_REF_SO)
+
+
+class ScoreOracle:
+    """StrippedSW::BatchScore checker.  kind: 'port' | 'reference'."""
+
+    def __init__(self, kind: str = "port"):
+        path = SCORE_PORT_SO if kind == "port" else SCORE_REF_SO
+        if not os.path.exists(path):
+            if kind == "port":
+                build("port")
+            else:
+                raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+        self.lib.score_oracle_create.restype = C.c_void_p
+        self.lib.score_oracle_destroy.argtypes = [C.c_void_p]
+        self.lib.score_oracle_kind.restype = C.c_char_p
+        self.lib.score_oracle_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p]
+        assert self.lib.score_oracle_kind().decode() == kind
+        self.h = C.c_void_p(self.lib.score_oracle_create())
+
+    def scores(self, refs, qrys) -> np.ndarray:
+        n = len(refs)
+        r = (C.c_char_p * n)(*refs)
+        q = (C.c_char_p * n)(*qrys)
+        out = np.zeros(n, dtype=np.float32)
+        self.lib.score_oracle_batch(self.h, n, r, q, out.ctypes.data)
+        return out

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "convex_align_hip.h"
+#include "stripped_sw_hip.h"
 
 static bool rd(FILE * f, void * p, size_t n) { return fread(p, 1, n, f) == n; }
 
@@ -119,6 +120,21 @@ int main(int argc, char ** argv) {
 			}
 		}
 		if (why) { bad++; fprintf(stderr, "tile %zu: %s (ret %d vs %d)\n", i, why, ret, r.ret); }
+	}
+	/* scoring calls of the same plugin surface: a perfect 40-mer scores 40,
+	 * an N column scores 0, too-long input scores -1 with return value 0 */
+	{
+		StrippedSWHip sw(0);
+		IAlignment * scorer = &sw;
+		char const * refs[2] = { "TTTTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTGGGG", "ACGTNACGT" };
+		char const * qrys[2] = { "ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT", "ACGTAACGT" };
+		float sc[2] = { 0, 0 };
+		if (scorer->BatchScore(0, 2, refs, qrys, sc, 0) != 2 || sc[0] != 40.0f || sc[1] != 8.0f) {
+			fprintf(stderr, "scoring shim: %f %f\n", sc[0], sc[1]);
+			bad++;
+		}
+		float one = 0;
+		if (scorer->SingleScore(0, 0, refs[0], qrys[0], one, 0) != 1 || one != 40.0f) bad++;
 	}
 	printf("shim_test: %zu tiles, %d valid, %d mismatches (%s)\n", recs.size(), valid, bad, batch ? "AlignTiles" : "SingleAlign");
 	delete aligner;
