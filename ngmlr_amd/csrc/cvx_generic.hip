@@ -137,8 +137,8 @@ fill_generic_kernel(const FillArgs a, uint8_t *scratch, const uint64_t *scratch_
 			(void) me;
 			st.dg = up.S;
 			st.cnt += 1;
-			st.accA = (st.accA << 1) | (code & 1u);
-			st.accB = (st.accB << 1) | (code >> 1);
+			st.accA = (st.accA << 1) | ((code == 1u || code == 2u) ? 1u : 0u);   /* plane 0: I or D */
+			st.accB = (st.accB << 1) | ((code & 1u));                            /* plane 1: I or diagonal */
 			if (flush) {
 				const int done = (step & 31) + 1;
 				uint32_t *d = dirs + ((size_t) (step >> 5) * Ng + s) * 2;

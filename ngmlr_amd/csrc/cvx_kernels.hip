@@ -221,7 +221,10 @@ CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int 
 		/* getDirection, src/AlignmentMatrixFast.cpp:185-195: outside -> STOP */
 		const bool in_row = inside && tt >= 0 && cx >= ol.x && cx < ol.x + ol.y;
 		const int bit = 31 - (ttc & 31);
-		unsigned code = ((w.x >> bit) & 1u) | (((w.y >> bit) & 1u) << 1);
+		/* plane 0: cell is a gap (I or D); plane 1: cell consumes a read base on the way
+		 * back (I or diagonal) */
+		const unsigned px = (w.x >> bit) & 1u, py = (w.y >> bit) & 1u;
+		unsigned code = px ? (py ? 1u : 2u) : (py ? 3u : 0u);
 		if (!in_row) code = 0u;
 
 		const u64 run = ballot(code == want);
@@ -462,7 +465,8 @@ fill_ring_kernel(const FillArgs a) {
 					const u64 c2 = isIu & eU;
 					const u64 nD = eL & (isDl | ~(c2 | eG)) & act;
 					const u64 nI = ~nD & eU & (isIu | ~eG) & act;
-					const u64 nG = eG & ~nD & ~nI & act;
+					const u64 gap = nD | nI;
+					const u64 nG = eG & ~gap & act;
 
 					/* outside the row the new "cell" is the empty element: score 0 */
 					const float sc = lanes(act) ? mx : 0.0f;
@@ -494,8 +498,8 @@ fill_ring_kernel(const FillArgs a) {
 					mD[j] = nD;
 					mI[j] = nI;
 					cnt[j] += 1;
-					accA[j] = shl1_in(accA[j], nI | nG);   /* code bit 0: I or diagonal */
-					accB[j] = shl1_in(accB[j], nD | nG);   /* code bit 1: D or diagonal */
+					accA[j] = shl1_in(accA[j], gap);       /* plane 0: I or D */
+					accB[j] = shl1_in(accB[j], nI | nG);   /* plane 1: I or diagonal */
 				}
 				r += 1;
 			}

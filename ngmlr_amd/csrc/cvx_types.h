@@ -17,12 +17,13 @@
  * Direction matrix layout.  The reference keeps 1 byte per corridor cell, row-major
  * (directionMatrix, src/AlignmentMatrixFast.h:261).  The device fill walks the
  * corridor by anti-diagonals r = x + y, holding read row y in ring slot s = y mod N
- * (slot s = thread * M + j).  A cell's 2-bit code (0 stop / outside, 1 insertion = up,
- * 2 deletion = left, 3 diagonal -- EQ or X is re-derived from the sequences) is kept
- * as two bit-plane words per slot per 32 steps: for step t = r - r0
+ * (slot s = thread * M + j).  A cell's direction (stop / outside, insertion = up,
+ * deletion = left, diagonal -- EQ or X is re-derived from the sequences) is kept as two
+ * bit-plane words per slot per 32 steps: for step t = r - r0
  *
  *      dword  dir_off + ((t >> 5) * N + s) * 2 + plane ,   bit 31 - (t & 31)
- *      plane 0 = code bit 0 (I or diagonal), plane 1 = code bit 1 (D or diagonal)
+ *      plane 0 = "gap" (I or D), plane 1 = "consumes a read base" (I or diagonal)
+ *      (1,0) deletion, (1,1) insertion, (0,1) diagonal, (0,0) stop
  *
  * The fill shifts the per-step lane masks of the recurrence into the words with one
  * add-with-carry each; a lane stores its 2*M words every 32 steps (coalesced), and the
