@@ -160,11 +160,24 @@ def main() -> int:
     parity = None
     cpu = None
     valid = None
+    text_stage = None
     if rank == 0:
         got = batch.alignments(want_nm=False)
         valid = sum(1 for g in got if g["ret"] >= 0)
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(tiles, args.cpu_seconds)
+        # host text stage (CIGAR/MD/NM/profile) on a sample, all host threads: reported
+        # beside `value`, never part of it
+        try:
+            k = min(len(tiles), 2048)
+            sub = al.upload(tiles[:k])
+            sub.run()
+            dtxt, _, _ = sub.format_batch(n_threads=0, want_nm=True)
+            sub.free()
+            text_stage = {"Gbp_per_h": sum(t.H for t in tiles[:k]) / dtxt * 3600.0 / 1e9, "seconds": dtxt,
+                          "tiles": k, "threads": os.cpu_count(), "what": "cvx_format_batch: CIGAR + MD + NM + per-position profile"}
+        except Exception as e:  # never let the extra measurement break the contract line
+            text_stage = {"error": str(e)}
             from oracle.pyoracle import same_alignment
             chk = cpu.pop("_check")
             ok = sum(1 for i, want in enumerate(chk) if same_alignment(
@@ -235,6 +248,7 @@ def main() -> int:
             "valid_alignments": "%d/%d" % (valid, len(tiles)) if valid is not None else None,
             "parity": parity,
             "cpu_baseline": cpu,
+            "text_stage_host": text_stage,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -197,6 +197,22 @@ int cvx_format_alignment(const cvx_result *r, const uint32_t *ops_arena,
 		char *cigar, int32_t cigar_cap, char *md, int32_t md_cap,
 		int32_t *nm_triples, int32_t nm_cap, cvx_alignment_text *out);
 
+/* The same for a whole batch on `n_threads` host threads (once the fill is on
+ * the GPU, text generation is the serial tail).  tiles[i] supplies ref/ref_len/qry_len;
+ * bufs[i] the caller's per-tile output buffers (any pointer may be NULL with capacity 0).
+ * n_threads <= 0 picks the hardware concurrency.  Returns the first error, else CVX_OK. */
+typedef struct {
+	char *cigar;
+	char *md;
+	int32_t *nm_triples;
+	int32_t cigar_cap, md_cap, nm_cap;
+	int32_t ext_qstart, ext_qend;
+} cvx_text_buffers;
+
+int cvx_format_batch(int32_t n, const cvx_result *results, const uint32_t *ops_arena,
+		const cvx_tile *tiles, const cvx_text_buffers *bufs, cvx_alignment_text *out,
+		int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

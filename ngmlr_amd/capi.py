@@ -20,7 +20,7 @@ TILE_STATUS = {0: "ok", 1: "invalid-row0", 2: "invalid-edge", 3: "invalid-length
 
 EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_create", "cvx_destroy",
            "cvx_align_batch", "cvx_batch_upload", "cvx_batch_run", "cvx_batch_timing",
-           "cvx_batch_ops_total", "cvx_batch_launch_info", "cvx_batch_download", "cvx_batch_free", "cvx_format_alignment", "cvx_score_batch")
+           "cvx_batch_ops_total", "cvx_batch_launch_info", "cvx_batch_download", "cvx_batch_free", "cvx_format_alignment", "cvx_format_batch", "cvx_score_batch")
 
 
 class CvxParams(C.Structure):
@@ -62,6 +62,12 @@ class CvxAlignmentText(C.Structure):
                 ("md_len", C.c_int32)]
 
 
+class CvxTextBuffers(C.Structure):
+    _fields_ = [("cigar", C.c_void_p), ("md", C.c_void_p), ("nm_triples", C.c_void_p),
+                ("cigar_cap", C.c_int32), ("md_cap", C.c_int32), ("nm_cap", C.c_int32),
+                ("ext_qstart", C.c_int32), ("ext_qend", C.c_int32)]
+
+
 class CvxError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__("%s: %s" % (ERR_NAMES.get(code, str(code)), msg))
@@ -98,6 +104,8 @@ def load() -> C.CDLL:
                                        C.c_uint64, C.POINTER(C.c_uint64)]
     lib.cvx_batch_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.cvx_batch_free.restype = None
+    lib.cvx_format_batch.argtypes = [C.c_int32, C.POINTER(CvxResult), C.c_void_p, C.POINTER(CvxTile),
+                                     C.POINTER(CvxTextBuffers), C.POINTER(CvxAlignmentText), C.c_int32]
     lib.cvx_score_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p]
     lib.cvx_format_alignment.argtypes = [C.POINTER(CvxResult), C.c_void_p, C.c_char_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,

@@ -182,3 +182,38 @@ extern "C" int cvx_format_alignment(const cvx_result *r, const uint32_t *ops_are
 	out->sv_type = sv;
 	return CVX_OK;
 }
+
+/* ---- batch form: a parallel-for over tiles (dynamic chunks of 16) ---- */
+#include <atomic>
+#include <thread>
+#include <vector>
+
+extern "C" int cvx_format_batch(int32_t n, const cvx_result *results, const uint32_t *ops_arena,
+		const cvx_tile *tiles, const cvx_text_buffers *bufs, cvx_alignment_text *out,
+		int32_t n_threads) {
+	if (n < 0 || (n > 0 && (!results || !tiles || !bufs || !out))) return CVX_ERR_ARG;
+	if (n == 0) return CVX_OK;
+	int nt = n_threads > 0 ? n_threads : (int) std::thread::hardware_concurrency();
+	if (nt < 1) nt = 1;
+	if (nt > (n + 15) / 16) nt = (n + 15) / 16;
+	std::atomic<int> next(0), err(CVX_OK);
+	auto work = [&]() {
+		for (;;) {
+			const int b = next.fetch_add(16);
+			if (b >= n) break;
+			const int e = b + 16 < n ? b + 16 : n;
+			for (int i = b; i < e; ++i) {
+				const cvx_text_buffers &tb = bufs[i];
+				const int rc = cvx_format_alignment(&results[i], ops_arena, tiles[i].ref, tiles[i].ref_len,
+						tiles[i].qry_len, tb.ext_qstart, tb.ext_qend, tb.cigar, tb.cigar_cap, tb.md, tb.md_cap,
+						tb.nm_triples, tb.nm_cap, &out[i]);
+				if (rc != CVX_OK) { int ok = CVX_OK; err.compare_exchange_strong(ok, rc); }
+			}
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < nt; ++t) th.emplace_back(work);
+	work();
+	for (auto &t : th) t.join();
+	return err.load();
+}

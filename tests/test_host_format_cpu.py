@@ -73,3 +73,52 @@ def test_text_truncation_reports_full_length(port_oracle):
     assert capi.load().cvx_format_alignment(C.byref(r), ops.ctypes.data, t.ref, t.W, t.H, t.ext_qstart, t.ext_qend, cig, 8, md, 8, None, 0, C.byref(txt)) == 0
     assert txt.cigar_len == len(want["cigar"]) and txt.md_len == len(want["md"])
     assert cig.value == want["cigar"][:7].encode()
+
+
+def test_threaded_batch_text_stage_equals_single_calls(port_oracle):
+    """cvx_format_batch (threaded host text stage) == cvx_format_alignment per tile."""
+    from ngmlr_amd import capi
+    lib = capi.load()
+    tiles = [t for t in util.tile_zoo(seed=55, n=70, max_w=1500)]
+    res = (capi.CvxResult * len(tiles))()
+    arena = []
+    want = []
+    for i, t in enumerate(tiles):
+        w = port_oracle.align(t)
+        want.append(w)
+        if w["ret"] < 0:
+            res[i].status = 2
+            continue
+        f, ops = port_oracle.last_fwd(), port_oracle.last_ops()
+        res[i].status = 0
+        res[i].score = w["score"]
+        res[i].ref_position, res[i].qstart, res[i].qend = f["ref_position"], f["qstart"], f["qend"]
+        res[i].n_ops = len(ops)
+        res[i].ops_begin = sum(len(a) for a in arena)
+        arena.append(ops)
+    ops_all = np.concatenate(arena).astype(np.uint32)
+    ct = (capi.CvxTile * len(tiles))()
+    bufs = (capi.CvxTextBuffers * len(tiles))()
+    keep = []
+    for i, t in enumerate(tiles):
+        ct[i].ref, ct[i].qry, ct[i].ref_len, ct[i].qry_len = t.ref, t.qry, t.W, t.H
+        cap = 4 * t.H + 64
+        cig, md = C.create_string_buffer(cap), C.create_string_buffer(cap)
+        nm = np.zeros((2 * (t.H + 1) + t.W + 16, 3), dtype=np.int32)
+        keep.append((cig, md, nm))
+        bufs[i].cigar, bufs[i].md, bufs[i].nm_triples = C.addressof(cig), C.addressof(md), nm.ctypes.data
+        bufs[i].cigar_cap = bufs[i].md_cap = cap
+        bufs[i].nm_cap = len(nm)
+        bufs[i].ext_qstart, bufs[i].ext_qend = t.ext_qstart, t.ext_qend
+    out = (capi.CvxAlignmentText * len(tiles))()
+    for threads in (1, 4):
+        assert lib.cvx_format_batch(len(tiles), res, ops_all.ctypes.data, ct, bufs, out, threads) == 0
+        for i, t in enumerate(tiles):
+            w = want[i]
+            if w["ret"] < 0:
+                assert out[i].ret == -1
+                continue
+            assert out[i].ret == w["ret"] and keep[i][0].value.decode() == w["cigar"] and keep[i][1].value.decode() == w["md"]
+            assert out[i].nm == w["nm"] and out[i].position_offset == w["position_offset"]
+            n = w["alignment_length"]
+            assert np.array_equal(keep[i][2][:n], w["nm_per_position"])
