@@ -178,6 +178,7 @@ def main() -> int:
                           "tiles": k, "threads": os.cpu_count(), "what": "cvx_format_batch: CIGAR + MD + NM + per-position profile"}
         except Exception as e:  # never let the extra measurement break the contract line
             text_stage = {"error": str(e)}
+        if cpu is not None:
             from oracle.pyoracle import same_alignment
             chk = cpu.pop("_check")
             ok = sum(1 for i, want in enumerate(chk) if same_alignment(

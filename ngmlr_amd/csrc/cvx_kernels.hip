@@ -167,8 +167,7 @@ CVX_DEV bool valid_path(const int off, const int width, int x) {
  */
 CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int r0, const int ops_cap,
 		const int2 *rows, const uint2 *dirs, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
-	/* the argmax may arrive in VGPRs (fused call after a lane reduction): make the walk's
-	 * state provably wave-uniform so that it runs on scalar branches */
+	/* make the walk's state provably wave-uniform so that it runs on scalar branches */
 	const int best_x = __builtin_amdgcn_readfirstlane(o.best_x);
 	const int best_y = __builtin_amdgcn_readfirstlane(o.best_y);
 	/* src/ConvexAlignFast.cpp:338 */
@@ -271,6 +270,34 @@ CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int 
 		if (H != consumed) status = 3;
 	}
 	o.status = status;
+}
+
+
+/* first cell of the tile in (y, x) order: *fy = -1 when no row has a cell inside [0, W).
+ * Rare path (a tile without any positive score), run by backtrack_kernel. */
+CVX_DEV void first_cell(const int2 *rows, int H, int W, int lane, int *fy, int *fx) {
+	*fy = -1;
+	*fx = 0;
+	for (int y0 = 0; y0 < H; y0 += 64) {
+		const int yy = y0 + lane;
+		bool has = false;
+		int lo_i = 0;
+		if (yy < H) {
+			const int2 ol = rows[yy];
+			long long lo = ol.x > 0 ? ol.x : 0;
+			long long hi = (long long) ol.x + (long long) ol.y;
+			if (hi > W) hi = W;
+			has = hi > lo;
+			lo_i = (int) lo;
+		}
+		const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+		if (m != 0ull) {
+			const int l = __builtin_ctzll(m);
+			*fy = y0 + l;
+			*fx = __builtin_amdgcn_readlane(lo_i, l);
+			return;
+		}
+	}
 }
 
 template <bool WRAP> struct RunT { typedef float type; };
@@ -384,7 +411,7 @@ fill_ring_kernel(const FillArgs a) {
 			s_besty[j][tid] = 0;
 			S[j] = 0.0f; Hc[j] = go; V[j] = go; dg[j] = 0.0f;
 			drun[j] = 0; irun[j] = 0;
-			best[j] = -1.0f; best_r[j] = 0;
+			best[j] = 0.0f; best_r[j] = 0;
 			accA[j] = accB[j] = 0u;
 			mD[j] = 0; mI[j] = 0;
 			bind_row(j, tr.r0);
@@ -466,7 +493,9 @@ fill_ring_kernel(const FillArgs a) {
 					const u64 nD = eL & (isDl | ~(c2 | eG)) & act;
 					const u64 nI = ~nD & eU & (isIu | ~eG) & act;
 					const u64 gap = nD | nI;
-					const u64 nG = eG & ~gap & act;
+					/* plane 1 = nI | nG with nG = eG & ~gap & act; the act term is dropped: direction
+					 * bits of cells outside a row are never read (backtrack_walk masks them) */
+					const u64 cread = nI | (eG & ~nD);
 
 					/* outside the row the new "cell" is the empty element: score 0 */
 					const float sc = lanes(act) ? mx : 0.0f;
@@ -483,9 +512,12 @@ fill_ring_kernel(const FillArgs a) {
 						runf = (float) nd + (float) ni;   /* one of them is 0: exact */
 					}
 					const float pen = fminf(gem, gext + runf * decay);
-					const float E = (sc == 0.0f) ? 0.0f : sc + pen;   /* :669-675 */
+					/* :669-675  E = (score == 0) ? 0 : score + pen.  score >= 0 and pen < 0, so this is
+					 * max(score + pen, score * -2^100): -0 for score 0 (compares equal to the reference's
+					 * +0 and never reaches an output), score + pen otherwise. */
+					const float E = fmaxf(sc + pen, sc * -0x1p100f);
 					const float O = sc + go;
-					const u64 better = ballot(mx > best[j]) & act;
+					const u64 better = ballot(sc > best[j]);   /* sc is 0 outside the row, best >= 0 */
 
 					dg[j] = uS;
 					S[j] = sc;
@@ -499,7 +531,7 @@ fill_ring_kernel(const FillArgs a) {
 					mI[j] = nI;
 					cnt[j] += 1;
 					accA[j] = shl1_in(accA[j], gap);       /* plane 0: I or D */
-					accB[j] = shl1_in(accB[j], nI | nG);   /* plane 1: I or diagonal */
+					accB[j] = shl1_in(accB[j], cread);     /* plane 1: I or diagonal */
 				}
 				r += 1;
 			}
@@ -508,7 +540,7 @@ fill_ring_kernel(const FillArgs a) {
 			 * by the row below one step after it was computed, so wait for cnt > len */
 #pragma unroll
 			for (int j = 0; j < M; ++j) {
-				if (cnt[j] > len[j] && cnt[j] < (1 << 29)) {     /* finished a real row */
+				if (cnt[j] > len[j]) {     /* finished a real row (unbound slots count up from -2^30) */
 					const int yy = s_y[j][tid];
 					if (best_r[j] >= r - cnt[j]) s_besty[j][tid] = yy;
 					s_y[j][tid] = yy + N;
@@ -537,7 +569,7 @@ fill_ring_kernel(const FillArgs a) {
 			if (s_y[j][tid] < H && best_r[j] >= r - cnt[j]) vy = s_y[j][tid];
 			const float v = best[j];
 			const int vx = best_r[j] - vy;
-			if (v > -1.0f) {
+			if (v > 0.0f) {     /* best[] starts at 0: a slot that never saw a positive score has no candidate */
 				if (v > b || (v == b && (vy < by || (vy == by && vx < bx)))) { b = v; by = vy; bx = vx; }
 			}
 		}
@@ -560,11 +592,9 @@ fill_ring_kernel(const FillArgs a) {
 				}
 			}
 		}
-		/* backtrack right here, by wave 0, while the other waves of the SIMD keep filling
-		 * their tiles: the walk is a chain of HBM round trips and costs them almost nothing */
 		if (NW > 1) {
 			if (tid == 0) { s_rbest[0] = b; s_ry[0] = by; s_rx[0] = bx; }
-			__syncthreads();       /* also orders every wave's direction stores before the walk */
+			__syncthreads();
 			b = s_rbest[0]; by = s_ry[0]; bx = s_rx[0];
 		}
 		/* wave-uniform copies (after the reductions every lane of wave 0 holds the same
@@ -573,35 +603,23 @@ fill_ring_kernel(const FillArgs a) {
 		by = __builtin_amdgcn_readfirstlane(by);
 		bx = __builtin_amdgcn_readfirstlane(bx);
 		if (wave == 0) {
+			/* b == -1: no positive score anywhere.  The reference (curr_max starts at -1) then takes
+			 * the first cell in (y, x) order, score 0; backtrack_kernel resolves that rare case. */
 			TileOut o;
 			o.score = b;
-			o.status = (b > -1.0f) ? 0 : 5;
+			o.status = 0;
 			o.best_x = (b > -1.0f) ? bx : 0;
 			o.best_y = (b > -1.0f) ? by : 0;
 			o.ref_position = 0; o.qstart = 0; o.qend = 0; o.n_ops = 0; o.ops_first = 0;
-#ifndef CVX_FUSE_BT
-#define CVX_FUSE_BT 0      /* 0: never (default), 1: single-wave tiles, 2: all ring tiles.
-                            * EXPERIMENTAL: the in-kernel walk hangs on gfx950/ROCm 7.2 (the persistent
-                            * tile loop gets restructured as a divergent loop); kept for round 2 */
-#endif
-			const bool fuse = (CVX_FUSE_BT == 2) || (CVX_FUSE_BT == 1 && NW == 1);
-			o.pad = fuse ? 1 : 0;  /* 1 = backtracked here: the stand-alone kernel skips this tile */
-			if (fuse && o.status == 0) {
-				__builtin_amdgcn_s_waitcnt(0);          /* own direction stores have landed */
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#if defined(CVX_DBG_BT) && CVX_DBG_BT == 1
-				if (false)
-#endif
-				backtrack_walk(lane, H, N, tr.r0, tr.ops_cap, rows,
-						reinterpret_cast<const uint2 *>(dirs), seq + ti.ref_off, seq + ti.qry_off,
-						a.ops + tr.ops_off, o);
-			}
+			/* pad = 0: not backtracked yet.  (Walking the tile right here, inside the persistent loop,
+			 * was measured slower: the walking wave holds one of the SIMD's six fill slots) */
+			o.pad = 0;
 			if (lane == 0) a.tout[t] = o;
 		}
 	}
 }
 
-/* stand-alone form (tiles filled by the catch-all kernel): one wave per tile */
+/* one wave per tile, after every fill launch of the batch has finished */
 __global__ void __launch_bounds__(64)
 backtrack_kernel(const BacktrackArgs a) {
 	const int t = blockIdx.x;
@@ -612,6 +630,19 @@ backtrack_kernel(const BacktrackArgs a) {
 	const TileIn ti = a.tin[t];
 	TileOut o = a.tout[t];
 	if (o.status != 0 || o.pad != 0) return;
+	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off;
+	if (!(o.score > 0.0f)) {
+		/* no positive score: the reference's best cell is the first cell in (y, x) order with
+		 * score 0 (curr_max starts at -1, src/ConvexAlignFast.cpp:758-763) */
+		int fy, fx;
+		first_cell(rows, ti.H, ti.W, lane, &fy, &fx);
+		if (fy < 0) {
+			o.score = -1.0f; o.status = 5; o.pad = 1;
+			if (lane == 0) a.tout[t] = o;
+			return;
+		}
+		o.score = 0.0f; o.best_x = fx; o.best_y = fy;
+	}
 	backtrack_walk(lane, ti.H, tr.ring, tr.r0, tr.ops_cap,
 			reinterpret_cast<const int2 *>(a.rows) + ti.row_off,
 			reinterpret_cast<const uint2 *>(a.dirs + tr.dir_off),

@@ -6,5 +6,5 @@ HERE="$(cd "$(dirname "$0")/.." && pwd)"
 mkdir -p "$HERE/ngmlr_amd/variants" /tmp/cvx_variant_$1
 cd "$HERE/ngmlr_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-honor-nans -fPIC -I../../include -I. $2 -c cvx_kernels.hip -o /tmp/cvx_variant_$1/k.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$HERE/ngmlr_amd/variants/libcvxalign_$1.so" /tmp/cvx_variant_$1/k.o build/cvx_generic.o build/cvx_runtime.o build/cvx_format.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$HERE/ngmlr_amd/variants/libcvxalign_$1.so" /tmp/cvx_variant_$1/k.o $(ls build/*.o | grep -v cvx_kernels.o) -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 echo built $1
