@@ -89,7 +89,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tiles", type=int, default=12288, help="tiles per GPU per step (>= 2 full rounds of resident waves)")
+    ap.add_argument("--tiles", type=int, default=24576, help="tiles per GPU per step (4 rounds of the 6144 resident fill waves; ~21 GB of direction words)")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,8 +162,10 @@ def main() -> int:
     valid = None
     text_stage = None
     if rank == 0:
-        got = batch.alignments(want_nm=False)
-        valid = sum(1 for g in got if g["ret"] >= 0)
+        from ngmlr_amd.aligner import format_alignment
+        res, ops = batch.download()
+        valid = sum(1 for i in range(len(tiles)) if res[i].status == 0)
+        got = [format_alignment(al.lib, res[i], ops, tiles[i], False) for i in range(min(4, len(tiles)))]
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(tiles, args.cpu_seconds)
         # host text stage (CIGAR/MD/NM/profile) on a sample, all host threads: reported

@@ -619,23 +619,37 @@ fill_ring_kernel(const FillArgs a) {
 	}
 }
 
-/* one wave per tile, after every fill launch of the batch has finished */
-__global__ void __launch_bounds__(64)
-backtrack_kernel(const BacktrackArgs a) {
-	const int t = blockIdx.x;
-	if (t >= a.n_tiles) return;
-	const int lane = threadIdx.x;
-	const TileRun tr = a.trun[t];
-	if (tr.skip) return;
-	const TileIn ti = a.tin[t];
-	TileOut o = a.tout[t];
+/* A tile record read by a whole wave: lane i fetches dword i, fields come back as SGPRs
+ * through v_readlane: three VGPRs instead of one per field. */
+CVX_DEV int rec_load(const void *rec, const int n_dwords, const int lane) {
+	return lane < n_dwords ? reinterpret_cast<const int *>(rec)[lane] : 0;
+}
+CVX_DEV int fld(const int w, const int k) { return __builtin_amdgcn_readlane(w, k); }
+CVX_DEV unsigned long long fld64(const int w, const int k) {
+	return ((unsigned long long) (unsigned) fld(w, k + 1) << 32) | (unsigned) fld(w, k);
+}
+
+/* backtrack of one tile by one wave (nothing to do for skipped, invalid or already walked tiles) */
+CVX_DEV void walk_tile(const BacktrackArgs &a, const int t, const int lane) {
+	static_assert(sizeof(TileRun) == 40 && sizeof(TileIn) == 32 && sizeof(TileOut) == 40, "record layout");
+	const int wr = rec_load(a.trun + t, 10, lane);   /* dir_off 0-1, ops_off 2-3, ring 4, ops_cap 5, r0 6, nsteps 7, skip 8 */
+	const int wo = rec_load(a.tout + t, 10, lane);   /* score 0, status 1, best_x 2, best_y 3, ..., pad 9 */
+	if (fld(wr, 8) != 0) return;
+	TileOut o;
+	o.score = __int_as_float(fld(wo, 0));
+	o.status = fld(wo, 1);
+	o.best_x = fld(wo, 2); o.best_y = fld(wo, 3);
+	o.ref_position = 0; o.qstart = 0; o.qend = 0; o.n_ops = 0; o.ops_first = 0;
+	o.pad = fld(wo, 9);
 	if (o.status != 0 || o.pad != 0) return;
-	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off;
+	const int wi = rec_load(a.tin + t, 8, lane);     /* ref_off 0, qry_off 1, W 2, H 3, row_off 4-5 */
+	const int H = fld(wi, 3), W = fld(wi, 2);
+	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + fld64(wi, 4);
 	if (!(o.score > 0.0f)) {
 		/* no positive score: the reference's best cell is the first cell in (y, x) order with
 		 * score 0 (curr_max starts at -1, src/ConvexAlignFast.cpp:758-763) */
 		int fy, fx;
-		first_cell(rows, ti.H, ti.W, lane, &fy, &fx);
+		first_cell(rows, H, W, lane, &fy, &fx);
 		if (fy < 0) {
 			o.score = -1.0f; o.status = 5; o.pad = 1;
 			if (lane == 0) a.tout[t] = o;
@@ -643,14 +657,24 @@ backtrack_kernel(const BacktrackArgs a) {
 		}
 		o.score = 0.0f; o.best_x = fx; o.best_y = fy;
 	}
-	backtrack_walk(lane, ti.H, tr.ring, tr.r0, tr.ops_cap,
-			reinterpret_cast<const int2 *>(a.rows) + ti.row_off,
-			reinterpret_cast<const uint2 *>(a.dirs + tr.dir_off),
-			a.seq + ti.ref_off, a.seq + ti.qry_off, a.ops + tr.ops_off, o);
+	backtrack_walk(lane, H, fld(wr, 4), fld(wr, 6), fld(wr, 5), rows,
+			reinterpret_cast<const uint2 *>(a.dirs + fld64(wr, 0)),
+			a.seq + (unsigned) fld(wi, 0), a.seq + (unsigned) fld(wi, 1),
+			a.ops + fld64(wr, 2), o);
 	o.pad = 1;
 	if (lane == 0) a.tout[t] = o;
 }
 
+/* one wave per tile, after every fill launch of the batch has finished.  (Walkers running
+ * BESIDE the fill, in the two wave slots per SIMD it leaves free, were tried: the fill slowed
+ * down by as much as the backtrack took -- both phases are bound by instruction issue,
+ * DESIGN.md 5.) */
+__global__ void __launch_bounds__(64)
+backtrack_kernel(const BacktrackArgs a) {
+	const int t = blockIdx.x;
+	if (t >= a.n_tiles) return;
+	walk_tile(a, t, threadIdx.x);
+}
 
 /* dense[dst_off[t] .. +n_ops) = region of tile t */
 __global__ void __launch_bounds__(256)

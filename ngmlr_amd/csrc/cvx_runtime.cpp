@@ -457,7 +457,6 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		const int grid = std::min(a.list_n, h->num_cus * per_cu);
 		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, a, grid, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2 + 1], ls));
-		HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) launches * 2 + 1], 0));
 		launches++;
 	}
 	if (!generic.empty()) {
@@ -494,9 +493,9 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		a.sp = h->sp;
 		HIP_TRY(launch_fill_generic(a, b->d_gscratch.p, b->d_gscratch_off.p, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2 + 1], ls));
-		HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) launches * 2 + 1], 0));
 		launches++;
 	}
+	for (int i = 0; i < launches; ++i) HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) i * 2 + 1], 0));
 	HIP_TRY(hipEventRecord(b->ev[2], st));
 
 	/* ---- backtrack + ops compaction */
@@ -509,7 +508,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	ba.dirs = b->d_dirs.p;
 	ba.ops = b->d_regions.p;
 	ba.n_tiles = n;
-	HIP_TRY(launch_backtrack(ba, st));   /* only tiles the fill kernels did not backtrack in place */
+	HIP_TRY(launch_backtrack(ba, st));
 	HIP_TRY(hipMemcpyAsync(b->tout.data(), b->d_tout.p, (size_t) n * sizeof(TileOut), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	b->dst_off.assign((size_t) n, 0);

@@ -105,7 +105,7 @@ struct FillArgs {
 	const int32_t *list;   /* tile indices of this kernel class, largest first */
 	int32_t list_n;
 	int32_t *queue_head;   /* work-queue cursor (zeroed before launch) */
-	int32_t *ops;          /* per-tile op regions (the fill kernels backtrack their own tiles) */
+	int32_t *ops;          /* per-tile op regions */
 	ScoreParams sp;
 };
 
