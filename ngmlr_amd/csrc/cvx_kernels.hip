@@ -148,11 +148,17 @@ CVX_DEV unsigned shl1_in(unsigned acc, u64 m) {
 /* ------------------------------------------------------------------ backtrack */
 
 /* validPath, src/AlignmentMatrixFast.cpp:213-220: float arithmetic, int truncation,
- * no contraction. */
-CVX_DEV bool valid_path(const int off, const int width, int x) {
-	const int minC = (int) ((float) off + 0.1f * (float) width);
-	const int maxC = (int) ((float) (minC + width) - 0.1f * (float) width);
-	return x > minC && x < maxC;
+ * no contraction.  A cell (x, row) is valid iff minC < x < maxC. */
+CVX_DEV void valid_bounds(const int off, const int width, int &minC, int &maxC) {
+	minC = (int) ((float) off + 0.1f * (float) width);
+	maxC = (int) ((float) (minC + width) - 0.1f * (float) width);
+}
+
+/* direction code of bit `bit` of a plane pair: plane 0 = gap (I or D), plane 1 = the cell
+ * consumes a read base on the way back (I or diagonal) */
+CVX_DEV unsigned plane_code(const unsigned wx, const unsigned wy, const int bit) {
+	const unsigned px = (wx >> bit) & 1u, py = (wy >> bit) & 1u;
+	return px ? (py ? 1u : 2u) : (py ? 3u : 0u);
 }
 
 /*
@@ -160,10 +166,12 @@ CVX_DEV bool valid_path(const int off, const int width, int x) {
  * a chain of runs (diagonal runs broken by short gaps); instead of one dependent load per
  * cell, the 64 lanes probe the next 64 cells along the current direction at once (lane i
  * looks at the i-th cell back), a ballot finds how far the run goes, and the walk jumps to
- * its end.  A 10-kb PacBio tile is ~3 000 probes instead of ~20 000 dependent steps.
- * Every probe is four coalesced loads (corridor rows, plane words, both sequences).  The
- * walk state is wave-uniform; lane 0 writes the run-length ops.  `o` carries the argmax
- * in (score, best_x, best_y) and returns the FwdResults.
+ * its end.  Every probe is four coalesced loads (corridor rows, plane words, both sequences).
+ * The gap that ends a diagonal run is then resolved from the SAME probe whenever the words
+ * already in registers cover it (a deletion run lies in one lane's word, an insertion run in
+ * the words of the following lanes), so a 10-kb PacBio tile costs ~1 500 probes instead of
+ * ~20 000 dependent steps.  The walk state is wave-uniform; lane 0 writes the run-length ops.
+ * `o` carries the argmax in (score, best_x, best_y) and returns the FwdResults.
  */
 CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int r0, const int ops_cap,
 		const int2 *rows, const uint2 *dirs, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
@@ -172,9 +180,6 @@ CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int 
 	const int best_y = __builtin_amdgcn_readfirstlane(o.best_y);
 	/* src/ConvexAlignFast.cpp:338 */
 	if (best_y <= 0) { o.status = 1; return; }
-#if defined(CVX_DBG_BT) && CVX_DBG_BT == 2
-	if (best_y > 0) { o.status = 1; return; }
-#endif
 
 	const int qend = (H - best_y) - 1;
 	int idx = ops_cap - 1;
@@ -203,9 +208,6 @@ CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int 
 	int budget = 2 * (best_x + best_y) + 8;
 	for (;;) {
 		if (--budget < 0) { status = 3; break; }
-#if defined(CVX_DBG_BT) && CVX_DBG_BT == 3
-		if (budget >= 0) { status = 3; break; }
-#endif
 		const int dx = (want != 1u) ? 1 : 0, dy = (want != 2u) ? 1 : 0;
 		const int cx = x - lane * dx, cy = y - lane * dy;
 		const bool inside = (cx >= 0 && cy >= 0);
@@ -217,24 +219,23 @@ CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int 
 		const int2 ol = rows[ly];
 		const uint2 w = dirs[(size_t) (ttc >> 5) * N + sl];
 		const int rc = ref[lx], qc = qry[ly];
+		/* used by every probe on purpose: keeps all four loads in one round trip */
+		const u64 eqm = ballot(rc == qc);
 		/* getDirection, src/AlignmentMatrixFast.cpp:185-195: outside -> STOP */
 		const bool in_row = inside && tt >= 0 && cx >= ol.x && cx < ol.x + ol.y;
-		const int bit = 31 - (ttc & 31);
-		/* plane 0: cell is a gap (I or D); plane 1: cell consumes a read base on the way
-		 * back (I or diagonal) */
-		const unsigned px = (w.x >> bit) & 1u, py = (w.y >> bit) & 1u;
-		unsigned code = px ? (py ? 1u : 2u) : (py ? 3u : 0u);
+		unsigned code = plane_code(w.x, w.y, 31 - (ttc & 31));
 		if (!in_row) code = 0u;
+		int minC, maxC;
+		valid_bounds(ol.x, ol.y, minC, maxC);
 
 		const u64 run = ballot(code == want);
 		const int L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);   /* cells of this run */
 		const u64 low = (L == 64) ? ~0ull : ((1ull << L) - 1ull);
 		/* every visited cell must pass validPath before the move (:368-373) */
-		const u64 vp = ballot(valid_path(ol.x, ol.y, cx));
+		const u64 vp = ballot(cx > minC && cx < maxC);
 		if ((~vp & low) != 0ull) { status = 2; break; }
 
 		if (want == 3u) {
-			const u64 eqm = ballot(rc == qc);
 			int pos = 0;
 			while (pos < L) {
 				const int isq = (int) ((eqm >> pos) & 1ull);
@@ -253,10 +254,58 @@ CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int 
 			x -= L;
 		}
 		if (want != 2u) { s -= L; if (s < 0) s += N; }
-		if (L < 64) {
-			const unsigned nxt = (unsigned) __builtin_amdgcn_readlane((int) code, L);
-			if (nxt == 0u) break;     /* CIGAR_STOP (or outside the matrix) */
-			want = nxt;
+		if (L == 64) continue;
+		const unsigned nxt = (unsigned) __builtin_amdgcn_readlane((int) code, L);
+		if (nxt == 0u) break;     /* CIGAR_STOP (or outside the matrix) */
+		if (want != 3u) { want = nxt; continue; }
+
+		/* A diagonal run ended in a gap at (x, y) = lane L's cell.  Follow the gap run inside the
+		 * words this probe already holds; whatever they do not cover goes to the next probe. */
+		const int tp = x + y - r0;                       /* step index of (x, y), >= 0 inside a row */
+		if (nxt == 2u) {
+			/* deletion run: same row, earlier steps = higher bits of lane L's word */
+			const unsigned wx = (unsigned) __builtin_amdgcn_readlane((int) w.x, L);
+			const unsigned wy = (unsigned) __builtin_amdgcn_readlane((int) w.y, L);
+			const int row_lo = max(__builtin_amdgcn_readlane(ol.x, L), 0);
+			const int b0 = 31 - (tp & 31);
+			const unsigned dm = (wx & ~wy) >> b0;        /* bit k: cell (x - k, y) is D; bit 0 is set */
+			int Ld = (~dm == 0u) ? 32 : __builtin_ctz(~dm);   /* <= 32 - b0: the shift filled in zeros */
+			const int in_word = 32 - b0;
+			const int in_rowc = x - row_lo + 1;          /* cells down to the start of the row */
+			if (Ld > in_rowc) Ld = in_rowc;
+			const int rminC = __builtin_amdgcn_readlane(minC, L), rmaxC = __builtin_amdgcn_readlane(maxC, L);
+			if (!(x - (Ld - 1) > rminC && x < rmaxC)) { status = 2; break; }
+			emit(2, Ld);
+			x -= Ld;
+			if (Ld == in_rowc) break;                    /* next cell is left of the row: STOP */
+			if (Ld == in_word) { want = 2u; continue; }  /* the run may go on in the previous word */
+			const unsigned c2 = plane_code(wx, wy, b0 + Ld);
+			if (c2 == 0u) break;
+			want = c2;
+		} else {
+			/* insertion run: same column, cell k is in lane L+k's row and slot; it is step tp - k,
+			 * which that lane's word covers unless a 32-step boundary lies in between */
+			const int k = lane - L;
+			const int tn = tp - k;
+			const bool have = (k >= 0) && (cy >= 0) && (tn >= 0) && ((tn >> 5) == (ttc >> 5));
+			const bool col_in = (x >= ol.x) && (x < ol.x + ol.y);
+			unsigned c2 = plane_code(w.x, w.y, 31 - (tn & 31));
+			if (!col_in) c2 = 0u;
+			const u64 im = ballot(have && c2 == 1u) >> L;       /* bit k: cell (x, y - k) is I; bit 0 is set */
+			const int Li = (~im == 0ull) ? 64 : __builtin_ctzll(~im);   /* <= 64 - L */
+			const u64 ilow = (Li == 64) ? ~0ull : ((1ull << Li) - 1ull);
+			const u64 vpi = ballot(x > minC && x < maxC) >> L;
+			if ((~vpi & ilow) != 0ull) { status = 2; break; }
+			emit(1, Li);
+			y -= Li; consumed += Li;
+			s -= Li; if (s < 0) s += N;
+			const int e = L + Li;
+			want = 1u;                                   /* default: let the next probe look again */
+			if (e < 64 && ((ballot(have) >> e) & 1ull) != 0ull) {
+				const unsigned c3 = (unsigned) __builtin_amdgcn_readlane((int) c2, e);
+				if (c3 == 0u) break;
+				want = c3;
+			}
 		}
 	}
 	if (status == 0) {
@@ -271,7 +320,6 @@ CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int 
 	}
 	o.status = status;
 }
-
 
 /* first cell of the tile in (y, x) order: *fy = -1 when no row has a cell inside [0, W).
  * Rare path (a tile without any positive score), run by backtrack_kernel. */
