@@ -555,9 +555,15 @@ fill_ring_kernel(const FillArgs a) {
 						ni = lanes(nI) ? (lanes(isIu) ? (run_t) (short) ((int) uI + 1) : (run_t) 1) : (run_t) 0;
 						runf = (float) (lanes(nD) ? nd : ni);
 					} else {
-						nd = lanes(nD) ? (run_t) (drun[j] + 1) : (run_t) 0;
-						ni = lanes(nI) ? (run_t) (uI + 1) : (run_t) 0;
-						runf = (float) nd + (float) ni;   /* one of them is 0: exact */
+						/* One run register per cell: the run of a gap cell, anything otherwise.  It is only
+						 * ever read through the masks "left cell was D" / "up cell was I" (isDl, isIu), so
+						 * nothing needs zeroing: an extension continues the run of the cell it extends, an
+						 * opening starts at 1 (src/ConvexAlignFast.cpp:655-668,703-738). */
+						const u64 extD = nD & isDl, extI = nI & isIu;
+						const float prev = lanes(extD) ? (float) drun[j] : (float) uI;
+						runf = lanes(extD | extI) ? prev + 1.0f : 1.0f;
+						nd = (run_t) runf;
+						ni = (run_t) runf;
 					}
 					const float pen = fminf(gem, gext + runf * decay);
 					/* :669-675  E = (score == 0) ? 0 : score + pen.  score >= 0 and pen < 0, so this is
