@@ -66,6 +66,45 @@ def test_short_reads(hip_aligner, port_oracle):
     _check(hip_aligner, port_oracle, synth.workload_short(200, seed=5))
 
 
+def _sv_tile(rng, flank, dels, inss, corridor):
+    """Clean flanks around engineered long gaps: the path carries deletion / insertion runs far
+    longer than a probe (64 cells) or a direction word (32 steps)."""
+    from ngmlr_amd import synth
+    ref_parts, qry_parts = [], []
+    for k in range(max(len(dels), len(inss)) + 1):
+        f = synth.random_ref(rng, flank)
+        ref_parts.append(f)
+        qry_parts.append(synth.mutate(rng, f, 0.03, (1, 1, 1)))
+        if k < len(dels):
+            ref_parts.append(synth.random_ref(rng, dels[k]))          # in the reference only: D run
+        if k < len(inss):
+            qry_parts.append(synth.random_ref(rng, inss[k]))          # in the read only: I run
+    ref = np.concatenate(ref_parts)
+    qry = np.concatenate(qry_parts)
+    H, W = len(qry), len(ref)
+    if corridor == "full":
+        off, ln = synth.corridor_full(H, W)
+    else:
+        off, ln = synth.corridor_endpoints(H, W, synth.estimate_corridor(H, W, W) * 3, realign=True)
+    return synth.Tile(ref=ref.tobytes(), qry=qry.tobytes(), row_offset=off, row_length=ln,
+                      tag="sv d%s i%s %s" % (dels, inss, corridor))
+
+
+def test_long_gap_runs(hip_aligner, port_oracle):
+    """The backtrack resolves the gap that ends a diagonal run from the words of the same probe
+    and hands over to plain gap probes where those end: runs of 1 ... 400, both kinds."""
+    rng = np.random.default_rng(4242)
+    tiles = []
+    for g in (1, 2, 5, 17, 31, 32, 33, 63, 64, 65, 97, 130, 257, 400):
+        tiles.append(_sv_tile(rng, 420, [g], [], "full"))
+        tiles.append(_sv_tile(rng, 420, [], [g], "full"))
+        tiles.append(_sv_tile(rng, 380, [g, 3], [2, g], "endpoints"))
+    got = _check(hip_aligner, port_oracle, tiles)
+    # the engineered gaps really are on the reported paths
+    longest = max(int(m) for g in got if g["ret"] >= 0 for m in re.findall(r"(\d+)[ID]", g["cigar"]))
+    assert longest >= 257
+
+
 def test_every_ring_class(hip_aligner, port_oracle):
     """Corridor widths chosen to land in each fill kernel class (ring 64 ... 4096),
     including the lock-stepped multi-wave classes."""
