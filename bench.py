@@ -161,6 +161,7 @@ def main() -> int:
     cpu = None
     valid = None
     text_stage = None
+    host_path = None
     if rank == 0:
         from ngmlr_amd.aligner import format_alignment
         res, ops = batch.download()
@@ -180,6 +181,19 @@ def main() -> int:
                           "tiles": k, "threads": os.cpu_count(), "what": "cvx_format_batch: CIGAR + MD + NM + per-position profile"}
         except Exception as e:  # never let the extra measurement break the contract line
             text_stage = {"error": str(e)}
+        # host buffers in -> results out (what cvx_align_batch does, PCIe included) on a sample, twice:
+        # the second call reuses the handle's pinned staging.  Reported beside `value`, never part of it.
+        try:
+            k = min(len(tiles), 4096)
+            al.timed_host_path(tiles[:k])
+            hp = al.timed_host_path(tiles[:k])
+            kb = sum(t.H for t in tiles[:k])
+            host_path = {"Gbp_per_h": kb / hp["total_s"] * 3600.0 / 1e9, "tiles": k,
+                         "h2d_bytes": int(sum(len(t.ref) + 9 * t.H for t in tiles[:k])),
+                         **{k_: round(v, 5) for k_, v in hp.items()},
+                         "what": "cvx_batch_upload (parallel pack into pinned staging + H2D) + run + download + free"}
+        except Exception as e:
+            host_path = {"error": str(e)}
         if cpu is not None:
             from oracle.pyoracle import same_alignment
             chk = cpu.pop("_check")
@@ -252,6 +266,7 @@ def main() -> int:
             "parity": parity,
             "cpu_baseline": cpu,
             "text_stage_host": text_stage,
+            "host_buffer_path": host_path,
         }
         print(json.dumps(out))
     if dist is not None:

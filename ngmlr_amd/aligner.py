@@ -72,6 +72,26 @@ class ConvexAlignHip:
         capi.check(self.lib.cvx_batch_upload(self.h, len(tiles), arr, C.byref(b)))
         return DeviceBatch(self, b, list(tiles))
 
+    def timed_host_path(self, tiles: Sequence) -> dict:
+        """Host buffers in, results out: what cvx_align_batch does, with the stages timed
+        separately (seconds of the C calls only; ctypes packing of the tile table excluded)."""
+        import time
+        arr, keep = self._pack(tiles)
+        b = C.c_void_p()
+        t0 = time.perf_counter()
+        capi.check(self.lib.cvx_batch_upload(self.h, len(tiles), arr, C.byref(b)))
+        t1 = time.perf_counter()
+        batch = DeviceBatch(self, b, list(tiles))
+        try:
+            batch.run()
+            t2 = time.perf_counter()
+            batch.download()
+            t3 = time.perf_counter()
+        finally:
+            batch.free()
+        t4 = time.perf_counter()
+        return {"upload_s": t1 - t0, "run_s": t2 - t1, "download_s": t3 - t2, "free_s": t4 - t3, "total_s": t4 - t0}
+
     # ------------------------------------------------------------------ reference-shaped API
     def batch_align(self, tiles: Sequence, want_nm: bool = True) -> List[dict]:
         """N x SingleAlign: returns one Align-like dict per tile (keys = the Align fields)."""

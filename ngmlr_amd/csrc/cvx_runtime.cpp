@@ -22,6 +22,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cvx_align.h"
@@ -100,7 +101,52 @@ struct cvx_context {
 	int num_cus = 256;
 	int tune_min_slots = 0;   /* tuning knob (env CVX_TUNE_MIN_M): smallest M*NW a tile may use */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
+	/* pinned (page-locked) upload staging, grown on demand and reused by every upload on this
+	 * handle: sequences and corridor rows are packed here by several host threads and go to the
+	 * device as two DMA copies */
+	void *stage_seq = nullptr, *stage_rows = nullptr;
+	size_t stage_seq_cap = 0, stage_rows_cap = 0;
+	/* freed batches keep their device arenas and wait here for the next upload (at most
+	 * kPoolBatches): hipMalloc / hipFree of multi-GB arenas per call are slow, and hipFree
+	 * synchronises the whole device, which would serialise handles that work side by side */
+	std::vector<struct cvx_batch_s *> pool;
 };
+static const size_t kPoolBatches = 2;
+
+namespace {
+
+/* grow-only pinned buffer; false if the host cannot pin that much (caller falls back to pageable) */
+bool ensure_pinned(void **p, size_t *cap, size_t need) {
+	if (need <= *cap) return true;
+	if (*p) { (void) hipHostFree(*p); *p = nullptr; *cap = 0; }
+	const size_t want = need + need / 8 + 4096;
+	if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); *p = nullptr; return false; }
+	*cap = want;
+	return true;
+}
+
+/* fn(begin, end) over [0, n) on up to `threads` host threads, ranges balanced by weight[] */
+template <typename F>
+void parallel_ranges(int n, const std::vector<uint64_t> &prefix, int threads, F fn) {
+	if (threads <= 1 || n < 2 * threads) { fn(0, n); return; }
+	const uint64_t total = prefix[(size_t) n];
+	std::vector<std::thread> th;
+	int begin = 0;
+	for (int k = 1; k <= threads && begin < n; ++k) {
+		int end = n;
+		if (k < threads) {
+			const uint64_t target = total / (uint64_t) threads * (uint64_t) k;
+			end = (int) (std::upper_bound(prefix.begin(), prefix.begin() + n + 1, target) - prefix.begin());
+			if (end <= begin) end = begin + 1;
+			if (end > n) end = n;
+		}
+		th.emplace_back(fn, begin, end);
+		begin = end;
+	}
+	for (auto &t : th) t.join();
+}
+
+}  // namespace
 
 struct cvx_batch_s {
 	int n = 0;
@@ -215,6 +261,10 @@ void cvx_destroy(cvx_handle h) {
 	(void) hipSetDevice(h->device);
 	if (h->stream) (void) hipStreamDestroy(h->stream);
 	for (auto &a : h->aux) if (a) (void) hipStreamDestroy(a);
+	for (cvx_batch_s *b : h->pool) { b->release(); delete b; }
+	h->pool.clear();
+	if (h->stage_seq) (void) hipHostFree(h->stage_seq);
+	if (h->stage_rows) (void) hipHostFree(h->stage_rows);
 	delete h;
 }
 
@@ -244,40 +294,79 @@ int cvx_batch_upload(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_batch *
 		return CVX_ERR_ARG;
 	}
 
-	cvx_batch_s *b = new (std::nothrow) cvx_batch_s();
+	cvx_batch_s *b;
+	if (!h->pool.empty()) {
+		b = h->pool.back();
+		h->pool.pop_back();
+	} else {
+		b = new (std::nothrow) cvx_batch_s();
+	}
 	if (!b) return CVX_ERR_OOM;
 	b->n = n;
+	b->ran = false;
+	b->ops_total = 0;
 	memset(&b->timing, 0, sizeof(b->timing));
 	int rc = CVX_OK;
 	try {
 		b->tin.resize((size_t) n);
-		std::vector<uint8_t> hseq((size_t) seq_total, (uint8_t) 0);
-		std::vector<RowDesc> hrows((size_t) std::max<uint64_t>(n_rows, 1));
+		/* layout first (serial, O(n)), then the bytes (parallel) */
+		std::vector<uint64_t> wprefix((size_t) n + 1, 0);     /* packing work per tile ~ bytes moved */
 		uint64_t so = pad, ro = 0;
 		for (int i = 0; i < n; ++i) {
 			const cvx_tile &t = tiles[i];
 			TileIn &ti = b->tin[(size_t) i];
 			ti.ref_off = (uint32_t) so;
-			if (t.ref_len) memcpy(&hseq[(size_t) so], t.ref, (size_t) t.ref_len);
 			so += (uint64_t) t.ref_len;
 			ti.qry_off = (uint32_t) so;
-			if (t.qry_len) memcpy(&hseq[(size_t) so], t.qry, (size_t) t.qry_len);
 			so += (uint64_t) t.qry_len;
 			ti.W = t.ref_len;
 			ti.H = t.qry_len;
 			ti.row_off = ro;
 			ti.reserved = 0;
-			const char *po = (const char *) t.row_offset;
-			const char *pl = (const char *) t.row_length;
-			for (int y = 0; y < t.qry_len; ++y) {
-				RowDesc rd;
-				memcpy(&rd.off, po + (size_t) y * (size_t) t.row_stride_bytes, 4);
-				memcpy(&rd.len, pl + (size_t) y * (size_t) t.row_stride_bytes, 4);
-				hrows[(size_t) ro++] = rd;
-			}
+			ro += (uint64_t) t.qry_len;
+			wprefix[(size_t) i + 1] = wprefix[(size_t) i] + (uint64_t) t.ref_len + 9ull * (uint64_t) t.qry_len + 64;
 		}
+		const size_t rows_bytes = (size_t) std::max<uint64_t>(n_rows, 1) * sizeof(RowDesc);
+		std::vector<uint8_t> pg_seq;       /* pageable fallbacks when pinning fails */
+		std::vector<RowDesc> pg_rows;
+		uint8_t *hseq;
+		RowDesc *hrows;
+		if (ensure_pinned(&h->stage_seq, &h->stage_seq_cap, (size_t) seq_total) &&
+				ensure_pinned(&h->stage_rows, &h->stage_rows_cap, rows_bytes)) {
+			hseq = static_cast<uint8_t *>(h->stage_seq);
+			hrows = static_cast<RowDesc *>(h->stage_rows);
+		} else {
+			pg_seq.resize((size_t) seq_total);
+			pg_rows.resize(rows_bytes / sizeof(RowDesc));
+			hseq = pg_seq.data();
+			hrows = pg_rows.data();
+		}
+		/* the kernels prefetch a little past either end of a tile: both pads must be defined */
+		memset(hseq, 0, (size_t) pad);
+		memset(hseq + (size_t) (seq_total - pad - 64), 0, (size_t) pad + 64);
+		int threads = (int) std::thread::hardware_concurrency();
+		threads = std::max(1, std::min(threads, 16));
+		if (wprefix[(size_t) n] < (8u << 20)) threads = 1;      /* not worth a thread below ~8 MB */
+		auto pack = [&](int begin, int end) {
+			for (int i = begin; i < end; ++i) {
+				const cvx_tile &t = tiles[i];
+				const TileIn &ti = b->tin[(size_t) i];
+				if (t.ref_len) memcpy(hseq + ti.ref_off, t.ref, (size_t) t.ref_len);
+				if (t.qry_len) memcpy(hseq + ti.qry_off, t.qry, (size_t) t.qry_len);
+				RowDesc *dst = hrows + ti.row_off;
+				const char *po = (const char *) t.row_offset;
+				const char *pl = (const char *) t.row_length;
+				const size_t stride = (size_t) t.row_stride_bytes;
+				for (int y = 0; y < t.qry_len; ++y) {
+					RowDesc rd;
+					memcpy(&rd.off, po + (size_t) y * stride, 4);
+					memcpy(&rd.len, pl + (size_t) y * stride, 4);
+					dst[y] = rd;
+				}
+			}
+		};
 		if ((rc = b->d_seq.ensure((size_t) seq_total)) == CVX_OK &&
-				(rc = b->d_rows.ensure(hrows.size())) == CVX_OK &&
+				(rc = b->d_rows.ensure(rows_bytes / sizeof(RowDesc))) == CVX_OK &&
 				(rc = b->d_tin.ensure((size_t) std::max(n, 1))) == CVX_OK &&
 				(rc = b->d_plan.ensure((size_t) std::max(n, 1))) == CVX_OK &&
 				(rc = b->d_trun.ensure((size_t) std::max(n, 1))) == CVX_OK &&
@@ -285,10 +374,38 @@ int cvx_batch_upload(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_batch *
 				(rc = b->d_dstoff.ensure((size_t) std::max(n, 1))) == CVX_OK &&
 				(rc = b->d_lists.ensure((size_t) std::max(n, 1))) == CVX_OK &&
 				(rc = b->d_heads.ensure(64)) == CVX_OK) {
-			hipError_t e = hipMemcpy(b->d_seq.p, hseq.data(), (size_t) seq_total, hipMemcpyHostToDevice);
-			if (e == hipSuccess && n_rows) e = hipMemcpy(b->d_rows.p, hrows.data(), (size_t) n_rows * sizeof(RowDesc), hipMemcpyHostToDevice);
-			if (e == hipSuccess && n) e = hipMemcpy(b->d_tin.p, b->tin.data(), (size_t) n * sizeof(TileIn), hipMemcpyHostToDevice);
-			for (auto &ev : b->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+			/* pack and copy in a few pieces, so that the DMA of one piece runs under the packing
+			 * of the next (pieces are contiguous in both arenas) */
+			hipStream_t st = h->stream;
+			hipError_t e = hipSuccess;
+			const int pieces = threads > 1 ? 4 : 1;
+			int t0 = 0;
+			uint64_t seq_done = 0;                   /* bytes of hseq already on their way */
+			for (int pc = 1; pc <= pieces && e == hipSuccess; ++pc) {
+				int t1 = n;
+				if (pc < pieces) {
+					const uint64_t target = wprefix[(size_t) n] / (uint64_t) pieces * (uint64_t) pc;
+					t1 = (int) (std::upper_bound(wprefix.begin(), wprefix.end(), target) - wprefix.begin());
+					t1 = std::min(std::max(t1, t0), n);
+				}
+				if (t1 > t0) {
+					std::vector<uint64_t> wp((size_t) (t1 - t0) + 1);
+					for (int i = t0; i <= t1; ++i) wp[(size_t) (i - t0)] = wprefix[(size_t) i] - wprefix[(size_t) t0];
+					parallel_ranges(t1 - t0, wp, threads, [&](int bg, int en) { pack(t0 + bg, t0 + en); });
+				}
+				const uint64_t seq_end = (t1 == n) ? seq_total : (uint64_t) b->tin[(size_t) t1].ref_off;
+				if (seq_end > seq_done)
+					e = hipMemcpyAsync(b->d_seq.p + seq_done, hseq + seq_done, (size_t) (seq_end - seq_done), hipMemcpyHostToDevice, st);
+				seq_done = seq_end;
+				const uint64_t r0 = (t0 < n) ? b->tin[(size_t) t0].row_off : n_rows;
+				const uint64_t r1 = (t1 < n) ? b->tin[(size_t) t1].row_off : n_rows;
+				if (e == hipSuccess && r1 > r0)
+					e = hipMemcpyAsync(b->d_rows.p + r0, hrows + r0, (size_t) (r1 - r0) * sizeof(RowDesc), hipMemcpyHostToDevice, st);
+				t0 = t1;
+			}
+			if (e == hipSuccess && n) e = hipMemcpyAsync(b->d_tin.p, b->tin.data(), (size_t) n * sizeof(TileIn), hipMemcpyHostToDevice, st);
+			if (e == hipSuccess) e = hipStreamSynchronize(st);    /* the staging buffers are reused by the next upload */
+			for (auto &ev : b->ev) if (e == hipSuccess && !ev) e = hipEventCreate(&ev);
 			if (e != hipSuccess) { set_err("upload copy failed: %s", hipGetErrorString(e)); rc = CVX_ERR_HIP; }
 		}
 	} catch (const std::bad_alloc &) {
@@ -591,6 +708,11 @@ int cvx_batch_download(cvx_handle h, cvx_batch b, cvx_result *results, uint32_t 
 void cvx_batch_free(cvx_handle h, cvx_batch b) {
 	if (!b) return;
 	if (h) (void) hipSetDevice(h->device);
+	if (h && h->pool.size() < kPoolBatches) {
+		b->ran = false;
+		h->pool.push_back(b);      /* arenas and events stay allocated for the next upload */
+		return;
+	}
 	b->release();
 	delete b;
 }
