@@ -88,14 +88,36 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 			row_span(r[y - 1], W, y - 1, pgs, pge);
 			if (gs <= pgs) flags |= kPlanIrregular;  /* ring schedule needs increasing row starts */
 		}
-		/* first row y' > y that starts at or after ge + margin (gs is increasing) */
+		/* first row y' > y that starts at or after ge + margin (gs is increasing): gallop out from
+		 * a guess -- row starts advance by about two anti-diagonals per row in a sloped corridor --
+		 * then bisect; a handful of row reads instead of log2(H) */
 		const int lim = ge + kSwitchMargin;
-		int lo = y + 1, hi = H;
+		auto starts_before = [&](int yy) {       /* gs(yy) < lim */
+			int mgs, mge;
+			row_span(r[yy], W, yy, mgs, mge);
+			return mgs < lim;
+		};
+		int lo = y + 1, hi = H;                  /* rows < lo start before lim, rows >= hi do not */
+		int g = y + 1 + ((lim - gs) >> 1);
+		g = g < lo ? lo : g;
+		if (g < hi) {
+			if (starts_before(g)) {
+				lo = g + 1;
+				for (int step = 1; lo < hi; step <<= 1) {
+					const int p = (lo + step - 1 < hi) ? lo + step - 1 : hi - 1;
+					if (starts_before(p)) lo = p + 1; else { hi = p; break; }
+				}
+			} else {
+				hi = g;
+				for (int step = 1; lo < hi; step <<= 1) {
+					const int p = (hi - step > lo) ? hi - step : lo;
+					if (starts_before(p)) { lo = p + 1; break; } else hi = p;
+				}
+			}
+		}
 		while (lo < hi) {
 			const int mid = (lo + hi) >> 1;
-			int mgs, mge;
-			row_span(r[mid], W, mid, mgs, mge);
-			if (mgs >= lim) hi = mid; else lo = mid + 1;
+			if (starts_before(mid)) lo = mid + 1; else hi = mid;
 		}
 		const int n = lo - y + 1;
 		if (n > need) need = n;
