@@ -505,11 +505,28 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	std::vector<int> seg_begin(cls.size(), 0);
 	for (size_t c = 0; c < cls.size(); ++c) {
 		auto &v = cls[c];
-		/* longest processing time first: the persistent waves pull from the front */
-		std::sort(v.begin(), v.end(), [&](int32_t x, int32_t y) {
-			const uint64_t ax = b->plan[(size_t) x].active, ay = b->plan[(size_t) y].active;
-			return ax != ay ? ax > ay : x < y;
-		});
+		/* longest processing time first (most cells first, index as tie-break): the persistent
+		 * waves pull from the front.  Sorted as packed 64-bit keys when they fit (they always do
+		 * below a million tiles of less than 2^43 cells), which is several times faster than
+		 * comparing through the plan array. */
+		bool packed = v.size() < (1u << 20);
+		if (packed) {
+			std::vector<uint64_t> keys(v.size());
+			for (size_t q = 0; q < v.size() && packed; ++q) {
+				const uint64_t a = b->plan[(size_t) v[q]].active;
+				if (a >= (1ull << 43) || (uint32_t) v[q] >= (1u << 20)) packed = false;
+				keys[q] = (((1ull << 43) - 1 - a) << 20) | (uint64_t) (uint32_t) v[q];
+			}
+			if (packed) {
+				std::sort(keys.begin(), keys.end());
+				for (size_t q = 0; q < v.size(); ++q) v[q] = (int32_t) (keys[q] & ((1u << 20) - 1));
+			}
+		}
+		if (!packed)
+			std::sort(v.begin(), v.end(), [&](int32_t x, int32_t y) {
+				const uint64_t ax = b->plan[(size_t) x].active, ay = b->plan[(size_t) y].active;
+				return ax != ay ? ax > ay : x < y;
+			});
 		seg_begin[c] = (int) b->lists.size();
 		b->lists.insert(b->lists.end(), v.begin(), v.end());
 	}
