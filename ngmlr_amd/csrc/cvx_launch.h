@@ -9,10 +9,6 @@
 
 namespace cvx {
 
-struct RowDesc {
-	int32_t off, len;
-};
-
 /* (m, nw) pairs that exist: m in {1,2,3,4,5,6,8} with nw = 1; m = 4 with nw in {2,4,8,16}. */
 hipError_t launch_fill(int m, int nw, bool wrap, const FillArgs &a, int grid, hipStream_t st);
 /* sub-read scoring (cvx_score.hip) */

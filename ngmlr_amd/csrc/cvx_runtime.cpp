@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "cvx_align.h"
+#include "cvx_host_logic.h"
 #include "cvx_launch.h"
 #include "cvx_types.h"
 
@@ -52,17 +53,6 @@ void set_err(const char *fmt, ...) {
 			return (e_ == hipErrorOutOfMemory) ? CVX_ERR_OOM : CVX_ERR_HIP;        \
 		}                                                                          \
 	} while (0)
-
-struct KernelClass {
-	int m, nw;
-	int ring() const { return 64 * m * nw; }
-};
-
-/* smallest ring first */
-const KernelClass kClasses[] = {
-	{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}, {8, 1}, {4, 4}, {4, 8}, {4, 16},
-};
-const int kNumClasses = (int) (sizeof(kClasses) / sizeof(kClasses[0]));
 
 template <typename T>
 struct DevBuf {
@@ -123,27 +113,6 @@ bool ensure_pinned(void **p, size_t *cap, size_t need) {
 	if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); *p = nullptr; return false; }
 	*cap = want;
 	return true;
-}
-
-/* fn(begin, end) over [0, n) on up to `threads` host threads, ranges balanced by weight[] */
-template <typename F>
-void parallel_ranges(int n, const std::vector<uint64_t> &prefix, int threads, F fn) {
-	if (threads <= 1 || n < 2 * threads) { fn(0, n); return; }
-	const uint64_t total = prefix[(size_t) n];
-	std::vector<std::thread> th;
-	int begin = 0;
-	for (int k = 1; k <= threads && begin < n; ++k) {
-		int end = n;
-		if (k < threads) {
-			const uint64_t target = total / (uint64_t) threads * (uint64_t) k;
-			end = (int) (std::upper_bound(prefix.begin(), prefix.begin() + n + 1, target) - prefix.begin());
-			if (end <= begin) end = begin + 1;
-			if (end > n) end = n;
-		}
-		th.emplace_back(fn, begin, end);
-		begin = end;
-	}
-	for (auto &t : th) t.join();
 }
 
 }  // namespace
@@ -273,26 +242,24 @@ int cvx_batch_upload(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_batch *
 	*out = nullptr;
 	HIP_TRY(hipSetDevice(h->device));
 
-	uint64_t seq_bytes = 0, n_rows = 0;
-	int64_t max_hw = 0;
-	for (int i = 0; i < n; ++i) {
-		const cvx_tile &t = tiles[i];
-		if (t.ref_len < 0 || t.qry_len < 0 || (t.ref_len > 0 && !t.ref) || (t.qry_len > 0 && !t.qry) ||
-				(t.qry_len > 0 && (!t.row_offset || !t.row_length)) || (t.row_stride_bytes & 3) || t.row_stride_bytes < 4) {
-			set_err("cvx_batch_upload: tile %d malformed", i);
-			return CVX_ERR_ARG;
-		}
-		seq_bytes += (uint64_t) t.ref_len + (uint64_t) t.qry_len;
-		n_rows += (uint64_t) t.qry_len;
-		max_hw = std::max<int64_t>(max_hw, (int64_t) t.ref_len + t.qry_len);
+	UploadLayout L;
+	std::vector<TileIn> tin;
+	int bad = -1;
+	int lrc;
+	try {
+		lrc = upload_layout(n, tiles, tin, L, &bad);
+	} catch (const std::bad_alloc &) {
+		set_err("cvx_batch_upload: host allocation failed");
+		return CVX_ERR_OOM;
 	}
-	const uint64_t pad = (uint64_t) max_hw + kRingMax + 256;
-	const uint64_t seq_total = seq_bytes + 2 * pad + 64;
-	if (seq_total >= 0xFFFF0000ull) {
+	if (lrc == kLayoutMalformed) { set_err("cvx_batch_upload: tile %d malformed", bad); return CVX_ERR_ARG; }
+	if (lrc == kLayoutTooLarge) {
 		set_err("cvx_batch_upload: %llu sequence bytes exceed one batch (4 GiB); split the batch",
-				(unsigned long long) seq_total);
+				(unsigned long long) L.seq_total);
 		return CVX_ERR_ARG;
 	}
+	const uint64_t seq_total = L.seq_total, n_rows = L.n_rows;
+	const std::vector<uint64_t> &wprefix = L.wprefix;
 
 	cvx_batch_s *b;
 	if (!h->pool.empty()) {
@@ -308,24 +275,7 @@ int cvx_batch_upload(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_batch *
 	memset(&b->timing, 0, sizeof(b->timing));
 	int rc = CVX_OK;
 	try {
-		b->tin.resize((size_t) n);
-		/* layout first (serial, O(n)), then the bytes (parallel) */
-		std::vector<uint64_t> wprefix((size_t) n + 1, 0);     /* packing work per tile ~ bytes moved */
-		uint64_t so = pad, ro = 0;
-		for (int i = 0; i < n; ++i) {
-			const cvx_tile &t = tiles[i];
-			TileIn &ti = b->tin[(size_t) i];
-			ti.ref_off = (uint32_t) so;
-			so += (uint64_t) t.ref_len;
-			ti.qry_off = (uint32_t) so;
-			so += (uint64_t) t.qry_len;
-			ti.W = t.ref_len;
-			ti.H = t.qry_len;
-			ti.row_off = ro;
-			ti.reserved = 0;
-			ro += (uint64_t) t.qry_len;
-			wprefix[(size_t) i + 1] = wprefix[(size_t) i] + (uint64_t) t.ref_len + 9ull * (uint64_t) t.qry_len + 64;
-		}
+		b->tin.swap(tin);
 		const size_t rows_bytes = (size_t) std::max<uint64_t>(n_rows, 1) * sizeof(RowDesc);
 		std::vector<uint8_t> pg_seq;       /* pageable fallbacks when pinning fails */
 		std::vector<RowDesc> pg_rows;
@@ -341,30 +291,11 @@ int cvx_batch_upload(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_batch *
 			hseq = pg_seq.data();
 			hrows = pg_rows.data();
 		}
-		/* the kernels prefetch a little past either end of a tile: both pads must be defined */
-		memset(hseq, 0, (size_t) pad);
-		memset(hseq + (size_t) (seq_total - pad - 64), 0, (size_t) pad + 64);
+		upload_zero_pads(L, hseq);
 		int threads = (int) std::thread::hardware_concurrency();
 		threads = std::max(1, std::min(threads, 16));
 		if (wprefix[(size_t) n] < (8u << 20)) threads = 1;      /* not worth a thread below ~8 MB */
-		auto pack = [&](int begin, int end) {
-			for (int i = begin; i < end; ++i) {
-				const cvx_tile &t = tiles[i];
-				const TileIn &ti = b->tin[(size_t) i];
-				if (t.ref_len) memcpy(hseq + ti.ref_off, t.ref, (size_t) t.ref_len);
-				if (t.qry_len) memcpy(hseq + ti.qry_off, t.qry, (size_t) t.qry_len);
-				RowDesc *dst = hrows + ti.row_off;
-				const char *po = (const char *) t.row_offset;
-				const char *pl = (const char *) t.row_length;
-				const size_t stride = (size_t) t.row_stride_bytes;
-				for (int y = 0; y < t.qry_len; ++y) {
-					RowDesc rd;
-					memcpy(&rd.off, po + (size_t) y * stride, 4);
-					memcpy(&rd.len, pl + (size_t) y * stride, 4);
-					dst[y] = rd;
-				}
-			}
-		};
+		auto pack = [&](int begin, int end) { upload_pack(begin, end, tiles, b->tin, hseq, hrows); };
 		if ((rc = b->d_seq.ensure((size_t) seq_total)) == CVX_OK &&
 				(rc = b->d_rows.ensure(rows_bytes / sizeof(RowDesc))) == CVX_OK &&
 				(rc = b->d_tin.ensure((size_t) std::max(n, 1))) == CVX_OK &&
@@ -439,64 +370,15 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	HIP_TRY(hipMemcpyAsync(b->plan.data(), b->d_plan.p, (size_t) n * sizeof(TilePlan), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 
-	/* ---- host planning: kernel class, arena offsets, work lists */
-	b->trun.assign((size_t) n, TileRun());
-	b->tout.assign((size_t) n, TileOut());
-	std::vector<std::vector<int32_t>> cls((size_t) kNumClasses * 2);
-	std::vector<int32_t> generic;
-	uint64_t dir_dwords = 0, ops_ints = 0, cells = 0, active = 0;
-	int n_fast = 0;
-	for (int i = 0; i < n; ++i) {
-		const TilePlan &p = b->plan[(size_t) i];
-		TileRun &r = b->trun[(size_t) i];
-		TileOut &o = b->tout[(size_t) i];
-		memset(&r, 0, sizeof(r));
-		memset(&o, 0, sizeof(o));
-		o.score = -1.0f;
-		cells += p.cells;
-		r.skip = 1;
-		if (p.flags & kPlanTooLarge) { o.status = CVX_TILE_TOO_LARGE; continue; }
-		if (p.flags & kPlanEmpty) { o.status = CVX_TILE_EMPTY; continue; }
-		int k = -1;
-		if (!(p.flags & kPlanIrregular)) {
-			for (int c = 0; c < kNumClasses; ++c)
-				if (kClasses[c].ring() >= p.need && kClasses[c].m * kClasses[c].nw >= h->tune_min_slots) { k = c; break; }
-		}
-		if (k < 0) {
-			/* catch-all kernel: ring = need (regular, too wide for registers) or one slot per
-			 * row (irregular row starts) */
-			const int64_t want = (p.flags & kPlanIrregular) ? (int64_t) b->tin[(size_t) i].H : (int64_t) p.need;
-			const int64_t ring = ((want > 0 ? want : 1) + 63) / 64 * 64;
-			const uint64_t dd = (uint64_t) ((p.rend - p.r0 + 31) / 32) * (uint64_t) ring * 2ull;
-			if (ring > (1 << 30) || dd > (4ull << 30)) { o.status = CVX_TILE_UNSUPPORTED; continue; }  /* > 16 GiB of codes */
-			r.skip = 0;
-			r.ring = (int32_t) ring;
-			r.r0 = p.r0;
-			r.nsteps = p.rend - p.r0;
-			r.dir_off = dir_dwords;
-			dir_dwords += dd;
-			r.mnw = 0;
-			r.ops_cap = b->tin[(size_t) i].H + b->tin[(size_t) i].W + 8;
-			r.ops_off = ops_ints;
-			ops_ints += (uint64_t) r.ops_cap;
-			active += p.active;
-			generic.push_back(i);
-			continue;
-		}
-		r.skip = 0;
-		r.ring = kClasses[k].ring();
-		r.r0 = p.r0;
-		r.nsteps = p.rend - p.r0;
-		r.dir_off = dir_dwords;
-		dir_dwords += (uint64_t) ((r.nsteps + 31) / 32) * (uint64_t) r.ring * 2ull;
-		r.mnw = kClasses[k].m | (kClasses[k].nw << 8);
-		r.ops_cap = b->tin[(size_t) i].H + b->tin[(size_t) i].W + 8;
-		r.ops_off = ops_ints;
-		ops_ints += (uint64_t) r.ops_cap;
-		active += p.active;
-		if (kClasses[k].nw == 1) n_fast++;
-		cls[(size_t) k * 2 + (((p.flags & kPlanWrap16) || h->tune_force_wrap) ? 1 : 0)].push_back(i);
-	}
+	/* ---- host planning: kernel class, arena offsets, work lists (cvx_host_logic.h) */
+	HostPlan hp;
+	host_plan(n, b->plan.data(), b->tin.data(), h->tune_min_slots, h->tune_force_wrap, hp);
+	b->trun.swap(hp.trun);
+	b->tout.swap(hp.tout);
+	std::vector<std::vector<int32_t>> &cls = hp.cls;
+	std::vector<int32_t> &generic = hp.generic;
+	const uint64_t dir_dwords = hp.dir_dwords, ops_ints = hp.ops_ints, cells = hp.cells, active = hp.active;
+	const int n_fast = hp.n_fast;
 	int rc;
 	if ((rc = b->d_dirs.ensure((size_t) dir_dwords + 64)) != CVX_OK) return rc;
 	if ((rc = b->d_regions.ensure((size_t) ops_ints + 64)) != CVX_OK) return rc;
@@ -504,29 +386,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	b->lists.clear();
 	std::vector<int> seg_begin(cls.size(), 0);
 	for (size_t c = 0; c < cls.size(); ++c) {
-		auto &v = cls[c];
-		/* longest processing time first (most cells first, index as tie-break): the persistent
-		 * waves pull from the front.  Sorted as packed 64-bit keys when they fit (they always do
-		 * below a million tiles of less than 2^43 cells), which is several times faster than
-		 * comparing through the plan array. */
-		bool packed = v.size() < (1u << 20);
-		if (packed) {
-			std::vector<uint64_t> keys(v.size());
-			for (size_t q = 0; q < v.size() && packed; ++q) {
-				const uint64_t a = b->plan[(size_t) v[q]].active;
-				if (a >= (1ull << 43) || (uint32_t) v[q] >= (1u << 20)) packed = false;
-				keys[q] = (((1ull << 43) - 1 - a) << 20) | (uint64_t) (uint32_t) v[q];
-			}
-			if (packed) {
-				std::sort(keys.begin(), keys.end());
-				for (size_t q = 0; q < v.size(); ++q) v[q] = (int32_t) (keys[q] & ((1u << 20) - 1));
-			}
-		}
-		if (!packed)
-			std::sort(v.begin(), v.end(), [&](int32_t x, int32_t y) {
-				const uint64_t ax = b->plan[(size_t) x].active, ay = b->plan[(size_t) y].active;
-				return ax != ay ? ax > ay : x < y;
-			});
+		auto &v = cls[c];      /* already in LPT order */
 		seg_begin[c] = (int) b->lists.size();
 		b->lists.insert(b->lists.end(), v.begin(), v.end());
 	}

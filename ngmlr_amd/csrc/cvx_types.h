@@ -39,6 +39,7 @@
 namespace cvx {
 
 struct RowDesc2 { int32_t x, y; };  /* (offset, length); same layout as HIP's int2 */
+struct RowDesc { int32_t off, len; }; /* the same pair under the host's names */
 
 /* A finished row's slot is cleared one step after its last cell (the row below still
  * reads that cell) and handed to row y+N at the next 4-step group boundary, so row

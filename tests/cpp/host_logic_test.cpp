@@ -1,0 +1,170 @@
+// CPU test of the device-independent host logic (ngmlr_amd/csrc/cvx_host_logic.h): upload layout and
+// packing (ragged, empty and strided tiles, multi-threaded == single-threaded), kernel-class choice,
+// arena offsets and the LPT work lists.  Built with plain g++ by tests/test_host_logic_cpu.py.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+
+#include "cvx_host_logic.h"
+
+using namespace cvx;
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
+
+struct CorridorLine16 { int32_t offset, length; uint64_t offsetInMatrix; };   // the reference's 16-byte row
+
+int main() {
+	std::mt19937 rng(7);
+	// ---------------------------------------------------------------- layout + packing
+	const int n = 200;
+	std::vector<std::string> refs(n), qrys(n);
+	std::vector<std::vector<int32_t>> off(n), len(n);
+	std::vector<std::vector<CorridorLine16>> lines(n);
+	std::vector<cvx_tile> tiles(n);
+	for (int i = 0; i < n; ++i) {
+		const int W = (i % 17 == 0) ? 0 : (int) (rng() % 5000);
+		const int H = (i % 13 == 0) ? 0 : (int) (rng() % 4000);
+		refs[i].resize(W); qrys[i].resize(H);
+		for (auto &c : refs[i]) c = "ACGTN"[rng() % 5];
+		for (auto &c : qrys[i]) c = "ACGT"[rng() % 4];
+		off[i].resize(H); len[i].resize(H); lines[i].resize(H);
+		for (int y = 0; y < H; ++y) {
+			off[i][y] = (int32_t) (y - 150 + (int) (rng() % 7));
+			len[i][y] = (int32_t) (300 + rng() % 70);
+			lines[i][y] = {off[i][y], len[i][y], 0xdeadbeefull};
+		}
+		cvx_tile &t = tiles[i];
+		memset(&t, 0, sizeof(t));
+		t.ref = refs[i].data(); t.qry = qrys[i].data();
+		t.ref_len = W; t.qry_len = H;
+		if (i & 1) {       // CorridorLine[] passed directly, stride 16
+			t.row_offset = H ? &lines[i][0].offset : nullptr;
+			t.row_length = H ? &lines[i][0].length : nullptr;
+			t.row_stride_bytes = 16;
+		} else {
+			t.row_offset = off[i].data(); t.row_length = len[i].data();
+			t.row_stride_bytes = 4;
+		}
+	}
+	UploadLayout L;
+	std::vector<TileIn> tin;
+	int bad = -1;
+	CHECK(upload_layout(n, tiles.data(), tin, L, &bad) == kLayoutOk);
+	CHECK(L.pad >= (uint64_t) kRingMax + 256);
+	uint64_t so = L.pad, ro = 0;
+	for (int i = 0; i < n; ++i) {
+		CHECK(tin[i].ref_off == so); so += tiles[i].ref_len;
+		CHECK(tin[i].qry_off == so); so += tiles[i].qry_len;
+		CHECK(tin[i].row_off == ro); ro += tiles[i].qry_len;
+		CHECK(tin[i].H == tiles[i].qry_len && tin[i].W == tiles[i].ref_len);
+	}
+	CHECK(so + L.pad + 64 == L.seq_total && ro == L.n_rows);
+	CHECK(L.wprefix.size() == (size_t) n + 1 && L.wprefix[0] == 0);
+
+	std::vector<uint8_t> a(L.seq_total, 0xAA), b(L.seq_total, 0x55);
+	std::vector<RowDesc> ra(L.n_rows + 1), rb(L.n_rows + 1);
+	upload_zero_pads(L, a.data());
+	upload_zero_pads(L, b.data());
+	upload_pack(0, n, tiles.data(), tin, a.data(), ra.data());                      // one thread
+	parallel_ranges(n, L.wprefix, 7, [&](int bg, int en) { upload_pack(bg, en, tiles.data(), tin, b.data(), rb.data()); });
+	CHECK(a == b);                                                                   // every byte defined, same result
+	CHECK(memcmp(ra.data(), rb.data(), L.n_rows * sizeof(RowDesc)) == 0);
+	for (uint64_t k = 0; k < L.pad; ++k) if (a[k] != 0 || a[L.seq_total - 1 - k] != 0) { CHECK(!"pads zeroed"); break; }
+	for (int i = 0; i < n; ++i) {
+		CHECK(memcmp(a.data() + tin[i].ref_off, refs[i].data(), refs[i].size()) == 0);
+		CHECK(memcmp(a.data() + tin[i].qry_off, qrys[i].data(), qrys[i].size()) == 0);
+		for (int y = 0; y < tiles[i].qry_len; ++y) {
+			const RowDesc &rd = ra[tin[i].row_off + y];
+			if (rd.off != off[i][y] || rd.len != len[i][y]) { CHECK(!"row copied"); break; }
+		}
+	}
+	// ranges handed to the threads tile [0, n) exactly once
+	{
+		std::vector<int> seen(n, 0);
+		std::vector<std::pair<int, int>> got(64, {-1, -1});
+		std::atomic<int> slot{0};
+		parallel_ranges(n, L.wprefix, 16, [&](int bg, int en) { got[slot++] = {bg, en}; });
+		for (auto &g : got) if (g.first >= 0) for (int i = g.first; i < g.second; ++i) seen[i]++;
+		for (int i = 0; i < n; ++i) if (seen[i] != 1) { CHECK(!"range cover"); break; }
+	}
+	// malformed input is refused with the index of the offender
+	{
+		std::vector<cvx_tile> t2(tiles.begin(), tiles.begin() + 5);
+		t2[3].row_stride_bytes = 6;
+		CHECK(upload_layout(5, t2.data(), tin, L, &bad) == kLayoutMalformed && bad == 3);
+		t2[3].row_stride_bytes = 4; t2[2].qry_len = 10; t2[2].row_offset = nullptr;
+		CHECK(upload_layout(5, t2.data(), tin, L, &bad) == kLayoutMalformed && bad == 2);
+		CHECK(upload_layout(0, nullptr, tin, L, &bad) == kLayoutOk && L.n_rows == 0 && L.seq_total == 2 * L.pad + 64);
+	}
+
+	// ---------------------------------------------------------------- host planning
+	const int m = 3000;
+	std::vector<TilePlan> plan(m);
+	std::vector<TileIn> pin(m);
+	for (int i = 0; i < m; ++i) {
+		TilePlan &p = plan[i];
+		p.r0 = (int) (rng() % 50); p.rend = p.r0 + 100 + (int) (rng() % 20000);
+		p.need = 1 + (int) (rng() % 5000);
+		p.flags = 0;
+		if (i % 97 == 0) p.flags |= kPlanEmpty;
+		if (i % 89 == 0) p.flags |= kPlanTooLarge;
+		if (i % 53 == 0) p.flags |= kPlanIrregular;
+		if (i % 31 == 0) p.flags |= kPlanWrap16;
+		p.active = (i % 7 == 0) ? 12345 : rng() % 100000000ull;     // ties on purpose
+		p.cells = p.active + rng() % 1000;
+		pin[i].H = 10 + (int) (rng() % 20000); pin[i].W = 10 + (int) (rng() % 20000);
+	}
+	HostPlan hp;
+	host_plan(m, plan.data(), pin.data(), 0, 0, hp);
+	uint64_t dir = 0, ops = 0;
+	std::vector<int> where(m, -1);
+	for (size_t c = 0; c < hp.cls.size(); ++c) for (int32_t t : hp.cls[c]) { CHECK(where[t] == -1); where[t] = (int) c; }
+	for (int32_t t : hp.generic) { CHECK(where[t] == -1); where[t] = 1000; }
+	for (int i = 0; i < m; ++i) {
+		const TilePlan &p = plan[i];
+		const TileRun &r = hp.trun[i];
+		if (p.flags & kPlanTooLarge) { CHECK(r.skip && hp.tout[i].status == CVX_TILE_TOO_LARGE && where[i] == -1); continue; }
+		if (p.flags & kPlanEmpty) { CHECK(r.skip && hp.tout[i].status == CVX_TILE_EMPTY && where[i] == -1); continue; }
+		CHECK(!r.skip && hp.tout[i].status == 0 && hp.tout[i].score == -1.0f);
+		CHECK(r.dir_off == dir && r.ops_off == ops);                 // arenas are dense, in tile order
+		CHECK(r.nsteps == p.rend - p.r0 && r.r0 == p.r0 && r.ops_cap == pin[i].H + pin[i].W + 8);
+		dir += (uint64_t) ((r.nsteps + 31) / 32) * (uint64_t) r.ring * 2ull;
+		ops += (uint64_t) r.ops_cap;
+		if ((p.flags & kPlanIrregular) || p.need > kRingMax) {
+			CHECK(where[i] == 1000 && r.mnw == 0 && r.ring % 64 == 0);
+			CHECK(r.ring >= ((p.flags & kPlanIrregular) ? pin[i].H : p.need));
+		} else {
+			CHECK(where[i] >= 0 && where[i] < 1000);
+			const KernelClass &kc = kClasses[where[i] / 2];
+			CHECK(kc.ring() == r.ring && kc.ring() >= p.need && r.mnw == (kc.m | (kc.nw << 8)));
+			if (where[i] / 2 > 0) CHECK(kClasses[where[i] / 2 - 1].ring() < p.need);   // smallest class that fits
+			CHECK((where[i] & 1) == ((p.flags & kPlanWrap16) ? 1 : 0));
+		}
+	}
+	CHECK(dir == hp.dir_dwords && ops == hp.ops_ints);
+	for (auto &v : hp.cls)           // LPT: most cells first, index breaks ties
+		for (size_t q = 1; q < v.size(); ++q) {
+			const uint64_t x = plan[v[q - 1]].active, y = plan[v[q]].active;
+			if (!(x > y || (x == y && v[q - 1] < v[q]))) { CHECK(!"LPT order"); break; }
+		}
+	// the packed-key sort equals the comparator sort, also when it has to fall back
+	{
+		std::vector<int32_t> v1, v2;
+		for (int i = 0; i < m; ++i) { v1.push_back(i); v2.push_back(i); }
+		plan[5].active = 1ull << 50;                                      // does not fit a packed key
+		lpt_sort(v1, plan.data());
+		std::sort(v2.begin(), v2.end(), [&](int32_t x, int32_t y) {
+			const uint64_t ax = plan[x].active, ay = plan[y].active; return ax != ay ? ax > ay : x < y; });
+		CHECK(v1 == v2 && v1[0] == 5);
+	}
+	// tuning knobs: a floor on the ring class, forced int16-run kernels
+	host_plan(m, plan.data(), pin.data(), 8, 1, hp);
+	for (size_t c = 0; c < hp.cls.size(); ++c) {
+		if (!hp.cls[c].empty()) CHECK((c & 1) == 1 && kClasses[c / 2].m * kClasses[c / 2].nw >= 8);
+	}
+	printf(fails ? "host_logic_test: %d FAILED\n" : "host_logic_test: ok\n", fails);
+	return fails ? 1 : 0;
+}
