@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CVX_ABI_VERSION 1
+#define CVX_ABI_VERSION 2
 
 /* return codes */
 enum {
@@ -127,6 +127,8 @@ typedef struct {
 	uint64_t dir_bytes; /* bytes of direction codes written to HBM */
 	int32_t n_fill_launches;
 	int32_t n_tiles_fast; /* tiles taken by the single-wave ring kernels */
+	int32_t n_tiles_redone; /* tiles whose best cell was not in the exactly tracked tail (second fill pass) */
+	int32_t reserved;
 } cvx_timing;
 
 /* One forward-fill launch of the last cvx_batch_run (HIP-event timed on the stream). */

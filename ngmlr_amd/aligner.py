@@ -23,8 +23,8 @@ DEFAULT_SCORING = dict(match=2.0, mismatch=-5.0, gap_open=-5.0, gap_extend=-5.0,
 
 
 class ConvexAlignHip:
-    def __init__(self, device: int = 0, max_matrix_mb: int = 10000, **scoring):
-        self.lib = capi.load()
+    def __init__(self, device: int = 0, max_matrix_mb: int = 10000, lib_path: str = None, **scoring):
+        self.lib = capi.load(lib_path)
         sc = dict(DEFAULT_SCORING)
         sc.update(scoring)
         self.params = capi.CvxParams(sc["match"], sc["mismatch"], sc["gap_open"], sc["gap_extend"],

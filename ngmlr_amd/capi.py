@@ -44,7 +44,8 @@ class CvxResult(C.Structure):
 class CvxTiming(C.Structure):
     _fields_ = [("plan_ms", C.c_float), ("fill_ms", C.c_float), ("backtrack_ms", C.c_float),
                 ("total_ms", C.c_float), ("cells", C.c_uint64), ("active_cells", C.c_uint64),
-                ("dir_bytes", C.c_uint64), ("n_fill_launches", C.c_int32), ("n_tiles_fast", C.c_int32)]
+                ("dir_bytes", C.c_uint64), ("n_fill_launches", C.c_int32), ("n_tiles_fast", C.c_int32),
+                ("n_tiles_redone", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CvxLaunchInfo(C.Structure):
@@ -74,19 +75,20 @@ class CvxError(RuntimeError):
         self.code = code
 
 
-_lib = None
+_libs = {}
 
 
-def load() -> C.CDLL:
-    """Load libcvxalign.so (raises if it has not been built)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path: str = None) -> C.CDLL:
+    """Load libcvxalign.so (raises if it has not been built).  `path`: another build of the
+    library (A/B runs while tuning, tools/ab_fill.py); default the in-tree one / $CVX_LIB."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise FileNotFoundError(
             "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(the HIP path has no fallback)" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "(the HIP path has no fallback)" % path)
+    lib = C.CDLL(path)
     lib.cvx_last_error.restype = C.c_char_p
     lib.cvx_abi_version.restype = C.c_int
     lib.cvx_device_count.restype = C.c_int
@@ -111,7 +113,7 @@ def load() -> C.CDLL:
                                          C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
                                          C.c_char_p, C.c_int32, C.c_void_p, C.c_int32,
                                          C.POINTER(CvxAlignmentText)]
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 

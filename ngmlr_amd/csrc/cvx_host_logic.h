@@ -195,8 +195,11 @@ inline void host_plan(int n, const TilePlan *plan, const TileIn *tin, int tune_m
 		int64_t ring;
 		if (k < 0) {
 			/* catch-all kernel: ring = need (regular, too wide for registers) or one slot per
-			 * row (irregular row starts) */
-			const int64_t want = (p.flags & kPlanIrregular) ? (int64_t) tin[(size_t) i].H : (int64_t) p.need;
+			 * row PLUS ONE (irregular row starts): slot 0 reads its "up" neighbour from the last
+			 * slot of the ring, which must therefore never hold a row -- with a ring of exactly H
+			 * slots row 0 would see row H-1's live cells instead of the empty element
+			 * (getElement(x, -1), src/AlignmentMatrixFast.h:74-111) */
+			const int64_t want = (p.flags & kPlanIrregular) ? (int64_t) tin[(size_t) i].H + 1 : (int64_t) p.need;
 			ring = ((want > 0 ? want : 1) + 63) / 64 * 64;
 			const uint64_t dd = (uint64_t) ((p.rend - p.r0 + 31) / 32) * (uint64_t) ring * 2ull;
 			if (ring > (1 << 30) || dd > (4ull << 30)) { o.status = CVX_TILE_UNSUPPORTED; continue; }  /* > 16 GiB of codes */

@@ -370,8 +370,10 @@ CVX_DEV void first_cell(const int2 *rows, int H, int W, int lane, int *fy, int *
 	}
 }
 
+
 template <bool WRAP> struct RunT { typedef float type; };
 template <> struct RunT<true> { typedef int type; };
+template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 /* Occupancy target.  The M = 3 single-wave kernel (corridors of 310-370 columns, i.e. almost
  * every PacBio/ONT tile) is measured ~14 % faster at 6 waves/SIMD (80 VGPRs, the few spilled
@@ -383,7 +385,23 @@ template <> struct RunT<true> { typedef int type; };
 #define CVX_FILL_OCC(M, NW) __attribute__((amdgpu_waves_per_eu( \
 		((M) == 3 && (NW) == 1) ? CVX_FILL_WAVES_PER_EU : 1, ((M) == 3 && (NW) == 1) ? CVX_FILL_WAVES_PER_EU : 8)))
 
-template <int M, int NW, bool WRAP>
+/*
+ * One workgroup (NW waves) per tile: block b takes tile list[b].  The list is in LPT order and
+ * the hardware dispatches workgroups in index order as wave slots free up, which is the work
+ * queue a persistent kernel would build by hand -- without the atomic cursor and without a
+ * tile loop around the step loop.
+ *
+ * Best-cell tracking (src/ConvexAlignFast.cpp:758-763: first strict maximum in (y, x) order)
+ * is two-phase.  Exact (score, step, row) tracking costs three half-rate VALU ops per cell; the
+ * best cell of an alignment that reaches the end of the read lies in the last few anti-
+ * diagonals, so the EXACT = false instantiation only keeps a per-lane running maximum
+ * (2 ops per M cells) up to the last `late` groups and tracks exactly from there on.  The
+ * late result is the tile's answer iff it strictly beats every earlier score; otherwise the
+ * tile is flagged (TileOut::pad = kPadRedo) and the EXACT = true instantiation, launched right
+ * behind on the same stream over the same list, redoes just the flagged tiles with exact
+ * tracking from the first step.
+ */
+template <int M, int NW, bool WRAP, bool EXACT>
 __global__ void __launch_bounds__(64 * NW) CVX_FILL_OCC(M, NW)
 fill_ring_kernel(const FillArgs a) {
 	constexpr int N = 64 * M * NW;
@@ -397,301 +415,313 @@ fill_ring_kernel(const FillArgs a) {
 	float vmat = a.sp.mat, vmis = a.sp.mis;
 	asm volatile("" : "+v"(vmat), "+v"(vmis));
 
-	__shared__ int s_tile;
 	__shared__ float s_xf[2][NW > 1 ? NW : 1][2];
 	__shared__ run_t s_xi[2][NW > 1 ? NW : 1];
 	__shared__ int s_xm[2][NW > 1 ? NW : 1];
-	__shared__ float s_rbest[NW > 1 ? NW : 1];
+	__shared__ float s_rbest[NW > 1 ? NW : 1], s_rearly[NW > 1 ? NW : 1];
 	__shared__ int s_ry[NW > 1 ? NW : 1], s_rx[NW > 1 ? NW : 1];
 	/* rarely touched per-slot state lives in LDS to keep VGPRs for occupancy: the read
 	 * row a slot holds and the row of its best cell (both only change at a row switch) */
 	__shared__ int s_y[M][64 * NW];
 	__shared__ int s_besty[M][64 * NW];
 
-	for (;;) {
-		int qi;
-		if (NW == 1) {
-			qi = 0;
-			if (lane == 0) qi = atomicAdd(a.queue_head, 1);
-			qi = __builtin_amdgcn_readfirstlane(qi);
+	const int t = a.list[blockIdx.x];
+	if (EXACT) {
+		if (a.tout[t].pad != kPadRedo) return;   /* block-uniform */
+		if (tid == 0) atomicAdd(a.redo_count, 1);
+	}
+	const TileIn ti = a.tin[t];
+	const TileRun tr = a.trun[t];
+	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off;
+	const uint8_t *seq = a.seq;
+	const int H = ti.H, W = ti.W;
+	uint32_t *dirs = a.dirs + tr.dir_off;
+
+	/* per-slot state in VGPRs (static indexing only).  A slot that is not inside its
+	 * row's range holds the reference's empty element (score 0, run 0, STOP:
+	 * src/AlignmentMatrixFast.h:49-53), i.e. S = 0, runs = 0, V = Hc = gap_open;
+	 * the update below produces exactly that for inactive lanes by itself. */
+	float S[M];        /* score of the slot's latest cell                            */
+	float Hc[M];       /* left candidate that cell offers to the next column         */
+	float V[M];        /* up candidate it offers to the next row                     */
+	float dg[M];       /* diagonal score for the slot's next cell                    */
+	run_t drun[M];     /* deletion run of the latest cell: the run itself (0 unless D) in the int16   */
+	run_t irun[M];     /* kernels, run + 1 in the float ones (read only through mD / mI); same for I  */
+	int cnt[M];        /* next column index inside the row (negative: not started)   */
+	int len[M];        /* row length after clipping to [0,W)                         */
+	int qch[M];        /* read character of the row                                  */
+	unsigned xa[M];    /* seq-arena offset of the next reference dword to prefetch   */
+	unsigned cwn[M];   /* reference characters of the NEXT 4-step group              */
+	float best[M];
+	int best_r[M];
+	float lbest = 0.0f;          /* early phase: running maximum of this lane's cells */
+	unsigned accA[M], accB[M];   /* direction bit-planes of the current 32-step block */
+	/* per-slot lane masks in SGPRs */
+	u64 mD[M];         /* latest cell is a deletion (run > 0)  */
+	u64 mI[M];         /* latest cell is an insertion          */
+
+	/* (re)bind slot j to its row y[j]; rnext = index of the next step.  Leaves the
+	 * reference characters of the group starting at rnext in cwn[j]. */
+	auto bind_row = [&](int j, int rnext) {
+		const int yy = s_y[j][tid];
+		if (yy < H) {
+			const int2 ol = rows[yy];
+			long long lo = ol.x > 0 ? ol.x : 0;
+			long long hi = (long long) ol.x + (long long) ol.y;
+			if (hi > W) hi = W;
+			if (hi < lo) hi = lo;
+			cnt[j] = rnext - (yy + (int) lo);
+			len[j] = (int) (hi - lo);
+			qch[j] = seq[ti.qry_off + (unsigned) yy];
+			xa[j] = ti.ref_off + (unsigned) (rnext - yy);
 		} else {
-			__syncthreads();
-			if (tid == 0) s_tile = atomicAdd(a.queue_head, 1);
-			__syncthreads();
-			qi = s_tile;
+			cnt[j] = -(1 << 30);
+			len[j] = 0;
+			qch[j] = 0;
+			xa[j] = ti.ref_off;
 		}
-		if (qi >= a.list_n) break;
-		const int t = a.list[qi];
-		const TileIn ti = a.tin[t];
-		const TileRun tr = a.trun[t];
-		const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off;
-		const uint8_t *seq = a.seq;
-		const int H = ti.H, W = ti.W;
-		uint32_t *dirs = a.dirs + tr.dir_off;
+		cwn[j] = *reinterpret_cast<const unsigned *>(seq + xa[j]);
+		xa[j] += 4u;
+	};
 
-		/* per-slot state in VGPRs (static indexing only).  A slot that is not inside its
-		 * row's range holds the reference's empty element (score 0, run 0, STOP:
-		 * src/AlignmentMatrixFast.h:49-53), i.e. S = 0, runs = 0, V = Hc = gap_open;
-		 * the update below produces exactly that for inactive lanes by itself. */
-		float S[M];        /* score of the slot's latest cell                            */
-		float Hc[M];       /* left candidate that cell offers to the next column         */
-		float V[M];        /* up candidate it offers to the next row                     */
-		float dg[M];       /* diagonal score for the slot's next cell                    */
-		run_t drun[M];     /* deletion run of the latest cell (0 unless direction D)     */
-		run_t irun[M];     /* insertion run (0 unless direction I)                       */
-		int cnt[M];        /* next column index inside the row (negative: not started)   */
-		int len[M];        /* row length after clipping to [0,W)                         */
-		int qch[M];        /* read character of the row                                  */
-		unsigned xa[M];    /* seq-arena offset of the next reference dword to prefetch   */
-		unsigned cwn[M];   /* reference characters of the NEXT 4-step group              */
-		float best[M];
-		int best_r[M];
-		unsigned accA[M], accB[M];   /* direction bit-planes of the current 32-step block */
-		/* per-slot lane masks in SGPRs */
-		u64 mD[M];         /* latest cell is a deletion (run > 0)  */
-		u64 mI[M];         /* latest cell is an insertion          */
+#pragma unroll
+	for (int j = 0; j < M; ++j) {
+		s_y[j][tid] = tid * M + j;
+		s_besty[j][tid] = 0;
+		S[j] = 0.0f; Hc[j] = go; V[j] = go; dg[j] = 0.0f;
+		drun[j] = 0; irun[j] = 0;
+		best[j] = 0.0f; best_r[j] = 0;
+		accA[j] = accB[j] = 0u;
+		mD[j] = 0; mI[j] = 0;
+		bind_row(j, tr.r0);
+	}
 
-		/* (re)bind slot j to its row y[j]; rnext = index of the next step.  Leaves the
-		 * reference characters of the group starting at rnext in cwn[j]. */
-		auto bind_row = [&](int j, int rnext) {
-			const int yy = s_y[j][tid];
-			if (yy < H) {
-				const int2 ol = rows[yy];
-				long long lo = ol.x > 0 ? ol.x : 0;
-				long long hi = (long long) ol.x + (long long) ol.y;
-				if (hi > W) hi = W;
-				if (hi < lo) hi = lo;
-				cnt[j] = rnext - (yy + (int) lo);
-				len[j] = (int) (hi - lo);
-				qch[j] = seq[ti.qry_off + (unsigned) yy];
-				xa[j] = ti.ref_off + (unsigned) (rnext - yy);
-			} else {
-				cnt[j] = -(1 << 30);
-				len[j] = 0;
-				qch[j] = 0;
-				xa[j] = ti.ref_off;
-			}
+	const int ngroups = (tr.nsteps + 3) >> 2;
+	int late = ngroups >> 3;
+	if (late < a.late_min_groups) late = a.late_min_groups;
+	const int gswitch = (EXACT || late >= ngroups) ? 0 : ngroups - late;   /* first exactly tracked group */
+	int r = tr.r0;
+
+	/* one 4-step group; TRACK: exact best-cell tracking (else only the lane maximum) */
+	auto group = [&](auto track_tag, const int g) {
+		constexpr bool TRACK = decltype(track_tag)::value;
+		/* this group's reference characters were fetched one group ago */
+		unsigned cw[M];
+#pragma unroll
+		for (int j = 0; j < M; ++j) {
+			cw[j] = cwn[j];
 			cwn[j] = *reinterpret_cast<const unsigned *>(seq + xa[j]);
 			xa[j] += 4u;
-		};
-
+		}
+		/* flush the previous 32-step block of direction words HERE, right after the
+		 * wait for this group's characters: gfx9 counts loads and stores in one vmcnt,
+		 * so a store issued just before that wait would be waited for in full */
+		if (g != 0 && (g & 7) == 0) {
+			uint32_t *d = dirs + ((size_t) ((g >> 3) - 1) * N + (size_t) tid * M) * 2;
 #pragma unroll
-		for (int j = 0; j < M; ++j) {
-			s_y[j][tid] = tid * M + j;
-			s_besty[j][tid] = 0;
-			S[j] = 0.0f; Hc[j] = go; V[j] = go; dg[j] = 0.0f;
-			drun[j] = 0; irun[j] = 0;
-			best[j] = 0.0f; best_r[j] = 0;
-			accA[j] = accB[j] = 0u;
-			mD[j] = 0; mI[j] = 0;
-			bind_row(j, tr.r0);
+			for (int j = 0; j < M; ++j) { d[2 * j] = accA[j]; d[2 * j + 1] = accB[j]; }
 		}
 
-		const int ngroups = (tr.nsteps + 3) >> 2;
-		int r = tr.r0;
-		for (int g = 0; g < ngroups; ++g) {
-			/* this group's reference characters were fetched one group ago */
-			unsigned cw[M];
 #pragma unroll
-			for (int j = 0; j < M; ++j) {
-				cw[j] = cwn[j];
-				cwn[j] = *reinterpret_cast<const unsigned *>(seq + xa[j]);
-				xa[j] += 4u;
-			}
-			/* flush the previous 32-step block of direction words HERE, right after the
-			 * wait for this group's characters: gfx9 counts loads and stores in one vmcnt,
-			 * so a store issued just before that wait would be waited for in full */
-			if (g != 0 && (g & 7) == 0) {
-				uint32_t *d = dirs + ((size_t) ((g >> 3) - 1) * N + (size_t) tid * M) * 2;
-#pragma unroll
-				for (int j = 0; j < M; ++j) { d[2 * j] = accA[j]; d[2 * j + 1] = accB[j]; }
-			}
-
-#pragma unroll
-			for (int i = 0; i < 4; ++i) {
-				/* lane boundary: previous lane's last slot, values of step r-1 */
-				float uV0 = rot1_f(V[M - 1]);
-				float uS0 = rot1_f(S[M - 1]);
-				run_t uI0;
-				if (WRAP) uI0 = (run_t) rot1_i((int) irun[M - 1]);
-				else uI0 = (run_t) rot1_f((float) irun[M - 1]);
-				u64 mIu0 = rot1_m(mI[M - 1]);
-				if (NW > 1) {
-					const int par = (r & 1);
-					if (lane == 63) {
-						s_xf[par][wave][0] = V[M - 1];
-						s_xf[par][wave][1] = S[M - 1];
-						s_xi[par][wave] = irun[M - 1];
-						s_xm[par][wave] = (int) (mI[M - 1] >> 63);
-					}
-					__syncthreads();
-					const int pw = (wave + NW - 1) % NW;
-					if (lane == 0) {
-						uV0 = s_xf[par][pw][0];
-						uS0 = s_xf[par][pw][1];
-						uI0 = s_xi[par][pw];
-					}
-					const int bit = __builtin_amdgcn_readfirstlane(s_xm[par][pw]);
-					mIu0 = (mIu0 & ~1ull) | (u64) (bit & 1);
+		for (int i = 0; i < 4; ++i) {
+			/* lane boundary: previous lane's last slot, values of step r-1 */
+			float uV0 = rot1_f(V[M - 1]);
+			float uS0 = rot1_f(S[M - 1]);
+			run_t uI0;
+			if (WRAP) uI0 = (run_t) rot1_i((int) irun[M - 1]);
+			else uI0 = (run_t) rot1_f((float) irun[M - 1]);
+			u64 mIu0 = rot1_m(mI[M - 1]);
+			if (NW > 1) {
+				const int par = (r & 1);
+				if (lane == 63) {
+					s_xf[par][wave][0] = V[M - 1];
+					s_xf[par][wave][1] = S[M - 1];
+					s_xi[par][wave] = irun[M - 1];
+					s_xm[par][wave] = (int) (mI[M - 1] >> 63);
 				}
+				__syncthreads();
+				const int pw = (wave + NW - 1) % NW;
+				if (lane == 0) {
+					uV0 = s_xf[par][pw][0];
+					uS0 = s_xf[par][pw][1];
+					uI0 = s_xi[par][pw];
+				}
+				const int bit = __builtin_amdgcn_readfirstlane(s_xm[par][pw]);
+				mIu0 = (mIu0 & ~1ull) | (u64) (bit & 1);
+			}
 
-				/* descending j: slot j reads slot j-1 before slot j-1 is advanced */
-#pragma unroll
-				for (int j = M - 1; j >= 0; --j) {
-					const float uV = (j > 0) ? V[j > 0 ? j - 1 : 0] : uV0;
-					const float uS = (j > 0) ? S[j > 0 ? j - 1 : 0] : uS0;
-					const run_t uI = (j > 0) ? irun[j > 0 ? j - 1 : 0] : uI0;
-					const u64 mIu = (j > 0) ? mI[j > 0 ? j - 1 : 0] : mIu0;
+			/* The cell update in three phases per slot: (1) candidates, maximum and the equality /
+			 * activity lane masks; (2) the priority chain on the masks (SALU); (3) the new slot state.
+			 * Slot j reads slot j-1's values of the previous step: phase 3 runs in descending j. */
+			float p_lc[M], p_dc[M], p_uc[M], p_mx[M];
+			u64 p_eL[M], p_eU[M], p_eG[M], p_act[M], p_isDl[M], p_isIu[M];
+			u64 p_nD[M], p_nI[M], p_gap[M], p_cread[M];
+			auto phase1 = [&](const int j) {
+				const float uV = (j > 0) ? V[j > 0 ? j - 1 : 0] : uV0;
+				const run_t uI = (j > 0) ? irun[j > 0 ? j - 1 : 0] : uI0;
+				const u64 mIu = (j > 0) ? mI[j > 0 ? j - 1 : 0] : mIu0;
+				const int refc = (int) ((cw[j] >> (8 * i)) & 0xffu);
+				const bool eq = (refc == qch[j]);
+				const float diag_cell = dg[j] + (eq ? vmat : vmis);
+				float lc = Hc[j], dc = diag_cell, uc = uV;
+				const float mx = fmaxf(fmaxf(fmaxf(lc, dc), uc), 0.0f);
+				p_lc[j] = lc; p_dc[j] = dc; p_uc[j] = uc; p_mx[j] = mx;
+				p_eL[j] = ballot(mx == lc);
+				p_eU[j] = ballot(mx == uc);
+				p_eG[j] = ballot(mx == dc);
+				p_act[j] = ballot((unsigned) cnt[j] < (unsigned) len[j]);
+				p_isDl[j] = WRAP ? ballot(drun[j] > 0) : mD[j];
+				p_isIu[j] = WRAP ? ballot(uI > 0) : mIu;
+			};
+			auto phase2 = [&](const int j) {
+				const u64 eL = p_eL[j], eU = p_eU[j], eG = p_eG[j], act = p_act[j], isDl = p_isDl[j], isIu = p_isIu[j];
+				/* priority: del-extend > ins-extend > diag > del-open > ins-open > stop
+				 * (src/ConvexAlignFast.cpp:703-738), on lane masks; nothing fires on a
+				 * lane that is outside its row */
+				const u64 c2 = isIu & eU;
+				const u64 nD = eL & (isDl | ~(c2 | eG)) & act;
+				const u64 nI = ~nD & eU & (isIu | ~eG) & act;
+				p_nD[j] = nD; p_nI[j] = nI;
+				p_gap[j] = nD | nI;
+				/* plane 1 = nI | nG with nG = eG & ~gap & act; the act term is dropped: direction
+				 * bits of cells outside a row are never read (backtrack_walk masks them) */
+				p_cread[j] = nI | (eG & ~nD);
+			};
+			auto phase3 = [&](const int j) {
+				const float uS = (j > 0) ? S[j > 0 ? j - 1 : 0] : uS0;
+				const run_t uI = (j > 0) ? irun[j > 0 ? j - 1 : 0] : uI0;
+				const u64 nD = p_nD[j], nI = p_nI[j], isDl = p_isDl[j], isIu = p_isIu[j];
+				const float mx = p_mx[j];
+				/* outside the row the new "cell" is the empty element: score 0 */
+				const float sc = lanes(p_act[j]) ? mx : 0.0f;
+				run_t nd, ni;
+				float runf;
+				if (WRAP) {
+					/* indelRun is a short in the reference (src/AlignmentMatrixFast.h:43) */
+					nd = lanes(nD) ? (lanes(isDl) ? (run_t) (short) ((int) drun[j] + 1) : (run_t) 1) : (run_t) 0;
+					ni = lanes(nI) ? (lanes(isIu) ? (run_t) (short) ((int) uI + 1) : (run_t) 1) : (run_t) 0;
+					runf = (float) (lanes(nD) ? nd : ni);
+				} else {
+					/* One run register per cell: the run of a gap cell (plus one), anything otherwise.  It is only
+					 * ever read through the masks "left cell was D" / "up cell was I" (isDl, isIu), so
+					 * nothing needs zeroing: an extension continues the run of the cell it extends, an
+					 * opening starts at 1 (src/ConvexAlignFast.cpp:655-668,703-738). */
+					/* The register holds run + 1, the run of a cell that extends this one, so an extension
+					 * is one select and needs no "either extension" mask. */
+					const u64 extD = nD & isDl, extI = nI & isIu;
+					const float t1 = lanes(extI) ? (float) uI : 1.0f;
+					runf = lanes(extD) ? (float) drun[j] : t1;
+					nd = (run_t) (runf + 1.0f);
+					ni = nd;
+				}
+				const float pen = fminf(gem, gext + runf * decay);
+				/* :669-675  E = (score == 0) ? 0 : score + pen.  score >= 0 and pen < 0, so this is
+				 * max(score + pen, score * -2^100): -0 for score 0 (compares equal to the reference's
+				 * +0 and never reaches an output), score + pen otherwise. */
+				const float E = fmaxf(sc + pen, sc * -0x1p100f);
+				const float O = sc + go;
 
-					const int refc = (int) ((cw[j] >> (8 * i)) & 0xffu);
-					const bool eq = (refc == qch[j]);
-					const float diag_cell = dg[j] + (eq ? vmat : vmis);
-					const float up_cell = uV;
-					const float left_cell = Hc[j];
-					const float mx = fmaxf(fmaxf(fmaxf(left_cell, diag_cell), up_cell), 0.0f);
-
-					const u64 eL = ballot(mx == left_cell);
-					const u64 eU = ballot(mx == up_cell);
-					const u64 eG = ballot(mx == diag_cell);
-					const u64 act = ballot((unsigned) cnt[j] < (unsigned) len[j]);
-					const u64 isDl = WRAP ? ballot(drun[j] > 0) : mD[j];
-					const u64 isIu = WRAP ? ballot(uI > 0) : mIu;
-					/* priority: del-extend > ins-extend > diag > del-open > ins-open > stop
-					 * (src/ConvexAlignFast.cpp:703-738), on lane masks; nothing fires on a
-					 * lane that is outside its row */
-					const u64 c2 = isIu & eU;
-					const u64 nD = eL & (isDl | ~(c2 | eG)) & act;
-					const u64 nI = ~nD & eU & (isIu | ~eG) & act;
-					const u64 gap = nD | nI;
-					/* plane 1 = nI | nG with nG = eG & ~gap & act; the act term is dropped: direction
-					 * bits of cells outside a row are never read (backtrack_walk masks them) */
-					const u64 cread = nI | (eG & ~nD);
-
-					/* outside the row the new "cell" is the empty element: score 0 */
-					const float sc = lanes(act) ? mx : 0.0f;
-					run_t nd, ni;
-					float runf;
-					if (WRAP) {
-						/* indelRun is a short in the reference (src/AlignmentMatrixFast.h:43) */
-						nd = lanes(nD) ? (lanes(isDl) ? (run_t) (short) ((int) drun[j] + 1) : (run_t) 1) : (run_t) 0;
-						ni = lanes(nI) ? (lanes(isIu) ? (run_t) (short) ((int) uI + 1) : (run_t) 1) : (run_t) 0;
-						runf = (float) (lanes(nD) ? nd : ni);
-					} else {
-						/* One run register per cell: the run of a gap cell, anything otherwise.  It is only
-						 * ever read through the masks "left cell was D" / "up cell was I" (isDl, isIu), so
-						 * nothing needs zeroing: an extension continues the run of the cell it extends, an
-						 * opening starts at 1 (src/ConvexAlignFast.cpp:655-668,703-738). */
-						const u64 extD = nD & isDl, extI = nI & isIu;
-						const float prev = lanes(extD) ? (float) drun[j] : (float) uI;
-						runf = lanes(extD | extI) ? prev + 1.0f : 1.0f;
-						nd = (run_t) runf;
-						ni = (run_t) runf;
-					}
-					const float pen = fminf(gem, gext + runf * decay);
-					/* :669-675  E = (score == 0) ? 0 : score + pen.  score >= 0 and pen < 0, so this is
-					 * max(score + pen, score * -2^100): -0 for score 0 (compares equal to the reference's
-					 * +0 and never reaches an output), score + pen otherwise. */
-					const float E = fmaxf(sc + pen, sc * -0x1p100f);
-					const float O = sc + go;
+				dg[j] = uS;
+				S[j] = sc;
+				drun[j] = nd;
+				irun[j] = ni;
+				V[j] = lanes(nI) ? E : O;
+				Hc[j] = lanes(nD) ? E : O;
+				if (TRACK) {
 					const u64 better = ballot(sc > best[j]);   /* sc is 0 outside the row, best >= 0 */
-
-					dg[j] = uS;
-					S[j] = sc;
-					drun[j] = nd;
-					irun[j] = ni;
-					V[j] = lanes(nI) ? E : O;
-					Hc[j] = lanes(nD) ? E : O;
 					best[j] = lanes(better) ? mx : best[j];
 					best_r[j] = lanes(better) ? r : best_r[j];
-					mD[j] = nD;
-					mI[j] = nI;
-					cnt[j] += 1;
-					accA[j] = shl1_in(accA[j], gap);       /* plane 0: I or D */
-					accB[j] = shl1_in(accB[j], cread);     /* plane 1: I or diagonal */
+				} else {
+					lbest = fmaxf(lbest, sc);
 				}
-				r += 1;
-			}
-
-			/* hand finished slots to their next row (y + N): a row's last cell is consumed
-			 * by the row below one step after it was computed, so wait for cnt > len */
+				mD[j] = nD;
+				mI[j] = nI;
+				cnt[j] += 1;
+				accA[j] = shl1_in(accA[j], p_gap[j]);       /* plane 0: I or D */
+				accB[j] = shl1_in(accB[j], p_cread[j]);     /* plane 1: I or diagonal */
+			};
 #pragma unroll
-			for (int j = 0; j < M; ++j) {
-				if (cnt[j] > len[j]) {     /* finished a real row (unbound slots count up from -2^30) */
-					const int yy = s_y[j][tid];
-					if (best_r[j] >= r - cnt[j]) s_besty[j][tid] = yy;
-					s_y[j][tid] = yy + N;
-					bind_row(j, r);
-				}
-			}
-
+			for (int j = M - 1; j >= 0; --j) { phase1(j); phase2(j); phase3(j); }
+			r += 1;
 		}
-		if (ngroups > 0) {
-			/* last block (complete or partial): left-align so that step (t & 31) sits at
-			 * bit 31 - (t & 31) */
-			const int done = ((ngroups - 1) & 7) + 1;     /* groups in the last block */
-			const int sh = 32 - 4 * done;
-			uint32_t *d = dirs + ((size_t) ((ngroups - 1) >> 3) * N + (size_t) tid * M) * 2;
-#pragma unroll
-			for (int j = 0; j < M; ++j) { d[2 * j] = sh ? accA[j] << sh : accA[j]; d[2 * j + 1] = sh ? accB[j] << sh : accB[j]; }
-		}
-
-		/* argmax with the reference's tie-break: first strict maximum in (y, x) order
-		 * (src/ConvexAlignFast.cpp:758-763 / :1165-1170) */
-		float b = -1.0f;
-		int by = 0x7fffffff, bx = 0x7fffffff;
+		/* hand finished slots to their next row (y + N): a row's last cell is consumed
+		 * by the row below one step after it was computed, so wait for cnt > len */
 #pragma unroll
 		for (int j = 0; j < M; ++j) {
-			int vy = s_besty[j][tid];
-			if (s_y[j][tid] < H && best_r[j] >= r - cnt[j]) vy = s_y[j][tid];
-			const float v = best[j];
-			const int vx = best_r[j] - vy;
-			if (v > 0.0f) {     /* best[] starts at 0: a slot that never saw a positive score has no candidate */
-				if (v > b || (v == b && (vy < by || (vy == by && vx < bx)))) { b = v; by = vy; bx = vx; }
-			}
-		}
-#pragma unroll
-		for (int off = 32; off >= 1; off >>= 1) {
-			const float ob = __shfl_xor(b, off, 64);
-			const int oy = __shfl_xor(by, off, 64);
-			const int ox = __shfl_xor(bx, off, 64);
-			if (ob > b || (ob == b && (oy < by || (oy == by && ox < bx)))) { b = ob; by = oy; bx = ox; }
-		}
-		if (NW > 1) {
-			__syncthreads();
-			if (lane == 0) { s_rbest[wave] = b; s_ry[wave] = by; s_rx[wave] = bx; }
-			__syncthreads();
-			if (tid == 0) {
-				for (int w = 1; w < NW; ++w) {
-					const float ob = s_rbest[w];
-					const int oy = s_ry[w], ox = s_rx[w];
-					if (ob > b || (ob == b && (oy < by || (oy == by && ox < bx)))) { b = ob; by = oy; bx = ox; }
+			if (cnt[j] > len[j]) {     /* finished a real row (unbound slots count up from -2^30) */
+				const int yy = s_y[j][tid];
+				if (TRACK) {
+					if (best_r[j] >= r - cnt[j]) s_besty[j][tid] = yy;
 				}
+				s_y[j][tid] = yy + N;
+				bind_row(j, r);
 			}
 		}
-		if (NW > 1) {
-			if (tid == 0) { s_rbest[0] = b; s_ry[0] = by; s_rx[0] = bx; }
-			__syncthreads();
-			b = s_rbest[0]; by = s_ry[0]; bx = s_rx[0];
+	};
+
+	for (int g = 0; g < gswitch; ++g) group(BoolTag<false>(), g);
+	for (int g = gswitch; g < ngroups; ++g) group(BoolTag<true>(), g);
+
+	if (ngroups > 0) {
+		/* last block (complete or partial): left-align so that step (t & 31) sits at
+		 * bit 31 - (t & 31) */
+		const int done = ((ngroups - 1) & 7) + 1;     /* groups in the last block */
+		const int sh = 32 - 4 * done;
+		uint32_t *d = dirs + ((size_t) ((ngroups - 1) >> 3) * N + (size_t) tid * M) * 2;
+#pragma unroll
+		for (int j = 0; j < M; ++j) { d[2 * j] = sh ? accA[j] << sh : accA[j]; d[2 * j + 1] = sh ? accB[j] << sh : accB[j]; }
+	}
+
+	/* argmax with the reference's tie-break: first strict maximum in (y, x) order
+	 * (src/ConvexAlignFast.cpp:758-763 / :1165-1170) among the exactly tracked cells */
+	float b = -1.0f;
+	int by = 0x7fffffff, bx = 0x7fffffff;
+#pragma unroll
+	for (int j = 0; j < M; ++j) {
+		int vy = s_besty[j][tid];
+		if (s_y[j][tid] < H && best_r[j] >= r - cnt[j]) vy = s_y[j][tid];
+		const float v = best[j];
+		const int vx = best_r[j] - vy;
+		if (v > 0.0f) {     /* best[] starts at 0: a slot that never saw a positive score has no candidate */
+			if (v > b || (v == b && (vy < by || (vy == by && vx < bx)))) { b = v; by = vy; bx = vx; }
 		}
-		/* wave-uniform copies (after the reductions every lane of wave 0 holds the same
-		 * values; telling the compiler keeps the tile loop on scalar branches) */
-		b = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(b)));
-		by = __builtin_amdgcn_readfirstlane(by);
-		bx = __builtin_amdgcn_readfirstlane(bx);
-		if (wave == 0) {
-			/* b == -1: no positive score anywhere.  The reference (curr_max starts at -1) then takes
-			 * the first cell in (y, x) order, score 0; backtrack_kernel resolves that rare case. */
-			TileOut o;
-			o.score = b;
-			o.status = 0;
-			o.best_x = (b > -1.0f) ? bx : 0;
-			o.best_y = (b > -1.0f) ? by : 0;
-			o.ref_position = 0; o.qstart = 0; o.qend = 0; o.n_ops = 0; o.ops_first = 0;
-			/* pad = 0: not backtracked yet.  (Walking the tile right here, inside the persistent loop,
-			 * was measured slower: the walking wave holds one of the SIMD's six fill slots) */
-			o.pad = 0;
-			if (lane == 0) a.tout[t] = o;
+	}
+	float be = lbest;       /* maximum over the cells that were not tracked exactly */
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		const float ob = __shfl_xor(b, off, 64);
+		const int oy = __shfl_xor(by, off, 64);
+		const int ox = __shfl_xor(bx, off, 64);
+		if (ob > b || (ob == b && (oy < by || (oy == by && ox < bx)))) { b = ob; by = oy; bx = ox; }
+		if (!EXACT) be = fmaxf(be, __shfl_xor(be, off, 64));
+	}
+	if (NW > 1) {
+		__syncthreads();
+		if (lane == 0) { s_rbest[wave] = b; s_ry[wave] = by; s_rx[wave] = bx; s_rearly[wave] = be; }
+		__syncthreads();
+		if (tid == 0) {
+			for (int w = 1; w < NW; ++w) {
+				const float ob = s_rbest[w];
+				const int oy = s_ry[w], ox = s_rx[w];
+				if (ob > b || (ob == b && (oy < by || (oy == by && ox < bx)))) { b = ob; by = oy; bx = ox; }
+				be = fmaxf(be, s_rearly[w]);
+			}
 		}
+	}
+	if ((NW > 1 ? tid : lane) == 0) {
+		/* b == -1: no positive score among the tracked cells.  If there is none anywhere either,
+		 * the reference (curr_max starts at -1) takes the first cell in (y, x) order, score 0;
+		 * backtrack_kernel resolves that rare case. */
+		TileOut o;
+		o.score = b;
+		o.status = 0;
+		o.best_x = (b > -1.0f) ? bx : 0;
+		o.best_y = (b > -1.0f) ? by : 0;
+		o.ref_position = 0; o.qstart = 0; o.qend = 0; o.n_ops = 0; o.ops_first = 0;
+		/* pad = 0: filled, not backtracked yet; kPadRedo: an untracked cell scored at least as much
+		 * as the best tracked one, so the first strict maximum is not known -> exact pass */
+		o.pad = (!EXACT && be > 0.0f && !(b > be)) ? kPadRedo : 0;
+		a.tout[t] = o;
 	}
 }
 
@@ -768,35 +798,38 @@ compact_ops_kernel(const int32_t *regions, const TileRun *trun, const TileOut *t
 /* ------------------------------------------------------------------ launchers */
 
 template <int M, int NW, bool WRAP>
-static hipError_t launch_fill_t(const FillArgs &a, int grid, hipStream_t st) {
-	hipLaunchKernelGGL((fill_ring_kernel<M, NW, WRAP>), dim3(grid), dim3(64 * NW), 0, st, a);
+static hipError_t launch_fill_t(const FillArgs &a, bool exact, hipStream_t st) {
+	/* one workgroup per tile of the list */
+	if (exact) hipLaunchKernelGGL((fill_ring_kernel<M, NW, WRAP, true>), dim3(a.list_n), dim3(64 * NW), 0, st, a);
+	else hipLaunchKernelGGL((fill_ring_kernel<M, NW, WRAP, false>), dim3(a.list_n), dim3(64 * NW), 0, st, a);
 	return hipGetLastError();
 }
 
 template <int M, int NW>
-static hipError_t launch_fill_w(const FillArgs &a, bool wrap, int grid, hipStream_t st) {
-	return wrap ? launch_fill_t<M, NW, true>(a, grid, st) : launch_fill_t<M, NW, false>(a, grid, st);
+static hipError_t launch_fill_w(const FillArgs &a, bool wrap, bool exact, hipStream_t st) {
+	return wrap ? launch_fill_t<M, NW, true>(a, exact, st) : launch_fill_t<M, NW, false>(a, exact, st);
 }
 
-hipError_t launch_fill(int m, int nw, bool wrap, const FillArgs &a, int grid, hipStream_t st) {
+hipError_t launch_fill(int m, int nw, bool wrap, bool exact, const FillArgs &a, hipStream_t st) {
+	if (a.list_n <= 0) return hipSuccess;
 	if (nw == 1) {
 		switch (m) {
-		case 1: return launch_fill_w<1, 1>(a, wrap, grid, st);
-		case 2: return launch_fill_w<2, 1>(a, wrap, grid, st);
-		case 3: return launch_fill_w<3, 1>(a, wrap, grid, st);
-		case 4: return launch_fill_w<4, 1>(a, wrap, grid, st);
-		case 5: return launch_fill_w<5, 1>(a, wrap, grid, st);
-		case 6: return launch_fill_w<6, 1>(a, wrap, grid, st);
-		case 8: return launch_fill_w<8, 1>(a, wrap, grid, st);
+		case 1: return launch_fill_w<1, 1>(a, wrap, exact, st);
+		case 2: return launch_fill_w<2, 1>(a, wrap, exact, st);
+		case 3: return launch_fill_w<3, 1>(a, wrap, exact, st);
+		case 4: return launch_fill_w<4, 1>(a, wrap, exact, st);
+		case 5: return launch_fill_w<5, 1>(a, wrap, exact, st);
+		case 6: return launch_fill_w<6, 1>(a, wrap, exact, st);
+		case 8: return launch_fill_w<8, 1>(a, wrap, exact, st);
 		default: return hipErrorInvalidValue;
 		}
 	}
 	if (m != 4) return hipErrorInvalidValue;
 	switch (nw) {
-	case 2: return launch_fill_w<4, 2>(a, wrap, grid, st);
-	case 4: return launch_fill_w<4, 4>(a, wrap, grid, st);
-	case 8: return launch_fill_w<4, 8>(a, wrap, grid, st);
-	case 16: return launch_fill_w<4, 16>(a, wrap, grid, st);
+	case 2: return launch_fill_w<4, 2>(a, wrap, exact, st);
+	case 4: return launch_fill_w<4, 4>(a, wrap, exact, st);
+	case 8: return launch_fill_w<4, 8>(a, wrap, exact, st);
+	case 16: return launch_fill_w<4, 16>(a, wrap, exact, st);
 	default: return hipErrorInvalidValue;
 	}
 }

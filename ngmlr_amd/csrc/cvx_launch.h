@@ -10,7 +10,9 @@
 namespace cvx {
 
 /* (m, nw) pairs that exist: m in {1,2,3,4,5,6,8} with nw = 1; m = 4 with nw in {2,4,8,16}. */
-hipError_t launch_fill(int m, int nw, bool wrap, const FillArgs &a, int grid, hipStream_t st);
+/* exact = false: two-phase best-cell tracking, flags undecided tiles; exact = true: the pass that
+ * redoes the flagged tiles of the same list (launch both, in this order, on one stream) */
+hipError_t launch_fill(int m, int nw, bool wrap, bool exact, const FillArgs &a, hipStream_t st);
 /* sub-read scoring (cvx_score.hip) */
 struct ScorePair {
 	uint64_t ref_off, qry_off;   /* byte offsets in the sequence buffer (strings keep their NUL) */

@@ -90,6 +90,7 @@ struct cvx_context {
 	uint64_t max_matrix_mb = 10000;
 	int num_cus = 256;
 	int tune_min_slots = 0;   /* tuning knob (env CVX_TUNE_MIN_M): smallest M*NW a tile may use */
+	int tune_late_min = kLateMinGroups;  /* test knob (env CVX_TUNE_LATE_MIN): groups of the exactly tracked tail (huge: exact everywhere) */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
 	/* pinned (page-locked) upload staging, grown on demand and reused by every upload on this
 	 * handle: sequences and corridor rows are packed here by several host threads and go to the
@@ -144,7 +145,7 @@ struct cvx_batch_s {
 	DevBuf<uint64_t> d_gscratch_off;
 
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-	std::vector<hipEvent_t> lev;          /* 2 events per fill launch */
+	std::vector<hipEvent_t> lev;          /* 3 events per fill class: start, two-phase pass done, exact pass done */
 	std::vector<cvx_launch_info> launches;
 	cvx_timing timing;
 
@@ -214,6 +215,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	c->max_matrix_mb = max_matrix_mb ? max_matrix_mb : 10000;
 	if (const char *e = getenv("CVX_TUNE_MIN_M")) c->tune_min_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_FORCE_WRAP16")) c->tune_force_wrap = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
 	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
 	if (e != hipSuccess) {
@@ -416,7 +418,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		const size_t c = (size_t) cc;
 		if (cls[c].empty()) continue;
 		const KernelClass &kc = kClasses[c / 2];
-		while (b->lev.size() < (size_t) (launches + 1) * 2) {
+		while (b->lev.size() < (size_t) (launches + 1) * 3) {
 			hipEvent_t e;
 			HIP_TRY(hipEventCreate(&e));
 			b->lev.push_back(e);
@@ -434,7 +436,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		b->launches.push_back(li);
 		hipStream_t ls = h->aux[launches % kAuxStreams];
 		HIP_TRY(hipStreamWaitEvent(ls, b->ev[1], 0));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2], ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3], ls));
 		FillArgs a;
 		a.seq = b->d_seq.p;
 		a.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
@@ -444,17 +446,19 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		a.dirs = b->d_dirs.p;
 		a.list = b->d_lists.p + seg_begin[c];
 		a.list_n = (int) cls[c].size();
-		a.queue_head = b->d_heads.p + c;
+		a.late_min_groups = h->tune_late_min;
+		a.redo_count = b->d_heads.p;
 		a.ops = b->d_regions.p;
 		a.sp = h->sp;
-		const int per_cu = kc.nw == 1 ? 32 : std::max(1, 16 / kc.nw);
-		const int grid = std::min(a.list_n, h->num_cus * per_cu);
-		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, a, grid, ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2 + 1], ls));
+		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, false, a, ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
+		/* exact-tracking pass over the tiles the two-phase pass flagged (usually none) */
+		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, true, a, ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
 		launches++;
 	}
 	if (!generic.empty()) {
-		while (b->lev.size() < (size_t) (launches + 1) * 2) {
+		while (b->lev.size() < (size_t) (launches + 1) * 3) {
 			hipEvent_t e;
 			HIP_TRY(hipEventCreate(&e));
 			b->lev.push_back(e);
@@ -472,7 +476,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		b->launches.push_back(li);
 		hipStream_t ls = h->aux[launches % kAuxStreams];
 		HIP_TRY(hipStreamWaitEvent(ls, b->ev[1], 0));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2], ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3], ls));
 		FillArgs a;
 		a.seq = b->d_seq.p;
 		a.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
@@ -482,14 +486,16 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 		a.dirs = b->d_dirs.p;
 		a.list = b->d_lists.p + generic_begin;
 		a.list_n = (int) generic.size();
-		a.queue_head = b->d_heads.p + 63;
+		a.late_min_groups = h->tune_late_min;
+		a.redo_count = b->d_heads.p;
 		a.ops = b->d_regions.p;
 		a.sp = h->sp;
 		HIP_TRY(launch_fill_generic(a, b->d_gscratch.p, b->d_gscratch_off.p, ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 2 + 1], ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
 		launches++;
 	}
-	for (int i = 0; i < launches; ++i) HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) i * 2 + 1], 0));
+	for (int i = 0; i < launches; ++i) HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) i * 3 + 2], 0));
 	HIP_TRY(hipEventRecord(b->ev[2], st));
 
 	/* ---- backtrack + ops compaction */
@@ -504,6 +510,8 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	ba.n_tiles = n;
 	HIP_TRY(launch_backtrack(ba, st));
 	HIP_TRY(hipMemcpyAsync(b->tout.data(), b->d_tout.p, (size_t) n * sizeof(TileOut), hipMemcpyDeviceToHost, st));
+	int32_t redone = 0;
+	HIP_TRY(hipMemcpyAsync(&redone, b->d_heads.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	b->dst_off.assign((size_t) n, 0);
 	uint64_t total = 0;
@@ -518,7 +526,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	HIP_TRY(hipEventRecord(b->ev[3], st));
 	HIP_TRY(hipStreamSynchronize(st));
 
-	for (int i = 0; i < launches; ++i) b->launches[(size_t) i].ms = ev_ms(b->lev[(size_t) i * 2], b->lev[(size_t) i * 2 + 1]);
+	for (int i = 0; i < launches; ++i) b->launches[(size_t) i].ms = ev_ms(b->lev[(size_t) i * 3], b->lev[(size_t) i * 3 + 1]);
 	b->timing.plan_ms = ev_ms(b->ev[0], b->ev[1]);
 	b->timing.fill_ms = ev_ms(b->ev[1], b->ev[2]);
 	b->timing.backtrack_ms = ev_ms(b->ev[2], b->ev[3]);
@@ -528,6 +536,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	b->timing.dir_bytes = dir_dwords * 4;
 	b->timing.n_fill_launches = launches;
 	b->timing.n_tiles_fast = n_fast;
+	b->timing.n_tiles_redone = redone;
 	b->ran = true;
 	return CVX_OK;
 }

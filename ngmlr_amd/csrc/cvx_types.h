@@ -46,6 +46,11 @@ struct RowDesc { int32_t off, len; }; /* the same pair under the host's names */
  * y+N-1 must not start earlier than 4 steps after row y ended. */
 static const int kSwitchMargin = 4;
 static const int kRingMax = 4096;      /* largest ring any fill kernel provides */
+/* two-phase best-cell tracking of the ring fill (cvx_kernels.hip): the last
+ * max(kLateMinGroups, groups / 8) four-step groups are tracked exactly; TileOut::pad == kPadRedo
+ * marks a tile whose best cell may lie before them (redone by the exact instantiation) */
+static const int kLateMinGroups = 128;
+static const int kPadRedo = 2;
 
 struct ScoreParams {
 	float mat, mis, go, ge, gem, decay;
@@ -93,7 +98,7 @@ struct TileOut {
 	int32_t ref_position, qstart, qend;
 	int32_t n_ops;
 	int32_t ops_first;     /* index of the first op inside the tile's region */
-	int32_t pad;           /* 1 once the tile has been backtracked */
+	int32_t pad;           /* 0 filled, 1 backtracked, kPadRedo: needs the exact-tracking fill pass */
 };
 
 struct FillArgs {
@@ -104,8 +109,9 @@ struct FillArgs {
 	TileOut *tout;
 	uint32_t *dirs;
 	const int32_t *list;   /* tile indices of this kernel class, largest first */
-	int32_t list_n;
-	int32_t *queue_head;   /* work-queue cursor (zeroed before launch) */
+	int32_t list_n;        /* = grid size: one workgroup per tile */
+	int32_t *redo_count;   /* statistics: tiles redone by the exact pass */
+	int32_t late_min_groups; /* exactly tracked tail, in 4-step groups (kLateMinGroups; a test knob raises it) */
 	int32_t *ops;          /* per-tile op regions */
 	ScoreParams sp;
 };
