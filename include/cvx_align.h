@@ -23,6 +23,10 @@
  *                             (the BatchAlign slot the reference leaves unimplemented,
  *                              src/ConvexAlignFast.cpp:441-450)
  * cvx_batch_* (staged form)   the same, with inputs resident in HBM between calls
+ * cvx_submit / cvx_wait       the same as a stream of batches: several in flight per handle,
+ *                             upload / kernels / download of neighbouring batches overlapped
+ *                             (what a batching host driver needs, SURVEY.md 8 f1;
+ *                              reference src/AlignmentBuffer.cpp:3361-3406)
  * cvx_format_alignment        convertCigar + N-clip flags    src/ConvexAlignFast.cpp:112-333,493-528
  * cvx_score_batch             StrippedSW::BatchScore/SingleScore  src/StrippedSW.cpp:118-203 (next-row f2)
  *
@@ -115,6 +119,7 @@ typedef struct {
 
 typedef struct cvx_context *cvx_handle;
 typedef struct cvx_batch_s *cvx_batch;
+typedef struct cvx_batch_s *cvx_job;      /* a batch travelling through the streaming form */
 
 /* Timing of the last cvx_batch_run, measured with HIP events on the library's stream. */
 typedef struct {
@@ -168,6 +173,25 @@ int cvx_batch_launch_info(cvx_batch b, int32_t i, cvx_launch_info *info);
 int cvx_batch_download(cvx_handle h, cvx_batch b, cvx_result *results,
 		uint32_t *ops_arena, uint64_t ops_capacity, uint64_t *ops_used);
 void cvx_batch_free(cvx_handle h, cvx_batch b);
+
+/* Streaming form: host buffers in, results out, several batches in flight on one handle.
+ *
+ *   cvx_submit  packs the tiles into the job's pinned staging (the caller's buffers are free again
+ *               when it returns), queues the upload and the corridor analysis and returns; it also
+ *               queues the kernels of earlier jobs whose inputs have arrived.  Nothing waits.
+ *   cvx_wait    blocks until the job is done; *results / *ops point into page-locked memory owned by
+ *               the job (cvx_result[n_tiles], the dense ops arena) and stay valid until
+ *               cvx_job_release.  Jobs complete in submission order.
+ *   cvx_job_release  returns the job's arenas to the handle (they are reused by the next submit).
+ *
+ * With two or three jobs in flight (submit k+1, then wait k-1) the upload of batch k+1 and the
+ * download of batch k-1 run under the kernels of batch k.  A handle is not re-entrant: one host
+ * thread per handle (one handle per device and thread, like the reference's aligner instances). */
+int cvx_submit(cvx_handle h, int32_t n_tiles, const cvx_tile *tiles, cvx_job *out);
+int cvx_wait(cvx_handle h, cvx_job job, const cvx_result **results, const uint32_t **ops, uint64_t *n_ops);
+int cvx_job_timing(cvx_job job, cvx_timing *t);                        /* after cvx_wait */
+int cvx_job_launch_info(cvx_job job, int32_t i, cvx_launch_info *info); /* after cvx_wait */
+void cvx_job_release(cvx_handle h, cvx_job job);
 
 /* Sub-read scoring: what StrippedSW::BatchScore / SingleScore return
  * (reference src/StrippedSW.cpp:118-203 over ssw.c): refs/qrys are NUL-terminated strings,

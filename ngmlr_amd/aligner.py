@@ -92,6 +92,22 @@ class ConvexAlignHip:
         t4 = time.perf_counter()
         return {"upload_s": t1 - t0, "run_s": t2 - t1, "download_s": t3 - t2, "free_s": t4 - t3, "total_s": t4 - t0}
 
+    # ------------------------------------------------------------------ streaming API
+    def submit(self, tiles) -> "Job":
+        """cvx_submit: host buffers in, nothing waits.  `tiles`: a synth.TileSet (its table points
+        into the flat arrays) or a sequence of Tile objects."""
+        if hasattr(tiles, "table"):
+            tab = tiles.table()
+            arr = tab.ctypes.data_as(C.POINTER(capi.CvxTile))
+            keep = (tiles, tab)
+            n = len(tab)
+        else:
+            arr, keep = self._pack(tiles)
+            n = len(tiles)
+        j = C.c_void_p()
+        capi.check(self.lib.cvx_submit(self.h, n, arr, C.byref(j)))
+        return Job(self, j, n, keep)
+
     # ------------------------------------------------------------------ reference-shaped API
     def batch_align(self, tiles: Sequence, want_nm: bool = True) -> List[dict]:
         """N x SingleAlign: returns one Align-like dict per tile (keys = the Align fields)."""
@@ -104,6 +120,90 @@ class ConvexAlignHip:
 
     def single_align(self, tile, want_nm: bool = True) -> dict:
         return self.batch_align([tile], want_nm=want_nm)[0]
+
+
+RESULT_DTYPE = np.dtype([("score", np.float32), ("status", np.int32), ("best_ref_index", np.int32),
+                         ("best_read_index", np.int32), ("ref_position", np.int32), ("qstart", np.int32),
+                         ("qend", np.int32), ("n_ops", np.int32), ("ops_begin", np.uint64), ("cells", np.uint64)])
+assert RESULT_DTYPE.itemsize == C.sizeof(capi.CvxResult)
+
+
+class Job:
+    """One batch travelling through the streaming form (cvx_submit / cvx_wait / cvx_job_release)."""
+
+    def __init__(self, aligner: "ConvexAlignHip", handle, n: int, keep):
+        self.al, self.j, self.n, self._keep = aligner, handle, n, keep
+        self.results = None
+        self.ops = None
+
+    def wait(self):
+        """Blocks until the job is done.  Returns (results, ops): numpy views of the job's pinned
+        result records (RESULT_DTYPE) and dense ops arena, valid until release()."""
+        res = C.POINTER(capi.CvxResult)()
+        ops = C.POINTER(C.c_uint32)()
+        n_ops = C.c_uint64()
+        capi.check(self.al.lib.cvx_wait(self.al.h, self.j, C.byref(res), C.byref(ops), C.byref(n_ops)))
+        self.res_ptr = res
+        self.results = (np.ctypeslib.as_array(C.cast(res, C.POINTER(C.c_uint8)), shape=(self.n * RESULT_DTYPE.itemsize,))
+                        .view(RESULT_DTYPE) if self.n else np.zeros(0, RESULT_DTYPE))
+        self.ops = (np.ctypeslib.as_array(ops, shape=(int(n_ops.value),)) if n_ops.value else np.zeros(0, np.uint32))
+        return self.results, self.ops
+
+    def timing(self) -> capi.CvxTiming:
+        t = capi.CvxTiming()
+        capi.check(self.al.lib.cvx_job_timing(self.j, C.byref(t)))
+        return t
+
+    def launches(self) -> list:
+        t = self.timing()
+        out = []
+        for i in range(t.n_fill_launches):
+            li = capi.CvxLaunchInfo()
+            capi.check(self.al.lib.cvx_job_launch_info(self.j, i, C.byref(li)))
+            out.append({k: getattr(li, k) for k, _ in capi.CvxLaunchInfo._fields_})
+        return out
+
+    def release(self) -> None:
+        if self.j:
+            self.al.lib.cvx_job_release(self.al.h, self.j)
+            self.j = None
+            self.results = self.ops = None
+
+
+def format_tileset(lib, tileset, idx, results, ops, n_threads: int = 0):
+    """Host text stage (cvx_format_batch, all host threads) for tiles `idx` of a TileSet whose
+    result records / ops arena are `results` / `ops` (numpy, RESULT_DTYPE).  Returns a list of
+    dicts with the text-level Align fields (ret, score bits, CIGAR, MD, ...), no NM profile."""
+    idx = np.asarray(idx, dtype=np.int64)
+    n = len(idx)
+    tab = np.ascontiguousarray(tileset.table()[idx])
+    res = np.ascontiguousarray(results[idx])
+    H = tileset.H[idx]
+    caps = (4 * H + 64).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(caps)])
+    cig = np.zeros(int(offs[-1]), dtype=np.uint8)
+    md = np.zeros(int(offs[-1]), dtype=np.uint8)
+    bufs = (capi.CvxTextBuffers * max(n, 1))()
+    for k in range(n):
+        bufs[k].cigar = cig.ctypes.data + int(offs[k])
+        bufs[k].md = md.ctypes.data + int(offs[k])
+        bufs[k].nm_triples = None
+        bufs[k].cigar_cap = int(caps[k])
+        bufs[k].md_cap = int(caps[k])
+        bufs[k].nm_cap = 0
+    out = (capi.CvxAlignmentText * max(n, 1))()
+    capi.check(lib.cvx_format_batch(n, res.ctypes.data_as(C.POINTER(capi.CvxResult)), ops.ctypes.data,
+                                    tab.ctypes.data_as(C.POINTER(capi.CvxTile)), bufs, out, n_threads))
+    texts = []
+    for k in range(n):
+        t = out[k]
+        d = {f: getattr(t, f) for f, _ in capi.CvxAlignmentText._fields_}
+        d["score_bits"] = int(np.float32(t.score).view(np.uint32))
+        o = int(offs[k])
+        d["cigar"] = cig[o:o + t.cigar_len].tobytes().decode() if t.cigar_len < caps[k] else None
+        d["md"] = md[o:o + t.md_len].tobytes().decode() if t.md_len < caps[k] else None
+        texts.append(d)
+    return texts
 
 
 class StrippedSWHip:

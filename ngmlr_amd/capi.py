@@ -20,7 +20,9 @@ TILE_STATUS = {0: "ok", 1: "invalid-row0", 2: "invalid-edge", 3: "invalid-length
 
 EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_create", "cvx_destroy",
            "cvx_align_batch", "cvx_batch_upload", "cvx_batch_run", "cvx_batch_timing",
-           "cvx_batch_ops_total", "cvx_batch_launch_info", "cvx_batch_download", "cvx_batch_free", "cvx_format_alignment", "cvx_format_batch", "cvx_score_batch")
+           "cvx_batch_ops_total", "cvx_batch_launch_info", "cvx_batch_download", "cvx_batch_free",
+           "cvx_submit", "cvx_wait", "cvx_job_timing", "cvx_job_launch_info", "cvx_job_release",
+           "cvx_format_alignment", "cvx_format_batch", "cvx_score_batch")
 
 
 class CvxParams(C.Structure):
@@ -106,6 +108,13 @@ def load(path: str = None) -> C.CDLL:
                                        C.c_uint64, C.POINTER(C.c_uint64)]
     lib.cvx_batch_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.cvx_batch_free.restype = None
+    lib.cvx_submit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CvxTile), C.POINTER(C.c_void_p)]
+    lib.cvx_wait.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.POINTER(CvxResult)), C.POINTER(C.POINTER(C.c_uint32)),
+                             C.POINTER(C.c_uint64)]
+    lib.cvx_job_timing.argtypes = [C.c_void_p, C.POINTER(CvxTiming)]
+    lib.cvx_job_launch_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CvxLaunchInfo)]
+    lib.cvx_job_release.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cvx_job_release.restype = None
     lib.cvx_format_batch.argtypes = [C.c_int32, C.POINTER(CvxResult), C.c_void_p, C.POINTER(CvxTile),
                                      C.POINTER(CvxTextBuffers), C.POINTER(CvxAlignmentText), C.c_int32]
     lib.cvx_score_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p]

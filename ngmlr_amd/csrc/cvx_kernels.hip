@@ -782,16 +782,77 @@ backtrack_kernel(const BacktrackArgs a) {
 	walk_tile(a, t, threadIdx.x);
 }
 
-/* dense[dst_off[t] .. +n_ops) = region of tile t */
+/*
+ * finalize_kernel -- what the host used to do between backtrack and compaction, on the device:
+ * exclusive prefix sum of the op counts of the valid tiles (= each tile's slice of the dense ops
+ * arena), the caller-facing result records (cvx_result layout) and the batch summary.  One
+ * workgroup; a thread takes a contiguous chunk of tiles.
+ */
+__global__ void __launch_bounds__(1024)
+finalize_kernel(const TileOut *tout, const TilePlan *plan, uint64_t *dst_off, ResultRec *res,
+		BatchSummary *sum, const int32_t *redo_count, int n_tiles, unsigned long long dense_cap) {
+	__shared__ unsigned long long s_part[1024];
+	const int tid = threadIdx.x;
+	const int per = (n_tiles + 1023) / 1024;
+	const int t0 = tid * per, t1 = min(n_tiles, t0 + per);
+	unsigned long long mine = 0;
+	for (int t = t0; t < t1; ++t) {
+		const TileOut o = tout[t];
+		if (o.status == 0 && o.n_ops > 0) mine += (unsigned long long) o.n_ops;
+	}
+	s_part[tid] = mine;
+	__syncthreads();
+	/* Hillis-Steele inclusive scan over the 1024 partial sums */
+	for (int d = 1; d < 1024; d <<= 1) {
+		const unsigned long long v = (tid >= d) ? s_part[tid - d] : 0ull;
+		__syncthreads();
+		s_part[tid] += v;
+		__syncthreads();
+	}
+	unsigned long long off = s_part[tid] - mine;
+	int n_valid = 0;
+	for (int t = t0; t < t1; ++t) {
+		const TileOut o = tout[t];
+		ResultRec r;
+		r.score = o.score;
+		r.status = o.status;
+		r.best_x = o.best_x; r.best_y = o.best_y;
+		r.ref_position = o.ref_position; r.qstart = o.qstart; r.qend = o.qend;
+		r.n_ops = (o.status == 0) ? o.n_ops : 0;
+		r.ops_begin = off;
+		r.cells = plan[t].cells;
+		res[t] = r;
+		dst_off[t] = off;
+		if (o.status == 0) { n_valid += 1; if (o.n_ops > 0) off += (unsigned long long) o.n_ops; }
+	}
+	__shared__ int s_valid;
+	if (tid == 0) s_valid = 0;
+	__syncthreads();
+	if (n_valid) atomicAdd(&s_valid, n_valid);
+	__syncthreads();
+	if (tid == 1023) {
+		BatchSummary b;
+		b.ops_total = s_part[1023];
+		b.dense_cap = dense_cap;
+		b.n_valid = s_valid;
+		b.n_redone = redo_count ? *redo_count : 0;
+		*sum = b;
+	}
+}
+
+/* dense[dst_off[t] .. +n_ops) = region of tile t (tiles that do not fit the arena are skipped:
+ * the host sees ops_total > dense_cap in the summary, grows the arena and compacts again) */
 __global__ void __launch_bounds__(256)
 compact_ops_kernel(const int32_t *regions, const TileRun *trun, const TileOut *tout,
-		const uint64_t *dst_off, uint32_t *dense, int n_tiles) {
+		const uint64_t *dst_off, uint32_t *dense, int n_tiles, unsigned long long dense_cap) {
 	const int t = blockIdx.x;
 	if (t >= n_tiles) return;
 	const TileOut o = tout[t];
 	if (o.status != 0 || o.n_ops <= 0) return;
+	const unsigned long long d0 = dst_off[t];
+	if (d0 + (unsigned long long) o.n_ops > dense_cap) return;
 	const int32_t *src = regions + trun[t].ops_off + o.ops_first;
-	uint32_t *dst = dense + dst_off[t];
+	uint32_t *dst = dense + d0;
 	for (int i = threadIdx.x; i < o.n_ops; i += blockDim.x) dst[i] = (uint32_t) src[i];
 }
 
@@ -848,10 +909,18 @@ hipError_t launch_backtrack(const BacktrackArgs &a, hipStream_t st) {
 	return hipGetLastError();
 }
 
+hipError_t launch_finalize(const TileOut *tout, const TilePlan *plan, uint64_t *dst_off, ResultRec *res,
+		BatchSummary *sum, const int32_t *redo_count, int n_tiles, uint64_t dense_cap, hipStream_t st) {
+	hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, tout, plan, dst_off, res, sum, redo_count,
+			n_tiles, (unsigned long long) dense_cap);
+	return hipGetLastError();
+}
+
 hipError_t launch_compact(const int32_t *regions, const TileRun *trun, const TileOut *tout,
-		const uint64_t *dst_off, uint32_t *dense, int n_tiles, hipStream_t st) {
+		const uint64_t *dst_off, uint32_t *dense, int n_tiles, uint64_t dense_cap, hipStream_t st) {
 	if (n_tiles <= 0) return hipSuccess;
-	hipLaunchKernelGGL(compact_ops_kernel, dim3(n_tiles), dim3(256), 0, st, regions, trun, tout, dst_off, dense, n_tiles);
+	hipLaunchKernelGGL(compact_ops_kernel, dim3(n_tiles), dim3(256), 0, st, regions, trun, tout, dst_off, dense, n_tiles,
+			(unsigned long long) dense_cap);
 	return hipGetLastError();
 }
 

@@ -1,17 +1,28 @@
 /*
  * cvx_runtime.cpp -- host side of libcvxalign.so: the C ABI of include/cvx_align.h
- * over the gfx950 kernels of cvx_kernels.hip.
+ * over the gfx950 kernels of cvx_kernels.hip / cvx_generic.hip / cvx_score.hip.
  *
- * One cvx_context = one device + one HIP stream (ngmlr creates one aligner per worker
- * thread, reference src/CS.cpp:418; contexts are independent, a context is not
- * re-entrant -- same contract as the reference's ConvexAlignFast instances).
+ * One cvx_context = one device (ngmlr creates one aligner per worker thread, reference
+ * src/CS.cpp:418; contexts are independent, a context is not re-entrant -- same contract as
+ * the reference's ConvexAlignFast instances).  A batch of tiles moves through four stages:
  *
- * cvx_batch_run():
- *   plan_kernel -> (readback, host assigns kernel class / arena offsets) ->
- *   fill_ring_kernel per class -> backtrack_kernel -> (readback n_ops) -> compact_ops_kernel
+ *   upload   host threads pack sequences + corridor rows into the batch's own pinned staging,
+ *            piece by piece, each piece's DMA running under the packing of the next  (stream `io`)
+ *   plan     plan_kernel, plan records back to pinned memory                          (stream `io`)
+ *   compute  host: kernel class / arena offsets / LPT lists from the plan records;
+ *            fill_ring_kernel per class (+ exact redo pass) on the aux streams,
+ *            backtrack_kernel, finalize_kernel (device-side prefix sums and result records),
+ *            compact_ops_kernel, result records back to pinned memory               (stream `main`)
+ *   finish   dense ops back to pinned memory                                          (stream `io`)
  *
- * There is no CPU compute path in this file: without a device every entry point
- * returns CVX_ERR_NO_DEVICE.
+ * The streaming entry points (cvx_submit / cvx_wait / cvx_job_release) keep several batches in
+ * flight on one handle: the upload and plan of batch k+1 and the download of batch k-1 run
+ * under the kernels of batch k, and the only host waits are on events of work that was queued a
+ * whole batch earlier.  The staged entry points (cvx_batch_*) and cvx_align_batch run the same
+ * stages back to back.
+ *
+ * There is no CPU compute path in this file: without a device every entry point returns
+ * CVX_ERR_NO_DEVICE.
  */
 #include <hip/hip_runtime_api.h>
 
@@ -53,6 +64,18 @@ void set_err(const char *fmt, ...) {
 			return (e_ == hipErrorOutOfMemory) ? CVX_ERR_OOM : CVX_ERR_HIP;        \
 		}                                                                          \
 	} while (0)
+#define RC_TRY(expr) do { int rc_ = (expr); if (rc_ != CVX_OK) return rc_; } while (0)
+
+/* no C++ exception may cross the C ABI (std::bad_alloc from the host-side vectors) */
+#define ABI_GUARD_BEGIN try {
+#define ABI_GUARD_END                                                              \
+	} catch (const std::bad_alloc &) {                                             \
+		set_err("host allocation failed");                                         \
+		return CVX_ERR_OOM;                                                        \
+	} catch (...) {                                                                \
+		set_err("unexpected C++ exception");                                       \
+		return CVX_ERR_HIP;                                                        \
+	}
 
 template <typename T>
 struct DevBuf {
@@ -78,56 +101,58 @@ struct DevBuf {
 	}
 };
 
-}  // namespace
-
-static const int kAuxStreams = 4;
-
-struct cvx_context {
-	int device = 0;
-	hipStream_t stream = nullptr;
-	hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};  /* concurrent fill classes */
-	ScoreParams sp;
-	uint64_t max_matrix_mb = 10000;
-	int num_cus = 256;
-	int tune_min_slots = 0;   /* tuning knob (env CVX_TUNE_MIN_M): smallest M*NW a tile may use */
-	int tune_late_min = kLateMinGroups;  /* test knob (env CVX_TUNE_LATE_MIN): groups of the exactly tracked tail (huge: exact everywhere) */
-	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
-	/* pinned (page-locked) upload staging, grown on demand and reused by every upload on this
-	 * handle: sequences and corridor rows are packed here by several host threads and go to the
-	 * device as two DMA copies */
-	void *stage_seq = nullptr, *stage_rows = nullptr;
-	size_t stage_seq_cap = 0, stage_rows_cap = 0;
-	/* freed batches keep their device arenas and wait here for the next upload (at most
-	 * kPoolBatches): hipMalloc / hipFree of multi-GB arenas per call are slow, and hipFree
-	 * synchronises the whole device, which would serialise handles that work side by side */
-	std::vector<struct cvx_batch_s *> pool;
+/* grow-only page-locked host buffer */
+struct PinBuf {
+	void *p = nullptr;
+	size_t cap = 0; /* bytes */
+	int ensure(size_t bytes) {
+		if (bytes <= cap) return CVX_OK;
+		if (p) { (void) hipHostFree(p); p = nullptr; cap = 0; }
+		const size_t want = bytes + bytes / 8 + 4096;
+		hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+		if (e != hipSuccess) {
+			(void) hipGetLastError();
+			set_err("hipHostMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+			p = nullptr;
+			return CVX_ERR_OOM;
+		}
+		cap = want;
+		return CVX_OK;
+	}
+	void release() {
+		if (p) (void) hipHostFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+	template <typename T> T *as() const { return static_cast<T *>(p); }
 };
-static const size_t kPoolBatches = 2;
-
-namespace {
-
-/* grow-only pinned buffer; false if the host cannot pin that much (caller falls back to pageable) */
-bool ensure_pinned(void **p, size_t *cap, size_t need) {
-	if (need <= *cap) return true;
-	if (*p) { (void) hipHostFree(*p); *p = nullptr; *cap = 0; }
-	const size_t want = need + need / 8 + 4096;
-	if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); *p = nullptr; return false; }
-	*cap = want;
-	return true;
-}
 
 }  // namespace
+
+/* Four streams per handle and not more: the ROCm runtime multiplexes the streams of a process onto
+ * (by default) four hardware queues, and two streams that land on the same queue serialise --
+ * measured: with seven streams the 18-tile M = 4 launch ran alone for 11 ms in front of the
+ * 24 558-tile M = 3 launch instead of beside it. */
+static const int kAuxStreams = 2;
+static const size_t kPoolBatches = 4;
+
+enum BatchState { kEmpty = 0, kUploaded = 1, kPlanned = 2, kComputed = 3, kFinished = 4 };
 
 struct cvx_batch_s {
 	int n = 0;
-	std::vector<TileIn> tin;
-	std::vector<TilePlan> plan;
-	std::vector<TileRun> trun;
-	std::vector<TileOut> tout;
-	std::vector<uint64_t> dst_off;
-	std::vector<int32_t> lists;
-	uint64_t ops_total = 0;
-	bool ran = false;
+	int state = kEmpty;
+	bool in_flight = false;          /* submitted through the streaming API and not yet released */
+	uint64_t seq_total = 0, n_rows = 0;
+	uint64_t ops_total = 0;          /* valid after the compute stage has been waited for */
+	uint64_t dense_cap = 0;
+	bool have_ops = false;           /* dense ops are in h_ops */
+
+	/* host side, page-locked */
+	PinBuf h_seq, h_rows, h_tin;     /* upload staging (owned by the batch: no wait before reuse by another batch) */
+	PinBuf h_plan;                   /* TilePlan[n] */
+	PinBuf h_trun, h_tout, h_lists, h_goff;   /* what the host planning produces */
+	PinBuf h_res;                    /* ResultRec[n] + BatchSummary */
+	PinBuf h_ops;                    /* dense ops */
 
 	DevBuf<uint8_t> d_seq;
 	DevBuf<RowDesc> d_rows;
@@ -138,26 +163,418 @@ struct cvx_batch_s {
 	DevBuf<uint32_t> d_dirs;
 	DevBuf<int32_t> d_regions;
 	DevBuf<int32_t> d_lists;
-	DevBuf<int32_t> d_heads;
+	DevBuf<int32_t> d_counters;
 	DevBuf<uint64_t> d_dstoff;
 	DevBuf<uint32_t> d_dense;
+	DevBuf<uint8_t> d_res;           /* ResultRec[n] + BatchSummary */
 	DevBuf<uint8_t> d_gscratch;      /* slot state of tiles taken by the catch-all kernel */
 	DevBuf<uint64_t> d_gscratch_off;
 
-	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-	std::vector<hipEvent_t> lev;          /* 3 events per fill class: start, two-phase pass done, exact pass done */
+	hipEvent_t ev_in = nullptr;      /* upload + plan records on the host */
+	hipEvent_t ev_res = nullptr;     /* result records on the host */
+	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   /* timing: plan begin/end, fills done, all done, fills may start */
+	std::vector<hipEvent_t> lev;     /* 3 events per fill class: start, two-phase pass done, exact pass done */
 	std::vector<cvx_launch_info> launches;
 	cvx_timing timing;
 
+	const TileIn *tin() const { return h_tin.as<TileIn>(); }
+	const TilePlan *plan() const { return h_plan.as<TilePlan>(); }
+	const ResultRec *res() const { return h_res.as<ResultRec>(); }
+	const BatchSummary *summary() const { return reinterpret_cast<const BatchSummary *>(h_res.as<uint8_t>() + (size_t) n * sizeof(ResultRec)); }
+
+	int make_events() {
+		if (!ev_in) HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+		if (!ev_res) HIP_TRY(hipEventCreateWithFlags(&ev_res, hipEventDisableTiming));
+		for (auto &e : ev) if (!e) HIP_TRY(hipEventCreate(&e));
+		return CVX_OK;
+	}
 	void release() {
+		h_seq.release(); h_rows.release(); h_tin.release(); h_plan.release(); h_trun.release(); h_tout.release();
+		h_lists.release(); h_goff.release(); h_res.release(); h_ops.release();
 		d_seq.release(); d_rows.release(); d_tin.release(); d_plan.release(); d_trun.release();
 		d_tout.release(); d_dirs.release(); d_regions.release(); d_lists.release();
-		d_heads.release(); d_dstoff.release(); d_dense.release(); d_gscratch.release(); d_gscratch_off.release();
+		d_counters.release(); d_dstoff.release(); d_dense.release(); d_res.release();
+		d_gscratch.release(); d_gscratch_off.release();
+		if (ev_in) { (void) hipEventDestroy(ev_in); ev_in = nullptr; }
+		if (ev_res) { (void) hipEventDestroy(ev_res); ev_res = nullptr; }
 		for (auto &e : ev) if (e) { (void) hipEventDestroy(e); e = nullptr; }
 		for (auto &e : lev) if (e) (void) hipEventDestroy(e);
 		lev.clear();
 	}
 };
+
+struct cvx_context {
+	int device = 0;
+	hipStream_t s_io = nullptr;      /* uploads, plan, downloads (high priority: its short kernels and copies
+	                                  * must not queue behind the fill's workgroups) */
+	hipStream_t s_main = nullptr;    /* compute */
+	hipStream_t aux[kAuxStreams] = {nullptr, nullptr};  /* concurrent fill classes */
+	ScoreParams sp;
+	uint64_t max_matrix_mb = 10000;
+	int num_cus = 256;
+	int pack_threads = 16;
+	int tune_min_slots = 0;   /* tuning knob (env CVX_TUNE_MIN_M): smallest M*NW a tile may use */
+	int tune_late_min = kLateMinGroups;  /* test knob (env CVX_TUNE_LATE_MIN): groups of the exactly tracked tail (huge: exact everywhere) */
+	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
+	/* freed batches keep their device arenas and pinned staging and wait here for the next upload
+	 * (at most kPoolBatches): hipMalloc / hipFree of multi-GB arenas per call are slow, and hipFree
+	 * synchronises the whole device, which would serialise handles that work side by side */
+	std::vector<cvx_batch_s *> pool;
+	std::vector<cvx_batch_s *> pending;      /* streaming jobs whose compute stage is not queued yet */
+	/* sub-read scoring (cvx_score_batch): persistent staging and device buffers */
+	PinBuf sc_hseq, sc_hpairs, sc_hout;
+	DevBuf<uint8_t> sc_seq;
+	DevBuf<ScorePair> sc_pairs;
+	DevBuf<int32_t> sc_rows;
+	DevBuf<float> sc_out;
+};
+
+namespace {
+
+cvx_batch_s *acquire_batch(cvx_context *h) {
+	if (!h->pool.empty()) {
+		cvx_batch_s *b = h->pool.back();
+		h->pool.pop_back();
+		return b;
+	}
+	return new (std::nothrow) cvx_batch_s();
+}
+
+void recycle_batch(cvx_context *h, cvx_batch_s *b) {
+	b->state = kEmpty;
+	b->in_flight = false;
+	b->have_ops = false;
+	if (h && h->pool.size() < kPoolBatches) { h->pool.push_back(b); return; }
+	b->release();
+	delete b;
+}
+
+/* something failed after work was queued: nothing may still be running on the arenas when they
+ * go back to the allocator (or to the pool) */
+void discard_batch(cvx_context *h, cvx_batch_s *b) {
+	(void) hipDeviceSynchronize();
+	if (h) {
+		auto it = std::find(h->pending.begin(), h->pending.end(), b);
+		if (it != h->pending.end()) h->pending.erase(it);
+	}
+	b->release();
+	delete b;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b) {
+	float ms = 0.0f;
+	if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void) hipGetLastError(); return 0.0f; }
+	return ms;
+}
+
+/* ---- stage 1: pack into pinned staging and copy to the device, piece by piece (stream `io`) */
+int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tiles) {
+	UploadLayout L;
+	std::vector<TileIn> tin;
+	int bad = -1;
+	const int lrc = upload_layout(n, tiles, tin, L, &bad);
+	if (lrc == kLayoutMalformed) { set_err("tile %d malformed", bad); return CVX_ERR_ARG; }
+	if (lrc == kLayoutTooLarge) {
+		set_err("%llu sequence bytes exceed one batch (4 GiB); split the batch", (unsigned long long) L.seq_total);
+		return CVX_ERR_ARG;
+	}
+	b->n = n;
+	b->state = kEmpty;
+	b->have_ops = false;
+	b->ops_total = 0;
+	b->seq_total = L.seq_total;
+	b->n_rows = L.n_rows;
+	memset(&b->timing, 0, sizeof(b->timing));
+	RC_TRY(b->make_events());
+	const size_t n1 = (size_t) std::max(n, 1);
+	const size_t rows1 = (size_t) std::max<uint64_t>(L.n_rows, 1);
+	RC_TRY(b->h_seq.ensure((size_t) L.seq_total));
+	RC_TRY(b->h_rows.ensure(rows1 * sizeof(RowDesc)));
+	RC_TRY(b->h_tin.ensure(n1 * sizeof(TileIn)));
+	RC_TRY(b->h_plan.ensure(n1 * sizeof(TilePlan)));
+	RC_TRY(b->h_res.ensure(n1 * sizeof(ResultRec) + sizeof(BatchSummary)));
+	RC_TRY(b->d_seq.ensure((size_t) L.seq_total));
+	RC_TRY(b->d_rows.ensure(rows1));
+	RC_TRY(b->d_tin.ensure(n1));
+	RC_TRY(b->d_plan.ensure(n1));
+	RC_TRY(b->d_trun.ensure(n1));
+	RC_TRY(b->d_tout.ensure(n1));
+	RC_TRY(b->d_dstoff.ensure(n1));
+	RC_TRY(b->d_lists.ensure(n1));
+	RC_TRY(b->d_counters.ensure(64));
+	RC_TRY(b->d_res.ensure(n1 * sizeof(ResultRec) + sizeof(BatchSummary)));
+	if (n) memcpy(b->h_tin.p, tin.data(), (size_t) n * sizeof(TileIn));
+
+	uint8_t *hseq = b->h_seq.as<uint8_t>();
+	RowDesc *hrows = b->h_rows.as<RowDesc>();
+	upload_zero_pads(L, hseq);
+	const std::vector<uint64_t> &wprefix = L.wprefix;
+	int threads = std::max(1, h->pack_threads);
+	if (wprefix[(size_t) n] < (8u << 20)) threads = 1;      /* not worth a thread below ~8 MB */
+	hipStream_t st = h->s_io;
+	const int pieces = threads > 1 ? 8 : 1;
+	int t0 = 0;
+	uint64_t seq_done = 0;                   /* bytes of hseq already on their way */
+	for (int pc = 1; pc <= pieces; ++pc) {
+		int t1 = n;
+		if (pc < pieces) {
+			const uint64_t target = wprefix[(size_t) n] / (uint64_t) pieces * (uint64_t) pc;
+			t1 = (int) (std::upper_bound(wprefix.begin(), wprefix.end(), target) - wprefix.begin());
+			t1 = std::min(std::max(t1, t0), n);
+		}
+		if (t1 > t0) {
+			std::vector<uint64_t> wp((size_t) (t1 - t0) + 1);
+			for (int i = t0; i <= t1; ++i) wp[(size_t) (i - t0)] = wprefix[(size_t) i] - wprefix[(size_t) t0];
+			const int base = t0;
+			parallel_ranges(t1 - t0, wp, threads, [&](int bg, int en) { upload_pack(base + bg, base + en, tiles, tin, hseq, hrows); });
+		}
+		const uint64_t seq_end = (t1 == n) ? L.seq_total : (uint64_t) tin[(size_t) t1].ref_off;
+		if (seq_end > seq_done)
+			HIP_TRY(hipMemcpyAsync(b->d_seq.p + seq_done, hseq + seq_done, (size_t) (seq_end - seq_done), hipMemcpyHostToDevice, st));
+		seq_done = seq_end;
+		const uint64_t r0 = (t0 < n) ? tin[(size_t) t0].row_off : L.n_rows;
+		const uint64_t r1 = (t1 < n) ? tin[(size_t) t1].row_off : L.n_rows;
+		if (r1 > r0)
+			HIP_TRY(hipMemcpyAsync(b->d_rows.p + r0, hrows + r0, (size_t) (r1 - r0) * sizeof(RowDesc), hipMemcpyHostToDevice, st));
+		t0 = t1;
+	}
+	if (n) HIP_TRY(hipMemcpyAsync(b->d_tin.p, b->h_tin.p, (size_t) n * sizeof(TileIn), hipMemcpyHostToDevice, st));
+	b->state = kUploaded;
+	return CVX_OK;
+}
+
+/* ---- stage 2: corridor analysis on `st`, records back to the host */
+int stage_plan(cvx_context *h, cvx_batch_s *b, hipStream_t st) {
+	const int n = b->n;
+	HIP_TRY(hipEventRecord(b->ev[0], st));
+	if (n) {
+		HIP_TRY(launch_plan(b->d_rows.p, b->d_tin.p, b->d_plan.p, n, h->max_matrix_mb, st));
+		HIP_TRY(hipMemcpyAsync(b->h_plan.p, b->d_plan.p, (size_t) n * sizeof(TilePlan), hipMemcpyDeviceToHost, st));
+	}
+	HIP_TRY(hipEventRecord(b->ev[1], st));
+	HIP_TRY(hipEventRecord(b->ev_in, st));
+	b->state = kPlanned;
+	return CVX_OK;
+}
+
+/* ---- stage 3: host planning, then every kernel of the batch on `main` (+ aux); nothing waits */
+int stage_compute(cvx_context *h, cvx_batch_s *b) {
+	const int n = b->n;
+	hipStream_t st = h->s_main;
+	HIP_TRY(hipEventSynchronize(b->ev_in));        /* queued a whole batch ago in the streaming case */
+	b->launches.clear();
+	b->ops_total = 0;
+	b->have_ops = false;
+	if (n == 0) {
+		HIP_TRY(hipEventRecord(b->ev[4], st));
+		HIP_TRY(hipEventRecord(b->ev[2], st));
+		HIP_TRY(hipEventRecord(b->ev[3], st));
+		HIP_TRY(hipEventRecord(b->ev_res, st));
+		b->state = kComputed;
+		return CVX_OK;
+	}
+
+	/* host planning: kernel class, arena offsets, work lists (cvx_host_logic.h) */
+	HostPlan hp;
+	host_plan(n, b->plan(), b->tin(), h->tune_min_slots, h->tune_force_wrap, hp);
+	std::vector<std::vector<int32_t>> &cls = hp.cls;
+	std::vector<int32_t> &generic = hp.generic;
+	RC_TRY(b->d_dirs.ensure((size_t) hp.dir_dwords + 64));
+	RC_TRY(b->d_regions.ensure((size_t) hp.ops_ints + 64));
+	/* dense ops arena: an alignment of H read bases has far fewer than H run-length ops (about
+	 * 0.3 H at 15 % error); if a batch ever needs more, finalize reports it and stage_ops
+	 * compacts again into a larger arena */
+	b->dense_cap = std::min<uint64_t>(hp.ops_ints, hp.ops_ints / 3 + 64ull * (uint64_t) n);
+	RC_TRY(b->d_dense.ensure((size_t) b->dense_cap + 64));
+	b->dense_cap = std::max<uint64_t>(b->dense_cap, b->d_dense.cap - 64);
+
+	RC_TRY(b->h_trun.ensure((size_t) n * sizeof(TileRun)));
+	RC_TRY(b->h_tout.ensure((size_t) n * sizeof(TileOut)));
+	RC_TRY(b->h_lists.ensure((size_t) n * sizeof(int32_t) + 64));
+	memcpy(b->h_trun.p, hp.trun.data(), (size_t) n * sizeof(TileRun));
+	memcpy(b->h_tout.p, hp.tout.data(), (size_t) n * sizeof(TileOut));
+	int32_t *lists = b->h_lists.as<int32_t>();
+	size_t n_listed = 0;
+	std::vector<int> seg_begin(cls.size(), 0);
+	for (size_t c = 0; c < cls.size(); ++c) {
+		seg_begin[c] = (int) n_listed;      /* already in LPT order */
+		if (!cls[c].empty()) memcpy(lists + n_listed, cls[c].data(), cls[c].size() * sizeof(int32_t));
+		n_listed += cls[c].size();
+	}
+	const int generic_begin = (int) n_listed;
+	if (!generic.empty()) memcpy(lists + n_listed, generic.data(), generic.size() * sizeof(int32_t));
+	n_listed += generic.size();
+	if (!generic.empty()) {
+		RC_TRY(b->h_goff.ensure((generic.size() + 1) * sizeof(uint64_t)));
+		uint64_t *goff = b->h_goff.as<uint64_t>();
+		goff[0] = 0;
+		for (size_t g = 0; g < generic.size(); ++g)
+			goff[g + 1] = goff[g] + (uint64_t) generic_scratch_bytes(hp.trun[(size_t) generic[g]].ring);
+		RC_TRY(b->d_gscratch.ensure((size_t) goff[generic.size()] + 256));
+		RC_TRY(b->d_gscratch_off.ensure(generic.size() + 1));
+		HIP_TRY(hipMemcpyAsync(b->d_gscratch_off.p, goff, (generic.size() + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_trun.p, b->h_trun.p, (size_t) n * sizeof(TileRun), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(b->d_tout.p, b->h_tout.p, (size_t) n * sizeof(TileOut), hipMemcpyHostToDevice, st));
+	if (n_listed) HIP_TRY(hipMemcpyAsync(b->d_lists.p, lists, n_listed * sizeof(int32_t), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync(b->d_counters.p, 0, 64 * sizeof(int32_t), st));
+	HIP_TRY(hipEventRecord(b->ev[4], st));        /* inputs of the fills are in place */
+
+	/* forward fill: one launch per populated kernel class (+ its exact redo pass), classes run
+	 * concurrently on separate streams (a sparsely populated class would otherwise serialise a
+	 * whole tile latency behind the big one); widest rings first, they have the longest tiles */
+	auto fill_args = [&](const int32_t *list, int list_n) {
+		FillArgs a;
+		a.seq = b->d_seq.p;
+		a.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
+		a.tin = b->d_tin.p;
+		a.trun = b->d_trun.p;
+		a.tout = b->d_tout.p;
+		a.dirs = b->d_dirs.p;
+		a.list = list;
+		a.list_n = list_n;
+		a.redo_count = b->d_counters.p;
+		a.late_min_groups = h->tune_late_min;
+		a.ops = b->d_regions.p;
+		a.sp = h->sp;
+		return a;
+	};
+	auto launch_stats = [&](const std::vector<int32_t> &v, int m, int nw, int wrap) {
+		cvx_launch_info li;
+		memset(&li, 0, sizeof(li));
+		li.slots_per_lane = m; li.waves = nw; li.wrap16 = wrap; li.n_tiles = (int) v.size();
+		for (int32_t ti : v) {
+			const TilePlan &p = b->plan()[(size_t) ti];
+			const TileIn &in = b->tin()[(size_t) ti];
+			li.cells += p.cells; li.active_cells += p.active;
+			li.alg_bytes += p.cells + 6ull * (uint64_t) in.H + 2ull * (uint64_t) in.W;
+			li.read_bases += (uint64_t) in.H;
+		}
+		b->launches.push_back(li);
+	};
+	int launches = 0;
+	auto begin_launch = [&](hipStream_t ls) -> int {
+		while (b->lev.size() < (size_t) (launches + 1) * 3) {
+			hipEvent_t e;
+			HIP_TRY(hipEventCreate(&e));
+			b->lev.push_back(e);
+		}
+		HIP_TRY(hipStreamWaitEvent(ls, b->ev[4], 0));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3], ls));
+		return CVX_OK;
+	};
+	for (int cc = (int) cls.size() - 1; cc >= 0; --cc) {
+		const size_t c = (size_t) cc;
+		if (cls[c].empty()) continue;
+		const KernelClass &kc = kClasses[c / 2];
+		launch_stats(cls[c], kc.m, kc.nw, (int) (c & 1));
+		hipStream_t ls = h->aux[launches % kAuxStreams];
+		RC_TRY(begin_launch(ls));
+		const FillArgs a = fill_args(b->d_lists.p + seg_begin[c], (int) cls[c].size());
+		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, false, a, ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
+		/* exact-tracking pass over the tiles the two-phase pass flagged (usually none) */
+		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, true, a, ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
+		launches++;
+	}
+	if (!generic.empty()) {
+		launch_stats(generic, 0, 16, 1);
+		hipStream_t ls = h->aux[launches % kAuxStreams];
+		RC_TRY(begin_launch(ls));
+		const FillArgs a = fill_args(b->d_lists.p + generic_begin, (int) generic.size());
+		HIP_TRY(launch_fill_generic(a, b->d_gscratch.p, b->d_gscratch_off.p, ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
+		launches++;
+	}
+	for (int i = 0; i < launches; ++i) HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) i * 3 + 2], 0));
+	HIP_TRY(hipEventRecord(b->ev[2], st));
+
+	/* backtrack, device-side result records + prefix sums, ops compaction */
+	BacktrackArgs ba;
+	ba.seq = b->d_seq.p;
+	ba.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
+	ba.tin = b->d_tin.p;
+	ba.trun = b->d_trun.p;
+	ba.tout = b->d_tout.p;
+	ba.dirs = b->d_dirs.p;
+	ba.ops = b->d_regions.p;
+	ba.n_tiles = n;
+	HIP_TRY(launch_backtrack(ba, st));
+	ResultRec *d_rec = reinterpret_cast<ResultRec *>(b->d_res.p);
+	BatchSummary *d_sum = reinterpret_cast<BatchSummary *>(b->d_res.p + (size_t) n * sizeof(ResultRec));
+	HIP_TRY(launch_finalize(b->d_tout.p, b->d_plan.p, b->d_dstoff.p, d_rec, d_sum, b->d_counters.p, n, b->dense_cap, st));
+	HIP_TRY(launch_compact(b->d_regions.p, b->d_trun.p, b->d_tout.p, b->d_dstoff.p, b->d_dense.p, n, b->dense_cap, st));
+	HIP_TRY(hipEventRecord(b->ev[3], st));
+	HIP_TRY(hipMemcpyAsync(b->h_res.p, b->d_res.p, (size_t) n * sizeof(ResultRec) + sizeof(BatchSummary), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(b->ev_res, st));
+
+	b->timing.cells = hp.cells;
+	b->timing.active_cells = hp.active;
+	b->timing.dir_bytes = hp.dir_dwords * 4;
+	b->timing.n_fill_launches = launches;
+	b->timing.n_tiles_fast = hp.n_fast;
+	b->state = kComputed;
+	return CVX_OK;
+}
+
+/* ---- wait for the result records; timing of the batch */
+int stage_results(cvx_context *h, cvx_batch_s *b) {
+	(void) h;
+	HIP_TRY(hipEventSynchronize(b->ev_res));
+	if (b->n == 0) { b->ops_total = 0; b->state = kFinished; return CVX_OK; }
+	const BatchSummary *s = b->summary();
+	b->ops_total = s->ops_total;
+	const int launches = b->timing.n_fill_launches;
+	for (int i = 0; i < launches; ++i) b->launches[(size_t) i].ms = ev_ms(b->lev[(size_t) i * 3], b->lev[(size_t) i * 3 + 1]);
+	b->timing.plan_ms = ev_ms(b->ev[0], b->ev[1]);
+	b->timing.fill_ms = ev_ms(b->ev[4], b->ev[2]);
+	b->timing.backtrack_ms = ev_ms(b->ev[2], b->ev[3]);
+	b->timing.total_ms = b->timing.plan_ms + ev_ms(b->ev[4], b->ev[3]);
+	b->timing.n_tiles_redone = s->n_redone;
+	b->state = kFinished;
+	return CVX_OK;
+}
+
+/* ---- stage 4: dense ops to pinned host memory (stream `io`) */
+int stage_ops(cvx_context *h, cvx_batch_s *b) {
+	if (b->have_ops) return CVX_OK;
+	if (b->ops_total > b->dense_cap) {
+		/* rare: more ops than the arena was sized for -- grow it and compact again */
+		const uint64_t cap = b->ops_total;
+		RC_TRY(b->d_dense.ensure((size_t) cap + 64));
+		b->dense_cap = b->d_dense.cap - 64;
+		HIP_TRY(launch_compact(b->d_regions.p, b->d_trun.p, b->d_tout.p, b->d_dstoff.p, b->d_dense.p, b->n, b->dense_cap, h->s_main));
+		HIP_TRY(hipStreamSynchronize(h->s_main));
+	}
+	if (b->ops_total) {
+		RC_TRY(b->h_ops.ensure((size_t) b->ops_total * sizeof(uint32_t)));
+		HIP_TRY(hipMemcpyAsync(b->h_ops.p, b->d_dense.p, (size_t) b->ops_total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s_io));
+		HIP_TRY(hipStreamSynchronize(h->s_io));
+	}
+	b->have_ops = true;
+	return CVX_OK;
+}
+
+/* queue the compute stage of every submitted batch whose plan records have arrived (all of them,
+ * up to `upto`, when `block`): keeps the device one batch ahead of the host */
+int pump(cvx_context *h, bool block, const cvx_batch_s *upto) {
+	while (!h->pending.empty()) {
+		cvx_batch_s *b = h->pending.front();
+		if (!block) {
+			hipError_t q = hipEventQuery(b->ev_in);
+			if (q == hipErrorNotReady) { (void) hipGetLastError(); break; }
+			if (q != hipSuccess) { set_err("hipEventQuery: %s", hipGetErrorString(q)); return CVX_ERR_HIP; }
+		}
+		h->pending.erase(h->pending.begin());
+		RC_TRY(stage_compute(h, b));
+		if (upto && b == upto) break;
+	}
+	return CVX_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -172,6 +589,7 @@ int cvx_device_count(void) {
 }
 
 int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_handle *out) {
+	ABI_GUARD_BEGIN
 	if (!p || !out) { set_err("cvx_create: NULL argument"); return CVX_ERR_ARG; }
 	*out = nullptr;
 	/* The device kernels implement the scalar recurrence (reference
@@ -213,332 +631,72 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	c->sp.mat = p->match; c->sp.mis = p->mismatch; c->sp.go = p->gap_open;
 	c->sp.ge = p->gap_extend; c->sp.gem = p->gap_extend_min; c->sp.decay = p->gap_decay;
 	c->max_matrix_mb = max_matrix_mb ? max_matrix_mb : 10000;
+	const int hw = (int) std::thread::hardware_concurrency();
+	c->pack_threads = std::max(1, std::min(hw > 0 ? hw : 1, 24));
+	if (const char *e = getenv("CVX_PACK_THREADS")) c->pack_threads = std::max(1, atoi(e));
 	if (const char *e = getenv("CVX_TUNE_MIN_M")) c->tune_min_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_FORCE_WRAP16")) c->tune_force_wrap = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
-	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	int prio_lo = 0, prio_hi = 0;
+	(void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     /* numerically lower = higher priority */
+	hipError_t e = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->s_io, hipStreamNonBlocking, prio_hi);
 	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
 	if (e != hipSuccess) {
 		set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
-		delete c;
+		cvx_destroy(c);
 		return CVX_ERR_HIP;
 	}
 	*out = c;
 	return CVX_OK;
+	ABI_GUARD_END
 }
 
 void cvx_destroy(cvx_handle h) {
 	if (!h) return;
 	(void) hipSetDevice(h->device);
-	if (h->stream) (void) hipStreamDestroy(h->stream);
+	(void) hipDeviceSynchronize();
+	if (h->s_main) (void) hipStreamDestroy(h->s_main);
+	if (h->s_io) (void) hipStreamDestroy(h->s_io);
+	if (h->s_io) (void) hipStreamDestroy(h->s_io);
 	for (auto &a : h->aux) if (a) (void) hipStreamDestroy(a);
 	for (cvx_batch_s *b : h->pool) { b->release(); delete b; }
 	h->pool.clear();
-	if (h->stage_seq) (void) hipHostFree(h->stage_seq);
-	if (h->stage_rows) (void) hipHostFree(h->stage_rows);
+	h->sc_hseq.release(); h->sc_hpairs.release(); h->sc_hout.release();
+	h->sc_seq.release(); h->sc_pairs.release(); h->sc_rows.release(); h->sc_out.release();
 	delete h;
 }
 
+/* ------------------------------------------------------------------ staged form */
+
 int cvx_batch_upload(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_batch *out) {
+	ABI_GUARD_BEGIN
 	if (!h || !out || n < 0 || (n > 0 && !tiles)) { set_err("cvx_batch_upload: bad argument"); return CVX_ERR_ARG; }
 	*out = nullptr;
 	HIP_TRY(hipSetDevice(h->device));
-
-	UploadLayout L;
-	std::vector<TileIn> tin;
-	int bad = -1;
-	int lrc;
-	try {
-		lrc = upload_layout(n, tiles, tin, L, &bad);
-	} catch (const std::bad_alloc &) {
-		set_err("cvx_batch_upload: host allocation failed");
-		return CVX_ERR_OOM;
-	}
-	if (lrc == kLayoutMalformed) { set_err("cvx_batch_upload: tile %d malformed", bad); return CVX_ERR_ARG; }
-	if (lrc == kLayoutTooLarge) {
-		set_err("cvx_batch_upload: %llu sequence bytes exceed one batch (4 GiB); split the batch",
-				(unsigned long long) L.seq_total);
-		return CVX_ERR_ARG;
-	}
-	const uint64_t seq_total = L.seq_total, n_rows = L.n_rows;
-	const std::vector<uint64_t> &wprefix = L.wprefix;
-
-	cvx_batch_s *b;
-	if (!h->pool.empty()) {
-		b = h->pool.back();
-		h->pool.pop_back();
-	} else {
-		b = new (std::nothrow) cvx_batch_s();
-	}
+	cvx_batch_s *b = acquire_batch(h);
 	if (!b) return CVX_ERR_OOM;
-	b->n = n;
-	b->ran = false;
-	b->ops_total = 0;
-	memset(&b->timing, 0, sizeof(b->timing));
-	int rc = CVX_OK;
-	try {
-		b->tin.swap(tin);
-		const size_t rows_bytes = (size_t) std::max<uint64_t>(n_rows, 1) * sizeof(RowDesc);
-		std::vector<uint8_t> pg_seq;       /* pageable fallbacks when pinning fails */
-		std::vector<RowDesc> pg_rows;
-		uint8_t *hseq;
-		RowDesc *hrows;
-		if (ensure_pinned(&h->stage_seq, &h->stage_seq_cap, (size_t) seq_total) &&
-				ensure_pinned(&h->stage_rows, &h->stage_rows_cap, rows_bytes)) {
-			hseq = static_cast<uint8_t *>(h->stage_seq);
-			hrows = static_cast<RowDesc *>(h->stage_rows);
-		} else {
-			pg_seq.resize((size_t) seq_total);
-			pg_rows.resize(rows_bytes / sizeof(RowDesc));
-			hseq = pg_seq.data();
-			hrows = pg_rows.data();
-		}
-		upload_zero_pads(L, hseq);
-		int threads = (int) std::thread::hardware_concurrency();
-		threads = std::max(1, std::min(threads, 16));
-		if (wprefix[(size_t) n] < (8u << 20)) threads = 1;      /* not worth a thread below ~8 MB */
-		auto pack = [&](int begin, int end) { upload_pack(begin, end, tiles, b->tin, hseq, hrows); };
-		if ((rc = b->d_seq.ensure((size_t) seq_total)) == CVX_OK &&
-				(rc = b->d_rows.ensure(rows_bytes / sizeof(RowDesc))) == CVX_OK &&
-				(rc = b->d_tin.ensure((size_t) std::max(n, 1))) == CVX_OK &&
-				(rc = b->d_plan.ensure((size_t) std::max(n, 1))) == CVX_OK &&
-				(rc = b->d_trun.ensure((size_t) std::max(n, 1))) == CVX_OK &&
-				(rc = b->d_tout.ensure((size_t) std::max(n, 1))) == CVX_OK &&
-				(rc = b->d_dstoff.ensure((size_t) std::max(n, 1))) == CVX_OK &&
-				(rc = b->d_lists.ensure((size_t) std::max(n, 1))) == CVX_OK &&
-				(rc = b->d_heads.ensure(64)) == CVX_OK) {
-			/* pack and copy in a few pieces, so that the DMA of one piece runs under the packing
-			 * of the next (pieces are contiguous in both arenas) */
-			hipStream_t st = h->stream;
-			hipError_t e = hipSuccess;
-			const int pieces = threads > 1 ? 4 : 1;
-			int t0 = 0;
-			uint64_t seq_done = 0;                   /* bytes of hseq already on their way */
-			for (int pc = 1; pc <= pieces && e == hipSuccess; ++pc) {
-				int t1 = n;
-				if (pc < pieces) {
-					const uint64_t target = wprefix[(size_t) n] / (uint64_t) pieces * (uint64_t) pc;
-					t1 = (int) (std::upper_bound(wprefix.begin(), wprefix.end(), target) - wprefix.begin());
-					t1 = std::min(std::max(t1, t0), n);
-				}
-				if (t1 > t0) {
-					std::vector<uint64_t> wp((size_t) (t1 - t0) + 1);
-					for (int i = t0; i <= t1; ++i) wp[(size_t) (i - t0)] = wprefix[(size_t) i] - wprefix[(size_t) t0];
-					parallel_ranges(t1 - t0, wp, threads, [&](int bg, int en) { pack(t0 + bg, t0 + en); });
-				}
-				const uint64_t seq_end = (t1 == n) ? seq_total : (uint64_t) b->tin[(size_t) t1].ref_off;
-				if (seq_end > seq_done)
-					e = hipMemcpyAsync(b->d_seq.p + seq_done, hseq + seq_done, (size_t) (seq_end - seq_done), hipMemcpyHostToDevice, st);
-				seq_done = seq_end;
-				const uint64_t r0 = (t0 < n) ? b->tin[(size_t) t0].row_off : n_rows;
-				const uint64_t r1 = (t1 < n) ? b->tin[(size_t) t1].row_off : n_rows;
-				if (e == hipSuccess && r1 > r0)
-					e = hipMemcpyAsync(b->d_rows.p + r0, hrows + r0, (size_t) (r1 - r0) * sizeof(RowDesc), hipMemcpyHostToDevice, st);
-				t0 = t1;
-			}
-			if (e == hipSuccess && n) e = hipMemcpyAsync(b->d_tin.p, b->tin.data(), (size_t) n * sizeof(TileIn), hipMemcpyHostToDevice, st);
-			if (e == hipSuccess) e = hipStreamSynchronize(st);    /* the staging buffers are reused by the next upload */
-			for (auto &ev : b->ev) if (e == hipSuccess && !ev) e = hipEventCreate(&ev);
-			if (e != hipSuccess) { set_err("upload copy failed: %s", hipGetErrorString(e)); rc = CVX_ERR_HIP; }
-		}
-	} catch (const std::bad_alloc &) {
-		set_err("cvx_batch_upload: host allocation failed");
-		rc = CVX_ERR_OOM;
+	int rc = stage_upload(h, b, n, tiles);
+	if (rc == CVX_OK) {
+		hipError_t e = hipStreamSynchronize(h->s_io);     /* inputs resident when this returns */
+		if (e != hipSuccess) { set_err("upload copy failed: %s", hipGetErrorString(e)); rc = CVX_ERR_HIP; }
 	}
-	if (rc != CVX_OK) { b->release(); delete b; return rc; }
+	if (rc != CVX_OK) { discard_batch(h, b); return rc; }
 	*out = b;
 	return CVX_OK;
-}
-
-static float ev_ms(hipEvent_t a, hipEvent_t b) {
-	float ms = 0.0f;
-	if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.0f;
-	return ms;
+	ABI_GUARD_END
 }
 
 int cvx_batch_run(cvx_handle h, cvx_batch b) {
-	if (!h || !b) { set_err("cvx_batch_run: NULL argument"); return CVX_ERR_ARG; }
+	ABI_GUARD_BEGIN
+	if (!h || !b || b->state < kUploaded) { set_err("cvx_batch_run: NULL argument / batch not uploaded"); return CVX_ERR_ARG; }
 	HIP_TRY(hipSetDevice(h->device));
-	const int n = b->n;
-	hipStream_t st = h->stream;
-	b->ran = false;
-	b->ops_total = 0;
-	memset(&b->timing, 0, sizeof(b->timing));
-	if (n == 0) { b->ran = true; return CVX_OK; }
-
-	HIP_TRY(hipEventRecord(b->ev[0], st));
-	HIP_TRY(launch_plan(b->d_rows.p, b->d_tin.p, b->d_plan.p, n, h->max_matrix_mb, st));
-	b->plan.resize((size_t) n);
-	HIP_TRY(hipMemcpyAsync(b->plan.data(), b->d_plan.p, (size_t) n * sizeof(TilePlan), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-
-	/* ---- host planning: kernel class, arena offsets, work lists (cvx_host_logic.h) */
-	HostPlan hp;
-	host_plan(n, b->plan.data(), b->tin.data(), h->tune_min_slots, h->tune_force_wrap, hp);
-	b->trun.swap(hp.trun);
-	b->tout.swap(hp.tout);
-	std::vector<std::vector<int32_t>> &cls = hp.cls;
-	std::vector<int32_t> &generic = hp.generic;
-	const uint64_t dir_dwords = hp.dir_dwords, ops_ints = hp.ops_ints, cells = hp.cells, active = hp.active;
-	const int n_fast = hp.n_fast;
-	int rc;
-	if ((rc = b->d_dirs.ensure((size_t) dir_dwords + 64)) != CVX_OK) return rc;
-	if ((rc = b->d_regions.ensure((size_t) ops_ints + 64)) != CVX_OK) return rc;
-
-	b->lists.clear();
-	std::vector<int> seg_begin(cls.size(), 0);
-	for (size_t c = 0; c < cls.size(); ++c) {
-		auto &v = cls[c];      /* already in LPT order */
-		seg_begin[c] = (int) b->lists.size();
-		b->lists.insert(b->lists.end(), v.begin(), v.end());
-	}
-	const int generic_begin = (int) b->lists.size();
-	b->lists.insert(b->lists.end(), generic.begin(), generic.end());
-	std::vector<uint64_t> goff(generic.size() + 1, 0);
-	for (size_t g = 0; g < generic.size(); ++g)
-		goff[g + 1] = goff[g] + (uint64_t) generic_scratch_bytes(b->trun[(size_t) generic[g]].ring);
-	if (!generic.empty()) {
-		if ((rc = b->d_gscratch.ensure((size_t) goff.back() + 256)) != CVX_OK) return rc;
-		if ((rc = b->d_gscratch_off.ensure(goff.size())) != CVX_OK) return rc;
-		HIP_TRY(hipMemcpyAsync(b->d_gscratch_off.p, goff.data(), goff.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-	}
-	HIP_TRY(hipMemcpyAsync(b->d_trun.p, b->trun.data(), (size_t) n * sizeof(TileRun), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(b->d_tout.p, b->tout.data(), (size_t) n * sizeof(TileOut), hipMemcpyHostToDevice, st));
-	if (!b->lists.empty())
-		HIP_TRY(hipMemcpyAsync(b->d_lists.p, b->lists.data(), b->lists.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemsetAsync(b->d_heads.p, 0, 64 * sizeof(int32_t), st));
-	HIP_TRY(hipEventRecord(b->ev[1], st));
-
-	/* ---- forward fill: one launch per populated kernel class, classes run concurrently
-	 * on separate streams (a sparsely populated class would otherwise serialise a whole
-	 * tile latency behind the big one); widest rings first, they have the longest tiles */
-	int launches = 0;
-	b->launches.clear();
-	for (int cc = (int) cls.size() - 1; cc >= 0; --cc) {
-		const size_t c = (size_t) cc;
-		if (cls[c].empty()) continue;
-		const KernelClass &kc = kClasses[c / 2];
-		while (b->lev.size() < (size_t) (launches + 1) * 3) {
-			hipEvent_t e;
-			HIP_TRY(hipEventCreate(&e));
-			b->lev.push_back(e);
-		}
-		cvx_launch_info li;
-		memset(&li, 0, sizeof(li));
-		li.slots_per_lane = kc.m; li.waves = kc.nw; li.wrap16 = (int) (c & 1); li.n_tiles = (int) cls[c].size();
-		for (int32_t ti : cls[c]) {
-			const TilePlan &p = b->plan[(size_t) ti];
-			const TileIn &in = b->tin[(size_t) ti];
-			li.cells += p.cells; li.active_cells += p.active;
-			li.alg_bytes += p.cells + 6ull * (uint64_t) in.H + 2ull * (uint64_t) in.W;
-			li.read_bases += (uint64_t) in.H;
-		}
-		b->launches.push_back(li);
-		hipStream_t ls = h->aux[launches % kAuxStreams];
-		HIP_TRY(hipStreamWaitEvent(ls, b->ev[1], 0));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3], ls));
-		FillArgs a;
-		a.seq = b->d_seq.p;
-		a.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
-		a.tin = b->d_tin.p;
-		a.trun = b->d_trun.p;
-		a.tout = b->d_tout.p;
-		a.dirs = b->d_dirs.p;
-		a.list = b->d_lists.p + seg_begin[c];
-		a.list_n = (int) cls[c].size();
-		a.late_min_groups = h->tune_late_min;
-		a.redo_count = b->d_heads.p;
-		a.ops = b->d_regions.p;
-		a.sp = h->sp;
-		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, false, a, ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
-		/* exact-tracking pass over the tiles the two-phase pass flagged (usually none) */
-		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, true, a, ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
-		launches++;
-	}
-	if (!generic.empty()) {
-		while (b->lev.size() < (size_t) (launches + 1) * 3) {
-			hipEvent_t e;
-			HIP_TRY(hipEventCreate(&e));
-			b->lev.push_back(e);
-		}
-		cvx_launch_info li;
-		memset(&li, 0, sizeof(li));
-		li.slots_per_lane = 0; li.waves = 16; li.wrap16 = 1; li.n_tiles = (int) generic.size();
-		for (int32_t ti : generic) {
-			const TilePlan &p = b->plan[(size_t) ti];
-			const TileIn &in = b->tin[(size_t) ti];
-			li.cells += p.cells; li.active_cells += p.active;
-			li.alg_bytes += p.cells + 6ull * (uint64_t) in.H + 2ull * (uint64_t) in.W;
-			li.read_bases += (uint64_t) in.H;
-		}
-		b->launches.push_back(li);
-		hipStream_t ls = h->aux[launches % kAuxStreams];
-		HIP_TRY(hipStreamWaitEvent(ls, b->ev[1], 0));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3], ls));
-		FillArgs a;
-		a.seq = b->d_seq.p;
-		a.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
-		a.tin = b->d_tin.p;
-		a.trun = b->d_trun.p;
-		a.tout = b->d_tout.p;
-		a.dirs = b->d_dirs.p;
-		a.list = b->d_lists.p + generic_begin;
-		a.list_n = (int) generic.size();
-		a.late_min_groups = h->tune_late_min;
-		a.redo_count = b->d_heads.p;
-		a.ops = b->d_regions.p;
-		a.sp = h->sp;
-		HIP_TRY(launch_fill_generic(a, b->d_gscratch.p, b->d_gscratch_off.p, ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
-		launches++;
-	}
-	for (int i = 0; i < launches; ++i) HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) i * 3 + 2], 0));
-	HIP_TRY(hipEventRecord(b->ev[2], st));
-
-	/* ---- backtrack + ops compaction */
-	BacktrackArgs ba;
-	ba.seq = b->d_seq.p;
-	ba.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
-	ba.tin = b->d_tin.p;
-	ba.trun = b->d_trun.p;
-	ba.tout = b->d_tout.p;
-	ba.dirs = b->d_dirs.p;
-	ba.ops = b->d_regions.p;
-	ba.n_tiles = n;
-	HIP_TRY(launch_backtrack(ba, st));
-	HIP_TRY(hipMemcpyAsync(b->tout.data(), b->d_tout.p, (size_t) n * sizeof(TileOut), hipMemcpyDeviceToHost, st));
-	int32_t redone = 0;
-	HIP_TRY(hipMemcpyAsync(&redone, b->d_heads.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	b->dst_off.assign((size_t) n, 0);
-	uint64_t total = 0;
-	for (int i = 0; i < n; ++i) {
-		b->dst_off[(size_t) i] = total;
-		if (b->tout[(size_t) i].status == 0) total += (uint64_t) b->tout[(size_t) i].n_ops;
-	}
-	b->ops_total = total;
-	if ((rc = b->d_dense.ensure((size_t) total + 64)) != CVX_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(b->d_dstoff.p, b->dst_off.data(), (size_t) n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-	HIP_TRY(launch_compact(b->d_regions.p, b->d_trun.p, b->d_tout.p, b->d_dstoff.p, b->d_dense.p, n, st));
-	HIP_TRY(hipEventRecord(b->ev[3], st));
-	HIP_TRY(hipStreamSynchronize(st));
-
-	for (int i = 0; i < launches; ++i) b->launches[(size_t) i].ms = ev_ms(b->lev[(size_t) i * 3], b->lev[(size_t) i * 3 + 1]);
-	b->timing.plan_ms = ev_ms(b->ev[0], b->ev[1]);
-	b->timing.fill_ms = ev_ms(b->ev[1], b->ev[2]);
-	b->timing.backtrack_ms = ev_ms(b->ev[2], b->ev[3]);
-	b->timing.total_ms = ev_ms(b->ev[0], b->ev[3]);
-	b->timing.cells = cells;
-	b->timing.active_cells = active;
-	b->timing.dir_bytes = dir_dwords * 4;
-	b->timing.n_fill_launches = launches;
-	b->timing.n_tiles_fast = n_fast;
-	b->timing.n_tiles_redone = redone;
-	b->ran = true;
+	RC_TRY(stage_plan(h, b, h->s_main));
+	RC_TRY(stage_compute(h, b));
+	RC_TRY(stage_results(h, b));
+	HIP_TRY(hipStreamSynchronize(h->s_main));
 	return CVX_OK;
+	ABI_GUARD_END
 }
 
 int cvx_batch_timing(cvx_batch b, cvx_timing *t) {
@@ -548,37 +706,25 @@ int cvx_batch_timing(cvx_batch b, cvx_timing *t) {
 }
 
 int cvx_batch_launch_info(cvx_batch b, int32_t i, cvx_launch_info *info) {
-	if (!b || !info || !b->ran || i < 0 || (size_t) i >= b->launches.size()) { set_err("cvx_batch_launch_info: bad index"); return CVX_ERR_ARG; }
+	if (!b || !info || b->state < kFinished || i < 0 || (size_t) i >= b->launches.size()) { set_err("cvx_batch_launch_info: bad index"); return CVX_ERR_ARG; }
 	*info = b->launches[(size_t) i];
 	return CVX_OK;
 }
 
 int cvx_batch_ops_total(cvx_batch b, uint64_t *n_ops) {
-	if (!b || !n_ops || !b->ran) { set_err("cvx_batch_ops_total: batch not run"); return CVX_ERR_ARG; }
+	if (!b || !n_ops || b->state < kFinished) { set_err("cvx_batch_ops_total: batch not run"); return CVX_ERR_ARG; }
 	*n_ops = b->ops_total;
 	return CVX_OK;
 }
 
 int cvx_batch_download(cvx_handle h, cvx_batch b, cvx_result *results, uint32_t *ops_arena,
 		uint64_t ops_capacity, uint64_t *ops_used) {
-	if (!h || !b || !b->ran || (b->n > 0 && !results)) { set_err("cvx_batch_download: bad argument / batch not run"); return CVX_ERR_ARG; }
+	ABI_GUARD_BEGIN
+	if (!h || !b || b->state < kFinished || (b->n > 0 && !results)) { set_err("cvx_batch_download: bad argument / batch not run"); return CVX_ERR_ARG; }
 	HIP_TRY(hipSetDevice(h->device));
 	if (ops_used) *ops_used = b->ops_total;
-	for (int i = 0; i < b->n; ++i) {
-		const TileOut &o = b->tout[(size_t) i];
-		cvx_result &r = results[i];
-		memset(&r, 0, sizeof(r));
-		r.score = o.score;
-		r.status = o.status;
-		r.best_ref_index = o.best_x;
-		r.best_read_index = o.best_y;
-		r.ref_position = o.ref_position;
-		r.qstart = o.qstart;
-		r.qend = o.qend;
-		r.n_ops = o.status == 0 ? o.n_ops : 0;
-		r.ops_begin = b->dst_off[(size_t) i];
-		r.cells = b->plan[(size_t) i].cells;
-	}
+	static_assert(sizeof(cvx_result) == sizeof(ResultRec), "ResultRec mirrors cvx_result");
+	if (b->n) memcpy(results, b->res(), (size_t) b->n * sizeof(cvx_result));
 	if (b->ops_total > ops_capacity) {
 		set_err("cvx_batch_download: ops arena too small (%llu needed, %llu given)",
 				(unsigned long long) b->ops_total, (unsigned long long) ops_capacity);
@@ -586,33 +732,114 @@ int cvx_batch_download(cvx_handle h, cvx_batch b, cvx_result *results, uint32_t 
 	}
 	if (b->ops_total) {
 		if (!ops_arena) { set_err("cvx_batch_download: NULL ops arena"); return CVX_ERR_ARG; }
-		HIP_TRY(hipMemcpy(ops_arena, b->d_dense.p, (size_t) b->ops_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		RC_TRY(stage_ops(h, b));
+		memcpy(ops_arena, b->h_ops.p, (size_t) b->ops_total * sizeof(uint32_t));
 	}
 	return CVX_OK;
+	ABI_GUARD_END
 }
 
 void cvx_batch_free(cvx_handle h, cvx_batch b) {
 	if (!b) return;
 	if (h) (void) hipSetDevice(h->device);
-	if (h && h->pool.size() < kPoolBatches) {
-		b->ran = false;
-		h->pool.push_back(b);      /* arenas and events stay allocated for the next upload */
-		return;
-	}
-	b->release();
-	delete b;
+	recycle_batch(h, b);
 }
 
+int cvx_align_batch(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_result *results,
+		uint32_t *ops_arena, uint64_t ops_capacity, uint64_t *ops_used) {
+	cvx_job j = nullptr;
+	int rc = cvx_submit(h, n, tiles, &j);
+	if (rc != CVX_OK) return rc;
+	const cvx_result *res = nullptr;
+	const uint32_t *ops = nullptr;
+	uint64_t n_ops = 0;
+	rc = cvx_wait(h, j, &res, &ops, &n_ops);
+	if (rc == CVX_OK) {
+		if (ops_used) *ops_used = n_ops;
+		if (n && results) memcpy(results, res, (size_t) n * sizeof(cvx_result));
+		if (n && !results) { set_err("cvx_align_batch: NULL results"); rc = CVX_ERR_ARG; }
+		else if (n_ops > ops_capacity) {
+			set_err("cvx_align_batch: ops arena too small (%llu needed, %llu given)",
+					(unsigned long long) n_ops, (unsigned long long) ops_capacity);
+			rc = CVX_ERR_CAPACITY;
+		} else if (n_ops) {
+			if (!ops_arena) { set_err("cvx_align_batch: NULL ops arena"); rc = CVX_ERR_ARG; }
+			else memcpy(ops_arena, ops, (size_t) n_ops * sizeof(uint32_t));
+		}
+		cvx_job_release(h, j);
+	}
+	return rc;
+}
+
+/* ------------------------------------------------------------------ streaming form */
+
+int cvx_submit(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_job *out) {
+	ABI_GUARD_BEGIN
+	if (!h || !out || n < 0 || (n > 0 && !tiles)) { set_err("cvx_submit: bad argument"); return CVX_ERR_ARG; }
+	*out = nullptr;
+	HIP_TRY(hipSetDevice(h->device));
+	/* first hand the device whatever is ready to run, then spend host time on packing */
+	RC_TRY(pump(h, false, nullptr));
+	cvx_batch_s *b = acquire_batch(h);
+	if (!b) return CVX_ERR_OOM;
+	int rc = stage_upload(h, b, n, tiles);
+	if (rc == CVX_OK) rc = stage_plan(h, b, h->s_io);
+	if (rc != CVX_OK) { discard_batch(h, b); return rc; }
+	b->in_flight = true;
+	h->pending.push_back(b);
+	(void) pump(h, false, nullptr);
+	*out = b;
+	return CVX_OK;
+	ABI_GUARD_END
+}
+
+int cvx_wait(cvx_handle h, cvx_job j, const cvx_result **results, const uint32_t **ops, uint64_t *n_ops) {
+	ABI_GUARD_BEGIN
+	if (!h || !j || !j->in_flight) { set_err("cvx_wait: not a submitted job"); return CVX_ERR_ARG; }
+	HIP_TRY(hipSetDevice(h->device));
+	int rc = CVX_OK;
+	if (j->state < kComputed) rc = pump(h, true, j);
+	if (rc == CVX_OK && j->state < kFinished) rc = stage_results(h, j);
+	if (rc == CVX_OK) rc = stage_ops(h, j);
+	if (rc != CVX_OK) { discard_batch(h, j); return rc; }
+	(void) pump(h, false, nullptr);      /* later jobs whose inputs have arrived meanwhile */
+	if (results) *results = reinterpret_cast<const cvx_result *>(j->res());
+	if (ops) *ops = j->h_ops.as<uint32_t>();
+	if (n_ops) *n_ops = j->ops_total;
+	return CVX_OK;
+	ABI_GUARD_END
+}
+
+int cvx_job_timing(cvx_job j, cvx_timing *t) { return cvx_batch_timing(j, t); }
+int cvx_job_launch_info(cvx_job j, int32_t i, cvx_launch_info *info) { return cvx_batch_launch_info(j, i, info); }
+
+void cvx_job_release(cvx_handle h, cvx_job j) {
+	if (!j) return;
+	if (h) {
+		(void) hipSetDevice(h->device);
+		auto it = std::find(h->pending.begin(), h->pending.end(), j);
+		if (it != h->pending.end()) h->pending.erase(it);
+		if (j->state >= kPlanned && j->state < kFinished) (void) hipDeviceSynchronize();   /* released without waiting */
+	}
+	recycle_batch(h, j);
+}
+
+/* ------------------------------------------------------------------ sub-read scoring */
+
 int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char *const *qrys, float *scores) {
+	ABI_GUARD_BEGIN
 	if (!h || n < 0 || (n > 0 && (!refs || !qrys || !scores))) { set_err("cvx_score_batch: bad argument"); return CVX_ERR_ARG; }
 	if (n == 0) return CVX_OK;
 	HIP_TRY(hipSetDevice(h->device));
-	std::vector<ScorePair> pairs((size_t) n);
+	/* persistent pinned staging and device buffers: no allocation on the steady-state path */
+	RC_TRY(h->sc_hpairs.ensure((size_t) n * sizeof(ScorePair)));
+	RC_TRY(h->sc_hout.ensure((size_t) n * sizeof(float)));
+	ScorePair *pairs = h->sc_hpairs.as<ScorePair>();
 	uint64_t bytes = 0, rows = 0;
 	for (int i = 0; i < n; ++i) {
 		if (!refs[i] || !qrys[i]) { set_err("cvx_score_batch: NULL sequence %d", i); return CVX_ERR_ARG; }
 		const size_t rl = strlen(refs[i]) + 1, ql = strlen(qrys[i]) + 1;
-		ScorePair &p = pairs[(size_t) i];
+		ScorePair &p = pairs[i];
 		p.ref_off = bytes; bytes += rl;
 		p.qry_off = bytes; bytes += ql;
 		p.ref_len = (int32_t) std::min<size_t>(rl, 0x7fffffff);
@@ -620,37 +847,25 @@ int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char
 		p.scratch_off = rows;
 		if (rl < 100000 && ql < 100000) rows += 2 * (uint64_t) rl;
 	}
-	std::vector<uint8_t> hseq((size_t) bytes + 16);
+	RC_TRY(h->sc_hseq.ensure((size_t) bytes + 16));
+	uint8_t *hseq = h->sc_hseq.as<uint8_t>();
 	for (int i = 0; i < n; ++i) {
-		memcpy(&hseq[(size_t) pairs[(size_t) i].ref_off], refs[i], (size_t) pairs[(size_t) i].ref_len);
-		memcpy(&hseq[(size_t) pairs[(size_t) i].qry_off], qrys[i], (size_t) pairs[(size_t) i].qry_len);
+		memcpy(hseq + pairs[i].ref_off, refs[i], (size_t) pairs[i].ref_len);
+		memcpy(hseq + pairs[i].qry_off, qrys[i], (size_t) pairs[i].qry_len);
 	}
-	DevBuf<uint8_t> d_seq; DevBuf<ScorePair> d_pairs; DevBuf<int32_t> d_rows; DevBuf<float> d_out;
-	int rc;
-	if ((rc = d_seq.ensure(hseq.size())) != CVX_OK || (rc = d_pairs.ensure((size_t) n)) != CVX_OK ||
-			(rc = d_rows.ensure((size_t) rows + 64)) != CVX_OK || (rc = d_out.ensure((size_t) n)) != CVX_OK) {
-		d_seq.release(); d_pairs.release(); d_rows.release(); d_out.release();
-		return rc;
-	}
-	hipError_t e = hipMemcpyAsync(d_seq.p, hseq.data(), hseq.size(), hipMemcpyHostToDevice, h->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(d_pairs.p, pairs.data(), (size_t) n * sizeof(ScorePair), hipMemcpyHostToDevice, h->stream);
-	if (e == hipSuccess) e = launch_score(d_seq.p, d_pairs.p, d_rows.p, d_out.p, n, h->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(scores, d_out.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
-	if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-	d_seq.release(); d_pairs.release(); d_rows.release(); d_out.release();
-	if (e != hipSuccess) { set_err("cvx_score_batch: %s", hipGetErrorString(e)); return CVX_ERR_HIP; }
+	RC_TRY(h->sc_seq.ensure((size_t) bytes + 16));
+	RC_TRY(h->sc_pairs.ensure((size_t) n));
+	RC_TRY(h->sc_rows.ensure((size_t) rows + 64));
+	RC_TRY(h->sc_out.ensure((size_t) n));
+	hipStream_t st = h->s_main;
+	HIP_TRY(hipMemcpyAsync(h->sc_seq.p, hseq, (size_t) bytes, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(h->sc_pairs.p, pairs, (size_t) n * sizeof(ScorePair), hipMemcpyHostToDevice, st));
+	HIP_TRY(launch_score(h->sc_seq.p, h->sc_pairs.p, h->sc_rows.p, h->sc_out.p, n, st));
+	HIP_TRY(hipMemcpyAsync(h->sc_hout.p, h->sc_out.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	memcpy(scores, h->sc_hout.p, (size_t) n * sizeof(float));
 	return CVX_OK;
-}
-
-int cvx_align_batch(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_result *results,
-		uint32_t *ops_arena, uint64_t ops_capacity, uint64_t *ops_used) {
-	cvx_batch b = nullptr;
-	int rc = cvx_batch_upload(h, n, tiles, &b);
-	if (rc != CVX_OK) return rc;
-	rc = cvx_batch_run(h, b);
-	if (rc == CVX_OK) rc = cvx_batch_download(h, b, results, ops_arena, ops_capacity, ops_used);
-	cvx_batch_free(h, b);
-	return rc;
+	ABI_GUARD_END
 }
 
 }  /* extern "C" */

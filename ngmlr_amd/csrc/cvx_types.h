@@ -101,6 +101,23 @@ struct TileOut {
 	int32_t pad;           /* 0 filled, 1 backtracked, kPadRedo: needs the exact-tracking fill pass */
 };
 
+struct ResultRec {         /* same layout as cvx_result (include/cvx_align.h), written by finalize_kernel */
+	float score;
+	int32_t status;
+	int32_t best_x, best_y;
+	int32_t ref_position, qstart, qend;
+	int32_t n_ops;
+	uint64_t ops_begin;
+	uint64_t cells;
+};
+
+struct BatchSummary {      /* follows the result records in the same buffer */
+	uint64_t ops_total;    /* ops of all valid tiles */
+	uint64_t dense_cap;    /* capacity the compaction ran with (ops_total > dense_cap: compact again) */
+	int32_t n_valid;
+	int32_t n_redone;      /* tiles that needed the exact-tracking fill pass */
+};
+
 struct FillArgs {
 	const uint8_t *seq;
 	const RowDesc2 *rows;

@@ -254,3 +254,93 @@ def workload_short(n_tiles: int, seed: int = 17) -> List[Tile]:
         pad = (256 + 2 * int(F32(0.15) * F32(L))) // 2
         tiles.append(make_tile(rng, L + 2 * pad, err=0.08, corridor="linear", ref_pad=pad, tag="short"))
     return tiles
+
+
+# --------------------------------------------------------------------------- flat tile sets
+# The bench moves tens of thousands of 10 kb tiles per step and per device.  A TileSet holds a whole
+# batch in four flat arrays (chunks of it can be generated on worker processes) and hands the C ABI
+# a tile table that points straight into those arrays.
+
+class TileSet:
+    """n tiles in flat arrays: ref / qry bytes, one (offset, length) per read row."""
+
+    def __init__(self, ref, ref_off, qry, qry_off, row_offset, row_length, tag=""):
+        self.ref, self.ref_off = ref, ref_off
+        self.qry, self.qry_off = qry, qry_off
+        self.row_offset, self.row_length = row_offset, row_length
+        self.tag = tag
+        self.n = len(ref_off) - 1
+        self.H = np.diff(qry_off).astype(np.int64)
+        self.W = np.diff(ref_off).astype(np.int64)
+        self._table = None
+
+    def __len__(self) -> int:
+        return self.n
+
+    @property
+    def read_bases(self) -> int:
+        return int(self.H.sum())
+
+    @property
+    def cells(self) -> int:
+        return int(self.row_length.astype(np.int64).sum())
+
+    def widths(self) -> np.ndarray:
+        return self.row_length[self.qry_off[:-1]]
+
+    def tile(self, i: int) -> Tile:
+        """Tile i as the per-tile object the oracle wrapper and the tests take (copies)."""
+        r0, r1 = int(self.ref_off[i]), int(self.ref_off[i + 1])
+        q0, q1 = int(self.qry_off[i]), int(self.qry_off[i + 1])
+        return Tile(ref=self.ref[r0:r1].tobytes(), qry=self.qry[q0:q1].tobytes(),
+                    row_offset=self.row_offset[q0:q1], row_length=self.row_length[q0:q1], tag=self.tag)
+
+    def table(self) -> np.ndarray:
+        """cvx_tile[n] (include/cvx_align.h) as a structured array whose pointers reference this
+        object's arrays -- keep the TileSet alive while the table is in use."""
+        if self._table is None:
+            dt = np.dtype([("ref", np.uint64), ("qry", np.uint64), ("row_offset", np.uint64), ("row_length", np.uint64),
+                           ("ref_len", np.int32), ("qry_len", np.int32), ("row_stride_bytes", np.int32), ("reserved", np.int32)])
+            assert dt.itemsize == 48
+            t = np.zeros(self.n, dtype=dt)
+            t["ref"] = self.ref.ctypes.data + self.ref_off[:-1].astype(np.uint64)
+            t["qry"] = self.qry.ctypes.data + self.qry_off[:-1].astype(np.uint64)
+            t["row_offset"] = self.row_offset.ctypes.data + 4 * self.qry_off[:-1].astype(np.uint64)
+            t["row_length"] = self.row_length.ctypes.data + 4 * self.qry_off[:-1].astype(np.uint64)
+            t["ref_len"] = self.W
+            t["qry_len"] = self.H
+            t["row_stride_bytes"] = 4
+            self._table = t
+        return self._table
+
+
+def _pacbio_chunk(args):
+    """`m` PacBio-like tiles (config C2, see workload_pacbio) as flat arrays; one process-pool task."""
+    seed, m, read_len, err, scatter = args
+    rng = np.random.default_rng(seed)
+    refs, qrys, offs, lens = [], [], [], []
+    for _ in range(m):
+        W = int(read_len * (0.9 + 0.2 * rng.random()))
+        t = make_tile(rng, W, err=err, ratio=(6, 3, 1), corridor="anchors", scatter=scatter)
+        refs.append(np.frombuffer(t.ref, dtype=np.uint8))
+        qrys.append(np.frombuffer(t.qry, dtype=np.uint8))
+        offs.append(t.row_offset)
+        lens.append(t.row_length)
+    W = np.array([len(r) for r in refs], dtype=np.int64)
+    H = np.array([len(q) for q in qrys], dtype=np.int64)
+    return np.concatenate(refs), np.concatenate(qrys), np.concatenate(offs), np.concatenate(lens), W, H
+
+
+def pacbio_tileset(n_tiles: int, seed: int = 7, read_len: int = 10000, err: float = 0.15,
+                   scatter: float = 25.0, chunk: int = 512, pool=None) -> TileSet:
+    """Config C2 as a TileSet: the tiles of workload_pacbio, generated `chunk` at a time (every
+    chunk has its own seed derived from `seed`), on the worker processes of `pool` (a
+    concurrent.futures executor) when one is given."""
+    tasks = [(seed * 100003 + c0, min(chunk, n_tiles - c0), read_len, err, scatter) for c0 in range(0, n_tiles, chunk)]
+    parts = list(pool.map(_pacbio_chunk, tasks)) if pool is not None else [_pacbio_chunk(t) for t in tasks]
+    W = np.concatenate([p[4] for p in parts]) if parts else np.zeros(0, np.int64)
+    H = np.concatenate([p[5] for p in parts]) if parts else np.zeros(0, np.int64)
+    cat = lambda k, dt: np.concatenate([p[k] for p in parts]) if parts else np.zeros(0, dt)  # noqa: E731
+    return TileSet(cat(0, np.uint8), np.concatenate([[0], np.cumsum(W)]).astype(np.int64),
+                   cat(1, np.uint8), np.concatenate([[0], np.cumsum(H)]).astype(np.int64),
+                   cat(2, np.int32), cat(3, np.int32), tag="pacbio")
