@@ -131,15 +131,15 @@ typedef struct {
 	uint64_t active_cells; /* cells inside [0,W): what the fill really computes */
 	uint64_t dir_bytes; /* bytes of direction codes written to HBM */
 	int32_t n_fill_launches;
-	int32_t n_tiles_fast; /* tiles taken by the single-wave ring kernels */
+	int32_t n_tiles_fast; /* tiles taken whole by one wave */
 	int32_t n_tiles_redone; /* tiles whose best cell was not in the exactly tracked tail (second fill pass) */
-	int32_t reserved;
+	int32_t n_tiles_chained; /* wide tiles cut into chained row blocks */
 } cvx_timing;
 
 /* One forward-fill launch of the last cvx_batch_run (HIP-event timed on the stream). */
 typedef struct {
 	int32_t slots_per_lane;  /* M */
-	int32_t waves;           /* NW: waves cooperating on one tile */
+	int32_t waves;           /* 1; for chained tiles the number of row-block tasks of the launch */
 	int32_t wrap16;          /* int16 gap-run wrap emulation compiled in */
 	int32_t n_tiles;
 	float ms;                /* kernel duration */

@@ -20,15 +20,35 @@ namespace cvx {
 /* ------------------------------------------------------------------ kernel classes */
 
 struct KernelClass {
-	int m, nw;                       /* slots per lane, waves per tile */
-	int ring() const { return 64 * m * nw; }
+	int m;                           /* slots per lane; one wave per tile */
+	int ring() const { return 64 * m; }
 };
 
-/* fill_ring_kernel instantiations the runtime dispatches to, smallest ring first */
-static const KernelClass kClasses[] = {
-	{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {6, 1}, {8, 1}, {4, 4}, {4, 8}, {4, 16},
-};
+/* fill_ring_kernel instantiations the runtime dispatches whole tiles to, smallest ring first.
+ * Rings of more than 256 slots need so many registers (M = 6: 133, M = 8: 170 VGPRs) that only two
+ * or three waves fit a SIMD; such tiles are chained instead (ONT mix, 60 000 tiles: 5 950 -> 7 180
+ * Gbp/h when everything above M = 4 goes to 64-row blocks). */
+static const KernelClass kClasses[] = { {1}, {2}, {3}, {4} };
 static const int kNumClasses = (int) (sizeof(kClasses) / sizeof(kClasses[0]));
+
+/* Corridors with more live rows than the widest single-wave ring are cut into row blocks that run
+ * as a dependency chain (kFillChain).  Smaller blocks = more blocks of a tile in flight at once
+ * (about need / rows-per-block): aim for 16 or more. */
+static const int kChainClasses[] = {1, 2, 4};          /* M of the chain kernels: 64, 128, 256 rows per block */
+static const int kNumChainClasses = 3;
+/* A batch with fewer whole-tile waves than this cannot fill the device by tile parallelism alone:
+ * its chains use the smallest blocks (a tile's time is then about (2 H + w) single-wave steps,
+ * whatever its width), and its very long tiles are chained even if a ring would hold them. */
+static const int kSmallBatchTiles = 2048;
+static const int kLongTileSteps = 32768;
+inline int chain_class_for(int need, bool small_batch) {
+	/* measured (C5 mix, 96 tiles): 64-row blocks 100 ms, 128-row 117 ms, 256-row 174 ms -- a tile's
+	 * time is its block count times the lag between neighbouring blocks (~2 N + 2 chunks of steps),
+	 * and a step of a 64-row block is the shortest.  The larger classes stay selectable
+	 * (CVX_TUNE_CHAIN_M) for batches that are throughput- rather than latency-bound. */
+	(void) need; (void) small_batch;
+	return 0;
+}
 
 /* ------------------------------------------------------------------ host threads */
 
@@ -139,9 +159,85 @@ struct HostPlan {
 	std::vector<TileOut> tout;
 	std::vector<std::vector<int32_t>> cls;   /* work list per kernel class x {float runs, int16 runs} */
 	std::vector<int32_t> generic;            /* tiles of the catch-all kernel */
+	/* chained tiles (row blocks): per chain class x {float runs, int16 runs} the tasks in launch
+	 * order, the tiles, and the per-block tables shared by all classes */
+	std::vector<std::vector<ChainTask>> chain_tasks;
+	std::vector<std::vector<int32_t>> chain_tiles;
+	std::vector<ChainBlk> chain_blk;
+	uint64_t bnd_recs = 0;                   /* BoundaryRec entries */
 	uint64_t dir_dwords = 0, ops_ints = 0, cells = 0, active = 0;
-	int n_fast = 0;                          /* tiles taken by single-wave ring kernels */
+	int n_fast = 0;                          /* tiles taken whole by one wave */
+	int n_chained = 0;
 };
+
+/* Row blocks of one chained tile: fills hp.chain_blk and returns the tile's tasks (block order).
+ * rows = the tile's (offset, length) rows as uploaded. */
+inline void plan_chain_tile(int tile, int m, const TilePlan &p, const TileIn &in, const RowDesc *rows,
+		HostPlan &hp, TileRun &r, std::vector<ChainTask> &out) {
+	const int N = 64 * m, H = in.H, W = in.W;
+	const int nblk = (H + N - 1) / N;
+	r.ring = N;
+	r.r0 = p.r0;
+	r.nsteps = p.rend - p.r0;
+	r.dir_off = 0;
+	r.mnw = m;
+	r.chain_blk0 = (int32_t) hp.chain_blk.size();
+	r.chain_nblk = nblk;
+	auto span = [&](int y, long long &lo, long long &hi) {
+		lo = rows[y].off > 0 ? rows[y].off : 0;
+		hi = (long long) rows[y].off + (long long) rows[y].len;
+		if (hi > W) hi = W;
+		if (hi < lo) hi = lo;
+	};
+	uint64_t prev_out = 0;
+	for (int g = 0; g < nblk; ++g) {
+		const int y0 = g * N, y1 = std::min(H, y0 + N);
+		long long gs_min = 0x7fffffff, ge_max = -0x7fffffff;
+		for (int y = y0; y < y1; ++y) {
+			long long lo, hi;
+			span(y, lo, hi);
+			if (hi > lo) { gs_min = std::min(gs_min, lo + y); ge_max = std::max(ge_max, hi + y); }
+		}
+		ChainTask t;
+		memset(&t, 0, sizeof(t));
+		t.tile = tile;
+		t.y0 = y0;
+		t.rows = y1 - y0;
+		if (ge_max > gs_min) {
+			t.r0 = p.r0 + (int) ((gs_min - p.r0) & ~31ll);       /* planes of all blocks share the tile's bit phase */
+			t.nsteps = (int) (ge_max - t.r0);
+		} else {
+			t.r0 = p.r0;
+			t.nsteps = 0;
+		}
+		t.blk = r.chain_blk0 + g;
+		t.prev = g > 0 ? t.blk - 1 : -1;
+		if (g > 0) {
+			long long lo, hi;
+			span(y0 - 1, lo, hi);
+			t.bnd_lo = (int32_t) lo;
+			t.bnd_len = (int32_t) (hi - lo);
+			t.bnd_in_off = prev_out;
+		}
+		t.has_next = (g + 1 < nblk) ? 1 : 0;
+		{
+			long long lo, hi;
+			span(y1 - 1, lo, hi);
+			t.bnd_out_off = hp.bnd_recs;
+			prev_out = hp.bnd_recs;
+			if (t.has_next) hp.bnd_recs += (uint64_t) (hi - lo);
+		}
+		const uint64_t nblk32 = (uint64_t) ((t.nsteps + 31) / 32);
+		t.dir_off = hp.dir_dwords;
+		ChainBlk cb;
+		cb.dir_off = hp.dir_dwords / 2;
+		cb.tblk0 = (t.r0 - p.r0) >> 5;
+		cb.nblk32 = (int32_t) std::max<uint64_t>(nblk32, 1);
+		hp.dir_dwords += std::max<uint64_t>(nblk32, 1) * (uint64_t) N * 2ull;
+		hp.chain_blk.push_back(cb);
+		out.push_back(t);
+	}
+}
 
 /* Longest processing time first (most cells first, index as tie-break): the persistent waves
  * pull from the front.  Sorted as packed 64-bit keys when they fit (always, below a million
@@ -168,14 +264,32 @@ inline void lpt_sort(std::vector<int32_t> &v, const TilePlan *plan) {
 }
 
 /* Kernel class, arena offsets and (sorted) work lists of every tile from its corridor plan.
- * tune_min_slots / tune_force_wrap: the CVX_TUNE_* knobs of the runtime (0 = off). */
-inline void host_plan(int n, const TilePlan *plan, const TileIn *tin, int tune_min_slots, int tune_force_wrap, HostPlan &hp) {
+ * tune: the CVX_TUNE_* knobs of the runtime. */
+/* tuning / test knobs of the runtime (CVX_TUNE_* environment variables; all 0 = off) */
+struct PlanTuning {
+	int min_slots = 0;     /* smallest M a whole tile may use */
+	int max_slots = 0;     /* largest M a whole tile may use (wider tiles are chained) */
+	int force_wrap = 0;    /* route every tile to the int16-run kernels */
+	int chain_m = 0;       /* 1, 2 or 4: force the row-block height class of chained tiles */
+};
+
+inline void host_plan(int n, const TilePlan *plan, const TileIn *tin, const RowDesc *rows, const PlanTuning &tune, HostPlan &hp) {
+	const int tune_min_slots = tune.min_slots, tune_force_wrap = tune.force_wrap;
 	hp.trun.assign((size_t) n, TileRun());
 	hp.tout.assign((size_t) n, TileOut());
 	hp.cls.assign((size_t) kNumClasses * 2, std::vector<int32_t>());
 	hp.generic.clear();
+	hp.chain_tasks.assign((size_t) kNumChainClasses * 2, std::vector<ChainTask>());
+	hp.chain_tiles.assign((size_t) kNumChainClasses * 2, std::vector<int32_t>());
+	hp.chain_blk.clear();
+	hp.bnd_recs = 0;
 	hp.dir_dwords = hp.ops_ints = hp.cells = hp.active = 0;
 	hp.n_fast = 0;
+	hp.n_chained = 0;
+	std::vector<std::vector<std::vector<ChainTask>>> per_tile((size_t) kNumChainClasses * 2);
+	int n_work = 0;
+	for (int i = 0; i < n; ++i) if (!(plan[(size_t) i].flags & (kPlanTooLarge | kPlanEmpty))) n_work++;
+	const bool small_batch = n_work < kSmallBatchTiles;
 	for (int i = 0; i < n; ++i) {
 		const TilePlan &p = plan[(size_t) i];
 		TileRun &r = hp.trun[(size_t) i];
@@ -187,39 +301,70 @@ inline void host_plan(int n, const TilePlan *plan, const TileIn *tin, int tune_m
 		r.skip = 1;
 		if (p.flags & kPlanTooLarge) { o.status = CVX_TILE_TOO_LARGE; continue; }
 		if (p.flags & kPlanEmpty) { o.status = CVX_TILE_EMPTY; continue; }
+		const bool wrap = (p.flags & kPlanWrap16) || tune_force_wrap;
+		const bool regular = !(p.flags & kPlanIrregular);
 		int k = -1;
-		if (!(p.flags & kPlanIrregular)) {
+		if (regular) {
 			for (int c = 0; c < kNumClasses; ++c)
-				if (kClasses[c].ring() >= p.need && kClasses[c].m * kClasses[c].nw >= tune_min_slots) { k = c; break; }
+				if (kClasses[c].ring() >= p.need && kClasses[c].m >= tune_min_slots &&
+						(tune.max_slots <= 0 || kClasses[c].m <= tune.max_slots)) { k = c; break; }
+		}
+		r.skip = 0;
+		r.chain_blk0 = -1;
+		r.chain_nblk = 0;
+		r.ops_cap = tin[(size_t) i].H + tin[(size_t) i].W + 8;
+		r.ops_off = hp.ops_ints;
+		hp.ops_ints += (uint64_t) r.ops_cap;
+		hp.active += p.active;
+		const bool long_tile = small_batch && p.need >= 128 && (p.rend - p.r0) >= kLongTileSteps;
+		if ((k < 0 || long_tile) && regular && rows && tune_min_slots == 0) {
+			/* more live rows than any ring (or one very long tile in a batch too small to fill the
+			 * device with whole tiles): row blocks chained through boundary streams */
+			int cc = chain_class_for(p.need, small_batch);
+			for (int q = 0; q < kNumChainClasses; ++q) if (kChainClasses[q] == tune.chain_m) cc = q;
+			const size_t slot = (size_t) cc * 2 + (wrap ? 1 : 0);
+			per_tile[slot].emplace_back();
+			plan_chain_tile(i, kChainClasses[cc], p, tin[(size_t) i], rows + tin[(size_t) i].row_off, hp, r, per_tile[slot].back());
+			hp.chain_tiles[slot].push_back(i);
+			hp.n_chained++;
+			continue;
 		}
 		int64_t ring;
 		if (k < 0) {
-			/* catch-all kernel: ring = need (regular, too wide for registers) or one slot per
-			 * row PLUS ONE (irregular row starts): slot 0 reads its "up" neighbour from the last
-			 * slot of the ring, which must therefore never hold a row -- with a ring of exactly H
-			 * slots row 0 would see row H-1's live cells instead of the empty element
+			/* catch-all kernel, irregular row starts: one slot per row PLUS ONE: slot 0 reads its "up"
+			 * neighbour from the last slot of the ring, which must therefore never hold a row -- with a
+			 * ring of exactly H slots row 0 would see row H-1's live cells instead of the empty element
 			 * (getElement(x, -1), src/AlignmentMatrixFast.h:74-111) */
-			const int64_t want = (p.flags & kPlanIrregular) ? (int64_t) tin[(size_t) i].H + 1 : (int64_t) p.need;
+			const int64_t want = regular ? (int64_t) p.need : (int64_t) tin[(size_t) i].H + 1;
 			ring = ((want > 0 ? want : 1) + 63) / 64 * 64;
 			const uint64_t dd = (uint64_t) ((p.rend - p.r0 + 31) / 32) * (uint64_t) ring * 2ull;
-			if (ring > (1 << 30) || dd > (4ull << 30)) { o.status = CVX_TILE_UNSUPPORTED; continue; }  /* > 16 GiB of codes */
+			if (ring > (1 << 30) || dd > (4ull << 30)) {     /* > 16 GiB of codes for one irregular tile */
+				o.status = CVX_TILE_UNSUPPORTED;
+				r.skip = 1;
+				hp.active -= p.active;
+				continue;
+			}
 		} else {
 			ring = kClasses[k].ring();
 		}
-		r.skip = 0;
 		r.ring = (int32_t) ring;
 		r.r0 = p.r0;
 		r.nsteps = p.rend - p.r0;
 		r.dir_off = hp.dir_dwords;
 		hp.dir_dwords += (uint64_t) ((r.nsteps + 31) / 32) * (uint64_t) r.ring * 2ull;
-		r.mnw = k < 0 ? 0 : (kClasses[k].m | (kClasses[k].nw << 8));
-		r.ops_cap = tin[(size_t) i].H + tin[(size_t) i].W + 8;
-		r.ops_off = hp.ops_ints;
-		hp.ops_ints += (uint64_t) r.ops_cap;
-		hp.active += p.active;
+		r.mnw = k < 0 ? 0 : kClasses[k].m;
 		if (k < 0) { hp.generic.push_back(i); continue; }
-		if (kClasses[k].nw == 1) hp.n_fast++;
-		hp.cls[(size_t) k * 2 + (((p.flags & kPlanWrap16) || tune_force_wrap) ? 1 : 0)].push_back(i);
+		hp.n_fast++;
+		hp.cls[(size_t) k * 2 + (wrap ? 1 : 0)].push_back(i);
+	}
+	/* chain tasks in launch order: block index major, tile minor -- a wave takes tasks in this order,
+	 * so all tiles advance together and the block above any task has always been taken before it */
+	for (size_t slot = 0; slot < per_tile.size(); ++slot) {
+		size_t deepest = 0;
+		for (auto &v : per_tile[slot]) deepest = std::max(deepest, v.size());
+		for (size_t g = 0; g < deepest; ++g)
+			for (auto &v : per_tile[slot])
+				if (g < v.size()) hp.chain_tasks[slot].push_back(v[g]);
 	}
 	for (auto &v : hp.cls) lpt_sort(v, plan);
 }

@@ -7,7 +7,7 @@
  *                     anti-diagonal schedule needs: ring size, first/last diagonal)
  *   fill_ring_kernel  forward fill (fwdFillMatrixSSESimple == scalar recurrence of
  *                     reference src/ConvexAlignFast.cpp:606-774), anti-diagonal
- *                     wavefront, one wave (or NW lock-stepped waves) per tile
+ *                     wavefront, one wave per tile (per row block for chained tiles)
  *   backtrack_kernel  revBacktrack + validPath (src/ConvexAlignFast.cpp:335-432,
  *                     src/AlignmentMatrixFast.cpp:213-220)
  *   compact_ops_kernel  gathers the per-tile op regions into one dense arena
@@ -15,7 +15,7 @@
  * Parallel scheme of the fill (see DESIGN.md for the derivation).  Cells on one
  * anti-diagonal r = x + y are independent: (x,y) needs left (x-1,y) and up (x,y-1)
  * from r-1 and diag (x-1,y-1) from r-2.  A wave keeps read ROWS in a ring of
- * N = 64*M*NW slots, row y in slot y mod N, M consecutive slots per lane.  Per step
+ * N = 64*M slots, row y in slot y mod N, M consecutive slots per lane.  Per step
  * every slot advances its row by one column, so "left" is the slot's own previous
  * value (a register), "up" is the previous slot's value (a register for M-1 of the M
  * slots, one DPP wave_ror:1 for the lane boundary) and "diag" is the up value the
@@ -44,6 +44,20 @@ CVX_DEV int rot1_i(int v) {
 }
 CVX_DEV float rot1_f(float v) {
 	return __int_as_float(rot1_i(__float_as_int(v)));
+}
+
+/* Boundary records of chained row blocks travel between workgroups through L2.  Write-through
+ * (sc0 sc1) 16-byte stores, a drained vmcnt before the progress counter is published, and sc0 sc1
+ * loads on the consumer side make that visible across CUs and XCDs without agent-scope fences
+ * (which write back / invalidate whole caches and cost microseconds per hand-off). */
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+CVX_DEV void store_through16(void *p, const v4u v) {
+	asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+CVX_DEV v4u load_through16(const void *p) {
+	v4u v;
+	asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+	return v;
 }
 
 /* ------------------------------------------------------------------ plan */
@@ -195,8 +209,9 @@ CVX_DEV unsigned plane_code(const unsigned wx, const unsigned wy, const int bit)
  * ~20 000 dependent steps.  The walk state is wave-uniform; lane 0 writes the run-length ops.
  * `o` carries the argmax in (score, best_x, best_y) and returns the FwdResults.
  */
+template <bool CHAINED>
 CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int r0, const int ops_cap,
-		const int2 *rows, const uint2 *dirs, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
+		const int2 *rows, const uint2 *dirs, const ChainBlk *blk, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
 	/* make the walk's state provably wave-uniform so that it runs on scalar branches */
 	const int best_x = __builtin_amdgcn_readfirstlane(o.best_x);
 	const int best_y = __builtin_amdgcn_readfirstlane(o.best_y);
@@ -239,7 +254,17 @@ CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int 
 		const int tt = cx + cy - r0;
 		const int ttc = tt > 0 ? tt : 0;
 		const int2 ol = rows[ly];
-		const uint2 w = dirs[(size_t) (ttc >> 5) * N + sl];
+		uint2 w;
+		if (CHAINED) {
+			/* row block of the probed cell -> its own region of direction words (N is a power of two here) */
+			const int gb = ly / N;
+			const ChainBlk cb = blk[gb];
+			int wr = (ttc >> 5) - cb.tblk0;
+			wr = wr < 0 ? 0 : (wr >= cb.nblk32 ? cb.nblk32 - 1 : wr);      /* cells outside their row are masked below */
+			w = dirs[cb.dir_off + (size_t) wr * N + (size_t) (ly - gb * N)];
+		} else {
+			w = dirs[(size_t) (ttc >> 5) * N + sl];
+		}
 		const int rc = ref[lx], qc = qry[ly];
 		/* used by every probe on purpose: keeps all four loads in one round trip */
 		const u64 eqm = ballot(rc == qc);
@@ -375,68 +400,98 @@ template <bool WRAP> struct RunT { typedef float type; };
 template <> struct RunT<true> { typedef int type; };
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 
-/* Occupancy target.  The M = 3 single-wave kernel (corridors of 310-370 columns, i.e. almost
- * every PacBio/ONT tile) is measured ~14 % faster at 6 waves/SIMD (80 VGPRs, the few spilled
- * values are tile constants outside the step loop) than at the 5 the allocator picks by itself;
- * the other classes keep the default.  CVX_FILL_WAVES_PER_EU overrides for A/B runs. */
+/* Occupancy target.  The M = 3 kernel (corridors of 310-370 columns, i.e. almost every
+ * PacBio/ONT tile) is measured ~14 % faster at 6 waves/SIMD (80 VGPRs, the few spilled values are
+ * tile constants outside the step loop) than at the 5 the allocator picks by itself; the other
+ * classes keep the default.  CVX_FILL_WAVES_PER_EU overrides for A/B runs. */
 #ifndef CVX_FILL_WAVES_PER_EU
 #define CVX_FILL_WAVES_PER_EU 6
 #endif
-#define CVX_FILL_OCC(M, NW) __attribute__((amdgpu_waves_per_eu( \
-		((M) == 3 && (NW) == 1) ? CVX_FILL_WAVES_PER_EU : 1, ((M) == 3 && (NW) == 1) ? CVX_FILL_WAVES_PER_EU : 8)))
+#ifndef CVX_FILL_WAVES_M4
+#define CVX_FILL_WAVES_M4 1
+#endif
+#define CVX_FILL_OCC(M) __attribute__((amdgpu_waves_per_eu( \
+		(M) == 3 ? CVX_FILL_WAVES_PER_EU : ((M) == 4 ? CVX_FILL_WAVES_M4 : 1), \
+		(M) == 3 ? CVX_FILL_WAVES_PER_EU : ((M) == 4 && CVX_FILL_WAVES_M4 > 1 ? CVX_FILL_WAVES_M4 : 8))))
+
+enum FillMode { kFillTwoPhase = 0, kFillExact = 1, kFillChain = 2 };
 
 /*
- * One workgroup (NW waves) per tile: block b takes tile list[b].  The list is in LPT order and
- * the hardware dispatches workgroups in index order as wave slots free up, which is the work
- * queue a persistent kernel would build by hand -- without the atomic cursor and without a
- * tile loop around the step loop.
+ * One wave per tile: block b takes tile list[b].  The list is in LPT order and the hardware
+ * dispatches workgroups in index order as wave slots free up, which is the work queue a
+ * persistent kernel would build by hand -- without the atomic cursor and without a tile loop
+ * around the step loop.
  *
  * Best-cell tracking (src/ConvexAlignFast.cpp:758-763: first strict maximum in (y, x) order)
  * is two-phase.  Exact (score, step, row) tracking costs three half-rate VALU ops per cell; the
  * best cell of an alignment that reaches the end of the read lies in the last few anti-
- * diagonals, so the EXACT = false instantiation only keeps a per-lane running maximum
+ * diagonals, so the kFillTwoPhase instantiation only keeps a per-lane running maximum
  * (2 ops per M cells) up to the last `late` groups and tracks exactly from there on.  The
  * late result is the tile's answer iff it strictly beats every earlier score; otherwise the
- * tile is flagged (TileOut::pad = kPadRedo) and the EXACT = true instantiation, launched right
+ * tile is flagged (TileOut::pad = kPadRedo) and the kFillExact instantiation, launched right
  * behind on the same stream over the same list, redoes just the flagged tiles with exact
  * tracking from the first step.
+ *
+ * kFillChain: corridors with more live rows than the widest ring (need > 512: the retry loop's
+ * widened corridors up to 8192 columns, full-matrix inversion tiles) are cut into blocks of N
+ * consecutive read rows; block g is an ordinary ring tile whose first row takes its "up" inputs
+ * from the boundary stream that block g-1 writes while it computes its last row.  Blocks of one
+ * tile run concurrently on different CUs, each a few hundred steps behind its predecessor
+ * (about need / N of them at a time), so a wide tile is spread over many CUs instead of living
+ * in one workgroup.  A wave takes the next task from a ticket counter (tasks are listed in
+ * dependency order, so the producer of anything a wave waits for is always running or done);
+ * the boundary goes through L2 with write-through stores and a progress counter every
+ * kChainChunk steps (a block trails the one above it by about 2 N + 2 kChainChunk steps, so a tile
+ * takes about nblk * that many single-wave steps: small chunks, small blocks).
  */
-template <int M, int NW, bool WRAP, bool EXACT>
-__global__ void __launch_bounds__(64 * NW) CVX_FILL_OCC(M, NW)
+template <int M, bool WRAP, int MODE>
+__global__ void __launch_bounds__(64) CVX_FILL_OCC(M)
 fill_ring_kernel(const FillArgs a) {
-	constexpr int N = 64 * M * NW;
+	constexpr int N = 64 * M;
+	constexpr bool EXACT = (MODE != kFillTwoPhase);
+	constexpr bool CHAIN = (MODE == kFillChain);
 	typedef typename RunT<WRAP>::type run_t;   /* gap run: float (exact small ints) or int16-emulating int */
 	const int tid = threadIdx.x;
-	const int lane = tid & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* provably wave-uniform */
+	const int lane = tid;
 	const float go = a.sp.go;
 	const float gext = a.sp.ge, gem = a.sp.gem, decay = a.sp.decay;
 	/* keep match / mismatch in VGPRs: v_cndmask cannot take two SGPR values plus a mask */
 	float vmat = a.sp.mat, vmis = a.sp.mis;
 	asm volatile("" : "+v"(vmat), "+v"(vmis));
 
-	__shared__ float s_xf[2][NW > 1 ? NW : 1][2];
-	__shared__ run_t s_xi[2][NW > 1 ? NW : 1];
-	__shared__ int s_xm[2][NW > 1 ? NW : 1];
-	__shared__ float s_rbest[NW > 1 ? NW : 1], s_rearly[NW > 1 ? NW : 1];
-	__shared__ int s_ry[NW > 1 ? NW : 1], s_rx[NW > 1 ? NW : 1];
 	/* rarely touched per-slot state lives in LDS to keep VGPRs for occupancy: the read
 	 * row a slot holds and the row of its best cell (both only change at a row switch) */
-	__shared__ int s_y[M][64 * NW];
-	__shared__ int s_besty[M][64 * NW];
+	__shared__ int s_y[M][64];
+	__shared__ int s_besty[M][64];
+	__shared__ BoundaryRec s_bnd[CHAIN ? kChainChunk : 1];      /* the predecessor's boundary records of the current chunk of steps */
 
-	const int t = a.list[blockIdx.x];
-	if (EXACT) {
-		if (a.tout[t].pad != kPadRedo) return;   /* block-uniform */
-		if (tid == 0) atomicAdd(a.redo_count, 1);
+	int t;                          /* tile */
+	int task_id = 0, y0 = 0;        /* chain: task index, first read row of the block */
+	ChainTask ct;
+	if (CHAIN) {
+		int tk = 0;
+		if (lane == 0) tk = atomicAdd(a.chain_ticket, 1);
+		task_id = __builtin_amdgcn_readfirstlane(tk);
+		if (task_id >= a.list_n) return;
+		ct = a.tasks[task_id];
+		t = ct.tile;
+		y0 = ct.y0;
+	} else {
+		t = a.list[blockIdx.x];
+		if (MODE == kFillExact) {
+			if (a.tout[t].pad != kPadRedo) return;   /* block-uniform */
+			if (tid == 0) atomicAdd(a.redo_count, 1);
+		}
 	}
 	const TileIn ti = a.tin[t];
 	const TileRun tr = a.trun[t];
-	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off;
+	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off + y0;
 	const uint8_t *seq = a.seq;
-	const int H = ti.H, W = ti.W;
-	uint32_t *dirs = a.dirs + tr.dir_off;
-
+	const int H = CHAIN ? ct.rows : ti.H, W = ti.W;     /* rows of this task */
+	const unsigned qry_off = ti.qry_off + (unsigned) y0;
+	const int r0 = CHAIN ? ct.r0 : tr.r0;
+	const int nsteps = CHAIN ? ct.nsteps : tr.nsteps;
+	uint32_t *dirs = a.dirs + (CHAIN ? ct.dir_off : tr.dir_off);
 	/* per-slot state in VGPRs (static indexing only).  A slot that is not inside its
 	 * row's range holds the reference's empty element (score 0, run 0, STOP:
 	 * src/AlignmentMatrixFast.h:49-53), i.e. S = 0, runs = 0, V = Hc = gap_open;
@@ -470,10 +525,10 @@ fill_ring_kernel(const FillArgs a) {
 			long long hi = (long long) ol.x + (long long) ol.y;
 			if (hi > W) hi = W;
 			if (hi < lo) hi = lo;
-			cnt[j] = rnext - (yy + (int) lo);
+			cnt[j] = rnext - (yy + y0 + (int) lo);
 			len[j] = (int) (hi - lo);
-			qch[j] = seq[ti.qry_off + (unsigned) yy];
-			xa[j] = ti.ref_off + (unsigned) (rnext - yy);
+			qch[j] = seq[qry_off + (unsigned) yy];
+			xa[j] = ti.ref_off + (unsigned) (rnext - (yy + y0));
 		} else {
 			cnt[j] = -(1 << 30);
 			len[j] = 0;
@@ -493,18 +548,58 @@ fill_ring_kernel(const FillArgs a) {
 		best[j] = 0.0f; best_r[j] = 0;
 		accA[j] = accB[j] = 0u;
 		mD[j] = 0; mI[j] = 0;
-		bind_row(j, tr.r0);
+		bind_row(j, r0);
 	}
 
-	const int ngroups = (tr.nsteps + 3) >> 2;
+	const int ngroups = (nsteps + 3) >> 2;
 	int late = ngroups >> 3;
 	if (late < a.late_min_groups) late = a.late_min_groups;
 	const int gswitch = (EXACT || late >= ngroups) ? 0 : ngroups - late;   /* first exactly tracked group */
-	int r = tr.r0;
+	int r = r0;
+
+	/* chain: where this block's last row lives (it feeds the next block) and what has been published */
+	const int out_slot = CHAIN ? (ct.rows - 1) : 0;
+	const int out_lane = out_slot / M, out_j = out_slot % M;
+	BoundaryRec *bnd_out = CHAIN ? a.bnd + ct.bnd_out_off : nullptr;
+	const BoundaryRec *bnd_in = CHAIN ? a.bnd + ct.bnd_in_off : nullptr;
+	int chain_failed = 0;
+	BoundaryRec bcur;               /* boundary record of the next step */
+	bcur.V = go; bcur.S = 0.0f; bcur.run = 0u; bcur.is_ins = 0u;
 
 	/* one 4-step group; TRACK: exact best-cell tracking (else only the lane maximum) */
 	auto group = [&](auto track_tag, const int g) {
 		constexpr bool TRACK = decltype(track_tag)::value;
+		if (CHAIN && (g & (kChainChunk / 4 - 1)) == 0) {
+			/* boundary records of the next kChainChunk steps: record i belongs to column lo + i of the row
+			 * above this block; wait until the producer has published them (it runs ahead of us) */
+			const int x = (r - y0) + lane;                     /* column of the first row's cell at step r + lane */
+			const int idx = x - ct.bnd_lo;
+			BoundaryRec br;
+			br.V = go; br.S = 0.0f; br.run = 0u; br.is_ins = 0u;     /* outside the row above: the empty element */
+			if (ct.prev >= 0) {
+				int need_n = (r - y0) + (kChainChunk - 1) - ct.bnd_lo + 1;      /* records up to the chunk's last step */
+				if (need_n > ct.bnd_len) need_n = ct.bnd_len;
+				if (need_n > 0 && !chain_failed) {
+					int spins = 0;
+					for (;;) {
+						const int have = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.progress + ct.prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+						if (have >= need_n) break;
+						if (++spins > (1 << 21)) { chain_failed = 1; break; }     /* seconds: never hang the device */
+						/* back off: a task that was dispatched long before its turn must not flood L2 with polls */
+						if (spins < 8) __builtin_amdgcn_s_sleep(4);
+						else if (spins < 64) __builtin_amdgcn_s_sleep(32);
+						else __builtin_amdgcn_s_sleep(127);
+					}
+				}
+				if (lane < kChainChunk && idx >= 0 && idx < ct.bnd_len && !chain_failed) {
+					const v4u q = load_through16(bnd_in + idx);
+					br.V = __uint_as_float(q.x); br.S = __uint_as_float(q.y); br.run = q.z; br.is_ins = q.w;
+				}
+			}
+			if (lane < kChainChunk) s_bnd[lane] = br;
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      /* one wave: LDS write -> read order */
+			bcur = s_bnd[0];
+		}
 		/* this group's reference characters were fetched one group ago */
 		unsigned cw[M];
 #pragma unroll
@@ -531,22 +626,17 @@ fill_ring_kernel(const FillArgs a) {
 			if (WRAP) uI0 = (run_t) rot1_i((int) irun[M - 1]);
 			else uI0 = (run_t) rot1_f((float) irun[M - 1]);
 			u64 mIu0 = rot1_m(mI[M - 1]);
-			if (NW > 1) {
-				const int par = (r & 1);
-				if (lane == 63) {
-					s_xf[par][wave][0] = V[M - 1];
-					s_xf[par][wave][1] = S[M - 1];
-					s_xi[par][wave] = irun[M - 1];
-					s_xm[par][wave] = (int) (mI[M - 1] >> 63);
-				}
-				__syncthreads();
-				const int pw = (wave + NW - 1) % NW;
+			if (CHAIN) {
+				/* the block's first row (lane 0, slot 0) has the previous block's last row above it */
+				/* (the record was fetched from LDS one step ago: its latency is off the step's critical path) */
+				const BoundaryRec br = bcur;
+				bcur = s_bnd[((r - r0) + 1) & (kChainChunk - 1)];
 				if (lane == 0) {
-					uV0 = s_xf[par][pw][0];
-					uS0 = s_xf[par][pw][1];
-					uI0 = s_xi[par][pw];
+					uV0 = br.V;
+					uS0 = br.S;
+					uI0 = WRAP ? (run_t) (int) br.run : (run_t) __uint_as_float(br.run);
 				}
-				const int bit = __builtin_amdgcn_readfirstlane(s_xm[par][pw]);
+				const int bit = __builtin_amdgcn_readfirstlane((int) br.is_ins);
 				mIu0 = (mIu0 & ~1ull) | (u64) (bit & 1);
 			}
 
@@ -641,14 +731,35 @@ fill_ring_kernel(const FillArgs a) {
 				accB[j] = shl1_in(accB[j], p_cread[j]);     /* plane 1: I or diagonal */
 			};
 #pragma unroll
-			for (int j = M - 1; j >= 0; --j) { phase1(j); phase2(j); phase3(j); }
+			for (int j = M - 1; j >= 0; --j) {
+				phase1(j); phase2(j); phase3(j);
+				if (CHAIN && j == out_j && ct.has_next) {
+					/* the last row's new cell goes to the boundary stream (record index = its column in the row) */
+					if (lane == out_lane && (unsigned) (cnt[j] - 1) < (unsigned) len[j]) {
+						v4u q;
+						q.x = __float_as_uint(V[j]); q.y = __float_as_uint(S[j]);
+						q.z = WRAP ? (unsigned) (int) irun[j] : __float_as_uint((float) irun[j]);
+						q.w = (unsigned) ((mI[j] >> out_lane) & 1ull);
+						store_through16(bnd_out + (cnt[j] - 1), q);
+					}
+				}
+			}
 			r += 1;
 		}
+		if (CHAIN && ct.has_next && (g & (kChainChunk / 4 - 1)) == (kChainChunk / 4 - 1)) {
+			/* publish what the last row has produced so far: records, release, counter */
+			int done_n = 0;
+#pragma unroll
+			for (int j = 0; j < M; ++j) if (j == out_j) done_n = __builtin_amdgcn_readlane(cnt[j] < 0 ? 0 : (cnt[j] > len[j] ? len[j] : cnt[j]), out_lane);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the write-through record stores have landed */
+			if (lane == 0) __hip_atomic_store(a.progress + ct.blk, done_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
 		/* hand finished slots to their next row (y + N): a row's last cell is consumed
-		 * by the row below one step after it was computed, so wait for cnt > len */
+		 * by the row below one step after it was computed, so wait for cnt > len
+		 * (a chained block has at most N rows: nothing is ever handed on) */
 #pragma unroll
 		for (int j = 0; j < M; ++j) {
-			if (cnt[j] > len[j]) {     /* finished a real row (unbound slots count up from -2^30) */
+			if (!CHAIN && cnt[j] > len[j]) {     /* finished a real row (unbound slots count up from -2^30) */
 				const int yy = s_y[j][tid];
 				if (TRACK) {
 					if (best_r[j] >= r - cnt[j]) s_besty[j][tid] = yy;
@@ -695,20 +806,23 @@ fill_ring_kernel(const FillArgs a) {
 		if (ob > b || (ob == b && (oy < by || (oy == by && ox < bx)))) { b = ob; by = oy; bx = ox; }
 		if (!EXACT) be = fmaxf(be, __shfl_xor(be, off, 64));
 	}
-	if (NW > 1) {
-		__syncthreads();
-		if (lane == 0) { s_rbest[wave] = b; s_ry[wave] = by; s_rx[wave] = bx; s_rearly[wave] = be; }
-		__syncthreads();
-		if (tid == 0) {
-			for (int w = 1; w < NW; ++w) {
-				const float ob = s_rbest[w];
-				const int oy = s_ry[w], ox = s_rx[w];
-				if (ob > b || (ob == b && (oy < by || (oy == by && ox < bx)))) { b = ob; by = oy; bx = ox; }
-				be = fmaxf(be, s_rearly[w]);
-			}
+	if (CHAIN) {
+		if (ct.has_next) {
+			/* everything the next block may still wait for is out */
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (lane == 0) __hip_atomic_store(a.progress + ct.blk, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
+		if (lane == 0) {
+			ChainOut co;
+			co.score = b;
+			co.best_y = (b > -1.0f) ? by + y0 : 0;
+			co.best_x = (b > -1.0f) ? bx - y0 : 0;      /* bx was computed against block-local rows */
+			co.failed = chain_failed;
+			a.chain_out[ct.blk] = co;
+		}
+		return;
 	}
-	if ((NW > 1 ? tid : lane) == 0) {
+	if (lane == 0) {
 		/* b == -1: no positive score among the tracked cells.  If there is none anywhere either,
 		 * the reference (curr_max starts at -1) takes the first cell in (y, x) order, score 0;
 		 * backtrack_kernel resolves that rare case. */
@@ -737,8 +851,8 @@ CVX_DEV unsigned long long fld64(const int w, const int k) {
 
 /* backtrack of one tile by one wave (nothing to do for skipped, invalid or already walked tiles) */
 CVX_DEV void walk_tile(const BacktrackArgs &a, const int t, const int lane) {
-	static_assert(sizeof(TileRun) == 40 && sizeof(TileIn) == 32 && sizeof(TileOut) == 40, "record layout");
-	const int wr = rec_load(a.trun + t, 10, lane);   /* dir_off 0-1, ops_off 2-3, ring 4, ops_cap 5, r0 6, nsteps 7, skip 8 */
+	static_assert(sizeof(TileRun) == 48 && sizeof(TileIn) == 32 && sizeof(TileOut) == 40, "record layout");
+	const int wr = rec_load(a.trun + t, 12, lane);   /* dir_off 0-1, ops_off 2-3, ring 4, ops_cap 5, r0 6, nsteps 7, skip 8, mnw 9, chain_blk0 10 */
 	const int wo = rec_load(a.tout + t, 10, lane);   /* score 0, status 1, best_x 2, best_y 3, ..., pad 9 */
 	if (fld(wr, 8) != 0) return;
 	TileOut o;
@@ -763,10 +877,17 @@ CVX_DEV void walk_tile(const BacktrackArgs &a, const int t, const int lane) {
 		}
 		o.score = 0.0f; o.best_x = fx; o.best_y = fy;
 	}
-	backtrack_walk(lane, H, fld(wr, 4), fld(wr, 6), fld(wr, 5), rows,
-			reinterpret_cast<const uint2 *>(a.dirs + fld64(wr, 0)),
-			a.seq + (unsigned) fld(wi, 0), a.seq + (unsigned) fld(wi, 1),
-			a.ops + fld64(wr, 2), o);
+	const int cb0 = fld(wr, 10);
+	if (cb0 >= 0)
+		backtrack_walk<true>(lane, H, fld(wr, 4), fld(wr, 6), fld(wr, 5), rows,
+				reinterpret_cast<const uint2 *>(a.dirs), a.chain_blk + cb0,
+				a.seq + (unsigned) fld(wi, 0), a.seq + (unsigned) fld(wi, 1),
+				a.ops + fld64(wr, 2), o);
+	else
+		backtrack_walk<false>(lane, H, fld(wr, 4), fld(wr, 6), fld(wr, 5), rows,
+				reinterpret_cast<const uint2 *>(a.dirs + fld64(wr, 0)), nullptr,
+				a.seq + (unsigned) fld(wi, 0), a.seq + (unsigned) fld(wi, 1),
+				a.ops + fld64(wr, 2), o);
 	o.pad = 1;
 	if (lane == 0) a.tout[t] = o;
 }
@@ -858,41 +979,74 @@ compact_ops_kernel(const int32_t *regions, const TileRun *trun, const TileOut *t
 
 /* ------------------------------------------------------------------ launchers */
 
-template <int M, int NW, bool WRAP>
-static hipError_t launch_fill_t(const FillArgs &a, bool exact, hipStream_t st) {
-	/* one workgroup per tile of the list */
-	if (exact) hipLaunchKernelGGL((fill_ring_kernel<M, NW, WRAP, true>), dim3(a.list_n), dim3(64 * NW), 0, st, a);
-	else hipLaunchKernelGGL((fill_ring_kernel<M, NW, WRAP, false>), dim3(a.list_n), dim3(64 * NW), 0, st, a);
+/* best cell of a chained tile = first strict maximum over its row blocks in block order (blocks
+ * are in row order and each block's own best is already its first strict maximum in (y, x) order) */
+__global__ void __launch_bounds__(64)
+chain_reduce_kernel(const int32_t *tiles, int n_tiles, const TileRun *trun, const ChainOut *cout, TileOut *tout) {
+	const int q = blockIdx.x;
+	if (q >= n_tiles) return;
+	const int t = tiles[q];
+	const TileRun tr = trun[t];
+	const int lane = threadIdx.x;
+	float b = -1.0f;
+	int by = 0x7fffffff, bx = 0x7fffffff, failed = 0;
+	for (int g = lane; g < tr.chain_nblk; g += 64) {
+		const ChainOut c = cout[tr.chain_blk0 + g];
+		failed |= c.failed;
+		if (c.score > b) { b = c.score; by = c.best_y; bx = c.best_x; }      /* g ascending: earlier blocks win ties */
+	}
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		const float ob = __shfl_xor(b, off, 64);
+		const int oy = __shfl_xor(by, off, 64);
+		const int ox = __shfl_xor(bx, off, 64);
+		failed |= __shfl_xor(failed, off, 64);
+		if (ob > b || (ob == b && (oy < by || (oy == by && ox < bx)))) { b = ob; by = oy; bx = ox; }
+	}
+	if (lane == 0) {
+		TileOut o;
+		o.score = b;
+		o.status = failed ? -1 : 0;          /* CVX_TILE_UNSUPPORTED: loud, never silent */
+		o.best_x = (b > -1.0f) ? bx : 0;
+		o.best_y = (b > -1.0f) ? by : 0;
+		o.ref_position = 0; o.qstart = 0; o.qend = 0; o.n_ops = 0; o.ops_first = 0;
+		o.pad = 0;
+		tout[t] = o;
+	}
+}
+
+template <int M, bool WRAP>
+static hipError_t launch_fill_t(const FillArgs &a, int mode, size_t pad_lds, hipStream_t st) {
+	/* one wave per tile of the list (per task for chained tiles; pad_lds = unused dynamic LDS that
+	 * caps how many waiting tasks are resident) */
+	if (mode == kFillChain) {
+		if constexpr (M == 1 || M == 2 || M == 4) hipLaunchKernelGGL((fill_ring_kernel<M, WRAP, kFillChain>), dim3(a.list_n), dim3(64), pad_lds, st, a);
+		else return hipErrorInvalidValue;
+	} else if (mode == kFillExact) hipLaunchKernelGGL((fill_ring_kernel<M, WRAP, kFillExact>), dim3(a.list_n), dim3(64), 0, st, a);
+	else hipLaunchKernelGGL((fill_ring_kernel<M, WRAP, kFillTwoPhase>), dim3(a.list_n), dim3(64), 0, st, a);
 	return hipGetLastError();
 }
 
-template <int M, int NW>
-static hipError_t launch_fill_w(const FillArgs &a, bool wrap, bool exact, hipStream_t st) {
-	return wrap ? launch_fill_t<M, NW, true>(a, exact, st) : launch_fill_t<M, NW, false>(a, exact, st);
+template <int M>
+static hipError_t launch_fill_w(const FillArgs &a, bool wrap, int mode, size_t pad_lds, hipStream_t st) {
+	return wrap ? launch_fill_t<M, true>(a, mode, pad_lds, st) : launch_fill_t<M, false>(a, mode, pad_lds, st);
 }
 
-hipError_t launch_fill(int m, int nw, bool wrap, bool exact, const FillArgs &a, hipStream_t st) {
+hipError_t launch_fill(int m, bool wrap, int mode, const FillArgs &a, size_t pad_lds, hipStream_t st) {
 	if (a.list_n <= 0) return hipSuccess;
-	if (nw == 1) {
-		switch (m) {
-		case 1: return launch_fill_w<1, 1>(a, wrap, exact, st);
-		case 2: return launch_fill_w<2, 1>(a, wrap, exact, st);
-		case 3: return launch_fill_w<3, 1>(a, wrap, exact, st);
-		case 4: return launch_fill_w<4, 1>(a, wrap, exact, st);
-		case 5: return launch_fill_w<5, 1>(a, wrap, exact, st);
-		case 6: return launch_fill_w<6, 1>(a, wrap, exact, st);
-		case 8: return launch_fill_w<8, 1>(a, wrap, exact, st);
-		default: return hipErrorInvalidValue;
-		}
-	}
-	if (m != 4) return hipErrorInvalidValue;
-	switch (nw) {
-	case 2: return launch_fill_w<4, 2>(a, wrap, exact, st);
-	case 4: return launch_fill_w<4, 4>(a, wrap, exact, st);
-	case 8: return launch_fill_w<4, 8>(a, wrap, exact, st);
-	case 16: return launch_fill_w<4, 16>(a, wrap, exact, st);
+	switch (m) {
+	case 1: return launch_fill_w<1>(a, wrap, mode, pad_lds, st);
+	case 2: return launch_fill_w<2>(a, wrap, mode, pad_lds, st);
+	case 3: return launch_fill_w<3>(a, wrap, mode, pad_lds, st);
+	case 4: return launch_fill_w<4>(a, wrap, mode, pad_lds, st);
 	default: return hipErrorInvalidValue;
 	}
+}
+
+hipError_t launch_chain_reduce(const int32_t *tiles, int n_tiles, const TileRun *trun, const ChainOut *cout, TileOut *tout, hipStream_t st) {
+	if (n_tiles <= 0) return hipSuccess;
+	hipLaunchKernelGGL(chain_reduce_kernel, dim3(n_tiles), dim3(64), 0, st, tiles, n_tiles, trun, cout, tout);
+	return hipGetLastError();
 }
 
 hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles,

@@ -9,10 +9,11 @@
 
 namespace cvx {
 
-/* (m, nw) pairs that exist: m in {1,2,3,4,5,6,8} with nw = 1; m = 4 with nw in {2,4,8,16}. */
-/* exact = false: two-phase best-cell tracking, flags undecided tiles; exact = true: the pass that
- * redoes the flagged tiles of the same list (launch both, in this order, on one stream) */
-hipError_t launch_fill(int m, int nw, bool wrap, bool exact, const FillArgs &a, hipStream_t st);
+/* m in {1,2,3,4}.  mode (cvx_kernels.hip FillMode): 0 two-phase best-cell tracking (flags
+ * undecided tiles), 1 the exact pass that redoes the flagged tiles of the same list (launch both, in
+ * this order, on one stream), 2 chained row blocks (a.tasks, list_n = number of tasks). */
+hipError_t launch_fill(int m, bool wrap, int mode, const FillArgs &a, size_t pad_lds, hipStream_t st);
+hipError_t launch_chain_reduce(const int32_t *tiles, int n_tiles, const TileRun *trun, const ChainOut *cout, TileOut *tout, hipStream_t st);
 /* sub-read scoring (cvx_score.hip) */
 struct ScorePair {
 	uint64_t ref_off, qry_off;   /* byte offsets in the sequence buffer (strings keep their NUL) */

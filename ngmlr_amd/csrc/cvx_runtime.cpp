@@ -169,6 +169,12 @@ struct cvx_batch_s {
 	DevBuf<uint8_t> d_res;           /* ResultRec[n] + BatchSummary */
 	DevBuf<uint8_t> d_gscratch;      /* slot state of tiles taken by the catch-all kernel */
 	DevBuf<uint64_t> d_gscratch_off;
+	/* chained tiles (row blocks) */
+	PinBuf h_chain;                  /* ChainTask[] of all chain classes, ChainBlk[], tile lists */
+	DevBuf<uint8_t> d_chain;
+	DevBuf<int32_t> d_progress;
+	DevBuf<BoundaryRec> d_bnd;
+	DevBuf<ChainOut> d_chain_out;
 
 	hipEvent_t ev_in = nullptr;      /* upload + plan records on the host */
 	hipEvent_t ev_res = nullptr;     /* result records on the host */
@@ -195,6 +201,7 @@ struct cvx_batch_s {
 		d_tout.release(); d_dirs.release(); d_regions.release(); d_lists.release();
 		d_counters.release(); d_dstoff.release(); d_dense.release(); d_res.release();
 		d_gscratch.release(); d_gscratch_off.release();
+		h_chain.release(); d_chain.release(); d_progress.release(); d_bnd.release(); d_chain_out.release();
 		if (ev_in) { (void) hipEventDestroy(ev_in); ev_in = nullptr; }
 		if (ev_res) { (void) hipEventDestroy(ev_res); ev_res = nullptr; }
 		for (auto &e : ev) if (e) { (void) hipEventDestroy(e); e = nullptr; }
@@ -215,6 +222,8 @@ struct cvx_context {
 	int pack_threads = 16;
 	int tune_min_slots = 0;   /* tuning knob (env CVX_TUNE_MIN_M): smallest M*NW a tile may use */
 	int tune_late_min = kLateMinGroups;  /* test knob (env CVX_TUNE_LATE_MIN): groups of the exactly tracked tail (huge: exact everywhere) */
+	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
+	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
 	/* freed batches keep their device arenas and pinned staging and wait here for the next upload
 	 * (at most kPoolBatches): hipMalloc / hipFree of multi-GB arenas per call are slow, and hipFree
@@ -376,7 +385,9 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 
 	/* host planning: kernel class, arena offsets, work lists (cvx_host_logic.h) */
 	HostPlan hp;
-	host_plan(n, b->plan(), b->tin(), h->tune_min_slots, h->tune_force_wrap, hp);
+	PlanTuning tune;
+	tune.min_slots = h->tune_min_slots; tune.max_slots = h->tune_max_slots; tune.force_wrap = h->tune_force_wrap; tune.chain_m = h->tune_chain_m;
+	host_plan(n, b->plan(), b->tin(), b->h_rows.as<RowDesc>(), tune, hp);
 	std::vector<std::vector<int32_t>> &cls = hp.cls;
 	std::vector<int32_t> &generic = hp.generic;
 	RC_TRY(b->d_dirs.ensure((size_t) hp.dir_dwords + 64));
@@ -414,6 +425,27 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		RC_TRY(b->d_gscratch_off.ensure(generic.size() + 1));
 		HIP_TRY(hipMemcpyAsync(b->d_gscratch_off.p, goff, (generic.size() + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
 	}
+	/* chained tiles: tasks of every chain class, block table and tile lists in one upload */
+	size_t chain_task_off[kNumChainClasses * 2] = {0}, chain_tile_off[kNumChainClasses * 2] = {0};
+	size_t chain_blk_off = 0, chain_bytes = 0;
+	if (hp.n_chained) {
+		for (size_t c = 0; c < hp.chain_tasks.size(); ++c) { chain_task_off[c] = chain_bytes; chain_bytes += hp.chain_tasks[c].size() * sizeof(ChainTask); }
+		chain_blk_off = chain_bytes; chain_bytes += hp.chain_blk.size() * sizeof(ChainBlk);
+		for (size_t c = 0; c < hp.chain_tiles.size(); ++c) { chain_tile_off[c] = chain_bytes; chain_bytes += (hp.chain_tiles[c].size() * sizeof(int32_t) + 7) / 8 * 8; }
+		RC_TRY(b->h_chain.ensure(chain_bytes));
+		uint8_t *hc = b->h_chain.as<uint8_t>();
+		for (size_t c = 0; c < hp.chain_tasks.size(); ++c)
+			if (!hp.chain_tasks[c].empty()) memcpy(hc + chain_task_off[c], hp.chain_tasks[c].data(), hp.chain_tasks[c].size() * sizeof(ChainTask));
+		memcpy(hc + chain_blk_off, hp.chain_blk.data(), hp.chain_blk.size() * sizeof(ChainBlk));
+		for (size_t c = 0; c < hp.chain_tiles.size(); ++c)
+			if (!hp.chain_tiles[c].empty()) memcpy(hc + chain_tile_off[c], hp.chain_tiles[c].data(), hp.chain_tiles[c].size() * sizeof(int32_t));
+		RC_TRY(b->d_chain.ensure(chain_bytes));
+		RC_TRY(b->d_progress.ensure(hp.chain_blk.size()));
+		RC_TRY(b->d_chain_out.ensure(hp.chain_blk.size()));
+		RC_TRY(b->d_bnd.ensure((size_t) hp.bnd_recs + 64));
+		HIP_TRY(hipMemcpyAsync(b->d_chain.p, hc, chain_bytes, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemsetAsync(b->d_progress.p, 0, hp.chain_blk.size() * sizeof(int32_t), st));
+	}
 	HIP_TRY(hipMemcpyAsync(b->d_trun.p, b->h_trun.p, (size_t) n * sizeof(TileRun), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(b->d_tout.p, b->h_tout.p, (size_t) n * sizeof(TileOut), hipMemcpyHostToDevice, st));
 	if (n_listed) HIP_TRY(hipMemcpyAsync(b->d_lists.p, lists, n_listed * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -435,6 +467,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		a.list_n = list_n;
 		a.redo_count = b->d_counters.p;
 		a.late_min_groups = h->tune_late_min;
+		a.tasks = nullptr; a.chain_ticket = nullptr; a.progress = nullptr; a.bnd = nullptr; a.chain_out = nullptr;
 		a.ops = b->d_regions.p;
 		a.sp = h->sp;
 		return a;
@@ -453,6 +486,11 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		b->launches.push_back(li);
 	};
 	int launches = 0;
+	/* fill launches go round-robin over the two aux streams and the main stream itself (which has
+	 * nothing else to do until they are all done): three classes side by side */
+	hipStream_t fill_streams[kAuxStreams + 1];
+	for (int i = 0; i < kAuxStreams; ++i) fill_streams[i] = h->aux[i];
+	fill_streams[kAuxStreams] = st;
 	auto begin_launch = [&](hipStream_t ls) -> int {
 		while (b->lev.size() < (size_t) (launches + 1) * 3) {
 			hipEvent_t e;
@@ -463,24 +501,54 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3], ls));
 		return CVX_OK;
 	};
+	/* chained tiles first (their dependency chains are the longest thing in a batch): the row-block
+	 * tasks of a class, then the per-tile reduction of the block results */
+	for (size_t c = 0; c < hp.chain_tasks.size(); ++c) {
+		if (hp.chain_tasks[c].empty()) continue;
+		const int m = kChainClasses[c / 2];
+		launch_stats(hp.chain_tiles[c], m, (int) hp.chain_tasks[c].size(), (int) (c & 1));     /* `waves` = row-block tasks */
+		hipStream_t ls = fill_streams[launches % (kAuxStreams + 1)];
+		RC_TRY(begin_launch(ls));
+		FillArgs a = fill_args(nullptr, (int) hp.chain_tasks[c].size());
+		a.tasks = reinterpret_cast<const ChainTask *>(b->d_chain.p + chain_task_off[c]);
+		a.chain_ticket = b->d_counters.p + 8 + (int) c;
+		a.progress = b->d_progress.p;
+		a.bnd = b->d_bnd.p;
+		a.chain_out = b->d_chain_out.p;
+		/* tasks are dispatched in order, long before their turn; resident tasks beyond the ones that can
+		 * actually run only poll.  Unused dynamic LDS caps the residency at ~1.5x the blocks that are
+		 * live at one time (need / rows-per-block per tile, + slack). */
+		uint64_t live = 0;
+		for (int32_t ti : hp.chain_tiles[c]) live += (uint64_t) b->plan()[(size_t) ti].need / (uint64_t) (64 * m + kChainChunk) + 2;
+		const uint64_t resident = std::min<uint64_t>(8192, std::max<uint64_t>(768, live + live / 2 + 256));
+		const size_t per_cu = (size_t) ((resident + (uint64_t) h->num_cus - 1) / (uint64_t) h->num_cus);
+		size_t pad_lds = per_cu >= 32 ? 0 : (size_t) (160 * 1024) / per_cu - 4096;
+		pad_lds = std::min<size_t>(pad_lds, 60 * 1024) / 256 * 256;
+		HIP_TRY(launch_fill(m, (c & 1) != 0, 2, a, pad_lds, ls));
+		HIP_TRY(launch_chain_reduce(reinterpret_cast<const int32_t *>(b->d_chain.p + chain_tile_off[c]), (int) hp.chain_tiles[c].size(),
+				b->d_trun.p, b->d_chain_out.p, b->d_tout.p, ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
+		launches++;
+	}
 	for (int cc = (int) cls.size() - 1; cc >= 0; --cc) {
 		const size_t c = (size_t) cc;
 		if (cls[c].empty()) continue;
 		const KernelClass &kc = kClasses[c / 2];
-		launch_stats(cls[c], kc.m, kc.nw, (int) (c & 1));
-		hipStream_t ls = h->aux[launches % kAuxStreams];
+		launch_stats(cls[c], kc.m, 1, (int) (c & 1));
+		hipStream_t ls = fill_streams[launches % (kAuxStreams + 1)];
 		RC_TRY(begin_launch(ls));
 		const FillArgs a = fill_args(b->d_lists.p + seg_begin[c], (int) cls[c].size());
-		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, false, a, ls));
+		HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 0, a, 0, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
 		/* exact-tracking pass over the tiles the two-phase pass flagged (usually none) */
-		HIP_TRY(launch_fill(kc.m, kc.nw, (c & 1) != 0, true, a, ls));
+		HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 1, a, 0, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
 		launches++;
 	}
 	if (!generic.empty()) {
 		launch_stats(generic, 0, 16, 1);
-		hipStream_t ls = h->aux[launches % kAuxStreams];
+		hipStream_t ls = fill_streams[launches % (kAuxStreams + 1)];
 		RC_TRY(begin_launch(ls));
 		const FillArgs a = fill_args(b->d_lists.p + generic_begin, (int) generic.size());
 		HIP_TRY(launch_fill_generic(a, b->d_gscratch.p, b->d_gscratch_off.p, ls));
@@ -493,6 +561,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 
 	/* backtrack, device-side result records + prefix sums, ops compaction */
 	BacktrackArgs ba;
+	ba.chain_blk = hp.n_chained ? reinterpret_cast<const ChainBlk *>(b->d_chain.p + chain_blk_off) : nullptr;
 	ba.seq = b->d_seq.p;
 	ba.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
 	ba.tin = b->d_tin.p;
@@ -515,6 +584,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	b->timing.dir_bytes = hp.dir_dwords * 4;
 	b->timing.n_fill_launches = launches;
 	b->timing.n_tiles_fast = hp.n_fast;
+	b->timing.n_tiles_chained = hp.n_chained;
 	b->state = kComputed;
 	return CVX_OK;
 }
@@ -636,6 +706,8 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_PACK_THREADS")) c->pack_threads = std::max(1, atoi(e));
 	if (const char *e = getenv("CVX_TUNE_MIN_M")) c->tune_min_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_FORCE_WRAP16")) c->tune_force_wrap = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_CHAIN_M")) c->tune_chain_m = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
 	int prio_lo = 0, prio_hi = 0;
 	(void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     /* numerically lower = higher priority */
@@ -657,7 +729,6 @@ void cvx_destroy(cvx_handle h) {
 	(void) hipSetDevice(h->device);
 	(void) hipDeviceSynchronize();
 	if (h->s_main) (void) hipStreamDestroy(h->s_main);
-	if (h->s_io) (void) hipStreamDestroy(h->s_io);
 	if (h->s_io) (void) hipStreamDestroy(h->s_io);
 	for (auto &a : h->aux) if (a) (void) hipStreamDestroy(a);
 	for (cvx_batch_s *b : h->pool) { b->release(); delete b; }

@@ -51,6 +51,7 @@ static const int kRingMax = 4096;      /* largest ring any fill kernel provides 
  * marks a tile whose best cell may lie before them (redone by the exact instantiation) */
 static const int kLateMinGroups = 128;
 static const int kPadRedo = 2;
+static const int kChainChunk = 16;     /* chained row blocks: steps per boundary hand-off (multiple of 4, power of two, <= 64) */
 
 struct ScoreParams {
 	float mat, mis, go, ge, gem, decay;
@@ -81,14 +82,51 @@ struct TilePlan {          /* written by plan_kernel, read back by the host */
 };
 
 struct TileRun {           /* written by the host after planning */
-	uint64_t dir_off;      /* dword offset in the dirs arena */
+	uint64_t dir_off;      /* dword offset in the dirs arena (chained tiles: see ChainBlk) */
 	uint64_t ops_off;      /* int offset of this tile's ops region */
-	int32_t ring;          /* N */
+	int32_t ring;          /* N (chained tiles: rows per block) */
 	int32_t ops_cap;
-	int32_t r0;
+	int32_t r0;            /* origin of the step index t = x + y - r0 */
 	int32_t nsteps;
 	int32_t skip;          /* != 0: tile not computed (status preset in TileOut) */
-	int32_t mnw;           /* M | NW << 8 of the fill kernel class that owns the tile */
+	int32_t mnw;           /* M of the fill kernel class that owns the tile (0: catch-all kernel) */
+	int32_t chain_blk0;    /* chained tiles: index of the tile's first ChainBlk / ChainTask, else -1 */
+	int32_t chain_nblk;    /* number of row blocks */
+};
+
+/* Chained tiles (cvx_kernels.hip, kFillChain): block g holds read rows [g * ring, (g + 1) * ring). */
+struct ChainBlk {          /* where the backtrack finds a block's direction words */
+	uint64_t dir_off;      /* uint2 offset of the block's region in the dirs arena */
+	int32_t tblk0;         /* (first step of the block - TileRun::r0) >> 5 */
+	int32_t nblk32;        /* 32-step word rows in the region */
+};
+
+struct ChainTask {         /* one row block = one wave's work */
+	int32_t tile;
+	int32_t y0;            /* first read row */
+	int32_t rows;          /* rows in the block (<= ring) */
+	int32_t r0;            /* first step; (r0 - TileRun::r0) is a multiple of 32 */
+	int32_t nsteps;
+	int32_t blk;           /* index of this block's ChainBlk / ChainOut / progress counter */
+	int32_t prev;          /* block index of the block above, -1 for the first block */
+	int32_t bnd_lo;        /* the row above this block: first column and number of cells inside [0, W) */
+	int32_t bnd_len;
+	int32_t has_next;      /* a block below consumes this block's last row */
+	uint64_t dir_off;      /* dword offset of the block's region */
+	uint64_t bnd_in_off;   /* BoundaryRec offset of the stream written by `prev` */
+	uint64_t bnd_out_off;  /* BoundaryRec offset of this block's own stream */
+};
+
+struct BoundaryRec {       /* what a cell of a block's last row offers the row below */
+	float V, S;            /* up candidate, score */
+	uint32_t run;          /* gap-run register (float bits, or the int16 run of the wrap kernels) */
+	uint32_t is_ins;       /* the cell is an insertion */
+};
+
+struct ChainOut {          /* best cell of one block, tile coordinates */
+	float score;           /* -1: no positive score in the block */
+	int32_t best_x, best_y;
+	int32_t failed;        /* the wave gave up waiting for its predecessor */
 };
 
 struct TileOut {
@@ -128,12 +166,19 @@ struct FillArgs {
 	const int32_t *list;   /* tile indices of this kernel class, largest first */
 	int32_t list_n;        /* = grid size: one workgroup per tile */
 	int32_t *redo_count;   /* statistics: tiles redone by the exact pass */
+	/* kFillChain only */
+	const ChainTask *tasks;  /* list_n tasks in dependency order */
+	int32_t *chain_ticket;   /* zeroed before the launch */
+	int32_t *progress;       /* per block: boundary records published (zeroed before the launch) */
+	BoundaryRec *bnd;
+	ChainOut *chain_out;     /* per block */
 	int32_t late_min_groups; /* exactly tracked tail, in 4-step groups (kLateMinGroups; a test knob raises it) */
 	int32_t *ops;          /* per-tile op regions */
 	ScoreParams sp;
 };
 
 struct BacktrackArgs {
+	const ChainBlk *chain_blk;
 	const uint8_t *seq;
 	const RowDesc2 *rows;
 	const TileIn *tin;

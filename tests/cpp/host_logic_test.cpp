@@ -118,7 +118,7 @@ int main() {
 		pin[i].H = 10 + (int) (rng() % 20000); pin[i].W = 10 + (int) (rng() % 20000);
 	}
 	HostPlan hp;
-	host_plan(m, plan.data(), pin.data(), 0, 0, hp);
+	host_plan(m, plan.data(), pin.data(), nullptr, PlanTuning(), hp);
 	uint64_t dir = 0, ops = 0;
 	std::vector<int> where(m, -1);
 	for (size_t c = 0; c < hp.cls.size(); ++c) for (int32_t t : hp.cls[c]) { CHECK(where[t] == -1); where[t] = (int) c; }
@@ -133,13 +133,13 @@ int main() {
 		CHECK(r.nsteps == p.rend - p.r0 && r.r0 == p.r0 && r.ops_cap == pin[i].H + pin[i].W + 8);
 		dir += (uint64_t) ((r.nsteps + 31) / 32) * (uint64_t) r.ring * 2ull;
 		ops += (uint64_t) r.ops_cap;
-		if ((p.flags & kPlanIrregular) || p.need > kRingMax) {
+		if ((p.flags & kPlanIrregular) || p.need > kClasses[kNumClasses - 1].ring()) {    /* (no rows given: no chaining) */
 			CHECK(where[i] == 1000 && r.mnw == 0 && r.ring % 64 == 0);
 			CHECK(r.ring >= ((p.flags & kPlanIrregular) ? pin[i].H : p.need));
 		} else {
 			CHECK(where[i] >= 0 && where[i] < 1000);
 			const KernelClass &kc = kClasses[where[i] / 2];
-			CHECK(kc.ring() == r.ring && kc.ring() >= p.need && r.mnw == (kc.m | (kc.nw << 8)));
+			CHECK(kc.ring() == r.ring && kc.ring() >= p.need && r.mnw == kc.m && r.chain_blk0 == -1);
 			if (where[i] / 2 > 0) CHECK(kClasses[where[i] / 2 - 1].ring() < p.need);   // smallest class that fits
 			CHECK((where[i] & 1) == ((p.flags & kPlanWrap16) ? 1 : 0));
 		}
@@ -161,9 +161,57 @@ int main() {
 		CHECK(v1 == v2 && v1[0] == 5);
 	}
 	// tuning knobs: a floor on the ring class, forced int16-run kernels
-	host_plan(m, plan.data(), pin.data(), 8, 1, hp);
+	{ PlanTuning tn; tn.min_slots = 4; tn.force_wrap = 1; host_plan(m, plan.data(), pin.data(), nullptr, tn, hp); }
 	for (size_t c = 0; c < hp.cls.size(); ++c) {
-		if (!hp.cls[c].empty()) CHECK((c & 1) == 1 && kClasses[c / 2].m * kClasses[c / 2].nw >= 8);
+		if (!hp.cls[c].empty()) CHECK((c & 1) == 1 && kClasses[c / 2].m >= 4);
+	}
+	// ---------------------------------------------------------------- chained tiles (row blocks)
+	{
+		const int H = 3001, W = 3300, w = 2100;            // slope-1 band, ~1050 live rows: no ring holds it
+		std::vector<RowDesc> rows((size_t) H + 10);
+		for (int y = 0; y < H; ++y) { rows[(size_t) y + 5].off = y - w / 2; rows[(size_t) y + 5].len = w; }
+		TilePlan p; memset(&p, 0, sizeof(p));
+		p.r0 = 0; p.rend = (H - 1) + std::min(W, (H - 1) - w / 2 + w); p.need = 1054; p.cells = (uint64_t) H * w; p.active = p.cells;
+		TileIn in; memset(&in, 0, sizeof(in));
+		in.H = H; in.W = W; in.row_off = 5;
+		HostPlan hc;
+		host_plan(1, &p, &in, rows.data(), PlanTuning(), hc);
+		CHECK(hc.n_chained == 1 && hc.generic.empty() && hc.n_fast == 0);
+		const TileRun &r = hc.trun[0];
+		const int cc = chain_class_for(p.need, true);
+		const int N = 64 * kChainClasses[cc];
+		CHECK(r.ring == N && r.chain_blk0 == 0 && r.chain_nblk == (H + N - 1) / N && r.mnw == kChainClasses[cc]);
+		const std::vector<ChainTask> &tk = hc.chain_tasks[(size_t) cc * 2];
+		CHECK((int) tk.size() == r.chain_nblk && (int) hc.chain_blk.size() == r.chain_nblk);
+		uint64_t dir = 0, bnd = 0;
+		for (int g = 0; g < (int) tk.size(); ++g) {
+			const ChainTask &t = tk[(size_t) g];
+			CHECK(t.tile == 0 && t.y0 == g * N && t.rows == std::min(N, H - g * N) && t.blk == g && t.prev == g - 1);
+			CHECK(((t.r0 - p.r0) & 31) == 0 && t.has_next == (g + 1 < (int) tk.size() ? 1 : 0));
+			// every cell of the block lies inside [r0, r0 + nsteps)
+			for (int y = t.y0; y < t.y0 + t.rows; ++y) {
+				const int lo = std::max(0, y - w / 2), hi = std::min(W, y - w / 2 + w);
+				if (hi > lo) CHECK(lo + y >= t.r0 && hi + y <= t.r0 + t.nsteps && lo + y - t.r0 < 32 + 2 * N);
+			}
+			CHECK(t.dir_off == dir && hc.chain_blk[(size_t) g].dir_off * 2 == dir && hc.chain_blk[(size_t) g].tblk0 == (t.r0 - p.r0) / 32);
+			dir += (uint64_t) hc.chain_blk[(size_t) g].nblk32 * N * 2;
+			if (g > 0) {
+				const int yb = t.y0 - 1;
+				CHECK(t.bnd_lo == std::max(0, yb - w / 2) && t.bnd_len == std::min(W, yb - w / 2 + w) - t.bnd_lo && t.bnd_in_off == tk[(size_t) g - 1].bnd_out_off);
+			}
+			CHECK(t.bnd_out_off == bnd);
+			if (t.has_next) { const int yl = t.y0 + t.rows - 1; bnd += (uint64_t) (std::min(W, yl - w / 2 + w) - std::max(0, yl - w / 2)); }
+		}
+		CHECK(dir == hc.dir_dwords && bnd == hc.bnd_recs);
+		// two wide tiles: tasks interleave by block index, every block after the one above it
+		const int nblk1 = r.chain_nblk;
+		TilePlan p2[2] = {p, p}; TileIn in2[2] = {in, in};
+		host_plan(2, p2, in2, rows.data(), PlanTuning(), hc);
+		const std::vector<ChainTask> &t2 = hc.chain_tasks[(size_t) cc * 2];
+		CHECK((int) t2.size() == 2 * nblk1);
+		std::vector<int> seen(hc.chain_blk.size(), 0);
+		for (const ChainTask &t : t2) { CHECK(t.prev < 0 || seen[(size_t) t.prev]); seen[(size_t) t.blk] = 1; }
+		CHECK(t2[0].tile == 0 && t2[1].tile == 1 && t2[2].tile == 0 && t2[2].y0 == N);
 	}
 	printf(fails ? "host_logic_test: %d FAILED\n" : "host_logic_test: ok\n", fails);
 	return fails ? 1 : 0;

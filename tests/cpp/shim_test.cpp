@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <execinfo.h>
+#include <signal.h>
 #include <stdint.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -18,7 +21,20 @@
 
 static bool rd(FILE * f, void * p, size_t n) { return fread(p, 1, n, f) == n; }
 
+/* a crash inside the library shows where (there is no debugger on the GPU boxes) */
+static void on_crash(int sig) {
+	/* async-signal-safe only: the heap may be the thing that is broken */
+	static char const msg[] = "shim_test: fatal signal, backtrace follows\n";
+	(void) !write(2, msg, sizeof(msg) - 1);
+	static void * frames[64];
+	int const n = backtrace(frames, 64);
+	backtrace_symbols_fd(frames, n, 2);
+	_exit(128 + sig);
+}
+
 int main(int argc, char ** argv) {
+	signal(SIGSEGV, on_crash);
+	signal(SIGABRT, on_crash);
 	if (argc < 2) { fprintf(stderr, "usage: shim_test records.bin [batch]\n"); return 2; }
 	bool const batch = argc > 2;
 	FILE * f = fopen(argv[1], "rb");
@@ -80,7 +96,9 @@ int main(int argc, char ** argv) {
 	if (batch) {
 		static_cast<Convex::ConvexAlignHip *>(aligner)->AlignTiles(tiles.data(), (int) tiles.size());
 	} else {
+		bool const verbose = getenv("SHIM_VERBOSE") != 0;
 		for (size_t i = 0; i < tiles.size(); ++i) {
+			if (verbose) fprintf(stderr, "tile %zu H %d W %zu\n", i, tiles[i].corridorHeight, strlen(tiles[i].refSeq));
 			tiles[i].ret = aligner->SingleAlign(0, tiles[i].corridor, tiles[i].corridorHeight, tiles[i].refSeq,
 					tiles[i].qrySeq, *tiles[i].result, tiles[i].externalQStart, tiles[i].externalQEnd, 0);
 		}
