@@ -334,9 +334,12 @@ def format_alignment(lib, res: capi.CvxResult, ops: np.ndarray, tile, want_nm: b
     d["score_bits"] = int(np.float32(txt.score).view(np.uint32))
     d["cigar"] = cig.value.decode()
     d["md"] = md.value.decode()
+    # What the reference's consumer reads: detectMisalignment walks nmPerPosition[i] for
+    # i < alignmentLength (src/AlignmentBuffer.cpp:1320-1321), although only txt.nm_count triples were
+    # written (positions > 16, none for insertion columns); the rest of the caller's buffer is zero here.
     n = min(txt.alignment_length, nm_cap) if (txt.ret >= 0 and want_nm) else 0
     d["nm_per_position"] = nm[:n].copy()
-    d["nm_count"] = n
+    d["nm_count"] = txt.nm_count      # triples actually written
     d["status"] = res.status
     d["fwd_score_bits"] = int(np.float32(res.score).view(np.uint32))
     d["best_x"] = res.best_ref_index

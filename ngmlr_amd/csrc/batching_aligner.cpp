@@ -2,11 +2,13 @@
 #include "batching_aligner.h"
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace Convex {
 
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
-		backend(be), workers(nWorkers > 0 ? nWorkers : 1), parked(0), leaderActive(false),
+		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0), leaderActive(false),
 		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), launches(0), requests(0) {
 }
 
@@ -20,6 +22,11 @@ void BatchingAligner::WorkerDone() {
 	if (!leaderActive && !queue.empty() && parked >= workers) flushLocked(lk);
 }
 
+void BatchingAligner::WorkerJoined() {
+	std::unique_lock<std::mutex> lk(mtx);
+	workers += 1;
+}
+
 /* called with the lock held by a parked thread: run everything that is queued */
 void BatchingAligner::flushLocked(std::unique_lock<std::mutex> & lk) {
 	leaderActive = true;
@@ -28,7 +35,7 @@ void BatchingAligner::flushLocked(std::unique_lock<std::mutex> & lk) {
 	lk.unlock();
 
 	std::vector<ConvexAlignHip::Tile> tiles(batch.size());
-	for (size_t i = 0; i < batch.size(); ++i) tiles[i] = batch[i]->tile;
+	for (size_t i = 0; i < batch.size(); ++i) { tiles[i] = batch[i]->tile; batch[i]->queued = false; }
 	bool failed = false;
 	try {
 		backend->AlignTiles(tiles.data(), (int) tiles.size());
@@ -59,25 +66,82 @@ int BatchingAligner::SingleAlign(int const mode, CorridorLine * corridor, int co
 
 	std::unique_lock<std::mutex> lk(mtx);
 	queue.push_back(&req);
+	req.queued = true;
 	requests += 1;
 	parked += 1;
-	std::chrono::steady_clock::time_point const deadline =
-			std::chrono::steady_clock::now() + std::chrono::microseconds(timeoutUs > 0 ? timeoutUs : 1000000);
+	std::chrono::microseconds const patience(timeoutUs > 0 ? timeoutUs : 1000000);
+	std::chrono::steady_clock::time_point deadline = std::chrono::steady_clock::now() + patience;
 	while (!req.done) {
+		bool const expired = timeoutUs > 0 && std::chrono::steady_clock::now() >= deadline;
 		bool const mine = !leaderActive && !queue.empty() &&
-				((int) queue.size() >= maxBatch || parked >= workers ||
-				 (timeoutUs > 0 && std::chrono::steady_clock::now() >= deadline));
+				((int) queue.size() >= maxBatch || parked >= workers || expired);
 		if (mine) {
 			flushLocked(lk);      /* may or may not contain my own request */
 			continue;
 		}
-		if (timeoutUs > 0) cv.wait_until(lk, deadline);
-		else cv.wait(lk);
+		/* The timed wait only makes sense while this request still sits in the queue and nobody is
+		 * flushing: once a leader has taken it (or is busy with an earlier batch) the only event to
+		 * wait for is the leader's notify_all -- a deadline that has already passed would turn
+		 * wait_until into a spin on the mutex the leader needs. */
+		if (timeoutUs > 0 && req.queued && !leaderActive) {
+			if (expired) deadline = std::chrono::steady_clock::now() + patience;   /* re-arm */
+			cv.wait_until(lk, deadline);
+		} else {
+			cv.wait(lk);
+		}
 	}
 	parked -= 1;
 	lk.unlock();
 	if (req.failed) throw 1;
 	return req.tile.ret;
 }
+
+/* ------------------------------------------------------------------ SharedAligner */
+
+namespace {
+std::mutex g_sharedMtx;
+ConvexAlignHip * g_backend = 0;
+BatchingAligner * g_shared = 0;
+int g_users = 0;
+long g_lastLaunches = 0, g_lastRequests = 0;
+}
+
+SharedAligner::SharedAligner(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
+		float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId) : shared(0) {
+	std::lock_guard<std::mutex> g(g_sharedMtx);
+	if (g_shared == 0) {
+		int maxBatch = 4096, timeoutUs = 2000;
+		if (const char * e = getenv("CVX_BATCH_MAX")) maxBatch = atoi(e);
+		if (const char * e = getenv("CVX_BATCH_TIMEOUT_US")) timeoutUs = atoi(e);
+		g_backend = new ConvexAlignHip(stdOutMode, match, mismatch, gapOpen, gapExtend, gapExtendMin, gapDecay, deviceId);
+		g_shared = new BatchingAligner(g_backend, 0, maxBatch, timeoutUs);   /* workers join one by one */
+	}
+	g_shared->WorkerJoined();
+	g_users += 1;
+	shared = g_shared;
+}
+
+SharedAligner::~SharedAligner() {
+	std::lock_guard<std::mutex> g(g_sharedMtx);
+	shared->WorkerDone();
+	g_users -= 1;
+	if (g_users == 0) {
+		g_lastLaunches = g_shared->Launches();
+		g_lastRequests = g_shared->Requests();
+		fprintf(stderr, "SharedAligner: %ld alignments in %ld device launches (%.1f per launch)\n", g_lastRequests,
+				g_lastLaunches, g_lastLaunches ? (double) g_lastRequests / (double) g_lastLaunches : 0.0);
+		delete g_shared; g_shared = 0;
+		delete g_backend; g_backend = 0;
+	}
+}
+
+int SharedAligner::SingleAlign(int const mode, CorridorLine * corridor, int const corridorHeight,
+		char const * const refSeq, char const * const qrySeq, Align & result,
+		int const externalQStart, int const externalQEnd, void * extData) {
+	return shared->SingleAlign(mode, corridor, corridorHeight, refSeq, qrySeq, result, externalQStart, externalQEnd, extData);
+}
+
+long SharedAligner::Launches() { std::lock_guard<std::mutex> g(g_sharedMtx); return g_shared ? g_shared->Launches() : g_lastLaunches; }
+long SharedAligner::Requests() { std::lock_guard<std::mutex> g(g_sharedMtx); return g_shared ? g_shared->Requests() : g_lastRequests; }
 
 }  // namespace Convex

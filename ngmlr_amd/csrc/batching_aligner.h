@@ -46,6 +46,8 @@ public:
 	/* a worker that stops calling (end of input) must say so, or the "everybody is parked"
 	 * rule would wait for it */
 	void WorkerDone();
+	/* a worker that joins after construction (SharedAligner: one per AlignmentBuffer) */
+	void WorkerJoined();
 
 	/* statistics */
 	long Launches() const { return launches; }
@@ -56,6 +58,7 @@ private:
 		ConvexAlignHip::Tile tile;
 		bool done;
 		bool failed;
+		bool queued;           /* still in the queue (no leader has taken it yet) */
 	};
 	ConvexAlignHip * backend;
 	std::mutex mtx;
@@ -69,6 +72,43 @@ private:
 	long launches, requests;
 
 	void flushLocked(std::unique_lock<std::mutex> & lk);
+};
+
+/*
+ * SharedAligner -- the form ngmlr's pipeline takes without any other change: every
+ * AlignmentBuffer (one per CS worker thread, reference src/CS.cpp:412-418) constructs "its"
+ * aligner at src/AlignmentBuffer.h:355 and deletes it in its destructor (:375).  Constructing a
+ * SharedAligner there instead gives each worker a thin IAlignment whose SingleAlign parks in ONE
+ * process-wide BatchingAligner over ONE ConvexAlignHip per device: with `-t N` up to N tiles
+ * travel per device launch.  The first SharedAligner creates the shared pair, the last one to be
+ * destroyed prints the launch statistics and deletes it.  Scoring parameters are those of the
+ * first construction (every worker passes the same Config values).
+ */
+class SharedAligner: public IAlignment {
+public:
+	SharedAligner(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
+			float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId = 0);
+	virtual ~SharedAligner();
+
+	virtual int GetScoreBatchSize() const { return 0; }
+	virtual int GetAlignBatchSize() const { return 0; }
+	virtual int BatchScore(int const, int const, char const * const * const, char const * const * const,
+			float * const, void *) { throw "Not implemented"; }
+	virtual int BatchAlign(int const, int const, char const * const * const, char const * const * const,
+			Align * const, void *) { throw "Not implemented"; }
+	virtual int SingleAlign(int const, int const, char const * const, char const * const, Align &, void *) {
+		throw "Not implemented";
+	}
+	virtual int SingleAlign(int const mode, CorridorLine * corridor, int const corridorHeight,
+			char const * const refSeq, char const * const qrySeq, Align & result,
+			int const externalQStart, int const externalQEnd, void * extData);
+
+	/* statistics of the process-wide aligner (0 when none exists) */
+	static long Launches();
+	static long Requests();
+
+private:
+	BatchingAligner * shared;
 };
 
 }  // namespace Convex

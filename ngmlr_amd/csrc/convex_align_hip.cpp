@@ -8,16 +8,25 @@
 #include <cstdio>
 #include <cstring>
 
+#ifdef CVX_IN_NGMLR_TREE
+#include "IConfig.h"       /* Config.getMaxMatrixSizeMB(), as ConvexAlignFast's ctor reads it (src/ConvexAlignFast.cpp:49) */
+#endif
+
 namespace Convex {
 
 ConvexAlignHip::ConvexAlignHip(int const stdOutMode, float const match, float const mismatch,
 		float const gapOpen, float const gapExtend, float const gapExtendMin, float const gapDecay,
-		int const deviceId) : handle(0) {
+		int const deviceId, unsigned long const maxMatrixSizeMB) : handle(0) {
 	(void) stdOutMode;
 	cvx_params p;
 	p.match = match; p.mismatch = mismatch; p.gap_open = gapOpen;
 	p.gap_extend = gapExtend; p.gap_extend_min = gapExtendMin; p.gap_decay = gapDecay;
-	if (cvx_create(deviceId, &p, 0, &handle) != CVX_OK) {
+	maxMatrixMB = maxMatrixSizeMB;
+#ifdef CVX_IN_NGMLR_TREE
+	if (maxMatrixMB == 0) maxMatrixMB = (unsigned long) Config.getMaxMatrixSizeMB();
+#endif
+	if (maxMatrixMB == 0) maxMatrixMB = 10000;      /* IConfig's default (src/IConfig.h:47) */
+	if (cvx_create(deviceId, &p, (uint64_t) maxMatrixMB, &handle) != CVX_OK) {
 		fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
 		throw "ConvexAlignHip: no usable MI355X / unsupported scoring";
 	}
@@ -115,8 +124,9 @@ void ConvexAlignHip::finish(Tile & t, cvx_result const & r, int refLen, int qryL
 	Align & a = *t.result;
 	if (r.status != CVX_TILE_OK) {
 		if (r.status == CVX_TILE_TOO_LARGE) {
-			fprintf(stderr, "Warning: Couldn't allocate alignment matrix. Required memory (%llu) > max matrix size\n\n",
-					(unsigned long long) (r.cells / 1000000ull));
+			/* the reference's message (src/AlignmentMatrixFast.cpp:56), same float arithmetic for the size */
+			fprintf(stderr, "Warning: Couldn't allocate alignment matrix. Required memory (%llu) > max matrix size (%lu)\n\n",
+					(long long) ((float) r.cells / 1000.0f / 1000.0f), maxMatrixMB);
 		} else if (a.pBuffer2 != 0) {
 			a.pBuffer2[0] = '\0';
 		}

@@ -28,7 +28,8 @@ namespace Convex {
 class ConvexAlignHip: public IAlignment {
 public:
 	ConvexAlignHip(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
-			float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId = 0);
+			float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId = 0,
+			unsigned long const maxMatrixSizeMB = 0 /* Config.getMaxMatrixSizeMB(); 0 = the reference's default 10000 */);
 	virtual ~ConvexAlignHip();
 
 	virtual int GetScoreBatchSize() const;
@@ -60,6 +61,7 @@ public:
 
 private:
 	cvx_handle handle;
+	unsigned long maxMatrixMB;
 	std::vector<cvx_tile> packed;
 	std::vector<cvx_result> results;
 	std::vector<uint32_t> ops;

@@ -414,6 +414,11 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 		(M) == 3 ? CVX_FILL_WAVES_PER_EU : ((M) == 4 ? CVX_FILL_WAVES_M4 : 1), \
 		(M) == 3 ? CVX_FILL_WAVES_PER_EU : ((M) == 4 && CVX_FILL_WAVES_M4 > 1 ? CVX_FILL_WAVES_M4 : 8))))
 
+/* instruction-order experiments on the cell update (0: leave it to the compiler) */
+#ifndef CVX_FILL_SCHED
+#define CVX_FILL_SCHED 0
+#endif
+
 enum FillMode { kFillTwoPhase = 0, kFillExact = 1, kFillChain = 2 };
 
 /*
@@ -730,9 +735,32 @@ fill_ring_kernel(const FillArgs a) {
 				accA[j] = shl1_in(accA[j], p_gap[j]);       /* plane 0: I or D */
 				accB[j] = shl1_in(accB[j], p_cread[j]);     /* plane 1: I or diagonal */
 			};
+#if CVX_FILL_SCHED == 1
+			/* all candidates / compares first, then all mask logic, then all state updates */
+#pragma unroll
+			for (int j = M - 1; j >= 0; --j) phase1(j);
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int j = M - 1; j >= 0; --j) phase2(j);
+			__builtin_amdgcn_sched_barrier(0);
+#elif CVX_FILL_SCHED == 2
+			/* software pipeline over the slots: the mask logic of slot j runs beside the compares of slot j-1 */
+#pragma unroll
+			for (int q = M; q >= -1; --q) {
+				if (q < M && q >= 0) phase1(q);
+				if (q + 1 < M && q + 1 >= 0) phase2(q + 1);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+#endif
 #pragma unroll
 			for (int j = M - 1; j >= 0; --j) {
-				phase1(j); phase2(j); phase3(j);
+#if CVX_FILL_SCHED == 0 || CVX_FILL_SCHED == 3
+				phase1(j); phase2(j);
+#endif
+				phase3(j);
+#if CVX_FILL_SCHED == 3
+				__builtin_amdgcn_sched_barrier(0);
+#endif
 				if (CHAIN && j == out_j && ct.has_next) {
 					/* the last row's new cell goes to the boundary stream (record index = its column in the row) */
 					if (lane == out_lane && (unsigned) (cnt[j] - 1) < (unsigned) len[j]) {

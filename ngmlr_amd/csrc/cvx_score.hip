@@ -23,8 +23,8 @@
 namespace cvx {
 
 __device__ __forceinline__ int nt_code(int c) {
-	c |= 0x20;                       /* nt_table is case-insensitive for ACGT */
-	return c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : c == 't' ? 3 : 4;
+	c |= 0x20;                       /* nt_table is case-insensitive; U/u map to 0 like A (src/StrippedSW.cpp:111-116) */
+	return (c == 'a' || c == 'u') ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : c == 't' ? 3 : 4;
 }
 
 __global__ void __launch_bounds__(64)

@@ -7,7 +7,7 @@
  * What the reference does, line by line:
  *  - both strings are taken WITH their terminating NUL (read_len = strlen + 1,
  *    src/StrippedSW.cpp:131-132) and mapped through nt_table (:108-114): A/C/G/T (either
- *    case) -> 0..3, everything else (N, x, NUL) -> 4;
+ *    case) -> 0..3, U/u -> 0, everything else (N, x, NUL) -> 4;
  *  - the 5x5 matrix is +1 on the ACGT diagonal, -1 off it, 0 in row/column 4
  *    (src/StrippedSW.h:20-36);
  *  - gap_open = gap_extension = -1 are passed to ssw_align's `const uint8_t weight_gapO/E`
@@ -30,7 +30,7 @@
 
 static int code_of(unsigned char c) {
 	switch (c) {
-	case 'A': case 'a': return 0;
+	case 'A': case 'a': case 'U': case 'u': return 0;   /* nt_table[85] = nt_table[117] = 0, src/StrippedSW.cpp:114-116 */
 	case 'C': case 'c': return 1;
 	case 'G': case 'g': return 2;
 	case 'T': case 't': return 3;

@@ -11,6 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip")
+BIN_BATCHED = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_batched")
 E2E = os.path.join(ROOT, "tests", "golden", "e2e")
 
 
@@ -18,10 +19,10 @@ def _records(text):
     return [l for l in text.splitlines() if l and not l.startswith("@")]
 
 
-def _run(args, tmp_path):
-    if not os.path.exists(BIN):
-        pytest.skip("oracle/_ref/ngmlr_hip not built (tools/build_ngmlr_hip.sh needs /root/reference)")
-    res = subprocess.run([BIN, "--skip-write"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+def _run(args, tmp_path, binary=BIN):
+    if not os.path.exists(binary):
+        pytest.skip("%s not built (tools/build_ngmlr_hip.sh needs /root/reference)" % os.path.relpath(binary, ROOT))
+    res = subprocess.run([binary, "--skip-write"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=600, cwd=str(tmp_path))
     assert res.returncode == 0, res.stderr[-3000:]
     maps = open("/proc/self/maps").read()  # noqa: F841  (the child loaded libcvxalign.so via its RUNPATH)
@@ -42,6 +43,45 @@ def test_test_4_sam_identical_to_reference(built, tmp_path):
     want = _records(open(os.path.join(ROOT, "tests", "golden", "test_4.sam")).read())
     assert len(want) == 1
     assert got == want
+
+
+def _test_3_args(tmp_path, threads):
+    import gzip
+    fq = os.path.join(str(tmp_path), "test_3.fq")          # FASTQ: FASTA + a reverse-strand hit crashes the reference
+    with gzip.open(os.path.join(E2E, "test_3_reads.fq.gz"), "rb") as f, open(fq, "wb") as o:
+        o.write(f.read())
+    return ["-x", "pacbio", "-t", str(threads), "-R", "0.01", "--no-progress",
+            "-r", os.path.join(E2E, "test_3_reference.fasta.gz"), "-q", fq]
+
+
+def _test_3_want():
+    import gzip
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "test_3.sorted.sam.gz"), "rt") as f:
+        return [l.rstrip("\n") for l in f if l.strip()]
+
+
+def test_test_3_sam_identical_to_reference(built, tmp_path):
+    """test/test_3.sh's input (142 PacBio reads, 985 convex alignments), one private aligner per worker."""
+    got, err = _run(_test_3_args(tmp_path, 1), tmp_path)
+    want = _test_3_want()
+    assert len(want) == 202
+    assert sorted(got) == want
+
+
+@pytest.mark.parametrize("threads", [16, 64])
+def test_test_3_batched_pipeline_sam_identical(built, tmp_path, threads):
+    """SURVEY 8 f1 inside the real pipeline: ngmlr -t N with every worker's AlignmentBuffer sharing ONE
+    BatchingAligner (Convex::SharedAligner constructed at src/AlignmentBuffer.h:355): many tiles per
+    device launch, SAM records identical to the unmodified reference (sorted: order is thread-dependent)."""
+    import re
+    got, err = _run(_test_3_args(tmp_path, threads), tmp_path, binary=BIN_BATCHED)
+    assert sorted(got) == _test_3_want()
+    m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", err)
+    assert m, err[-2000:]
+    requests, launches = int(m.group(1)), int(m.group(2))
+    assert requests == 985
+    assert launches < requests          # batching happened
+    print("test_3 -t %d: %d alignments in %d launches (%.1f per launch)" % (threads, requests, launches, requests / launches))
 
 
 def test_binary_links_the_device_library(built):

@@ -48,6 +48,25 @@ def test_golden_tiles_from_reference_pipeline(hip_aligner, name):
         assert util.golden_diff(exp, g) is None, (t.tag, util.golden_diff(exp, g))
 
 
+def test_every_recorded_test_3_call(hip_aligner):
+    """All 985 SingleAlign calls of the reference on its test_3 reads (142 PacBio reads, the only
+    multi-read long-read fixture it ships), not the committed 60-tile sample."""
+    path = util.full_golden_path()
+    if path is None:
+        pytest.skip("oracle/_ref/golden_full not generated (tools/make_golden.sh needs /root/reference)")
+    pairs = util.load_golden(path)
+    assert len(pairs) == 985
+    bad = []
+    for lo in range(0, len(pairs), 256):
+        chunk = pairs[lo:lo + 256]
+        got = hip_aligner.batch_align([t for t, _ in chunk])
+        for (t, exp), g in zip(chunk, got):
+            d = util.golden_diff(exp, g)
+            if d:
+                bad.append((t.tag, d))
+    assert not bad, bad[:5]
+
+
 def test_zoo_all_corridor_kinds(hip_aligner, port_oracle):
     _check(hip_aligner, port_oracle, util.tile_zoo(seed=31, n=240, max_w=3000))
 

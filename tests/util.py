@@ -6,6 +6,15 @@ import numpy as np
 from ngmlr_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# every SingleAlign call the reference makes on its test_3 reads (985 tiles, 1.26 G cells): written by
+# tools/make_golden.sh beside the other reference-derived build artefacts (git-ignored; it travels to
+# the GPU box with the snapshot).  tests/golden/ref_test_3.npz is the committed 60-tile subset.
+GOLDEN_FULL = os.path.join(os.path.dirname(GOLDEN), os.pardir, "oracle", "_ref", "golden_full")
+
+
+def full_golden_path(name="ref_test_3_full.npz"):
+    p = os.path.normpath(os.path.join(GOLDEN_FULL, name))
+    return p if os.path.exists(p) else None
 
 FIELD_NAMES = ("position_offset", "qstart", "qend", "nm", "alignment_length", "cigar_op_count", "sv_type",
                "first_ref", "first_read", "last_ref", "last_read")
@@ -14,7 +23,8 @@ FIELD_NAMES = ("position_offset", "qstart", "qend", "nm", "alignment_length", "c
 def load_golden(name):
     """-> list of (Tile, expected dict) recorded from the unmodified reference binary
     (tools/make_golden.sh) on its own test data."""
-    z = np.load(os.path.join(GOLDEN, name))
+    z = np.load(name if os.path.isabs(name) else os.path.join(GOLDEN, name))
+    name = os.path.basename(name)
     out = []
     for i in range(int(z["n"])):
         p = "t%d_" % i

@@ -13,29 +13,40 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 REPO="$(dirname "$HERE")"
 make -s -C "$REPO/ngmlr_amd/csrc"
 WORK="$(mktemp -d /tmp/ngmlr_hip.XXXXXX)"
-cp -r /root/reference "$WORK/src_tree"
-T="$WORK/src_tree"
-python3 - "$T" "$REPO" <<'PY'
+mkdir -p "$REPO/oracle/_ref"
+# build_variant OUT_NAME ALIGNER_CLASS: the class constructed at src/AlignmentBuffer.h:355
+#   ngmlr_hip          Convex::ConvexAlignHip  one private aligner per worker, one tile per launch
+#   ngmlr_hip_batched  Convex::SharedAligner   all -t N workers share one BatchingAligner per device
+build_variant() {
+local OUT_NAME=$1 CLASS=$2
+local T="$WORK/$OUT_NAME"
+cp -r /root/reference "$T"
+python3 - "$T" "$REPO" "$CLASS" <<'PY'
 import re, sys
-T, REPO = sys.argv[1], sys.argv[2]
+T, REPO, CLASS = sys.argv[1], sys.argv[2], sys.argv[3]
 p = T + '/src/AlignmentBuffer.h'
 s = open(p).read()
-s = s.replace('#include "ConvexAlignFast.h"', '#include "ConvexAlignFast.h"\n#include "convex_align_hip.h"', 1)
+s = s.replace('#include "ConvexAlignFast.h"', '#include "ConvexAlignFast.h"\n#include "convex_align_hip.h"\n#include "batching_aligner.h"', 1)
 pat = re.compile(r'aligner = new Convex::ConvexAlignFast\(', re.S)
 assert len(pat.findall(s)) == 1
-s = pat.sub('aligner = new Convex::ConvexAlignHip(', s)
+s = pat.sub('aligner = new %s(' % CLASS, s)
 open(p, 'w').write(s)
 p = T + '/src/CMakeLists.txt'
 c = open(p).read()
-c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp' % (REPO, REPO, REPO), 1)
+c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp\n%s/ngmlr_amd/csrc/batching_aligner.cpp' % (REPO, REPO, REPO, REPO), 1)
 c = c.replace('TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})', 'TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})\nTARGET_LINK_LIBRARIES(ngmlr %s/ngmlr_amd/libcvxalign.so)\nset_target_properties(ngmlr PROPERTIES BUILD_RPATH "\\$ORIGIN/../../ngmlr_amd;/opt/rocm/lib" SKIP_BUILD_RPATH FALSE)' % REPO, 1)
 open(p, 'w').write(c)
 PY
 mkdir -p "$T/build" && cd "$T/build"
-cmake .. -DCMAKE_POLICY_VERSION_MINIMUM=3.5 -DCMAKE_BUILD_TYPE=RELWITHDEBINFO > "$WORK/cmake.log" 2>&1
-make -j8 > "$WORK/make.log" 2>&1 || { tail -30 "$WORK/make.log"; exit 1; }
-BIN=$(ls "$T"/bin/ngmlr-*/ngmlr)
-mkdir -p "$REPO/oracle/_ref"
-cp "$BIN" "$REPO/oracle/_ref/ngmlr_hip"
-echo "built $REPO/oracle/_ref/ngmlr_hip"
+cmake .. -DCMAKE_POLICY_VERSION_MINIMUM=3.5 -DCMAKE_BUILD_TYPE=RELWITHDEBINFO > "$WORK/$OUT_NAME.cmake.log" 2>&1
+make -j16 > "$WORK/$OUT_NAME.make.log" 2>&1 || { tail -30 "$WORK/$OUT_NAME.make.log"; exit 1; }
+local BIN=$(ls "$T"/bin/ngmlr-*/ngmlr)
+cp "$BIN" "$REPO/oracle/_ref/$OUT_NAME"
+echo "built $REPO/oracle/_ref/$OUT_NAME"
+}
+build_variant ngmlr_hip Convex::ConvexAlignHip &
+build_variant ngmlr_hip_batched Convex::SharedAligner &
+wait
+test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched"
 readelf -d "$REPO/oracle/_ref/ngmlr_hip" | grep -E "RPATH|RUNPATH|NEEDED" | head
+rm -rf "$WORK"

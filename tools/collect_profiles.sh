@@ -3,7 +3,7 @@
 # roofline numbers come from.  Writes everything under gpurun_out/TAG_*; summarise afterwards with
 #   python tools/rocpd_summary.py gpurun_out/TAG_stats/*.db > profiles/TAG_stats.txt   (same for fetch/write/sq)
 # PMC passes are separate runs with --kernel-trace only (never combined with sys/hip traces).
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -11,7 +11,20 @@ cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 400 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o p -- python $R/bench.py --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
-timeout -s KILL 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o p -- python $R/bench.py --tiles 4096 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_fetch.log 2>&1
-timeout -s KILL 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o p -- python $R/bench.py --tiles 4096 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_write.log 2>&1
-timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES -d $OUT/${TAG}_sq -o p -- python $R/bench.py --tiles 12288 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_sq.log 2>&1
-ls -la $OUT/${TAG}_stats $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq 2>&1 | tail -12
+timeout -s KILL 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o p -- python $R/bench.py --tiles 4096 --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o p -- python $R/bench.py --tiles 4096 --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_write.log 2>&1
+# issue-side counters: instructions, wave cycles, and the three disjoint wave states (parked / issue-stalled / issuing)
+timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/${TAG}_sq -o p -- python $R/bench.py --tiles 12288 --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_sq.log 2>&1
+# VALU pipe occupancy proper (cycles the VALU is executing, not instruction counts), if this rocprofv3 has the counters
+rocprofv3 -L > $OUT/${TAG}_counters_list.txt 2>&1
+SQ2=""
+for c in SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES; do
+	grep -q "\b$c\b" $OUT/${TAG}_counters_list.txt && SQ2="$SQ2 $c"
+done
+echo "second SQ pass:$SQ2"
+timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $SQ2 -d $OUT/${TAG}_sq2 -o p -- python $R/bench.py --tiles 12288 --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_sq2.log 2>&1
+for p in stats fetch write sq sq2; do
+	db=$(ls $OUT/${TAG}_$p/*.db 2>/dev/null | head -1)
+	[ -n "$db" ] && python $R/tools/rocpd_summary.py $db > $OUT/${TAG}_$p.txt 2>&1
+done
+ls -la $OUT | tail -30

@@ -29,7 +29,7 @@ open(p, 'w').write(s)
 PY
 mkdir -p "$T/build" && cd "$T/build"
 cmake .. -DCMAKE_POLICY_VERSION_MINIMUM=3.5 -DCMAKE_BUILD_TYPE=RELWITHDEBINFO > "$WORK/cmake.log" 2>&1
-make -j8 > "$WORK/make.log" 2>&1
+make -j16 > "$WORK/make.log" 2>&1
 BIN=$(ls "$T"/bin/ngmlr-*/ngmlr)
 echo "built $BIN"
 D="$T/test/data"
@@ -58,5 +58,21 @@ for line in gzip.open(sys.argv[1], 'rt'):
 flush(); out.close()
 PY
 run test_3 -x pacbio -t 1 -R 0.01 -r "$D/test_3/reference.fasta.gz" -q "$WORK/test_3.fq"
-cp "$WORK/test_2.sam" "$WORK/test_4.sam" "$REPO/tests/golden/" 2>/dev/null || true
+# (the @PG header line carries the temporary directory: normalise it so that regenerating is a no-op)
+for t in test_2 test_4; do sed "s#$WORK#/tmp/ngmlr_rec.HzLyKR#g" "$WORK/$t.sam" > "$REPO/tests/golden/$t.sam"; done
+# test_3 end to end (tests/test_gpu_e2e.py): the FASTQ form of the reads, the reference genome and the
+# unmodified reference's SAM records (sorted: the output order depends on the thread count)
+gzip -9 -n -c "$WORK/test_3.fq" > "$REPO/tests/golden/e2e/test_3_reads.fq.gz"
+cp "$D/test_3/reference.fasta.gz" "$REPO/tests/golden/e2e/test_3_reference.fasta.gz"
+grep -v '^@' "$WORK/test_3.sam" | LC_ALL=C sort | gzip -9 -n > "$REPO/tests/golden/test_3.sorted.sam.gz"
 python3 "$HERE/pack_golden.py" "$WORK" "$REPO/tests/golden"
+# every recorded test_3 call (985 tiles): too large for the history, kept beside the other
+# reference-derived build artefacts (git-ignored, travels to the GPU box with the snapshot)
+mkdir -p "$REPO/oracle/_ref/golden_full"
+python3 - "$HERE" "$WORK" "$REPO/oracle/_ref/golden_full" <<'PY'
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import pack_golden
+pack_golden.pack(pack_golden.read_records(os.path.join(sys.argv[2], 'test_3.rec')), os.path.join(sys.argv[3], 'ref_test_3_full.npz'))
+PY
+rm -rf "$WORK"
