@@ -129,13 +129,16 @@ class Worker:
         self.stage = np.zeros(4)
         self.last = None                              # the last step's job (results kept for the checks)
         self.valid = 0
+        self.host_s = np.zeros(2)                     # host wall time inside cvx_submit / cvx_wait (timed steps)
 
     def steps(self, k, keep_last=False, record=True):
         jobs = []
 
         def retire(j, keep):
+            c0 = time.perf_counter()
             res, _ = j.wait()
             if record:
+                self.host_s[1] += time.perf_counter() - c0
                 tm = j.timing()
                 self.stage += (tm.plan_ms, tm.fill_ms, tm.backtrack_ms, tm.total_ms)
                 for li in j.launches():
@@ -149,7 +152,10 @@ class Worker:
                 j.release()
 
         for s in range(k):
+            c0 = time.perf_counter()
             jobs.append(self.al.submit(self.ts))
+            if record:
+                self.host_s[0] += time.perf_counter() - c0
             if len(jobs) >= self.depth:
                 retire(jobs.pop(0), False)
         while jobs:
@@ -371,6 +377,8 @@ def main() -> int:
                                    "what": "HIP-event stage times of the device-resident steps (in the pipelined steps the stages of neighbouring batches overlap)"}
                                   if resident and "fill_ms" in resident else None),
             "device_resident": resident,
+            "host_ms_per_step": {"cvx_submit": float(w0.host_s[0]) / args.steps * 1e3, "cvx_wait": float(w0.host_s[1]) / args.steps * 1e3,
+                                 "what": "wall time the device's host thread spends inside the two calls (packing + queueing / blocked on results)"},
             "valid_alignments": "%d/%d" % (valid, len(ts)),
             "parity": parity,
             "parity_detail": parity_detail,

@@ -726,7 +726,12 @@ fill_ring_kernel(const FillArgs a) {
 					const u64 better = ballot(sc > best[j]);   /* sc is 0 outside the row, best >= 0 */
 					best[j] = lanes(better) ? mx : best[j];
 					best_r[j] = lanes(better) ? r : best_r[j];
-				} else {
+				} else if (i >= 2) {
+					/* early phase: the running maximum samples steps 2 and 3 of every group only.  A cell of
+					 * step 0 or 1 scores at most `match` more than its best predecessor (left / up cost, the
+					 * diagonal adds at most `match`), and its predecessors lie in sampled steps (or in step 0,
+					 * bounded the same way), so every untracked score is <= lbest + match; the acceptance test
+					 * at the end carries that slack. */
 					lbest = fmaxf(lbest, sc);
 				}
 				mD[j] = nD;
@@ -862,7 +867,9 @@ fill_ring_kernel(const FillArgs a) {
 		o.ref_position = 0; o.qstart = 0; o.qend = 0; o.n_ops = 0; o.ops_first = 0;
 		/* pad = 0: filled, not backtracked yet; kPadRedo: an untracked cell scored at least as much
 		 * as the best tracked one, so the first strict maximum is not known -> exact pass */
-		o.pad = (!EXACT && be > 0.0f && !(b > be)) ? kPadRedo : 0;
+		/* be under-estimates the early maximum by at most `match` (steps 0 and 1 of a group are not sampled);
+		 * 2 * match + 1 also covers the rounding of the float adds behind that bound */
+		o.pad = (!EXACT && gswitch > 0 && !(b > be + 2.0f * a.sp.mat + 1.0f)) ? kPadRedo : 0;
 		a.tout[t] = o;
 	}
 }

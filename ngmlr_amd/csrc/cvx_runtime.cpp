@@ -10,9 +10,10 @@
  *            piece by piece, each piece's DMA running under the packing of the next  (stream `io`)
  *   plan     plan_kernel, plan records back to pinned memory                          (stream `io`)
  *   compute  host: kernel class / arena offsets / LPT lists from the plan records;
- *            fill_ring_kernel per class (+ exact redo pass) on the aux streams,
+ *            fill_ring_kernel per class (+ exact redo pass)                   (streams `main` + `aux`)
  *            backtrack_kernel, finalize_kernel (device-side prefix sums and result records),
- *            compact_ops_kernel, result records back to pinned memory               (stream `main`)
+ *            compact_ops_kernel, result records back to pinned memory               (stream `post`:
+ *            these run beside the next batch's fills, which `main` starts without waiting for them)
  *   finish   dense ops back to pinned memory                                          (stream `io`)
  *
  * The streaming entry points (cvx_submit / cvx_wait / cvx_job_release) keep several batches in
@@ -129,11 +130,11 @@ struct PinBuf {
 
 }  // namespace
 
-/* Four streams per handle and not more: the ROCm runtime multiplexes the streams of a process onto
+/* Four streams per handle (io, main, post, one aux) and not more: the ROCm runtime multiplexes the streams of a process onto
  * (by default) four hardware queues, and two streams that land on the same queue serialise --
  * measured: with seven streams the 18-tile M = 4 launch ran alone for 11 ms in front of the
  * 24 558-tile M = 3 launch instead of beside it. */
-static const int kAuxStreams = 2;
+static const int kAuxStreams = 1;
 static const size_t kPoolBatches = 4;
 
 enum BatchState { kEmpty = 0, kUploaded = 1, kPlanned = 2, kComputed = 3, kFinished = 4 };
@@ -214,8 +215,9 @@ struct cvx_context {
 	int device = 0;
 	hipStream_t s_io = nullptr;      /* uploads, plan, downloads (high priority: its short kernels and copies
 	                                  * must not queue behind the fill's workgroups) */
-	hipStream_t s_main = nullptr;    /* compute */
-	hipStream_t aux[kAuxStreams] = {nullptr, nullptr};  /* concurrent fill classes */
+	hipStream_t s_main = nullptr;    /* forward fills (and the small input copies in front of them) */
+	hipStream_t s_post = nullptr;    /* backtrack, finalize, compaction, result download: runs beside the NEXT batch's fill */
+	hipStream_t aux[kAuxStreams] = {nullptr};  /* concurrent fill classes */
 	ScoreParams sp;
 	uint64_t max_matrix_mb = 10000;
 	int num_cus = 256;
@@ -376,9 +378,10 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	b->have_ops = false;
 	if (n == 0) {
 		HIP_TRY(hipEventRecord(b->ev[4], st));
-		HIP_TRY(hipEventRecord(b->ev[2], st));
-		HIP_TRY(hipEventRecord(b->ev[3], st));
-		HIP_TRY(hipEventRecord(b->ev_res, st));
+		HIP_TRY(hipStreamWaitEvent(h->s_post, b->ev[4], 0));
+		HIP_TRY(hipEventRecord(b->ev[2], h->s_post));
+		HIP_TRY(hipEventRecord(b->ev[3], h->s_post));
+		HIP_TRY(hipEventRecord(b->ev_res, h->s_post));
 		b->state = kComputed;
 		return CVX_OK;
 	}
@@ -556,6 +559,13 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
 		launches++;
 	}
+	/* Everything after the fills runs on its own stream: `main` goes straight on to the next batch's
+	 * fills, whose first wave of workgroups fills the hole this batch's fill tail, backtrack (one
+	 * latency-bound wave per tile) and small kernels would otherwise leave. */
+	hipStream_t fs = st;                           /* the fill stream (named for the error paths below) */
+	(void) fs;
+	st = h->s_post;
+	HIP_TRY(hipStreamWaitEvent(st, b->ev[4], 0));  /* also orders `post` behind the input copies when no fill was launched */
 	for (int i = 0; i < launches; ++i) HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) i * 3 + 2], 0));
 	HIP_TRY(hipEventRecord(b->ev[2], st));
 
@@ -615,8 +625,8 @@ int stage_ops(cvx_context *h, cvx_batch_s *b) {
 		const uint64_t cap = b->ops_total;
 		RC_TRY(b->d_dense.ensure((size_t) cap + 64));
 		b->dense_cap = b->d_dense.cap - 64;
-		HIP_TRY(launch_compact(b->d_regions.p, b->d_trun.p, b->d_tout.p, b->d_dstoff.p, b->d_dense.p, b->n, b->dense_cap, h->s_main));
-		HIP_TRY(hipStreamSynchronize(h->s_main));
+		HIP_TRY(launch_compact(b->d_regions.p, b->d_trun.p, b->d_tout.p, b->d_dstoff.p, b->d_dense.p, b->n, b->dense_cap, h->s_post));
+		HIP_TRY(hipStreamSynchronize(h->s_post));
 	}
 	if (b->ops_total) {
 		RC_TRY(b->h_ops.ensure((size_t) b->ops_total * sizeof(uint32_t)));
@@ -712,6 +722,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	int prio_lo = 0, prio_hi = 0;
 	(void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     /* numerically lower = higher priority */
 	hipError_t e = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_post, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->s_io, hipStreamNonBlocking, prio_hi);
 	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
 	if (e != hipSuccess) {
@@ -729,6 +740,7 @@ void cvx_destroy(cvx_handle h) {
 	(void) hipSetDevice(h->device);
 	(void) hipDeviceSynchronize();
 	if (h->s_main) (void) hipStreamDestroy(h->s_main);
+	if (h->s_post) (void) hipStreamDestroy(h->s_post);
 	if (h->s_io) (void) hipStreamDestroy(h->s_io);
 	for (auto &a : h->aux) if (a) (void) hipStreamDestroy(a);
 	for (cvx_batch_s *b : h->pool) { b->release(); delete b; }
@@ -766,6 +778,7 @@ int cvx_batch_run(cvx_handle h, cvx_batch b) {
 	RC_TRY(stage_compute(h, b));
 	RC_TRY(stage_results(h, b));
 	HIP_TRY(hipStreamSynchronize(h->s_main));
+	HIP_TRY(hipStreamSynchronize(h->s_post));
 	return CVX_OK;
 	ABI_GUARD_END
 }

@@ -187,6 +187,19 @@ def test_int16_run_kernels(built, port_oracle, monkeypatch):
     al.close()
 
 
+def test_genuine_int16_wrap(hip_aligner, port_oracle):
+    """A gap run that really passes SHRT_MAX inside the best alignment (tests/util.py wrap16_tile;
+    the CPU suite pins the port to the reference's own output on it): the int16-run kernels must
+    break the insertion exactly where the reference's `short indelRun` wraps."""
+    t = util.wrap16_tile()
+    got = _check(hip_aligner, port_oracle, [t])
+    assert "32767I1M" in got[0]["cigar"]
+    batch = hip_aligner.upload([t])
+    batch.run()
+    assert all(li["wrap16"] == 1 for li in batch.launches())
+    batch.free()
+
+
 def test_irregular_corridors_take_the_catch_all_kernel(hip_aligner, port_oracle):
     """CorridorLine[] shapes no reference caller builds (row starts that do not increase):
     computed on the device by the catch-all kernel, never on the CPU, still bit-exact."""

@@ -57,6 +57,23 @@ def golden_diff(exp, got):
     return None
 
 
+def wrap16_tile(seed=5, pre=40000, ins=33000, post=20000, w=400):
+    """A tile whose BEST alignment carries an insertion run past SHRT_MAX: 40 kb matched, 33 kb of
+    junk inserted in the read, 20 kb matched again (score 80 k - 33 k + 40 k: bridging the gap pays),
+    corridor = a 400-column band that follows that path (diagonal, vertical for the insertion,
+    diagonal).  indelRun is a `short` in the reference (src/AlignmentMatrixFast.h:43): at run 32768 it
+    wraps negative, the extension test `ins_run > 0` fails and the CIGAR breaks into
+    ...32767I1M233I...; an aligner that keeps the run in a wider type reports one 33000I instead."""
+    rng = np.random.default_rng(seed)
+    ref = synth.random_ref(rng, pre + post + 200)
+    junk = synth.random_ref(rng, ins)
+    qry = np.concatenate([ref[:pre], junk, ref[pre:pre + post]])
+    H = len(qry)
+    y = np.arange(H)
+    off = np.where(y < pre, y - w // 2, np.where(y < pre + ins, pre - w // 2, y - ins - w // 2)).astype(np.int32)
+    return synth.Tile(ref.tobytes(), qry.tobytes(), off, np.full(H, w, np.int32), tag="wrap16")
+
+
 def tile_zoo(seed=123, n=60, max_w=2500):
     """Seeded mix over every corridor constructor, error model and the odd symbols."""
     rng = np.random.default_rng(seed)
