@@ -271,6 +271,7 @@ struct PlanTuning {
 	int max_slots = 0;     /* largest M a whole tile may use (wider tiles are chained) */
 	int force_wrap = 0;    /* route every tile to the int16-run kernels */
 	int chain_m = 0;       /* 1, 2 or 4: force the row-block height class of chained tiles */
+	int force_generic = 0; /* every tile to the catch-all kernel (scoring that needs its SSE-variant instantiation) */
 };
 
 inline void host_plan(int n, const TilePlan *plan, const TileIn *tin, const RowDesc *rows, const PlanTuning &tune, HostPlan &hp) {
@@ -304,7 +305,7 @@ inline void host_plan(int n, const TilePlan *plan, const TileIn *tin, const RowD
 		const bool wrap = (p.flags & kPlanWrap16) || tune_force_wrap;
 		const bool regular = !(p.flags & kPlanIrregular);
 		int k = -1;
-		if (regular) {
+		if (regular && !tune.force_generic) {
 			for (int c = 0; c < kNumClasses; ++c)
 				if (kClasses[c].ring() >= p.need && kClasses[c].m >= tune_min_slots &&
 						(tune.max_slots <= 0 || kClasses[c].m <= tune.max_slots)) { k = c; break; }
@@ -317,7 +318,7 @@ inline void host_plan(int n, const TilePlan *plan, const TileIn *tin, const RowD
 		hp.ops_ints += (uint64_t) r.ops_cap;
 		hp.active += p.active;
 		const bool long_tile = small_batch && p.need >= 128 && (p.rend - p.r0) >= kLongTileSteps;
-		if ((k < 0 || long_tile) && regular && rows && tune_min_slots == 0) {
+		if ((k < 0 || long_tile) && regular && rows && tune_min_slots == 0 && !tune.force_generic) {
 			/* more live rows than any ring (or one very long tile in a batch too small to fill the
 			 * device with whole tiles): row blocks chained through boundary streams */
 			int cc = chain_class_for(p.need, small_batch);

@@ -24,7 +24,8 @@ hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scr
 
 /* catch-all kernel (cvx_generic.hip): any ring size, state in a global scratch */
 size_t generic_scratch_bytes(int ring);
-hipError_t launch_fill_generic(const FillArgs &a, uint8_t *scratch, const uint64_t *scratch_off, hipStream_t st);
+/* sse_variant: the reference's SSE-path semantics for scoring outside the scalar-equivalent regime */
+hipError_t launch_fill_generic(const FillArgs &a, bool sse_variant, uint8_t *scratch, const uint64_t *scratch_off, hipStream_t st);
 hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles,
 		unsigned long long max_matrix_mb, hipStream_t st);
 hipError_t launch_backtrack(const BacktrackArgs &a, hipStream_t st);

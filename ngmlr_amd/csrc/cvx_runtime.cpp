@@ -28,6 +28,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -227,6 +228,8 @@ struct cvx_context {
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
+	bool sse_variant = false; /* scoring outside the regime where the reference's SSE path equals the scalar recurrence:
+	                           * every tile goes to the catch-all kernel's SSE-variant instantiation */
 	/* freed batches keep their device arenas and pinned staging and wait here for the next upload
 	 * (at most kPoolBatches): hipMalloc / hipFree of multi-GB arenas per call are slow, and hipFree
 	 * synchronises the whole device, which would serialise handles that work side by side */
@@ -299,12 +302,12 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	RC_TRY(b->make_events());
 	const size_t n1 = (size_t) std::max(n, 1);
 	const size_t rows1 = (size_t) std::max<uint64_t>(L.n_rows, 1);
-	RC_TRY(b->h_seq.ensure((size_t) L.seq_total));
+	RC_TRY(b->h_seq.ensure((size_t) L.seq_total + 256));
 	RC_TRY(b->h_rows.ensure(rows1 * sizeof(RowDesc)));
 	RC_TRY(b->h_tin.ensure(n1 * sizeof(TileIn)));
 	RC_TRY(b->h_plan.ensure(n1 * sizeof(TilePlan)));
 	RC_TRY(b->h_res.ensure(n1 * sizeof(ResultRec) + sizeof(BatchSummary)));
-	RC_TRY(b->d_seq.ensure((size_t) L.seq_total));
+	RC_TRY(b->d_seq.ensure((size_t) L.seq_total + 256));
 	RC_TRY(b->d_rows.ensure(rows1));
 	RC_TRY(b->d_tin.ensure(n1));
 	RC_TRY(b->d_plan.ensure(n1));
@@ -339,10 +342,17 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 			const int base = t0;
 			parallel_ranges(t1 - t0, wp, threads, [&](int bg, int en) { upload_pack(base + bg, base + en, tiles, tin, hseq, hrows); });
 		}
-		const uint64_t seq_end = (t1 == n) ? L.seq_total : (uint64_t) tin[(size_t) t1].ref_off;
+		/* Copy boundaries are multiples of 256 bytes: a host-to-device copy whose address or size is
+		 * not dword-aligned is not handed to the SDMA engines but to a blit kernel
+		 * (__amd_rocclr_copyBuffer) that pulls the bytes over PCIe with compute units the fill needs --
+		 * measured: 0.5 GB of sequence pieces per step at odd offsets cost the pipelined step ~7 ms.
+		 * The bytes below the rounded-down end are all packed; the remainder travels with the next
+		 * piece, and the last piece runs to the (256-aligned) end of the arena. */
+		uint64_t seq_end = (t1 == n) ? L.seq_total : (uint64_t) tin[(size_t) t1].ref_off;
+		seq_end = (t1 == n) ? (seq_end + 255) / 256 * 256 : seq_end / 256 * 256;
 		if (seq_end > seq_done)
 			HIP_TRY(hipMemcpyAsync(b->d_seq.p + seq_done, hseq + seq_done, (size_t) (seq_end - seq_done), hipMemcpyHostToDevice, st));
-		seq_done = seq_end;
+		seq_done = std::max(seq_done, seq_end);
 		const uint64_t r0 = (t0 < n) ? tin[(size_t) t0].row_off : L.n_rows;
 		const uint64_t r1 = (t1 < n) ? tin[(size_t) t1].row_off : L.n_rows;
 		if (r1 > r0)
@@ -390,6 +400,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	HostPlan hp;
 	PlanTuning tune;
 	tune.min_slots = h->tune_min_slots; tune.max_slots = h->tune_max_slots; tune.force_wrap = h->tune_force_wrap; tune.chain_m = h->tune_chain_m;
+	tune.force_generic = h->sse_variant ? 1 : 0;
 	host_plan(n, b->plan(), b->tin(), b->h_rows.as<RowDesc>(), tune, hp);
 	std::vector<std::vector<int32_t>> &cls = hp.cls;
 	std::vector<int32_t> &generic = hp.generic;
@@ -554,7 +565,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		hipStream_t ls = fill_streams[launches % (kAuxStreams + 1)];
 		RC_TRY(begin_launch(ls));
 		const FillArgs a = fill_args(b->d_lists.p + generic_begin, (int) generic.size());
-		HIP_TRY(launch_fill_generic(a, b->d_gscratch.p, b->d_gscratch_off.p, ls));
+		HIP_TRY(launch_fill_generic(a, h->sse_variant, b->d_gscratch.p, b->d_gscratch_off.p, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
 		launches++;
@@ -672,22 +683,25 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	ABI_GUARD_BEGIN
 	if (!p || !out) { set_err("cvx_create: NULL argument"); return CVX_ERR_ARG; }
 	*out = nullptr;
-	/* The device kernels implement the scalar recurrence (reference
-	 * src/ConvexAlignFast.cpp:606-774).  The SSE path the reference actually runs is
-	 * identical to it only while opening a gap directly off the other gap type can
-	 * never win: gap_open + gap_ext_min < mismatch.  Outside
-	 * that regime we refuse rather than compute something the reference would not. */
-	const bool sane = p->match > 0.0f && p->mismatch < 0.0f && p->gap_open < 0.0f &&
-			p->gap_extend < 0.0f && p->gap_extend_min < 0.0f && p->gap_decay >= 0.0f &&
-			p->gap_extend <= p->gap_extend_min &&
-			(p->gap_open + p->gap_extend_min) < p->mismatch - 0.25f;
-	if (!sane) {
-		set_err("cvx_create: scoring (%g,%g,%g,%g,%g,%g) outside the supported regime "
-				"(need match>0, penalties<0, gap_extend<=gap_extend_min, "
-				"gap_open+gap_extend_min < mismatch-0.25)",
+	/* The ring kernels implement the scalar recurrence (reference src/ConvexAlignFast.cpp:606-774)
+	 * and use its sign structure (match > 0 > every penalty, extension never dearer than its floor).
+	 * The SSE path the reference actually runs is identical to that recurrence only while opening a
+	 * gap directly off the other gap type can never win: gap_open + gap_ext_min < mismatch (SURVEY.md
+	 * Appendix A; the 0.25 keeps float rounding out of the argument).  Any other scoring -- the
+	 * reference accepts whatever --match/--mismatch/--gap-* the user passes -- is served by the
+	 * catch-all kernel's SSE-variant instantiation, which restates fwdFillMatrixSSESimple cell by cell
+	 * (cvx_generic.hip): slower per cell, same results as the reference. */
+	const bool finite = std::isfinite(p->match) && std::isfinite(p->mismatch) && std::isfinite(p->gap_open) &&
+			std::isfinite(p->gap_extend) && std::isfinite(p->gap_extend_min) && std::isfinite(p->gap_decay);
+	if (!finite) {
+		set_err("cvx_create: scoring (%g,%g,%g,%g,%g,%g) is not finite",
 				p->match, p->mismatch, p->gap_open, p->gap_extend, p->gap_extend_min, p->gap_decay);
 		return CVX_ERR_PARAMS;
 	}
+	const bool fast_regime = p->match > 0.0f && p->mismatch < 0.0f && p->gap_open < 0.0f &&
+			p->gap_extend < 0.0f && p->gap_extend_min < 0.0f && p->gap_decay >= 0.0f &&
+			p->gap_extend <= p->gap_extend_min &&
+			(p->gap_open + p->gap_extend_min) < p->mismatch - 0.25f;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
 		set_err("cvx_create: no HIP device available (the HIP path has no CPU fallback)");
@@ -711,6 +725,8 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	c->sp.mat = p->match; c->sp.mis = p->mismatch; c->sp.go = p->gap_open;
 	c->sp.ge = p->gap_extend; c->sp.gem = p->gap_extend_min; c->sp.decay = p->gap_decay;
 	c->max_matrix_mb = max_matrix_mb ? max_matrix_mb : 10000;
+	c->sse_variant = !fast_regime;
+	if (const char *e = getenv("CVX_TUNE_SSE_VARIANT")) c->sse_variant = c->sse_variant || atoi(e) != 0;   /* test knob */
 	const int hw = (int) std::thread::hardware_concurrency();
 	c->pack_threads = std::max(1, std::min(hw > 0 ? hw : 1, 24));
 	if (const char *e = getenv("CVX_PACK_THREADS")) c->pack_threads = std::max(1, atoi(e));
@@ -931,18 +947,18 @@ int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char
 		p.scratch_off = rows;
 		if (rl < 100000 && ql < 100000) rows += 2 * (uint64_t) rl;
 	}
-	RC_TRY(h->sc_hseq.ensure((size_t) bytes + 16));
+	RC_TRY(h->sc_hseq.ensure((size_t) bytes + 256));
 	uint8_t *hseq = h->sc_hseq.as<uint8_t>();
 	for (int i = 0; i < n; ++i) {
 		memcpy(hseq + pairs[i].ref_off, refs[i], (size_t) pairs[i].ref_len);
 		memcpy(hseq + pairs[i].qry_off, qrys[i], (size_t) pairs[i].qry_len);
 	}
-	RC_TRY(h->sc_seq.ensure((size_t) bytes + 16));
+	RC_TRY(h->sc_seq.ensure((size_t) bytes + 256));
 	RC_TRY(h->sc_pairs.ensure((size_t) n));
 	RC_TRY(h->sc_rows.ensure((size_t) rows + 64));
 	RC_TRY(h->sc_out.ensure((size_t) n));
 	hipStream_t st = h->s_main;
-	HIP_TRY(hipMemcpyAsync(h->sc_seq.p, hseq, (size_t) bytes, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(h->sc_seq.p, hseq, (size_t) ((bytes + 255) / 256 * 256), hipMemcpyHostToDevice, st));   /* dword-aligned size: SDMA, not a blit kernel */
 	HIP_TRY(hipMemcpyAsync(h->sc_pairs.p, pairs, (size_t) n * sizeof(ScorePair), hipMemcpyHostToDevice, st));
 	HIP_TRY(launch_score(h->sc_seq.p, h->sc_pairs.p, h->sc_rows.p, h->sc_out.p, n, st));
 	HIP_TRY(hipMemcpyAsync(h->sc_hout.p, h->sc_out.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, st));

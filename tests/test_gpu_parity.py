@@ -200,6 +200,49 @@ def test_genuine_int16_wrap(hip_aligner, port_oracle):
     batch.free()
 
 
+EXOTIC_SCORING = [
+    dict(match=2.0, mismatch=-10.0, gap_open=-5.0, gap_extend=-5.0, gap_extend_min=-1.0, gap_decay=0.15),   # 200/200 tiles differ
+    dict(match=2.0, mismatch=-6.0, gap_open=-5.0, gap_extend=-5.0, gap_extend_min=-1.0, gap_decay=0.15),    # equality: open + floor == mismatch
+    dict(match=2.0, mismatch=-7.0, gap_open=-4.0, gap_extend=-3.0, gap_extend_min=-2.0, gap_decay=0.5),
+    dict(match=1.0, mismatch=-4.0, gap_open=-1.0, gap_extend=-1.0, gap_extend_min=-0.5, gap_decay=0.05),
+    dict(match=3.0, mismatch=-20.0, gap_open=-2.0, gap_extend=-6.0, gap_extend_min=-1.0, gap_decay=0.3),
+]
+
+
+@pytest.mark.parametrize("k", range(len(EXOTIC_SCORING)))
+def test_sse_variant_scoring(built, k):
+    """Scoring for which the reference's SSE path and the scalar recurrence disagree
+    (gap_open + gap_ext_min >= mismatch): the product must reproduce the SSE path -- relaxed
+    extension tests, scalar recomputation of each row's last 12 cells, both feeding the running
+    maximum -- on every corridor kind, against the reference itself when oracle/_ref is there
+    (the port is pinned to it for this regime by tests/test_oracle_cpu.py)."""
+    from ngmlr_amd.aligner import ConvexAlignHip
+    from oracle.pyoracle import Oracle, have_ref
+    sc = EXOTIC_SCORING[k]
+    params = (sc["match"], sc["mismatch"], sc["gap_open"], sc["gap_extend"], sc["gap_extend_min"], sc["gap_decay"])
+    orc = Oracle("reference" if have_ref() else "port", params)
+    al = ConvexAlignHip(device=0, **sc)
+    tiles = util.tile_zoo(seed=50 + k, n=60, max_w=1800) + util.edge_tiles()
+    _check(al, orc, tiles)
+    if k == 0:
+        # and the regime really is different: the scalar recurrence gives other answers here
+        spec = Oracle("port", params)
+        spec.set_spec_fill(True)
+        got = al.batch_align(tiles[:40])
+        assert sum(same_alignment(spec.align(t), g) is not None for t, g in zip(tiles[:40], got)) > 0
+    al.close()
+
+
+def test_sse_variant_kernel_equals_ring_kernels_under_default_scoring(built, port_oracle, monkeypatch):
+    """Inside the default regime the SSE path IS the scalar recurrence: forcing the SSE-variant
+    kernel must change nothing."""
+    from ngmlr_amd.aligner import ConvexAlignHip
+    monkeypatch.setenv("CVX_TUNE_SSE_VARIANT", "1")
+    al = ConvexAlignHip(device=0)
+    _check(al, port_oracle, util.tile_zoo(seed=77, n=60, max_w=1500) + util.edge_tiles())
+    al.close()
+
+
 def test_irregular_corridors_take_the_catch_all_kernel(hip_aligner, port_oracle):
     """CorridorLine[] shapes no reference caller builds (row starts that do not increase):
     computed on the device by the catch-all kernel, never on the CPU, still bit-exact."""
