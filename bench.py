@@ -214,12 +214,17 @@ def main() -> int:
                     for d in range(n_local)]
     t_gen = time.perf_counter() - t_gen
 
-    import torch
     from ngmlr_amd import capi
-    dist = None
+    dist = torch = None
     if under_launcher:
+        import torch as _torch_first   # noqa: F401  (under the launcher torch and its RCCL come first, with the runtime they were built for)
+    lib = capi.load()             # launched directly: the HIP runtime this library links (/opt/rocm) is the process's runtime
+    if under_launcher:
+        # one rank per device: torch.distributed (RCCL) carries the barrier and the max-over-ranks
+        # reduction of the timing -- plumbing only, there is no collective on the data path
+        import torch as torch_mod
         import torch.distributed as dist_mod
-        dist = dist_mod
+        torch, dist = torch_mod, dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -227,11 +232,16 @@ def main() -> int:
     workers = [Worker(d, ts, args.depth) for d, ts in zip(devs, tilesets)]
 
     def sync_all():
+        # every device this process drives is idle: hipDeviceSynchronize behind the C ABI (what
+        # torch.cuda.synchronize() is; launched directly the bench does not load torch at all, whose
+        # wheel carries an older HIP runtime of its own that would replace the one the library links)
         for d in devs:
-            torch.cuda.synchronize(d)
+            capi.check(lib.cvx_device_synchronize(d))
         if dist is not None:
+            torch.cuda.synchronize(local_rank)
             dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(local_rank)
+            capi.check(lib.cvx_device_synchronize(local_rank))
 
     def run_on_all(fn):
         errs = []
@@ -250,6 +260,10 @@ def main() -> int:
         if errs:
             raise errs[0]
 
+    # one-time setup, untimed: every batch slot of the pipeline allocates its device arenas (~25 GB) and
+    # pinned staging (~3 GB) the first time it is used -- hundreds of ms per slot -- so cycle through
+    # all of them once before the W warm-up steps
+    run_on_all(lambda w: w.steps(args.depth + 2, record=False))
     run_on_all(lambda w: w.steps(args.warmup, record=False))
     sync_all()
     t0 = time.perf_counter()
@@ -299,10 +313,10 @@ def main() -> int:
                 capi.check(w0.al.lib.cvx_batch_upload(w0.al.h, len(tab), tab.ctypes.data_as(C.POINTER(capi.CvxTile)), C.byref(b)))
                 batch = DeviceBatch(w0.al, b, ts)
                 batch.run()
-                torch.cuda.synchronize(devs[0])
+                capi.check(lib.cvx_device_synchronize(devs[0]))
                 c0 = time.perf_counter()
                 tms = [batch.run() for _ in range(args.resident_steps)]
-                torch.cuda.synchronize(devs[0])
+                capi.check(lib.cvx_device_synchronize(devs[0]))
                 dres = (time.perf_counter() - c0) / args.resident_steps
                 resident = {"Gbp_per_h": ts.read_bases / dres * 3600.0 / 1e9, "ms_per_step": dres * 1e3,
                             "fill_ms": float(np.mean([t.fill_ms for t in tms])), "backtrack_ms": float(np.mean([t.backtrack_ms for t in tms])),

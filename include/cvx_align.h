@@ -152,6 +152,9 @@ typedef struct {
 const char *cvx_last_error(void);
 int cvx_abi_version(void);
 int cvx_device_count(void);
+/* Blocks until everything queued on `device_id` (by any handle of this process) has finished:
+ * hipDeviceSynchronize behind the C ABI, for callers that bracket a timed region. */
+int cvx_device_synchronize(int device_id);
 
 /* max_matrix_mb: IConfig::maxMatrixSizeMB (src/IConfig.h:47), 0 -> 10000. */
 int cvx_create(int device_id, const cvx_params *params, uint64_t max_matrix_mb, cvx_handle *out);

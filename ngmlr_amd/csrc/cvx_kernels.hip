@@ -944,13 +944,16 @@ backtrack_kernel(const BacktrackArgs a) {
  * arena), the caller-facing result records (cvx_result layout) and the batch summary.  One
  * workgroup; a thread takes a contiguous chunk of tiles.
  */
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 finalize_kernel(const TileOut *tout, const TilePlan *plan, uint64_t *dst_off, ResultRec *res,
-		BatchSummary *sum, const int32_t *redo_count, int n_tiles, unsigned long long dense_cap) {
-	__shared__ unsigned long long s_part[1024];
+		BatchSummary *sum, int32_t *counters, int n_tiles, unsigned long long dense_cap) {
+	/* 256 threads = one wave per SIMD: a workgroup that finds room on a CU the next batch's fill
+	 * already occupies (a 1024-thread group waited ~50 ms for sixteen free wave slots on one CU) */
+	constexpr int T = 256;
+	__shared__ unsigned long long s_part[T];
 	const int tid = threadIdx.x;
-	const int per = (n_tiles + 1023) / 1024;
-	const int t0 = tid * per, t1 = min(n_tiles, t0 + per);
+	const int per = (n_tiles + T - 1) / T;
+	const int t0 = min(n_tiles, tid * per), t1 = min(n_tiles, t0 + per);
 	unsigned long long mine = 0;
 	for (int t = t0; t < t1; ++t) {
 		const TileOut o = tout[t];
@@ -958,8 +961,8 @@ finalize_kernel(const TileOut *tout, const TilePlan *plan, uint64_t *dst_off, Re
 	}
 	s_part[tid] = mine;
 	__syncthreads();
-	/* Hillis-Steele inclusive scan over the 1024 partial sums */
-	for (int d = 1; d < 1024; d <<= 1) {
+	/* Hillis-Steele inclusive scan over the partial sums */
+	for (int d = 1; d < T; d <<= 1) {
 		const unsigned long long v = (tid >= d) ? s_part[tid - d] : 0ull;
 		__syncthreads();
 		s_part[tid] += v;
@@ -986,14 +989,18 @@ finalize_kernel(const TileOut *tout, const TilePlan *plan, uint64_t *dst_off, Re
 	__syncthreads();
 	if (n_valid) atomicAdd(&s_valid, n_valid);
 	__syncthreads();
-	if (tid == 1023) {
+	if (tid == T - 1) {
 		BatchSummary b;
-		b.ops_total = s_part[1023];
+		b.ops_total = s_part[T - 1];
 		b.dense_cap = dense_cap;
 		b.n_valid = s_valid;
-		b.n_redone = redo_count ? *redo_count : 0;
+		b.n_redone = counters ? counters[0] : 0;
 		*sum = b;
 	}
+	/* last reader of the batch's counters (redo statistics, chain tickets): leave them zeroed for the
+	 * batch's next run (after the summary above has read the redo count) */
+	__syncthreads();
+	if (counters && tid < 64) counters[tid] = 0;
 }
 
 /* dense[dst_off[t] .. +n_ops) = region of tile t (tiles that do not fit the arena are skipped:
@@ -1099,8 +1106,8 @@ hipError_t launch_backtrack(const BacktrackArgs &a, hipStream_t st) {
 }
 
 hipError_t launch_finalize(const TileOut *tout, const TilePlan *plan, uint64_t *dst_off, ResultRec *res,
-		BatchSummary *sum, const int32_t *redo_count, int n_tiles, uint64_t dense_cap, hipStream_t st) {
-	hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, tout, plan, dst_off, res, sum, redo_count,
+		BatchSummary *sum, int32_t *counters, int n_tiles, uint64_t dense_cap, hipStream_t st) {
+	hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, tout, plan, dst_off, res, sum, counters,
 			n_tiles, (unsigned long long) dense_cap);
 	return hipGetLastError();
 }

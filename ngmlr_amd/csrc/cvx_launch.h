@@ -30,7 +30,7 @@ hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, i
 		unsigned long long max_matrix_mb, hipStream_t st);
 hipError_t launch_backtrack(const BacktrackArgs &a, hipStream_t st);
 hipError_t launch_finalize(const TileOut *tout, const TilePlan *plan, uint64_t *dst_off, ResultRec *res,
-		BatchSummary *sum, const int32_t *redo_count, int n_tiles, uint64_t dense_cap, hipStream_t st);
+		BatchSummary *sum, int32_t *counters, int n_tiles, uint64_t dense_cap, hipStream_t st);
 hipError_t launch_compact(const int32_t *regions, const TileRun *trun, const TileOut *tout,
 		const uint64_t *dst_off, uint32_t *dense, int n_tiles, uint64_t dense_cap, hipStream_t st);
 

@@ -12,8 +12,8 @@
  *   compute  host: kernel class / arena offsets / LPT lists from the plan records;
  *            fill_ring_kernel per class (+ exact redo pass)                   (streams `main` + `aux`)
  *            backtrack_kernel, finalize_kernel (device-side prefix sums and result records),
- *            compact_ops_kernel, result records back to pinned memory               (stream `post`:
- *            these run beside the next batch's fills, which `main` starts without waiting for them)
+ *            compact_ops_kernel, result records back to pinned memory               (stream `main`;
+ *            optionally `post`, beside the next batch's fills: measured to gain nothing, see stage_compute)
  *   finish   dense ops back to pinned memory                                          (stream `io`)
  *
  * The streaming entry points (cvx_submit / cvx_wait / cvx_job_release) keep several batches in
@@ -228,6 +228,7 @@ struct cvx_context {
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
+	bool overlap_post = false; /* tuning knob (env CVX_TUNE_OVERLAP_POST): backtrack/finalize/compaction of batch k on their own stream, beside the fills of batch k+1 */
 	bool sse_variant = false; /* scoring outside the regime where the reference's SSE path equals the scalar recurrence:
 	                           * every tile goes to the catch-all kernel's SSE-variant instantiation */
 	/* freed batches keep their device arenas and pinned staging and wait here for the next upload
@@ -315,7 +316,10 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	RC_TRY(b->d_tout.ensure(n1));
 	RC_TRY(b->d_dstoff.ensure(n1));
 	RC_TRY(b->d_lists.ensure(n1));
-	RC_TRY(b->d_counters.ensure(64));
+	if (b->d_counters.cap < 64) {
+		RC_TRY(b->d_counters.ensure(64));
+		HIP_TRY(hipMemset(b->d_counters.p, 0, b->d_counters.cap * sizeof(int32_t)));
+	}
 	RC_TRY(b->d_res.ensure(n1 * sizeof(ResultRec) + sizeof(BatchSummary)));
 	if (n) memcpy(b->h_tin.p, tin.data(), (size_t) n * sizeof(TileIn));
 
@@ -388,10 +392,11 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	b->have_ops = false;
 	if (n == 0) {
 		HIP_TRY(hipEventRecord(b->ev[4], st));
-		HIP_TRY(hipStreamWaitEvent(h->s_post, b->ev[4], 0));
-		HIP_TRY(hipEventRecord(b->ev[2], h->s_post));
-		HIP_TRY(hipEventRecord(b->ev[3], h->s_post));
-		HIP_TRY(hipEventRecord(b->ev_res, h->s_post));
+		hipStream_t ps = h->overlap_post ? h->s_post : h->s_main;
+		HIP_TRY(hipStreamWaitEvent(ps, b->ev[4], 0));
+		HIP_TRY(hipEventRecord(b->ev[2], ps));
+		HIP_TRY(hipEventRecord(b->ev[3], ps));
+		HIP_TRY(hipEventRecord(b->ev_res, ps));
 		b->state = kComputed;
 		return CVX_OK;
 	}
@@ -463,7 +468,9 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	HIP_TRY(hipMemcpyAsync(b->d_trun.p, b->h_trun.p, (size_t) n * sizeof(TileRun), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(b->d_tout.p, b->h_tout.p, (size_t) n * sizeof(TileOut), hipMemcpyHostToDevice, st));
 	if (n_listed) HIP_TRY(hipMemcpyAsync(b->d_lists.p, lists, n_listed * sizeof(int32_t), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemsetAsync(b->d_counters.p, 0, 64 * sizeof(int32_t), st));
+	/* (the batch's counters are zero: cleared when the arena was allocated and again by finalize_kernel,
+	 * their last reader -- a memset here would be a tiny kernel that has to find a free wave slot among
+	 * the previous batch's 24 576 backtrack waves before this batch's fills may start: measured 7 ms) */
 	HIP_TRY(hipEventRecord(b->ev[4], st));        /* inputs of the fills are in place */
 
 	/* forward fill: one launch per populated kernel class (+ its exact redo pass), classes run
@@ -570,12 +577,14 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
 		launches++;
 	}
-	/* Everything after the fills runs on its own stream: `main` goes straight on to the next batch's
-	 * fills, whose first wave of workgroups fills the hole this batch's fill tail, backtrack (one
-	 * latency-bound wave per tile) and small kernels would otherwise leave. */
-	hipStream_t fs = st;                           /* the fill stream (named for the error paths below) */
-	(void) fs;
-	st = h->s_post;
+	/* Everything after the fills CAN run on its own stream, so that `main` goes straight on to the next
+	 * batch's fills while this batch's backtrack (one wave per tile) and small kernels run beside them. */
+	/* Measured (profiles/r02_timeline.txt): the overlap only moves time around -- fill and backtrack
+	 * are bound by the same issue slots, the step takes fill + backtrack either way (76 ms for 24 576
+	 * PacBio tiles), and the fill's own launch stretches from 66 to 76 ms.  It therefore stays OFF by
+	 * default (post == main, stages back to back, clean per-kernel timings); CVX_TUNE_OVERLAP_POST=1
+	 * turns it on. */
+	st = h->overlap_post ? h->s_post : h->s_main;
 	HIP_TRY(hipStreamWaitEvent(st, b->ev[4], 0));  /* also orders `post` behind the input copies when no fill was launched */
 	for (int i = 0; i < launches; ++i) HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) i * 3 + 2], 0));
 	HIP_TRY(hipEventRecord(b->ev[2], st));
@@ -636,8 +645,9 @@ int stage_ops(cvx_context *h, cvx_batch_s *b) {
 		const uint64_t cap = b->ops_total;
 		RC_TRY(b->d_dense.ensure((size_t) cap + 64));
 		b->dense_cap = b->d_dense.cap - 64;
-		HIP_TRY(launch_compact(b->d_regions.p, b->d_trun.p, b->d_tout.p, b->d_dstoff.p, b->d_dense.p, b->n, b->dense_cap, h->s_post));
-		HIP_TRY(hipStreamSynchronize(h->s_post));
+		hipStream_t ps = h->overlap_post ? h->s_post : h->s_main;
+		HIP_TRY(launch_compact(b->d_regions.p, b->d_trun.p, b->d_tout.p, b->d_dstoff.p, b->d_dense.p, b->n, b->dense_cap, ps));
+		HIP_TRY(hipStreamSynchronize(ps));
 	}
 	if (b->ops_total) {
 		RC_TRY(b->h_ops.ensure((size_t) b->ops_total * sizeof(uint32_t)));
@@ -677,6 +687,12 @@ int cvx_device_count(void) {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
+}
+
+int cvx_device_synchronize(int device_id) {
+	HIP_TRY(hipSetDevice(device_id));
+	HIP_TRY(hipDeviceSynchronize());
+	return CVX_OK;
 }
 
 int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_handle *out) {
@@ -726,6 +742,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	c->sp.ge = p->gap_extend; c->sp.gem = p->gap_extend_min; c->sp.decay = p->gap_decay;
 	c->max_matrix_mb = max_matrix_mb ? max_matrix_mb : 10000;
 	c->sse_variant = !fast_regime;
+	if (const char *e = getenv("CVX_TUNE_OVERLAP_POST")) c->overlap_post = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_SSE_VARIANT")) c->sse_variant = c->sse_variant || atoi(e) != 0;   /* test knob */
 	const int hw = (int) std::thread::hardware_concurrency();
 	c->pack_threads = std::max(1, std::min(hw > 0 ? hw : 1, 24));

@@ -40,5 +40,24 @@ int main() {
 				printf("%s %4zu MB %s: %.3f ms  %.1f GB/s\n", busy ? "busy" : "idle", sz / MB, dir ? "D2H" : "H2D", dt * 1e3, sz / dt / 1e9);
 				CK(hipDeviceSynchronize());
 			}
+	// does a kernel on the SAME stream change the engine?  (look for __amd_rocclr_copyBuffer in a kernel trace)
+	for (int mixed = 0; mixed < 2; ++mixed) {
+		CK(hipDeviceSynchronize());
+		double t0 = now();
+		for (int r = 0; r < 4; ++r) {
+			if (mixed) hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, s_io, dk, 10);
+			CK(hipMemcpyAsync(d, h, 64 * MB, hipMemcpyHostToDevice, s_io));
+			CK(hipMemcpyAsync((char *) d + 64 * MB, (char *) h + 64 * MB, 256 * MB, hipMemcpyHostToDevice, s_io));
+		}
+		CK(hipStreamSynchronize(s_io));
+		printf("%s stream, 4 x (64 + 256 MB) H2D: %.3f ms\n", mixed ? "kernel+copy" : "copy-only", (now() - t0) * 1e3);
+	}
+	// after a device-wide synchronize that followed kernels on another stream
+	for (int k = 0; k < 2; ++k) hipLaunchKernelGGL(spin, dim3(4096), dim3(256), 0, s_k, dk, 20000);
+	CK(hipDeviceSynchronize());
+	double t1 = now();
+	CK(hipMemcpyAsync(d, h, 256 * MB, hipMemcpyHostToDevice, s_io));
+	CK(hipStreamSynchronize(s_io));
+	printf("after device sync, 256 MB H2D: %.3f ms\n", (now() - t1) * 1e3);
 	return 0;
 }
