@@ -927,6 +927,285 @@ CVX_DEV void walk_tile(const BacktrackArgs &a, const int t, const int lane) {
 	if (lane == 0) a.tout[t] = o;
 }
 
+/* ------------------------------------------------------------------ backtrack, G lanes per tile */
+
+/*
+ * The same walk as backtrack_walk with G (= 16) lanes per tile and four tiles per wave.  The
+ * one-wave-per-tile walk keeps its state wave-uniform and therefore lives on the scalar unit: ~140
+ * SALU instructions per probe, and one scalar issue slot per SIMD every ~4.3 cycles makes that the
+ * bound (SQ counters: the scalar unit 78 % busy, VALU 30 %).  Diagonal runs between two gaps are
+ * ~7 cells long at 15 % error, so 64 probing lanes are mostly idle anyway.  Here the walk state is
+ * group-uniform in VGPRs, predicates replace the scalar branches, four tiles share every
+ * instruction, and the EQ / X sub-runs of a diagonal run are written by their own lanes instead of a
+ * scalar loop.  Probe geometry, run skipping, validPath and the op encoding are those of
+ * backtrack_walk (reference src/ConvexAlignFast.cpp:335-432, src/AlignmentMatrixFast.cpp:213-220).
+ */
+template <int G>
+struct Group {
+	int gl;        /* lane inside the group */
+	int base;      /* first lane of the group */
+	CVX_DEV unsigned ballot(bool p) const {
+		const u64 b = __builtin_amdgcn_ballot_w64(p);
+		return (unsigned) (b >> base) & ((1u << G) - 1u);
+	}
+	CVX_DEV int bcast(int v, int l) const { return __shfl(v, base + l, 64); }
+};
+
+template <bool CHAINED, int G>
+CVX_DEV void backtrack_walk_grp(const Group<G> g, const bool has_tile, const int H, const int N, const int r0, const int ops_cap,
+		const int2 *rows, const uint2 *dirs, const ChainBlk *blk, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
+	const int gl = g.gl;
+	const int best_x = o.best_x, best_y = o.best_y;
+	bool act = has_tile;
+	if (has_tile && best_y <= 0) { o.status = 1; act = false; }      /* src/ConvexAlignFast.cpp:338 */
+	const bool walked = act;
+
+	const int qend = (H - best_y) - 1;
+	int idx = ops_cap - 1;
+	int elem = 4;          /* CIGAR_S: the trailing clip is tracked but not stored */
+	int elem_len = qend;
+	int consumed = qend;
+	int x = best_x, y = best_y;
+	int s = act ? y % N : 0;
+	int status = 0;
+	unsigned want = 3u;
+	int budget = 2 * (best_x + best_y) + 8;
+
+	auto emit = [&](int cur, int n) {      /* revBacktrack's run-length bookkeeping (:395-403) */
+		if (n <= 0) return;
+		if (cur == elem) {
+			elem_len += n;
+		} else {
+			if (elem != 4) { if (gl == 0) ops[idx] = (elem_len << 4) | elem; idx -= 1; }
+			elem = cur;
+			elem_len = n;
+		}
+	};
+
+	while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+		if (act) {
+			bool go_on = true;
+			if (--budget < 0) { status = 3; go_on = false; }
+			else {
+				const int dx = (want != 1u) ? 1 : 0, dy = (want != 2u) ? 1 : 0;
+				const int cx = x - gl * dx, cy = y - gl * dy;
+				const bool inside = (cx >= 0 && cy >= 0);
+				const int lx = cx > 0 ? cx : 0, ly = cy > 0 ? cy : 0;
+				int sl = s - gl * dy;
+				if (sl < 0) sl += N;
+				const int tt = cx + cy - r0;
+				const int ttc = tt > 0 ? tt : 0;
+				const int2 ol = rows[ly];
+				uint2 w;
+				if (CHAINED) {
+					const int gb = ly / N;
+					const ChainBlk cb = blk[gb];
+					int wr = (ttc >> 5) - cb.tblk0;
+					wr = wr < 0 ? 0 : (wr >= cb.nblk32 ? cb.nblk32 - 1 : wr);
+					w = dirs[cb.dir_off + (size_t) wr * N + (size_t) (ly - gb * N)];
+				} else {
+					w = dirs[(size_t) (ttc >> 5) * N + sl];
+				}
+				const int rc = ref[lx], qc = qry[ly];
+				const unsigned eqm = g.ballot(rc == qc);
+				const bool in_row = inside && tt >= 0 && cx >= ol.x && cx < ol.x + ol.y;    /* getDirection: outside -> STOP */
+				unsigned code = plane_code(w.x, w.y, 31 - (ttc & 31));
+				if (!in_row) code = 0u;
+				int minC, maxC;
+				valid_bounds(ol.x, ol.y, minC, maxC);
+
+				const unsigned full = (1u << G) - 1u;
+				const unsigned run = g.ballot(code == want);
+				const int L = (run == full) ? G : __builtin_ctz(~run);
+				const unsigned low = (L == G) ? full : ((1u << L) - 1u);
+				const unsigned vp = g.ballot(cx > minC && cx < maxC);      /* validPath before every move (:368-373) */
+				if ((~vp & low) != 0u) { status = 2; go_on = false; }
+				else {
+					if (want == 3u) {
+						if (L > 0) {
+							/* EQ / X sub-runs of the diagonal run, lane-parallel: sub-run j (cells from the
+							 * current one backwards) goes to ops[idx - w0 - j]; the last one stays pending */
+							const unsigned e = eqm & low;
+							const unsigned starts = (((e ^ (e << 1)) & low) & ~1u) | 1u;
+							const int k = __builtin_popcount(starts);
+							const int op0 = (e & 1u) ? 7 : 8;
+							if (k == 1) {
+								emit(op0, L);
+							} else {
+								const unsigned after0 = starts & ~1u;
+								int len0 = __builtin_ctz(after0);
+								int w0 = 0;
+								if (op0 == elem) len0 += elem_len;
+								else if (elem != 4) { if (gl == 0) ops[idx] = (elem_len << 4) | elem; w0 = 1; }
+								const bool is_start = gl < L && ((starts >> gl) & 1u) != 0u;
+								const int j = __builtin_popcount(starts & ((1u << gl) - 1u));
+								const unsigned rest = (starts >> gl) >> 1;
+								int mylen = rest ? __builtin_ctz(rest) + 1 : L - gl;
+								if (gl == 0) mylen = len0;
+								const int myop = ((e >> gl) & 1u) ? 7 : 8;
+								if (is_start && j < k - 1) ops[idx - w0 - j] = (mylen << 4) | myop;
+								idx -= w0 + (k - 1);
+								const int lastpos = 31 - __builtin_clz(starts);
+								elem = ((e >> lastpos) & 1u) ? 7 : 8;
+								elem_len = L - lastpos;
+							}
+						}
+						x -= L; y -= L; consumed += L;
+					} else if (want == 1u) {
+						emit(1, L);
+						y -= L; consumed += L;
+					} else {
+						emit(2, L);
+						x -= L;
+					}
+					if (want != 2u) { s -= L; if (s < 0) s += N; }
+					if (L < G) {
+						const unsigned nxt = (unsigned) g.bcast((int) code, L);
+						if (nxt == 0u) go_on = false;                       /* CIGAR_STOP (or outside the matrix) */
+						else if (want != 3u) want = nxt;
+						else {
+							/* a diagonal run ended in a gap at (x, y) = lane L's cell: follow the gap run inside
+							 * the words this probe already holds */
+							const int tp = x + y - r0;
+							if (nxt == 2u) {
+								const unsigned wx = (unsigned) g.bcast((int) w.x, L);
+								const unsigned wy = (unsigned) g.bcast((int) w.y, L);
+								const int row_lo = max(g.bcast(ol.x, L), 0);
+								const int b0 = 31 - (tp & 31);
+								const unsigned dm = (wx & ~wy) >> b0;
+								int Ld = (~dm == 0u) ? 32 : __builtin_ctz(~dm);
+								const int in_word = 32 - b0;
+								const int in_rowc = x - row_lo + 1;
+								if (Ld > in_rowc) Ld = in_rowc;
+								const int rminC = g.bcast(minC, L), rmaxC = g.bcast(maxC, L);
+								if (!(x - (Ld - 1) > rminC && x < rmaxC)) { status = 2; go_on = false; }
+								else {
+									emit(2, Ld);
+									x -= Ld;
+									if (Ld == in_rowc) go_on = false;            /* next cell is left of the row: STOP */
+									else if (Ld == in_word) want = 2u;           /* the run may go on in the previous word */
+									else {
+										const unsigned c2 = plane_code(wx, wy, b0 + Ld);
+										if (c2 == 0u) go_on = false; else want = c2;
+									}
+								}
+							} else {
+								const int k = gl - L;
+								const int tn = tp - k;
+								const bool have = (k >= 0) && (cy >= 0) && (tn >= 0) && ((tn >> 5) == (ttc >> 5));
+								const bool col_in = (x >= ol.x) && (x < ol.x + ol.y);
+								unsigned c2 = plane_code(w.x, w.y, 31 - (tn & 31));
+								if (!col_in) c2 = 0u;
+								const unsigned im = g.ballot(have && c2 == 1u) >> L;      /* bit k: cell (x, y - k) is I; bit 0 is set */
+								const int Li = __builtin_ctz(~im);                          /* <= G - L */
+								const unsigned ilow = (1u << Li) - 1u;
+								const unsigned vpi = g.ballot(x > minC && x < maxC) >> L;
+								if ((~vpi & ilow) != 0u) { status = 2; go_on = false; }
+								else {
+									emit(1, Li);
+									y -= Li; consumed += Li;
+									s -= Li; if (s < 0) s += N;
+									const int en = L + Li;
+									want = 1u;                                   /* default: let the next probe look again */
+									const unsigned hv = g.ballot(have);
+									const int c3i = g.bcast((int) c2, en < G ? en : 0);
+									if (en < G && ((hv >> en) & 1u) != 0u) {
+										if (c3i == 0) go_on = false; else want = (unsigned) c3i;
+									}
+								}
+							}
+						}
+					}
+				}
+			}
+			if (!go_on) act = false;
+		}
+	}
+	if (walked) {
+		if (status == 0) {
+			if (elem != 4) { if (gl == 0) ops[idx] = (elem_len << 4) | elem; idx -= 1; }
+			consumed += (y + 1);
+			o.ref_position = x + 1;
+			o.qstart = y + 1;
+			o.qend = qend;
+			o.ops_first = idx + 1;
+			o.n_ops = ops_cap - 1 - idx;
+			if (H != consumed) status = 3;
+		}
+		o.status = status;
+	}
+}
+
+/* G lanes per tile: block b walks tiles order[b * (64 / G) ...] (largest first: the four tiles of a
+ * wave have paths of similar length) */
+template <int G>
+__global__ void __launch_bounds__(64)
+backtrack_grp_kernel(const BacktrackArgs a, const int32_t *order, const int n_order) {
+	const int lane = threadIdx.x;
+	Group<G> g;
+	g.gl = lane & (G - 1);
+	g.base = lane & ~(G - 1);
+	const int q = blockIdx.x * (64 / G) + lane / G;
+	bool has = q < n_order;
+	const int t = has ? order[q] : 0;
+	TileOut o;
+	o.score = -1.0f; o.status = 0; o.best_x = 0; o.best_y = 0;
+	o.ref_position = 0; o.qstart = 0; o.qend = 0; o.n_ops = 0; o.ops_first = 0; o.pad = 0;
+	TileRun tr;
+	TileIn ti;
+	tr.skip = 1; tr.ring = 64; tr.r0 = 0; tr.ops_cap = 8; tr.dir_off = 0; tr.ops_off = 0; tr.chain_blk0 = -1;
+	ti.H = 0; ti.W = 0; ti.row_off = 0; ti.ref_off = 0; ti.qry_off = 0;
+	if (has) {
+		tr = a.trun[t];
+		o = a.tout[t];
+		ti = a.tin[t];
+		if (tr.skip != 0 || o.status != 0 || o.pad != 0) has = false;
+	}
+	const int H = ti.H, W = ti.W;
+	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off;
+	bool dead = false;       /* no cell at all: status 5 */
+	if (__builtin_amdgcn_ballot_w64(has && !(o.score > 0.0f)) != 0ull) {
+		/* no positive score: the reference's best cell is the first cell in (y, x) order with score 0
+		 * (curr_max starts at -1, src/ConvexAlignFast.cpp:758-763) */
+		if (has && !(o.score > 0.0f)) {
+			int fy = -1, fx = 0;
+			bool searching = true;
+			for (int y0 = 0; __builtin_amdgcn_ballot_w64(searching && y0 < H) != 0ull; y0 += G) {
+				if (searching && y0 < H) {
+					const int yy = y0 + g.gl;
+					bool hc = false;
+					int lo_i = 0;
+					if (yy < H) {
+						const int2 ol = rows[yy];
+						long long lo = ol.x > 0 ? ol.x : 0;
+						long long hi = (long long) ol.x + (long long) ol.y;
+						if (hi > W) hi = W;
+						hc = hi > lo;
+						lo_i = (int) lo;
+					}
+					const unsigned m = g.ballot(hc);
+					const int l = m ? __builtin_ctz(m) : 0;
+					const int fxl = g.bcast(lo_i, l);
+					if (m != 0u) { fy = y0 + l; fx = fxl; searching = false; }
+				}
+			}
+			if (fy < 0) { dead = true; has = false; }
+			else { o.score = 0.0f; o.best_x = fx; o.best_y = fy; }
+		}
+	}
+	const bool chained = tr.chain_blk0 >= 0;
+	int *ops = a.ops + tr.ops_off;
+	const uint8_t *ref = a.seq + ti.ref_off, *qry = a.seq + ti.qry_off;
+	if (__builtin_amdgcn_ballot_w64(has && chained) != 0ull)
+		backtrack_walk_grp<true, G>(g, has && chained, H, tr.ring, tr.r0, tr.ops_cap, rows,
+				reinterpret_cast<const uint2 *>(a.dirs), a.chain_blk + (chained ? tr.chain_blk0 : 0), ref, qry, ops, o);
+	if (__builtin_amdgcn_ballot_w64(has && !chained) != 0ull)
+		backtrack_walk_grp<false, G>(g, has && !chained, H, tr.ring, tr.r0, tr.ops_cap, rows,
+				reinterpret_cast<const uint2 *>(a.dirs + tr.dir_off), nullptr, ref, qry, ops, o);
+	if (dead) { o.score = -1.0f; o.status = 5; }
+	if ((has || dead) && g.gl == 0) { o.pad = 1; a.tout[t] = o; }
+}
+
 /* one wave per tile, after every fill launch of the batch has finished.  (Walkers running
  * BESIDE the fill, in the two wave slots per SIMD it leaves free, were tried: the fill slowed
  * down by as much as the backtrack took -- both phases are bound by instruction issue,
@@ -1099,9 +1378,14 @@ hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, i
 	return hipGetLastError();
 }
 
-hipError_t launch_backtrack(const BacktrackArgs &a, hipStream_t st) {
+hipError_t launch_backtrack(const BacktrackArgs &a, const int32_t *order, int n_order, int group, hipStream_t st) {
 	if (a.n_tiles <= 0) return hipSuccess;
-	hipLaunchKernelGGL(backtrack_kernel, dim3(a.n_tiles), dim3(64), 0, st, a);   /* one wave per tile */
+	if (group == 16 && order != nullptr) {
+		if (n_order <= 0) return hipSuccess;
+		hipLaunchKernelGGL(backtrack_grp_kernel<16>, dim3((n_order + 3) / 4), dim3(64), 0, st, a, order, n_order);   /* four tiles per wave */
+	} else {
+		hipLaunchKernelGGL(backtrack_kernel, dim3(a.n_tiles), dim3(64), 0, st, a);   /* one wave per tile */
+	}
 	return hipGetLastError();
 }
 

@@ -28,7 +28,9 @@ size_t generic_scratch_bytes(int ring);
 hipError_t launch_fill_generic(const FillArgs &a, bool sse_variant, uint8_t *scratch, const uint64_t *scratch_off, hipStream_t st);
 hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles,
 		unsigned long long max_matrix_mb, hipStream_t st);
-hipError_t launch_backtrack(const BacktrackArgs &a, hipStream_t st);
+/* group: 16 = sixteen lanes per tile, four tiles per wave, tiles taken from order[0, n_order) (largest first);
+ * anything else = one wave per tile over all a.n_tiles */
+hipError_t launch_backtrack(const BacktrackArgs &a, const int32_t *order, int n_order, int group, hipStream_t st);
 hipError_t launch_finalize(const TileOut *tout, const TilePlan *plan, uint64_t *dst_off, ResultRec *res,
 		BatchSummary *sum, int32_t *counters, int n_tiles, uint64_t dense_cap, hipStream_t st);
 hipError_t launch_compact(const int32_t *regions, const TileRun *trun, const TileOut *tout,

@@ -228,6 +228,7 @@ struct cvx_context {
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
+	int bt_group = 16;         /* lanes per tile in the backtrack (16: four tiles per wave; 64: the one-wave-per-tile walk; env CVX_TUNE_BT_GROUP) */
 	bool overlap_post = false; /* tuning knob (env CVX_TUNE_OVERLAP_POST): backtrack/finalize/compaction of batch k on their own stream, beside the fills of batch k+1 */
 	bool sse_variant = false; /* scoring outside the regime where the reference's SSE path equals the scalar recurrence:
 	                           * every tile goes to the catch-all kernel's SSE-variant instantiation */
@@ -315,7 +316,7 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	RC_TRY(b->d_trun.ensure(n1));
 	RC_TRY(b->d_tout.ensure(n1));
 	RC_TRY(b->d_dstoff.ensure(n1));
-	RC_TRY(b->d_lists.ensure(n1));
+	RC_TRY(b->d_lists.ensure(2 * n1));             /* fill lists + backtrack order */
 	if (b->d_counters.cap < 64) {
 		RC_TRY(b->d_counters.ensure(64));
 		HIP_TRY(hipMemset(b->d_counters.p, 0, b->d_counters.cap * sizeof(int32_t)));
@@ -420,7 +421,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 
 	RC_TRY(b->h_trun.ensure((size_t) n * sizeof(TileRun)));
 	RC_TRY(b->h_tout.ensure((size_t) n * sizeof(TileOut)));
-	RC_TRY(b->h_lists.ensure((size_t) n * sizeof(int32_t) + 64));
+	RC_TRY(b->h_lists.ensure((size_t) 2 * n * sizeof(int32_t) + 64));
 	memcpy(b->h_trun.p, hp.trun.data(), (size_t) n * sizeof(TileRun));
 	memcpy(b->h_tout.p, hp.tout.data(), (size_t) n * sizeof(TileOut));
 	int32_t *lists = b->h_lists.as<int32_t>();
@@ -434,6 +435,21 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	const int generic_begin = (int) n_listed;
 	if (!generic.empty()) memcpy(lists + n_listed, generic.data(), generic.size() * sizeof(int32_t));
 	n_listed += generic.size();
+	/* behind the fill lists: every computed tile once, longest read first (counting sort on H / 32) --
+	 * the order in which the backtrack takes them, four to a wave: the walk of a tile is a serial
+	 * chain of ~H / 7 probes, so the long ones must start first and share their wave with their like */
+	const size_t bt_begin = n_listed;
+	{
+		const TileIn *tin = b->tin();
+		constexpr int kBuckets = 4096;
+		std::vector<int32_t> count((size_t) kBuckets + 1, 0);
+		auto bucket = [&](int32_t ti) { const int k = tin[(size_t) ti].H >> 5; return kBuckets - 1 - (k < kBuckets ? k : kBuckets - 1); };
+		for (int i = 0; i < n; ++i) if (!hp.trun[(size_t) i].skip) count[(size_t) bucket(i) + 1]++;
+		for (int k = 0; k < kBuckets; ++k) count[(size_t) k + 1] += count[(size_t) k];
+		n_listed += (size_t) count[(size_t) kBuckets];
+		for (int i = 0; i < n; ++i) if (!hp.trun[(size_t) i].skip) lists[bt_begin + (size_t) count[(size_t) bucket(i)]++] = i;
+	}
+	const int n_walk = (int) (n_listed - bt_begin);
 	if (!generic.empty()) {
 		RC_TRY(b->h_goff.ensure((generic.size() + 1) * sizeof(uint64_t)));
 		uint64_t *goff = b->h_goff.as<uint64_t>();
@@ -600,7 +616,10 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	ba.dirs = b->d_dirs.p;
 	ba.ops = b->d_regions.p;
 	ba.n_tiles = n;
-	HIP_TRY(launch_backtrack(ba, st));
+	/* few tiles: the walk is latency-bound and 64 probing lanes per tile take the long diagonal runs in
+	 * a quarter of the probes; many tiles: it is issue-bound and four tiles share a wave */
+	const int bt_group = (h->bt_group == 16 && n_walk < 4096) ? 64 : h->bt_group;
+	HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin, n_walk, bt_group, st));
 	ResultRec *d_rec = reinterpret_cast<ResultRec *>(b->d_res.p);
 	BatchSummary *d_sum = reinterpret_cast<BatchSummary *>(b->d_res.p + (size_t) n * sizeof(ResultRec));
 	HIP_TRY(launch_finalize(b->d_tout.p, b->d_plan.p, b->d_dstoff.p, d_rec, d_sum, b->d_counters.p, n, b->dense_cap, st));
@@ -742,6 +761,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	c->sp.ge = p->gap_extend; c->sp.gem = p->gap_extend_min; c->sp.decay = p->gap_decay;
 	c->max_matrix_mb = max_matrix_mb ? max_matrix_mb : 10000;
 	c->sse_variant = !fast_regime;
+	if (const char *e = getenv("CVX_TUNE_BT_GROUP")) c->bt_group = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_OVERLAP_POST")) c->overlap_post = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_SSE_VARIANT")) c->sse_variant = c->sse_variant || atoi(e) != 0;   /* test knob */
 	const int hw = (int) std::thread::hardware_concurrency();
