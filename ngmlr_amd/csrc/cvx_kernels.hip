@@ -73,22 +73,29 @@ CVX_DEV void row_span(const int2 ol, int W, int y, int &gs, int &ge) {
 	ge = (int) (hi + y);
 }
 
+/* TPT threads per tile, 256 / TPT tiles per workgroup: 256 for batches of long reads, 64 (a wave
+ * per tile) for batches of short ones, where a 256-thread group per 150-row tile was mostly idle
+ * threads and workgroup launches (short-read config: 1.7 of 8.9 ms per 100 000 tiles) */
+template <int TPT>
 __global__ void __launch_bounds__(256)
 plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, unsigned long long max_matrix_mb) {
-	const int t = blockIdx.x;
-	if (t >= n_tiles) return;
-	const TileIn ti = tin[t];
+	constexpr int TPB = 256 / TPT;                 /* tiles per block */
+	const int sub = threadIdx.x / TPT;             /* tile slot inside the block */
+	const int ltid = threadIdx.x % TPT;
+	const int t = blockIdx.x * TPB + sub;
+	const bool live = t < n_tiles;
+	const TileIn ti = tin[live ? t : 0];
 	const int2 *r = rows + ti.row_off;
-	const int H = ti.H, W = ti.W;
+	const int H = live ? ti.H : 0, W = ti.W;
 
-	__shared__ unsigned long long s_cells, s_active;
-	__shared__ int s_need, s_flags, s_maxlen, s_rend, s_r0;
-	if (threadIdx.x == 0) { s_cells = 0; s_active = 0; s_need = 1; s_flags = 0; s_maxlen = 0; s_rend = -0x7fffffff; s_r0 = 0x7fffffff; }
+	__shared__ unsigned long long s_cells[TPB], s_active[TPB];
+	__shared__ int s_need[TPB], s_flags[TPB], s_maxlen[TPB], s_rend[TPB], s_r0[TPB];
+	if (ltid == 0) { s_cells[sub] = 0; s_active[sub] = 0; s_need[sub] = 1; s_flags[sub] = 0; s_maxlen[sub] = 0; s_rend[sub] = -0x7fffffff; s_r0[sub] = 0x7fffffff; }
 	__syncthreads();
 
 	unsigned long long cells = 0, active = 0;
 	int need = 1, flags = 0, maxlen = 0, rendmax = -0x7fffffff, r0min = 0x7fffffff;
-	for (int y = threadIdx.x; y < H; y += blockDim.x) {
+	for (int y = ltid; y < H; y += TPT) {
 		const int2 ol = r[y];
 		int gs, ge;
 		row_span(ol, W, y, gs, ge);
@@ -136,28 +143,30 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 		const int n = lo - y + 1;
 		if (n > need) need = n;
 	}
-	atomicAdd(&s_cells, cells);
-	atomicAdd(&s_active, active);
-	atomicMax(&s_need, need);
-	atomicOr(&s_flags, flags);
-	atomicMax(&s_maxlen, maxlen);
-	atomicMax(&s_rend, rendmax);
-	atomicMin(&s_r0, r0min);
+	if (H > 0) {
+		atomicAdd(&s_cells[sub], cells);
+		atomicAdd(&s_active[sub], active);
+		atomicMax(&s_need[sub], need);
+		atomicOr(&s_flags[sub], flags);
+		atomicMax(&s_maxlen[sub], maxlen);
+		atomicMax(&s_rend[sub], rendmax);
+		atomicMin(&s_r0[sub], r0min);
+	}
 	__syncthreads();
 
-	if (threadIdx.x == 0) {
+	if (ltid == 0 && live) {
 		TilePlan p;
-		p.cells = s_cells;
-		p.active = s_active;
-		p.need = s_need;
-		int f = s_flags;
+		p.cells = s_cells[sub];
+		p.active = s_active[sub];
+		p.need = s_need[sub];
+		int f = s_flags[sub];
 		int r0 = 0, rend = 0;
-		if (H > 0) { r0 = s_r0; rend = s_rend; }   /* first / one-past-last anti-diagonal with a cell */
-		if (H <= 0 || s_active == 0) f |= kPlanEmpty;
+		if (H > 0) { r0 = s_r0[sub]; rend = s_rend[sub]; }   /* first / one-past-last anti-diagonal with a cell */
+		if (H <= 0 || s_active[sub] == 0) f |= kPlanEmpty;
 		/* src/AlignmentMatrixFast.cpp:45: (ulong)(matrixSize / 1000.0f / 1000.0f) < maxMatrixSizeMB */
-		const float mb = (float) s_cells / 1000.0f / 1000.0f;
+		const float mb = (float) s_cells[sub] / 1000.0f / 1000.0f;
 		if (!((unsigned long long) mb < max_matrix_mb)) f |= kPlanTooLarge;
-		if (H > 32767 || s_maxlen > 32767) f |= kPlanWrap16;
+		if (H > 32767 || s_maxlen[sub] > 32767) f |= kPlanWrap16;
 		p.r0 = r0;
 		p.rend = rend;
 		p.flags = f;
@@ -951,9 +960,11 @@ struct Group {
 	CVX_DEV int bcast(int v, int l) const { return __shfl(v, base + l, 64); }
 };
 
-template <bool CHAINED, int G>
-CVX_DEV void backtrack_walk_grp(const Group<G> g, const bool has_tile, const int H, const int N, const int r0, const int ops_cap,
+template <int G>
+CVX_DEV void backtrack_walk_grp(const Group<G> g, const bool has_tile, const bool chained, const int H, const int N, const int r0, const int ops_cap,
 		const int2 *rows, const uint2 *dirs, const ChainBlk *blk, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
+	/* `chained` is a property of the group's tile (a wave may carry both kinds): dirs is the tile's own
+	 * region for whole tiles and the arena for chained ones, whose blocks carry their offsets */
 	const int gl = g.gl;
 	const int best_x = o.best_x, best_y = o.best_y;
 	bool act = has_tile;
@@ -996,16 +1007,15 @@ CVX_DEV void backtrack_walk_grp(const Group<G> g, const bool has_tile, const int
 				const int tt = cx + cy - r0;
 				const int ttc = tt > 0 ? tt : 0;
 				const int2 ol = rows[ly];
-				uint2 w;
-				if (CHAINED) {
+				size_t widx = (size_t) (ttc >> 5) * N + sl;
+				if (chained) {
 					const int gb = ly / N;
 					const ChainBlk cb = blk[gb];
 					int wr = (ttc >> 5) - cb.tblk0;
 					wr = wr < 0 ? 0 : (wr >= cb.nblk32 ? cb.nblk32 - 1 : wr);
-					w = dirs[cb.dir_off + (size_t) wr * N + (size_t) (ly - gb * N)];
-				} else {
-					w = dirs[(size_t) (ttc >> 5) * N + sl];
+					widx = cb.dir_off + (size_t) wr * N + (size_t) (ly - gb * N);
 				}
+				const uint2 w = dirs[widx];
 				const int rc = ref[lx], qc = qry[ly];
 				const unsigned eqm = g.ballot(rc == qc);
 				const bool in_row = inside && tt >= 0 && cx >= ol.x && cx < ol.x + ol.y;    /* getDirection: outside -> STOP */
@@ -1196,12 +1206,9 @@ backtrack_grp_kernel(const BacktrackArgs a, const int32_t *order, const int n_or
 	const bool chained = tr.chain_blk0 >= 0;
 	int *ops = a.ops + tr.ops_off;
 	const uint8_t *ref = a.seq + ti.ref_off, *qry = a.seq + ti.qry_off;
-	if (__builtin_amdgcn_ballot_w64(has && chained) != 0ull)
-		backtrack_walk_grp<true, G>(g, has && chained, H, tr.ring, tr.r0, tr.ops_cap, rows,
-				reinterpret_cast<const uint2 *>(a.dirs), a.chain_blk + (chained ? tr.chain_blk0 : 0), ref, qry, ops, o);
-	if (__builtin_amdgcn_ballot_w64(has && !chained) != 0ull)
-		backtrack_walk_grp<false, G>(g, has && !chained, H, tr.ring, tr.r0, tr.ops_cap, rows,
-				reinterpret_cast<const uint2 *>(a.dirs + tr.dir_off), nullptr, ref, qry, ops, o);
+	const uint2 *dirs = reinterpret_cast<const uint2 *>(chained ? a.dirs : a.dirs + tr.dir_off);
+	backtrack_walk_grp<G>(g, has, chained, H, tr.ring, tr.r0, tr.ops_cap, rows, dirs,
+			a.chain_blk + (chained ? tr.chain_blk0 : 0), ref, qry, ops, o);
 	if (dead) { o.score = -1.0f; o.status = 5; }
 	if ((has || dead) && g.gl == 0) { o.pad = 1; a.tout[t] = o; }
 }
@@ -1370,11 +1377,15 @@ hipError_t launch_chain_reduce(const int32_t *tiles, int n_tiles, const TileRun 
 	return hipGetLastError();
 }
 
-hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles,
+hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles, uint64_t rows_per_tile,
 		unsigned long long max_matrix_mb, hipStream_t st) {
 	if (n_tiles <= 0) return hipSuccess;
-	hipLaunchKernelGGL(plan_kernel, dim3(n_tiles), dim3(256), 0, st,
-			reinterpret_cast<const int2 *>(rows), tin, plan, n_tiles, max_matrix_mb);
+	if (rows_per_tile >= 1024)
+		hipLaunchKernelGGL(plan_kernel<256>, dim3(n_tiles), dim3(256), 0, st,
+				reinterpret_cast<const int2 *>(rows), tin, plan, n_tiles, max_matrix_mb);
+	else
+		hipLaunchKernelGGL(plan_kernel<64>, dim3((n_tiles + 3) / 4), dim3(256), 0, st,
+				reinterpret_cast<const int2 *>(rows), tin, plan, n_tiles, max_matrix_mb);
 	return hipGetLastError();
 }
 

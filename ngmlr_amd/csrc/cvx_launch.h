@@ -26,7 +26,8 @@ hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scr
 size_t generic_scratch_bytes(int ring);
 /* sse_variant: the reference's SSE-path semantics for scoring outside the scalar-equivalent regime */
 hipError_t launch_fill_generic(const FillArgs &a, bool sse_variant, uint8_t *scratch, const uint64_t *scratch_off, hipStream_t st);
-hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles,
+/* rows_per_tile: mean read rows per tile of the batch (picks 256 threads or one wave per tile) */
+hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles, uint64_t rows_per_tile,
 		unsigned long long max_matrix_mb, hipStream_t st);
 /* group: 16 = sixteen lanes per tile, four tiles per wave, tiles taken from order[0, n_order) (largest first);
  * anything else = one wave per tile over all a.n_tiles */

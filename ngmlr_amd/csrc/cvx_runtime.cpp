@@ -374,7 +374,7 @@ int stage_plan(cvx_context *h, cvx_batch_s *b, hipStream_t st) {
 	const int n = b->n;
 	HIP_TRY(hipEventRecord(b->ev[0], st));
 	if (n) {
-		HIP_TRY(launch_plan(b->d_rows.p, b->d_tin.p, b->d_plan.p, n, h->max_matrix_mb, st));
+		HIP_TRY(launch_plan(b->d_rows.p, b->d_tin.p, b->d_plan.p, n, b->n_rows / (uint64_t) n, h->max_matrix_mb, st));
 		HIP_TRY(hipMemcpyAsync(b->h_plan.p, b->d_plan.p, (size_t) n * sizeof(TilePlan), hipMemcpyDeviceToHost, st));
 	}
 	HIP_TRY(hipEventRecord(b->ev[1], st));
