@@ -29,6 +29,8 @@
  *                              reference src/AlignmentBuffer.cpp:3361-3406)
  * cvx_format_alignment        convertCigar + N-clip flags    src/ConvexAlignFast.cpp:112-333,493-528
  * cvx_score_batch             StrippedSW::BatchScore/SingleScore  src/StrippedSW.cpp:118-203 (next-row f2)
+ * cvx_genome_* / cvx_submit_windows  SequenceProvider's 4-bit genome + DecodeRefSequenceExact
+ *                             src/SequenceProvider.cpp:333-386,475-565 (next-row f4, decode half)
  *
  * The binding a maintainer adds on the ngmlr side is in INTEGRATION.md
  * (ngmlr_amd/csrc/convex_align_hip.{h,cpp}: an IAlignment subclass over this ABI).
@@ -46,7 +48,7 @@
 extern "C" {
 #endif
 
-#define CVX_ABI_VERSION 2
+#define CVX_ABI_VERSION 3
 
 /* return codes */
 enum {
@@ -195,6 +197,41 @@ int cvx_wait(cvx_handle h, cvx_job job, const cvx_result **results, const uint32
 int cvx_job_timing(cvx_job job, cvx_timing *t);                        /* after cvx_wait */
 int cvx_job_launch_info(cvx_job job, int32_t i, cvx_launch_info *info); /* after cvx_wait */
 void cvx_job_release(cvx_handle h, cvx_job job);
+
+/* Reference genome resident in HBM (decode half).
+ *
+ * ngmlr keeps its reference 4 bits per base (src/SequenceProvider.cpp:76-113, :333-386) and expands a
+ * window to chars on the host for every alignment (DecodeRefSequenceExact :493-565, called with
+ * corridor 0 from src/AlignmentBuffer.cpp:199-223).  With the encoded genome on the device a tile
+ * carries (position, length) instead of decoded characters.
+ *
+ *   cvx_genome_encode   what _SequenceProvider::Init builds (binRef + the refStartPos table of
+ *                       :415-424) from n sequences: A 0, T 1, G 2, C 3, anything else 4 (case-
+ *                       insensitive), two bases per byte, high nibble first; 1000 N in front, after
+ *                       every sequence its pad nibble (odd lengths) and 1000 N; sequences of 10 bases
+ *                       or fewer are skipped (SequenceProvider.h:79).  bin_ref: cvx_genome_encoded_bytes()
+ *                       bytes; start_table: room for n + 1 entries, *n_starts of them are written
+ *                       (kept sequences + the upper bound).  Host only.
+ *   cvx_genome_upload   puts an encoded genome (ours or ngmlr's own binRef / refStartPos) into HBM.
+ *   cvx_genome_decode   DecodeRefSequenceExact(out + out_offset[i], position[i], length[i], 0) for n
+ *                       windows on the device, results back in host memory (length[i] bytes each, the
+ *                       last one NUL, as the reference writes them).
+ *   cvx_submit_windows  cvx_submit for tiles whose reference is a window of the resident genome:
+ *                       tiles[i].ref is ignored, the reference of tile i is the first tiles[i].ref_len
+ *                       characters of the window at ref_position[i] (= the string the reference's
+ *                       caller builds with length ref_len + 1), decoded on the device straight into
+ *                       the batch's sequence arena.  Everything else as cvx_submit. */
+typedef struct cvx_genome_s *cvx_genome;
+uint64_t cvx_genome_encoded_bytes(int32_t n, const uint64_t *lengths);
+int cvx_genome_encode(int32_t n, const char *const *seqs, const uint64_t *lengths, uint8_t *bin_ref,
+		uint64_t *n_nibbles, uint64_t *start_table, int32_t *n_starts);
+int cvx_genome_upload(cvx_handle h, const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table,
+		int32_t n_starts, cvx_genome *out);
+void cvx_genome_free(cvx_handle h, cvx_genome g);
+int cvx_genome_decode(cvx_handle h, cvx_genome g, int32_t n, const uint64_t *position, const int32_t *length,
+		const uint64_t *out_offset, char *out);
+int cvx_submit_windows(cvx_handle h, cvx_genome g, int32_t n_tiles, const cvx_tile *tiles,
+		const uint64_t *ref_position, cvx_job *out);
 
 /* Sub-read scoring: what StrippedSW::BatchScore / SingleScore return
  * (reference src/StrippedSW.cpp:118-203 over ssw.c): refs/qrys are NUL-terminated strings,

@@ -206,6 +206,53 @@ def format_tileset(lib, tileset, idx, results, ops, n_threads: int = 0):
     return texts
 
 
+def encode_genome(lib, seqs: Sequence[bytes]):
+    """cvx_genome_encode: ngmlr's 4-bit reference encoding (host only).  -> (binref uint8[], nibbles, start table uint64[])"""
+    n = len(seqs)
+    lens = np.array([len(x) for x in seqs], dtype=np.uint64)
+    arr = (C.c_char_p * max(n, 1))(*seqs)
+    binref = np.zeros(int(lib.cvx_genome_encoded_bytes(n, lens.ctypes.data)), dtype=np.uint8)
+    starts = np.zeros(n + 1, dtype=np.uint64)
+    nib = C.c_uint64()
+    ns = C.c_int32()
+    capi.check(lib.cvx_genome_encode(n, arr, lens.ctypes.data, binref.ctypes.data, C.byref(nib), starts.ctypes.data, C.byref(ns)))
+    return binref, int(nib.value), starts[:ns.value].copy()
+
+
+class Genome:
+    """An encoded reference genome resident in HBM (decode half): windows are decoded on the
+    device -- the counterpart of SequenceProvider.DecodeRefSequenceExact (reference src/SequenceProvider.cpp:493-565)."""
+
+    def __init__(self, aligner: ConvexAlignHip, binref: np.ndarray, nibbles: int, starts: np.ndarray):
+        self.al = aligner
+        self.g = C.c_void_p()
+        b = np.ascontiguousarray(binref, dtype=np.uint8)
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        capi.check(aligner.lib.cvx_genome_upload(aligner.h, b.ctypes.data, int(nibbles), st.ctypes.data, len(st), C.byref(self.g)))
+
+    def decode(self, positions, lengths) -> List[bytes]:
+        """DecodeRefSequenceExact(position, length, corridor 0) for every window, `length` bytes each (the last a NUL)."""
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.int32)
+        off = np.concatenate([[0], np.cumsum(ln.astype(np.int64))]).astype(np.uint64)
+        out = np.zeros(int(off[-1]) + 8, dtype=np.uint8)
+        capi.check(self.al.lib.cvx_genome_decode(self.al.h, self.g, len(pos), pos.ctypes.data, ln.ctypes.data, off.ctypes.data, out.ctypes.data))
+        return [out[int(off[i]):int(off[i + 1])].tobytes() for i in range(len(pos))]
+
+    def submit(self, tiles: Sequence, ref_positions) -> "Job":
+        """cvx_submit_windows: the tiles' references are windows of this genome (tile.ref is not uploaded)."""
+        arr, keep = self.al._pack(tiles)
+        pos = np.ascontiguousarray(ref_positions, dtype=np.uint64)
+        j = C.c_void_p()
+        capi.check(self.al.lib.cvx_submit_windows(self.al.h, self.g, len(tiles), arr, pos.ctypes.data, C.byref(j)))
+        return Job(self.al, j, len(tiles), (keep, pos))
+
+    def free(self) -> None:
+        if self.g:
+            self.al.lib.cvx_genome_free(self.al.h, self.g)
+            self.g = None
+
+
 class StrippedSWHip:
     """Mirror of the reference's StrippedSW for the scoring calls (src/StrippedSW.cpp:118-203):
     batch_score == BatchScore, single_score == SingleScore; alignment calls are not part of

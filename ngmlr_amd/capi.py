@@ -22,7 +22,9 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_align_batch", "cvx_batch_upload", "cvx_batch_run", "cvx_batch_timing",
            "cvx_batch_ops_total", "cvx_batch_launch_info", "cvx_batch_download", "cvx_batch_free",
            "cvx_submit", "cvx_wait", "cvx_job_timing", "cvx_job_launch_info", "cvx_job_release",
-           "cvx_format_alignment", "cvx_format_batch", "cvx_score_batch")
+           "cvx_format_alignment", "cvx_format_batch", "cvx_score_batch",
+           "cvx_genome_encoded_bytes", "cvx_genome_encode", "cvx_genome_upload", "cvx_genome_free",
+           "cvx_genome_decode", "cvx_submit_windows")
 
 
 class CvxParams(C.Structure):
@@ -118,6 +120,15 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_job_release.restype = None
     lib.cvx_format_batch.argtypes = [C.c_int32, C.POINTER(CvxResult), C.c_void_p, C.POINTER(CvxTile),
                                      C.POINTER(CvxTextBuffers), C.POINTER(CvxAlignmentText), C.c_int32]
+    lib.cvx_genome_encoded_bytes.restype = C.c_uint64
+    lib.cvx_genome_encoded_bytes.argtypes = [C.c_int32, C.c_void_p]
+    lib.cvx_genome_encode.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64),
+                                      C.c_void_p, C.POINTER(C.c_int32)]
+    lib.cvx_genome_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.cvx_genome_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cvx_genome_free.restype = None
+    lib.cvx_genome_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cvx_submit_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(CvxTile), C.c_void_p, C.POINTER(C.c_void_p)]
     lib.cvx_score_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p]
     lib.cvx_format_alignment.argtypes = [C.POINTER(CvxResult), C.c_void_p, C.c_char_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,

@@ -80,6 +80,8 @@ struct UploadLayout {
 	uint64_t pad = 0;               /* zeroed bytes before the first and after the last sequence */
 	uint64_t seq_total = 0;         /* bytes of the seq arena */
 	uint64_t n_rows = 0;            /* entries of the rows arena */
+	bool windows = false;           /* references decoded on the device: [pad][qry...][pad][ref...][pad] */
+	uint64_t upload_bytes = 0;      /* leading part of the seq arena that is packed on the host and uploaded */
 	std::vector<uint64_t> wprefix;  /* packing work per tile (bytes moved), prefix sums */
 };
 
@@ -87,32 +89,44 @@ enum { kLayoutOk = 0, kLayoutMalformed = 1, kLayoutTooLarge = 2 };
 
 /* Validates the tiles and assigns arena offsets (TileIn).  On kLayoutMalformed *bad is the
  * offending tile; kLayoutTooLarge: more than 4 GiB of bases (32-bit sequence offsets). */
-inline int upload_layout(int n, const cvx_tile *tiles, std::vector<TileIn> &tin, UploadLayout &L, int *bad) {
-	uint64_t seq_bytes = 0, n_rows = 0;
+/* windows: the tiles' references are decoded on the device from the resident genome (cvx_genome.hip):
+ * tile.ref is ignored, the arena becomes [pad][every qry][pad][every ref][pad] and only the part up to
+ * L.upload_bytes travels over PCIe. */
+inline int upload_layout(int n, const cvx_tile *tiles, std::vector<TileIn> &tin, UploadLayout &L, int *bad, bool windows = false) {
+	uint64_t seq_bytes = 0, n_rows = 0, qry_bytes = 0;
 	int64_t max_hw = 0;
 	for (int i = 0; i < n; ++i) {
 		const cvx_tile &t = tiles[i];
-		if (t.ref_len < 0 || t.qry_len < 0 || (t.ref_len > 0 && !t.ref) || (t.qry_len > 0 && !t.qry) ||
+		if (t.ref_len < 0 || t.qry_len < 0 || (t.ref_len > 0 && !t.ref && !windows) || (t.qry_len > 0 && !t.qry) ||
 				(t.qry_len > 0 && (!t.row_offset || !t.row_length)) || (t.row_stride_bytes & 3) || t.row_stride_bytes < 4) {
 			if (bad) *bad = i;
 			return kLayoutMalformed;
 		}
 		seq_bytes += (uint64_t) t.ref_len + (uint64_t) t.qry_len;
+		qry_bytes += (uint64_t) t.qry_len;
 		n_rows += (uint64_t) t.qry_len;
 		max_hw = std::max<int64_t>(max_hw, (int64_t) t.ref_len + t.qry_len);
 	}
 	L.pad = (uint64_t) max_hw + kRingMax + 256;
-	L.seq_total = seq_bytes + 2 * L.pad + 64;
+	L.seq_total = seq_bytes + (windows ? 3 : 2) * L.pad + 64;
 	L.n_rows = n_rows;
+	L.windows = windows;
+	L.upload_bytes = windows ? (L.pad + qry_bytes + L.pad) : L.seq_total;
 	if (L.seq_total >= 0xFFFF0000ull) return kLayoutTooLarge;
 	tin.resize((size_t) n);
 	L.wprefix.assign((size_t) n + 1, 0);
 	uint64_t so = L.pad, ro = 0;
+	uint64_t rso = L.pad + qry_bytes + L.pad;       /* windows: where the decoded references start */
 	for (int i = 0; i < n; ++i) {
 		const cvx_tile &t = tiles[i];
 		TileIn &ti = tin[(size_t) i];
-		ti.ref_off = (uint32_t) so;
-		so += (uint64_t) t.ref_len;
+		if (windows) {
+			ti.ref_off = (uint32_t) rso;
+			rso += (uint64_t) t.ref_len;
+		} else {
+			ti.ref_off = (uint32_t) so;
+			so += (uint64_t) t.ref_len;
+		}
 		ti.qry_off = (uint32_t) so;
 		so += (uint64_t) t.qry_len;
 		ti.W = t.ref_len;
@@ -120,7 +134,7 @@ inline int upload_layout(int n, const cvx_tile *tiles, std::vector<TileIn> &tin,
 		ti.row_off = ro;
 		ti.reserved = 0;
 		ro += (uint64_t) t.qry_len;
-		L.wprefix[(size_t) i + 1] = L.wprefix[(size_t) i] + (uint64_t) t.ref_len + 9ull * (uint64_t) t.qry_len + 64;
+		L.wprefix[(size_t) i + 1] = L.wprefix[(size_t) i] + (windows ? 0 : (uint64_t) t.ref_len) + 9ull * (uint64_t) t.qry_len + 64;
 	}
 	return kLayoutOk;
 }
@@ -128,16 +142,17 @@ inline int upload_layout(int n, const cvx_tile *tiles, std::vector<TileIn> &tin,
 /* the kernels prefetch a little past either end of a tile: both pads must be defined */
 inline void upload_zero_pads(const UploadLayout &L, uint8_t *hseq) {
 	memset(hseq, 0, (size_t) L.pad);
-	memset(hseq + (size_t) (L.seq_total - L.pad - 64), 0, (size_t) L.pad + 64);
+	if (L.windows) memset(hseq + (size_t) (L.upload_bytes - L.pad), 0, (size_t) L.pad);   /* the pad between reads and references */
+	else memset(hseq + (size_t) (L.seq_total - L.pad - 64), 0, (size_t) L.pad + 64);
 }
 
 /* copies tiles [begin, end) into the staging arenas (callable from several threads at once) */
 inline void upload_pack(int begin, int end, const cvx_tile *tiles, const std::vector<TileIn> &tin,
-		uint8_t *hseq, RowDesc *hrows) {
+		uint8_t *hseq, RowDesc *hrows, bool windows = false) {
 	for (int i = begin; i < end; ++i) {
 		const cvx_tile &t = tiles[i];
 		const TileIn &ti = tin[(size_t) i];
-		if (t.ref_len) memcpy(hseq + ti.ref_off, t.ref, (size_t) t.ref_len);
+		if (t.ref_len && !windows) memcpy(hseq + ti.ref_off, t.ref, (size_t) t.ref_len);
 		if (t.qry_len) memcpy(hseq + ti.qry_off, t.qry, (size_t) t.qry_len);
 		RowDesc *dst = hrows + ti.row_off;
 		const char *po = (const char *) t.row_offset;

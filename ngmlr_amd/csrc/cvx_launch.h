@@ -22,6 +22,10 @@ struct ScorePair {
 };
 hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scratch, float *out, int n, hipStream_t st);
 
+/* reference windows from the 4-bit genome resident in HBM (cvx_genome.hip) */
+hipError_t launch_decode_windows(const uint8_t *bin, const uint64_t *starts, int n_starts,
+		const WindowDesc *win, int n, uint8_t *dst, hipStream_t st);
+
 /* catch-all kernel (cvx_generic.hip): any ring size, state in a global scratch */
 size_t generic_scratch_bytes(int ring);
 /* sse_variant: the reference's SSE-path semantics for scoring outside the scalar-equivalent regime */

@@ -172,6 +172,8 @@ struct cvx_batch_s {
 	DevBuf<uint8_t> d_gscratch;      /* slot state of tiles taken by the catch-all kernel */
 	DevBuf<uint64_t> d_gscratch_off;
 	/* chained tiles (row blocks) */
+	PinBuf h_win;                    /* WindowDesc[n]: reference windows decoded on the device (cvx_submit_windows) */
+	DevBuf<WindowDesc> d_win;
 	PinBuf h_chain;                  /* ChainTask[] of all chain classes, ChainBlk[], tile lists */
 	DevBuf<uint8_t> d_chain;
 	DevBuf<int32_t> d_progress;
@@ -203,6 +205,7 @@ struct cvx_batch_s {
 		d_tout.release(); d_dirs.release(); d_regions.release(); d_lists.release();
 		d_counters.release(); d_dstoff.release(); d_dense.release(); d_res.release();
 		d_gscratch.release(); d_gscratch_off.release();
+		h_win.release(); d_win.release();
 		h_chain.release(); d_chain.release(); d_progress.release(); d_bnd.release(); d_chain_out.release();
 		if (ev_in) { (void) hipEventDestroy(ev_in); ev_in = nullptr; }
 		if (ev_res) { (void) hipEventDestroy(ev_res); ev_res = nullptr; }
@@ -245,6 +248,14 @@ struct cvx_context {
 	DevBuf<float> sc_out;
 };
 
+struct cvx_genome_s {            /* an encoded reference genome resident in HBM (cvx_genome.hip) */
+	int device = 0;
+	uint64_t n_nibbles = 0;
+	int32_t n_starts = 0;
+	DevBuf<uint8_t> d_bin;
+	DevBuf<uint64_t> d_starts;
+};
+
 namespace {
 
 cvx_batch_s *acquire_batch(cvx_context *h) {
@@ -284,11 +295,13 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
 }
 
 /* ---- stage 1: pack into pinned staging and copy to the device, piece by piece (stream `io`) */
-int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tiles) {
+int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tiles,
+		const cvx_genome_s *genome = nullptr, const uint64_t *ref_position = nullptr) {
 	UploadLayout L;
 	std::vector<TileIn> tin;
 	int bad = -1;
-	const int lrc = upload_layout(n, tiles, tin, L, &bad);
+	const bool windows = genome != nullptr;
+	const int lrc = upload_layout(n, tiles, tin, L, &bad, windows);
 	if (lrc == kLayoutMalformed) { set_err("tile %d malformed", bad); return CVX_ERR_ARG; }
 	if (lrc == kLayoutTooLarge) {
 		set_err("%llu sequence bytes exceed one batch (4 GiB); split the batch", (unsigned long long) L.seq_total);
@@ -345,7 +358,7 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 			std::vector<uint64_t> wp((size_t) (t1 - t0) + 1);
 			for (int i = t0; i <= t1; ++i) wp[(size_t) (i - t0)] = wprefix[(size_t) i] - wprefix[(size_t) t0];
 			const int base = t0;
-			parallel_ranges(t1 - t0, wp, threads, [&](int bg, int en) { upload_pack(base + bg, base + en, tiles, tin, hseq, hrows); });
+			parallel_ranges(t1 - t0, wp, threads, [&](int bg, int en) { upload_pack(base + bg, base + en, tiles, tin, hseq, hrows, windows); });
 		}
 		/* Copy boundaries are multiples of 256 bytes: a host-to-device copy whose address or size is
 		 * not dword-aligned is not handed to the SDMA engines but to a blit kernel
@@ -353,7 +366,9 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 		 * measured: 0.5 GB of sequence pieces per step at odd offsets cost the pipelined step ~7 ms.
 		 * The bytes below the rounded-down end are all packed; the remainder travels with the next
 		 * piece, and the last piece runs to the (256-aligned) end of the arena. */
-		uint64_t seq_end = (t1 == n) ? L.seq_total : (uint64_t) tin[(size_t) t1].ref_off;
+		/* (with device-decoded references only [pad][reads][pad] is uploaded; tiles are laid out in
+		 * order, so everything below tile t1's first byte is packed) */
+		uint64_t seq_end = (t1 == n) ? L.upload_bytes : (uint64_t) (windows ? tin[(size_t) t1].qry_off : tin[(size_t) t1].ref_off);
 		seq_end = (t1 == n) ? (seq_end + 255) / 256 * 256 : seq_end / 256 * 256;
 		if (seq_end > seq_done)
 			HIP_TRY(hipMemcpyAsync(b->d_seq.p + seq_done, hseq + seq_done, (size_t) (seq_end - seq_done), hipMemcpyHostToDevice, st));
@@ -365,6 +380,20 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 		t0 = t1;
 	}
 	if (n) HIP_TRY(hipMemcpyAsync(b->d_tin.p, b->h_tin.p, (size_t) n * sizeof(TileIn), hipMemcpyHostToDevice, st));
+	if (windows && n) {
+		/* the references: decoded from the resident genome straight into the arena (and its last pad cleared) */
+		RC_TRY(b->h_win.ensure((size_t) n * sizeof(WindowDesc)));
+		RC_TRY(b->d_win.ensure((size_t) n));
+		WindowDesc *hw = b->h_win.as<WindowDesc>();
+		for (int i = 0; i < n; ++i) {
+			hw[i].position = ref_position[i];
+			hw[i].dst_off = tin[(size_t) i].ref_off;
+			hw[i].n_chars = tiles[i].ref_len;
+		}
+		HIP_TRY(hipMemcpyAsync(b->d_win.p, hw, (size_t) n * sizeof(WindowDesc), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemsetAsync(b->d_seq.p + (L.seq_total - L.pad - 64), 0, (size_t) L.pad + 64, st));
+		HIP_TRY(launch_decode_windows(genome->d_bin.p, genome->d_starts.p, genome->n_starts, b->d_win.p, n, b->d_seq.p, st));
+	}
 	b->state = kUploaded;
 	return CVX_OK;
 }
@@ -525,9 +554,12 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	int launches = 0;
 	/* fill launches go round-robin over the two aux streams and the main stream itself (which has
 	 * nothing else to do until they are all done): three classes side by side */
-	hipStream_t fill_streams[kAuxStreams + 1];
-	for (int i = 0; i < kAuxStreams; ++i) fill_streams[i] = h->aux[i];
-	fill_streams[kAuxStreams] = st;
+	/* (the `post` stream carries a fill class too unless the post-fill overlap experiment owns it) */
+	hipStream_t fill_streams[kAuxStreams + 2];
+	int n_fill_streams = 0;
+	for (int i = 0; i < kAuxStreams; ++i) fill_streams[n_fill_streams++] = h->aux[i];
+	if (!h->overlap_post) fill_streams[n_fill_streams++] = h->s_post;
+	fill_streams[n_fill_streams++] = st;
 	auto begin_launch = [&](hipStream_t ls) -> int {
 		while (b->lev.size() < (size_t) (launches + 1) * 3) {
 			hipEvent_t e;
@@ -544,7 +576,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		if (hp.chain_tasks[c].empty()) continue;
 		const int m = kChainClasses[c / 2];
 		launch_stats(hp.chain_tiles[c], m, (int) hp.chain_tasks[c].size(), (int) (c & 1));     /* `waves` = row-block tasks */
-		hipStream_t ls = fill_streams[launches % (kAuxStreams + 1)];
+		hipStream_t ls = fill_streams[launches % n_fill_streams];
 		RC_TRY(begin_launch(ls));
 		FillArgs a = fill_args(nullptr, (int) hp.chain_tasks[c].size());
 		a.tasks = reinterpret_cast<const ChainTask *>(b->d_chain.p + chain_task_off[c]);
@@ -573,7 +605,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		if (cls[c].empty()) continue;
 		const KernelClass &kc = kClasses[c / 2];
 		launch_stats(cls[c], kc.m, 1, (int) (c & 1));
-		hipStream_t ls = fill_streams[launches % (kAuxStreams + 1)];
+		hipStream_t ls = fill_streams[launches % n_fill_streams];
 		RC_TRY(begin_launch(ls));
 		const FillArgs a = fill_args(b->d_lists.p + seg_begin[c], (int) cls[c].size());
 		HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 0, a, 0, ls));
@@ -585,7 +617,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	}
 	if (!generic.empty()) {
 		launch_stats(generic, 0, 16, 1);
-		hipStream_t ls = fill_streams[launches % (kAuxStreams + 1)];
+		hipStream_t ls = fill_streams[launches % n_fill_streams];
 		RC_TRY(begin_launch(ls));
 		const FillArgs a = fill_args(b->d_lists.p + generic_begin, (int) generic.size());
 		HIP_TRY(launch_fill_generic(a, h->sse_variant, b->d_gscratch.p, b->d_gscratch_off.p, ls));
@@ -910,16 +942,17 @@ int cvx_align_batch(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_result *
 
 /* ------------------------------------------------------------------ streaming form */
 
-int cvx_submit(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_job *out) {
+static int submit_common(cvx_handle h, int32_t n, const cvx_tile *tiles, const cvx_genome_s *genome, const uint64_t *ref_position, cvx_job *out) {
 	ABI_GUARD_BEGIN
-	if (!h || !out || n < 0 || (n > 0 && !tiles)) { set_err("cvx_submit: bad argument"); return CVX_ERR_ARG; }
+	if (!h || !out || n < 0 || (n > 0 && !tiles) || (genome && n > 0 && !ref_position)) { set_err("cvx_submit: bad argument"); return CVX_ERR_ARG; }
 	*out = nullptr;
+	if (genome && genome->device != h->device) { set_err("cvx_submit_windows: the genome lives on device %d, the handle on %d", genome->device, h->device); return CVX_ERR_ARG; }
 	HIP_TRY(hipSetDevice(h->device));
 	/* first hand the device whatever is ready to run, then spend host time on packing */
 	RC_TRY(pump(h, false, nullptr));
 	cvx_batch_s *b = acquire_batch(h);
 	if (!b) return CVX_ERR_OOM;
-	int rc = stage_upload(h, b, n, tiles);
+	int rc = stage_upload(h, b, n, tiles, genome, ref_position);
 	if (rc == CVX_OK) rc = stage_plan(h, b, h->s_io);
 	if (rc != CVX_OK) { discard_batch(h, b); return rc; }
 	b->in_flight = true;
@@ -928,6 +961,15 @@ int cvx_submit(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_job *out) {
 	*out = b;
 	return CVX_OK;
 	ABI_GUARD_END
+}
+
+int cvx_submit(cvx_handle h, int32_t n, const cvx_tile *tiles, cvx_job *out) {
+	return submit_common(h, n, tiles, nullptr, nullptr, out);
+}
+
+int cvx_submit_windows(cvx_handle h, cvx_genome g, int32_t n, const cvx_tile *tiles, const uint64_t *ref_position, cvx_job *out) {
+	if (!g) { set_err("cvx_submit_windows: NULL genome"); return CVX_ERR_ARG; }
+	return submit_common(h, n, tiles, g, ref_position, out);
 }
 
 int cvx_wait(cvx_handle h, cvx_job j, const cvx_result **results, const uint32_t **ops, uint64_t *n_ops) {
@@ -959,6 +1001,81 @@ void cvx_job_release(cvx_handle h, cvx_job j) {
 		if (j->state >= kPlanned && j->state < kFinished) (void) hipDeviceSynchronize();   /* released without waiting */
 	}
 	recycle_batch(h, j);
+}
+
+/* ------------------------------------------------------------------ resident genome (decode half) */
+
+int cvx_genome_upload(cvx_handle h, const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table, int32_t n_starts, cvx_genome *out) {
+	ABI_GUARD_BEGIN
+	if (!h || !out || !bin_ref || !start_table || n_starts < 2 || n_nibbles < 2) { set_err("cvx_genome_upload: bad argument"); return CVX_ERR_ARG; }
+	*out = nullptr;
+	for (int32_t i = 1; i < n_starts; ++i)
+		if (start_table[i] <= start_table[i - 1]) { set_err("cvx_genome_upload: start table not ascending at %d", i); return CVX_ERR_ARG; }
+	HIP_TRY(hipSetDevice(h->device));
+	cvx_genome_s *g = new (std::nothrow) cvx_genome_s();
+	if (!g) return CVX_ERR_OOM;
+	g->device = h->device;
+	g->n_nibbles = n_nibbles;
+	g->n_starts = n_starts;
+	/* a window may start or end in the last spacer: decode() reads up to a byte past the last nibble pair */
+	const size_t bytes = (size_t) ((n_nibbles + 1) / 2);
+	int rc = g->d_bin.ensure(bytes + 64);
+	if (rc == CVX_OK) rc = g->d_starts.ensure((size_t) n_starts);
+	if (rc != CVX_OK) { g->d_bin.release(); g->d_starts.release(); delete g; return rc; }
+	hipError_t e = hipMemset(g->d_bin.p, 0x44, g->d_bin.cap);        /* beyond the genome: N */
+	if (e == hipSuccess) e = hipMemcpy(g->d_bin.p, bin_ref, bytes, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(g->d_starts.p, start_table, (size_t) n_starts * sizeof(uint64_t), hipMemcpyHostToDevice);
+	if (e != hipSuccess) {
+		set_err("cvx_genome_upload: %s", hipGetErrorString(e));
+		g->d_bin.release(); g->d_starts.release(); delete g;
+		return CVX_ERR_HIP;
+	}
+	*out = g;
+	return CVX_OK;
+	ABI_GUARD_END
+}
+
+void cvx_genome_free(cvx_handle h, cvx_genome g) {
+	if (!g) return;
+	if (h) { (void) hipSetDevice(h->device); (void) hipDeviceSynchronize(); }
+	g->d_bin.release();
+	g->d_starts.release();
+	delete g;
+}
+
+int cvx_genome_decode(cvx_handle h, cvx_genome g, int32_t n, const uint64_t *position, const int32_t *length,
+		const uint64_t *out_offset, char *out) {
+	ABI_GUARD_BEGIN
+	if (!h || !g || n < 0 || (n > 0 && (!position || !length || !out_offset || !out))) { set_err("cvx_genome_decode: bad argument"); return CVX_ERR_ARG; }
+	if (n == 0) return CVX_OK;
+	HIP_TRY(hipSetDevice(h->device));
+	std::vector<WindowDesc> win((size_t) n);
+	uint64_t total = 0;
+	for (int i = 0; i < n; ++i) {
+		if (length[i] < 1) { set_err("cvx_genome_decode: window %d has length %d", i, length[i]); return CVX_ERR_ARG; }
+		win[(size_t) i].position = position[i];
+		win[(size_t) i].dst_off = total;
+		win[(size_t) i].n_chars = (int64_t) length[i] - 1;           /* the reference's last byte is the NUL */
+		total += (uint64_t) length[i];
+	}
+	DevBuf<uint8_t> d_out;
+	DevBuf<WindowDesc> d_win;
+	RC_TRY(d_out.ensure((size_t) total + 64));
+	int rc = d_win.ensure((size_t) n);
+	if (rc != CVX_OK) { d_out.release(); return rc; }
+	std::vector<uint8_t> host((size_t) total);
+	hipStream_t st = h->s_main;
+	hipError_t e = hipMemsetAsync(d_out.p, 0, (size_t) total, st);   /* the NUL that ends every window */
+	if (e == hipSuccess) e = hipMemcpyAsync(d_win.p, win.data(), (size_t) n * sizeof(WindowDesc), hipMemcpyHostToDevice, st);
+	if (e == hipSuccess) e = launch_decode_windows(g->d_bin.p, g->d_starts.p, g->n_starts, d_win.p, n, d_out.p, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out.p, (size_t) total, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	d_out.release();
+	d_win.release();
+	if (e != hipSuccess) { set_err("cvx_genome_decode: %s", hipGetErrorString(e)); return CVX_ERR_HIP; }
+	for (int i = 0; i < n; ++i) memcpy(out + out_offset[i], host.data() + win[(size_t) i].dst_off, (size_t) length[i]);
+	return CVX_OK;
+	ABI_GUARD_END
 }
 
 /* ------------------------------------------------------------------ sub-read scoring */

@@ -156,6 +156,12 @@ struct BatchSummary {      /* follows the result records in the same buffer */
 	int32_t n_redone;      /* tiles that needed the exact-tracking fill pass */
 };
 
+struct WindowDesc {        /* one reference window to decode from the resident genome (cvx_genome.hip) */
+	uint64_t position;     /* first base, concatenated-genome coordinates (ngmlr's onRefStart) */
+	uint64_t dst_off;      /* byte offset of the window's first character in the destination buffer */
+	int64_t n_chars;       /* characters to write = the reference call's sequenceLength - 1 (its NUL is not stored) */
+};
+
 struct FillArgs {
 	const uint8_t *seq;
 	const RowDesc2 *rows;

@@ -168,3 +168,38 @@ class ScoreOracle:
         out = np.zeros(n, dtype=np.float32)
         self.lib.score_oracle_batch(self.h, n, r, q, out.ctypes.data)
         return out
+
+
+DECODE_SO = os.path.join(HERE, "libdecode_oracle_port.so")
+
+
+class DecodeOracle:
+    """CPU restatement of ngmlr's genome encoding and DecodeRefSequenceExact (oracle/decode_oracle.c)."""
+
+    def __init__(self):
+        if not os.path.exists(DECODE_SO):
+            build("port")
+        self.lib = C.CDLL(DECODE_SO)
+        self.lib.decode_oracle_encoded_bytes.restype = C.c_uint64
+        self.lib.decode_oracle_encoded_bytes.argtypes = [C.c_int, C.c_void_p]
+        self.lib.decode_oracle_encode.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.decode_oracle_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_void_p]
+
+    def encode(self, seqs):
+        """-> (binref uint8[], nibbles, starts uint64[kept + 1])"""
+        n = len(seqs)
+        lens = np.array([len(x) for x in seqs], dtype=np.uint64)
+        arr = (C.c_char_p * max(n, 1))(*seqs)
+        nb = int(self.lib.decode_oracle_encoded_bytes(n, lens.ctypes.data))
+        binref = np.zeros(nb, dtype=np.uint8)
+        starts = np.zeros(n + 1, dtype=np.uint64)
+        nib = C.c_uint64()
+        kept = self.lib.decode_oracle_encode(n, arr, lens.ctypes.data, binref.ctypes.data, C.byref(nib), starts.ctypes.data)
+        return binref, int(nib.value), starts[:kept + 1].copy()
+
+    def window(self, binref, starts, pos: int, length: int) -> bytes:
+        out = np.zeros(length + 8, dtype=np.uint8)
+        b = np.ascontiguousarray(binref, dtype=np.uint8)
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        self.lib.decode_oracle_window(b.ctypes.data, st.ctypes.data, len(st), int(pos), int(length), out.ctypes.data)
+        return out[:length].tobytes()

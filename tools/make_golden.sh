@@ -27,6 +27,45 @@ assert m, "construction site not found"
 s = s[:m.start()] + 'aligner = new RecordingAligner(new Convex::ConvexAlignFast(' + m.group(1) + '));' + s[m.end():]
 open(p, 'w').write(s)
 PY
+# the reference's own 4-bit genome encoding and every window it decodes for an alignment
+# (SURVEY 8 f4): two more pass-through hooks in the temporary copy, switched on by environment variables
+python3 - "$T/src" <<'PY'
+import sys
+src = sys.argv[1]
+p = src + '/SequenceProvider.cpp'
+s = open(p).read()
+anchor = 'refStartPos[j] = refStartPos[j - 1] + SequenceProvider.GetRefLen(refCount - 1) + 1000;'
+assert s.count(anchor) == 1
+s = s.replace(anchor, anchor + """
+	if (getenv("CVX_RECORD_GENOME")) {   /* recorder hook (tools/make_golden.sh), not part of the reference */
+		FILE * gf = fopen(getenv("CVX_RECORD_GENOME"), "wb");
+		unsigned long long nib = binRefIndex, ns = (unsigned long long) (j + 1);
+		fwrite(&nib, 8, 1, gf); fwrite(&ns, 8, 1, gf);
+		for (int q = 0; q <= j; ++q) { unsigned long long v = refStartPos[q]; fwrite(&v, 8, 1, gf); }
+		fwrite(binRef, 1, (size_t) (nib / 2), gf);
+		fclose(gf);
+	}
+""")
+open(p, 'w').write(s)
+p = src + '/AlignmentBuffer.cpp'
+s = open(p).read()
+anchor = 'if (!SequenceProvider.DecodeRefSequenceExact(refSeq, onRefStart, refSeqLength, 0)) {'
+assert s.count(anchor) == 1
+s = s.replace(anchor, """{ bool cvx_ok = SequenceProvider.DecodeRefSequenceExact(refSeq, onRefStart, refSeqLength, 0);
+			if (cvx_ok && getenv("CVX_RECORD_DECODE")) {   /* recorder hook, not part of the reference */
+				FILE * df = fopen(getenv("CVX_RECORD_DECODE"), "ab");
+				unsigned long long pos = (unsigned long long) onRefStart; int len = refSeqLength;
+				fwrite(&pos, 8, 1, df); fwrite(&len, 4, 1, df); fwrite(refSeq, 1, (size_t) len, df);
+				fclose(df);
+			}
+		if (!cvx_ok) {""")
+# close the extra brace after the if-block: the block ends with "refSeq = 0;\n\t\t}"
+tail = 'delete[] refSeq;\n\t\t\trefSeq = 0;\n\t\t}'
+assert s.count(tail) >= 1
+i = s.index(tail, s.index('cvx_ok'))
+s = s[:i + len(tail)] + ' }' + s[i + len(tail):]
+open(p, 'w').write(s)
+PY
 mkdir -p "$T/build" && cd "$T/build"
 cmake .. -DCMAKE_POLICY_VERSION_MINIMUM=3.5 -DCMAKE_BUILD_TYPE=RELWITHDEBINFO > "$WORK/cmake.log" 2>&1
 make -j16 > "$WORK/make.log" 2>&1
@@ -35,7 +74,8 @@ echo "built $BIN"
 D="$T/test/data"
 run() { # name, args...
   local name=$1; shift
-  CVX_RECORD="$WORK/$name.rec" "$BIN" --skip-write "$@" > "$WORK/$name.sam" 2> "$WORK/$name.log" || true
+  CVX_RECORD="$WORK/$name.rec" CVX_RECORD_GENOME="$WORK/$name.genome" CVX_RECORD_DECODE="$WORK/$name.decode" \
+    "$BIN" --skip-write "$@" > "$WORK/$name.sam" 2> "$WORK/$name.log" || true
   echo "$name: $(grep -vc '^@' "$WORK/$name.sam") SAM records, $(stat -c %s "$WORK/$name.rec" 2>/dev/null || echo 0) bytes recorded"
 }
 run test_2 -t 1 -r "$D/test_2/ref_chr21_20kb.fa" -q "$D/test_2/reads_100_2200bp.fa"
@@ -74,5 +114,6 @@ import os, sys
 sys.path.insert(0, sys.argv[1])
 import pack_golden
 pack_golden.pack(pack_golden.read_records(os.path.join(sys.argv[2], 'test_3.rec')), os.path.join(sys.argv[3], 'ref_test_3_full.npz'))
+pack_golden.pack_decode(sys.argv[2], 'test_3', os.path.join(sys.argv[3], 'decode_test_3_full.npz'))
 PY
 rm -rf "$WORK"

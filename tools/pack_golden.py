@@ -61,6 +61,41 @@ def pack(recs, out, max_tiles=None, max_cells=None):
     print('%s: %d tiles (%d recorded), %.1f Mcells, %d bytes' % (out, len(keep), len(recs), cells / 1e6, os.path.getsize(out)))
 
 
+def read_genome(path):
+    data = open(path, 'rb').read()
+    nib, ns = struct.unpack_from('<2Q', data, 0)
+    starts = np.frombuffer(data, dtype='<u8', count=ns, offset=16).copy()
+    binref = np.frombuffer(data, dtype=np.uint8, count=nib // 2, offset=16 + 8 * ns).copy()
+    return nib, starts, binref
+
+
+def read_decodes(path):
+    data = open(path, 'rb').read()
+    pos = 0
+    out = []
+    while pos < len(data):
+        p, ln = struct.unpack_from('<Qi', data, pos); pos += 12
+        out.append((p, ln, data[pos:pos + ln])); pos += ln
+    return out
+
+
+def pack_decode(work, name, out, max_windows=None):
+    """The reference's encoded genome (binRef nibbles, chromosome start table) and the windows
+    DecodeRefSequenceExact produced for its alignments: position, length, the decoded bytes."""
+    nib, starts, binref = read_genome(os.path.join(work, name + '.genome'))
+    dec = read_decodes(os.path.join(work, name + '.decode'))
+    if max_windows is not None and len(dec) > max_windows:
+        # keep the interesting ones first: windows holding 'x' (outside a chromosome) or 'N', odd start positions
+        key = lambda d: (-(b'x' in d[2][:-1]), -(b'N' in d[2][:-1]), -(d[0] & 1))  # noqa: E731
+        dec = sorted(dec, key=key)[:max_windows]
+    d = {'nibbles': np.uint64(nib), 'starts': starts, 'binref': binref, 'n': np.int32(len(dec)),
+         'pos': np.array([x[0] for x in dec], dtype=np.uint64), 'len': np.array([x[1] for x in dec], dtype=np.int32),
+         'off': np.concatenate([[0], np.cumsum([x[1] for x in dec])]).astype(np.int64),
+         'bytes': np.frombuffer(b''.join(x[2] for x in dec), dtype=np.uint8)}
+    np.savez_compressed(out, **d)
+    print('%s: genome %d nibbles, %d chromosome starts, %d decoded windows, %d bytes' % (out, nib, len(starts), len(dec), os.path.getsize(out)))
+
+
 if __name__ == '__main__':
     work, outdir = sys.argv[1], sys.argv[2]
     os.makedirs(outdir, exist_ok=True)
@@ -68,3 +103,7 @@ if __name__ == '__main__':
     pack(read_records(os.path.join(work, 'test_4.rec')), os.path.join(outdir, 'ref_test_4.npz'))
     # test_3: ~985 calls; keep the first 60 below 2.5 Mcells (fixture size)
     pack(read_records(os.path.join(work, 'test_3.rec')), os.path.join(outdir, 'ref_test_3.npz'), max_tiles=60, max_cells=2500000)
+    # genome encoding + decoded windows: all of test_2 / test_4, a sample of test_3
+    pack_decode(work, 'test_2', os.path.join(outdir, 'decode_test_2.npz'))
+    pack_decode(work, 'test_4', os.path.join(outdir, 'decode_test_4.npz'))
+    pack_decode(work, 'test_3', os.path.join(outdir, 'decode_test_3.npz'), max_windows=40)
