@@ -20,7 +20,8 @@ struct ScorePair {
 	uint64_t scratch_off;        /* int offset of this pair's two DP rows */
 	int32_t ref_len, qry_len;    /* strlen + 1 */
 };
-hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scratch, float *out, int n, hipStream_t st);
+/* max_ref_len: longest reference string of the batch incl. its NUL (<= 512: rows in registers, four pairs per workgroup) */
+hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scratch, float *out, int n, int max_ref_len, hipStream_t st);
 
 /* reference windows from the 4-bit genome resident in HBM (cvx_genome.hip) */
 hipError_t launch_decode_windows(const uint8_t *bin, const uint64_t *starts, int n_starts,

@@ -1090,9 +1090,11 @@ int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char
 	RC_TRY(h->sc_hout.ensure((size_t) n * sizeof(float)));
 	ScorePair *pairs = h->sc_hpairs.as<ScorePair>();
 	uint64_t bytes = 0, rows = 0;
+	size_t max_rl = 0;
 	for (int i = 0; i < n; ++i) {
 		if (!refs[i] || !qrys[i]) { set_err("cvx_score_batch: NULL sequence %d", i); return CVX_ERR_ARG; }
 		const size_t rl = strlen(refs[i]) + 1, ql = strlen(qrys[i]) + 1;
+		max_rl = std::max(max_rl, rl);
 		ScorePair &p = pairs[i];
 		p.ref_off = bytes; bytes += rl;
 		p.qry_off = bytes; bytes += ql;
@@ -1114,7 +1116,7 @@ int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char
 	hipStream_t st = h->s_main;
 	HIP_TRY(hipMemcpyAsync(h->sc_seq.p, hseq, (size_t) ((bytes + 255) / 256 * 256), hipMemcpyHostToDevice, st));   /* dword-aligned size: SDMA, not a blit kernel */
 	HIP_TRY(hipMemcpyAsync(h->sc_pairs.p, pairs, (size_t) n * sizeof(ScorePair), hipMemcpyHostToDevice, st));
-	HIP_TRY(launch_score(h->sc_seq.p, h->sc_pairs.p, h->sc_rows.p, h->sc_out.p, n, st));
+	HIP_TRY(launch_score(h->sc_seq.p, h->sc_pairs.p, h->sc_rows.p, h->sc_out.p, n, (int) std::min<size_t>(max_rl, 0x7fffffff), st));
 	HIP_TRY(hipMemcpyAsync(h->sc_hout.p, h->sc_out.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	memcpy(scores, h->sc_hout.p, (size_t) n * sizeof(float));

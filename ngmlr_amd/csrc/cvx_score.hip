@@ -13,7 +13,14 @@
  * left dependency of a row is a max-plus scan: with a_k = max(0, diag + s, up - 255),
  * H[j] = max_{k<=j}(a_k + 255 k) - 255 j, i.e. an inclusive prefix MAX of a_k + 255 k --
  * done with 6 DPP/shuffle steps per 64 columns plus a carry between 64-column chunks.
- * Integer arithmetic, exact.  Rows live in a small global scratch (L1/L2 resident).
+ * Integer arithmetic, exact.
+ *
+ * score_reg_kernel<KC> is the kernel for the shape the reference actually batches (1024 pairs of a
+ * 256-base sub-read against a ~300-base window, src/ScoreBuffer.cpp:87-168): the previous DP row
+ * lives in registers -- lane l holds columns l, l + 64, ... (KC <= 8 chunks, windows up to 512
+ * columns) --, the diagonal input is a one-lane shuffle, nothing touches memory inside the row
+ * loop, and four pairs share a workgroup.  score_kernel keeps rows in a global scratch and takes
+ * whatever is longer (the inversion checks on kb-long sequences).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -85,9 +92,68 @@ score_kernel(const uint8_t *seq, const ScorePair *pairs, int32_t *scratch, float
 	if (lane == 0) out[p] = (float) best;
 }
 
-hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scratch, float *out, int n, hipStream_t st) {
+template <int KC>
+__global__ void __launch_bounds__(256)
+score_reg_kernel(const uint8_t *seq, const ScorePair *pairs, float *out, int n) {
+	const int lane = threadIdx.x & 63;
+	const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (p >= n) return;                                  /* wave-uniform */
+	const ScorePair pr = pairs[p];
+	const int R = pr.ref_len, Q = pr.qry_len;            /* lengths include the NUL (:131-132) */
+	if (R >= 100000 || Q >= 100000) {                    /* maxSeqLen, src/StrippedSW.h:88 */
+		if (lane == 0) out[p] = -1.0f;
+		return;
+	}
+	const uint8_t *ref = seq + pr.ref_off;
+	const uint8_t *qry = seq + pr.qry_off;
+	int rcode[KC], prev[KC];
+#pragma unroll
+	for (int k = 0; k < KC; ++k) {
+		const int j = lane + 64 * k;
+		rcode[k] = j < R ? nt_code(ref[j]) : 4;
+		prev[k] = 0;
+	}
+	int best = 0;
+	for (int i = 0; i < Q; ++i) {
+		const int qc = nt_code(qry[i]);
+		int carry = -0x40000000;                         /* max over the columns so far of a + 255 * column */
+		int prev_last = 0;                               /* H[i-1][64k - 1]: the diagonal input of a chunk's first column */
+#pragma unroll
+		for (int k = 0; k < KC; ++k) {
+			const int j = lane + 64 * k;
+			if (64 * k < R) {                            /* wave-uniform */
+				const bool valid = j < R;
+				const int up = prev[k];
+				int dg = __shfl_up(up, 1, 64);
+				if (lane == 0) dg = prev_last;           /* column 0 of the matrix: 0 */
+				prev_last = __builtin_amdgcn_readlane(up, 63);
+				const int s = (qc == 4 || rcode[k] == 4) ? 0 : (qc == rcode[k] ? 1 : -1);
+				int a = max(max(dg + s, up - 255), 0);
+				int key = valid ? a + 255 * j : -0x40000000;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) {
+					const int t = __shfl_up(key, d, 64);
+					if (lane >= d) key = max(key, t);
+				}
+				key = max(key, carry);
+				carry = __builtin_amdgcn_readlane(key, 63);
+				const int h = valid ? key - 255 * j : 0;
+				prev[k] = h;
+				best = max(best, h);
+			}
+		}
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
+	if (lane == 0) out[p] = (float) best;
+}
+
+hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scratch, float *out, int n, int max_ref_len, hipStream_t st) {
 	if (n <= 0) return hipSuccess;
-	hipLaunchKernelGGL(score_kernel, dim3(n), dim3(64), 0, st, seq, pairs, scratch, out, n);
+	const int blocks = (n + 3) / 4;
+	if (max_ref_len <= 64 * 5) hipLaunchKernelGGL(score_reg_kernel<5>, dim3(blocks), dim3(256), 0, st, seq, pairs, out, n);
+	else if (max_ref_len <= 64 * 8) hipLaunchKernelGGL(score_reg_kernel<8>, dim3(blocks), dim3(256), 0, st, seq, pairs, out, n);
+	else hipLaunchKernelGGL(score_kernel, dim3(n), dim3(64), 0, st, seq, pairs, scratch, out, n);
 	return hipGetLastError();
 }
 

@@ -36,3 +36,61 @@ def test_reference_batch_shape_1024_pairs(built):
     assert np.array_equal(sw.batch_score(refs, qrys), ScoreOracle("port").scores(refs, qrys))
     assert sw.batch_score([b"A" * 100000], [b"ACGT"])[0] == -1.0
     sw.close()
+
+
+def _oracle_scores_threaded(refs, qrys, kind="port", threads=16):
+    import threading
+    from oracle.pyoracle import ScoreOracle
+    n = len(refs)
+    out = np.zeros(n, dtype=np.float32)
+    step = (n + threads - 1) // threads
+
+    def work(k):
+        lo, hi = k * step, min(n, (k + 1) * step)
+        if lo < hi:
+            out[lo:hi] = ScoreOracle(kind).scores(refs[lo:hi], qrys[lo:hi])
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    return out
+
+
+def test_hundred_thousand_pairs_including_the_255_switch(built):
+    """parity at >= 1e5 pairs.  ScoreBuffer-shaped pairs (register-resident kernel, windows of
+    up to 512 columns) with identities from 0 to 100 %: scores from 0 to above 255, where ssw leaves its 8-bit
+    kernel (a 255-per-base gap can pay there), plus N / x / lower case; in batches of 1024 like the reference
+    (src/StrippedSW.h:53-55) and as one call."""
+    from ngmlr_amd import synth
+    from ngmlr_amd.aligner import StrippedSWHip
+    rng = np.random.default_rng(2026)
+    refs, qrys = [], []
+    for i in range(100000):
+        k = i % 5
+        if k == 0:
+            w = synth.random_ref(rng, 308)
+            a = int(rng.integers(0, 50))
+            q = synth.mutate(rng, w[a:a + 256], float(rng.choice([0.0, 0.02, 0.1, 0.25])))[:256]
+        elif k == 1:                                    # up to 500 columns, score well past 255
+            L = int(rng.integers(257, 480))
+            w = synth.random_ref(rng, L + 20)
+            q = synth.mutate(rng, w[10:10 + L], float(rng.choice([0.0, 0.004, 0.02])))
+        elif k == 2:
+            w = synth.random_ref(rng, int(rng.integers(1, 330)))
+            q = synth.random_ref(rng, int(rng.integers(0, 260)))
+        elif k == 3:
+            w = synth.random_ref(rng, 300, n_frac=0.05, x_frac=0.03)
+            q = synth.mutate(rng, w, 0.05, n_frac=0.03)[:280]
+        else:
+            L = int(rng.integers(250, 262))             # exactly around the switch
+            w = np.frombuffer(synth.random_ref(rng, L + 20).tobytes().lower(), dtype=np.uint8)
+            q = np.frombuffer(w[10:10 + L].tobytes().upper(), dtype=np.uint8)
+        refs.append(w.tobytes())
+        qrys.append(q.tobytes())
+    want = _oracle_scores_threaded(refs, qrys)
+    assert want.max() > 400 and (want > 255).sum() > 10000 and (want == 0).sum() > 0
+    sw = StrippedSWHip(device=0)
+    got = sw.batch_score(refs, qrys)
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
+    for lo in range(0, 8192, 1024):
+        assert np.array_equal(sw.batch_score(refs[lo:lo + 1024], qrys[lo:lo + 1024]), want[lo:lo + 1024])
+    sw.close()

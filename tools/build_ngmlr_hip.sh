@@ -17,10 +17,12 @@ mkdir -p "$REPO/oracle/_ref"
 # build_variant OUT_NAME ALIGNER_CLASS: the class constructed at src/AlignmentBuffer.h:355
 #   ngmlr_hip          Convex::ConvexAlignHip  one private aligner per worker, one tile per launch
 #   ngmlr_hip_batched  Convex::SharedAligner   all -t N workers share one BatchingAligner per device
+#   ngmlr_ref          (nothing changed)       the unmodified reference, for wall-clock comparison only
 build_variant() {
 local OUT_NAME=$1 CLASS=$2
 local T="$WORK/$OUT_NAME"
 cp -r /root/reference "$T"
+if [ "$CLASS" != "unmodified" ]; then
 python3 - "$T" "$REPO" "$CLASS" <<'PY'
 import re, sys
 T, REPO, CLASS = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -37,6 +39,7 @@ c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninc
 c = c.replace('TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})', 'TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})\nTARGET_LINK_LIBRARIES(ngmlr %s/ngmlr_amd/libcvxalign.so)\nset_target_properties(ngmlr PROPERTIES BUILD_RPATH "\\$ORIGIN/../../ngmlr_amd;/opt/rocm/lib" SKIP_BUILD_RPATH FALSE)' % REPO, 1)
 open(p, 'w').write(c)
 PY
+fi
 mkdir -p "$T/build" && cd "$T/build"
 cmake .. -DCMAKE_POLICY_VERSION_MINIMUM=3.5 -DCMAKE_BUILD_TYPE=RELWITHDEBINFO > "$WORK/$OUT_NAME.cmake.log" 2>&1
 make -j16 > "$WORK/$OUT_NAME.make.log" 2>&1 || { tail -30 "$WORK/$OUT_NAME.make.log"; exit 1; }
@@ -46,6 +49,7 @@ echo "built $REPO/oracle/_ref/$OUT_NAME"
 }
 build_variant ngmlr_hip Convex::ConvexAlignHip &
 build_variant ngmlr_hip_batched Convex::SharedAligner &
+build_variant ngmlr_ref unmodified &     # the reference as it is: wall-clock yardstick of tools/e2e_rates.py
 wait
 test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched"
 readelf -d "$REPO/oracle/_ref/ngmlr_hip" | grep -E "RPATH|RUNPATH|NEEDED" | head
