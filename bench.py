@@ -290,16 +290,37 @@ def main() -> int:
             cpu, parity, parity_detail = cpu_baseline_and_parity(w0.al, ts, res, ops, args.cpu_seconds)
         # host text stage (CIGAR/MD/NM) of a sample on all host threads: reported beside `value`
         text_stage = None
+        host_txt = []
         try:
             from ngmlr_amd.aligner import format_tileset
             k = min(len(ts), 2048)
             c0 = time.perf_counter()
-            format_tileset(w0.al.lib, ts, np.arange(k), res, ops)
+            host_txt = format_tileset(w0.al.lib, ts, np.arange(k), res, ops)
             dtxt = time.perf_counter() - c0
             text_stage = {"Gbp_per_h": float(ts.H[:k].sum()) / dtxt * 3600.0 / 1e9, "seconds": dtxt, "tiles": k,
                           "threads": os.cpu_count(), "what": "cvx_format_batch (CIGAR + MD + NM) incl. the python marshalling of this bench"}
         except Exception as e:  # never let the extra measurement break the contract line
             text_stage = {"error": str(e)}
+        # the same stage on the device (cvx_job_text): CIGAR + MD + fields of ALL tiles of the step, strings back on the host
+        text_dev = None
+        try:
+            w0.last.text_raw()                                # first call allocates the job's text buffers
+            c0 = time.perf_counter()
+            trec, toff, tbuf = w0.last.text_raw()
+            dtd = time.perf_counter() - c0
+            nbad = 0
+            if text_stage and "error" not in text_stage:
+                raw = tbuf.raw
+                for i_, h_ in enumerate(host_txt):            # cross-check against the host form on its sample
+                    t_ = trec[i_]
+                    o_ = int(toff[i_])
+                    if h_["cigar"] is None or raw[o_:o_ + t_.cigar_len].decode() != h_["cigar"] or raw[o_ + t_.cigar_len + 1:o_ + t_.cigar_len + 1 + t_.md_len].decode() != h_["md"]:
+                        nbad += 1
+            text_dev = {"Gbp_per_h": float(ts.read_bases) / dtd * 3600.0 / 1e9, "seconds": dtd, "tiles": len(ts), "text_bytes": len(tbuf),
+                        "equal_to_host_form": "%d/%d" % (len(host_txt) - nbad, len(host_txt)),
+                        "what": "cvx_job_text: text_kernel (lengths + fields), offsets scan, text_kernel (strings), D2H of the dense text"}
+        except Exception as e:
+            text_dev = {"error": str(e)}
         valid = w0.valid
         w0.last.release()
         # the same step with inputs already resident in HBM (plan -> fill -> backtrack -> compaction)
@@ -398,6 +419,7 @@ def main() -> int:
             "parity_detail": parity_detail,
             "cpu_baseline": cpu,
             "text_stage_host": text_stage,
+            "text_stage_device": text_dev,
             "tile_generation_s": t_gen,
         }
     for w in workers:

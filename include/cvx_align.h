@@ -28,6 +28,7 @@
  *                             (what a batching host driver needs, SURVEY.md 8 f1;
  *                              reference src/AlignmentBuffer.cpp:3361-3406)
  * cvx_format_alignment        convertCigar + N-clip flags    src/ConvexAlignFast.cpp:112-333,493-528
+ * cvx_job_text                the same for a whole finished job, on the device (next-row f3)
  * cvx_score_batch             StrippedSW::BatchScore/SingleScore  src/StrippedSW.cpp:118-203 (next-row f2)
  * cvx_genome_* / cvx_submit_windows  SequenceProvider's 4-bit genome + DecodeRefSequenceExact
  *                             src/SequenceProvider.cpp:333-386,475-565 (next-row f4, decode half)
@@ -278,6 +279,16 @@ typedef struct {
 int cvx_format_batch(int32_t n, const cvx_result *results, const uint32_t *ops_arena,
 		const cvx_tile *tiles, const cvx_text_buffers *bufs, cvx_alignment_text *out,
 		int32_t n_threads);
+
+/* The same on the device: CIGAR, MD and the scalar fields of every tile of a finished
+ * job, from the ops and sequences still resident in HBM -- one launch instead of a host core per ~70 Mbp/s.
+ * After cvx_wait and before cvx_job_release.  ext_qstart / ext_qend: externalQStart / externalQEnd per
+ * tile (NULL = zeros).  out[i] = what cvx_format_alignment would return for tile i (nm_count = the number
+ * of profile entries the host form would write; the profile itself stays with the host form).  *text
+ * points at page-locked memory owned by the job, valid until cvx_job_release: tile i's CIGAR is the
+ * NUL-terminated string at (*text)[text_off[i]], its MD follows that NUL. */
+int cvx_job_text(cvx_handle h, cvx_job job, const int32_t *ext_qstart, const int32_t *ext_qend,
+		cvx_alignment_text *out, uint64_t *text_off, const char **text, uint64_t *text_bytes);
 
 #ifdef __cplusplus
 }

@@ -163,6 +163,41 @@ class Job:
             out.append({k: getattr(li, k) for k, _ in capi.CvxLaunchInfo._fields_})
         return out
 
+    def text_raw(self, ext_qstart=None, ext_qend=None):
+        """cvx_job_text: the device-side text stage of every tile of this finished job.
+        -> (cvx_alignment_text array, text offsets uint64[n], text bytes)"""
+        n = self.n
+        out = (capi.CvxAlignmentText * max(n, 1))()
+        off = np.zeros(max(n, 1), dtype=np.uint64)
+        text = C.c_char_p()
+        nbytes = C.c_uint64()
+        eq = np.ascontiguousarray(ext_qstart, dtype=np.int32) if ext_qstart is not None else None
+        ee = np.ascontiguousarray(ext_qend, dtype=np.int32) if ext_qend is not None else None
+        lib = self.al.lib
+        lib.cvx_job_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(capi.CvxAlignmentText),
+                                     C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        tp = C.c_void_p()
+        capi.check(lib.cvx_job_text(self.al.h, self.j, eq.ctypes.data if eq is not None else None,
+                                    ee.ctypes.data if ee is not None else None, out, off.ctypes.data,
+                                    C.byref(tp), C.byref(nbytes)))
+        buf = (C.c_char * int(nbytes.value)).from_address(tp.value) if nbytes.value else None
+        return out, off, buf
+
+    def text(self, ext_qstart=None, ext_qend=None) -> List[dict]:
+        """-> one dict per tile with the cvx_alignment_text fields + 'cigar' / 'md' (device-side text stage)."""
+        out, off, buf = self.text_raw(ext_qstart, ext_qend)
+        raw = buf.raw if buf is not None else b""
+        res = []
+        for i in range(self.n):
+            t = out[i]
+            d = {f: getattr(t, f) for f, _ in capi.CvxAlignmentText._fields_}
+            d["score_bits"] = int(np.float32(t.score).view(np.uint32))
+            o = int(off[i])
+            d["cigar"] = raw[o:o + t.cigar_len].decode()
+            d["md"] = raw[o + t.cigar_len + 1:o + t.cigar_len + 1 + t.md_len].decode()
+            res.append(d)
+        return res
+
     def release(self) -> None:
         if self.j:
             self.al.lib.cvx_job_release(self.al.h, self.j)

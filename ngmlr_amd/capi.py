@@ -24,7 +24,7 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_submit", "cvx_wait", "cvx_job_timing", "cvx_job_launch_info", "cvx_job_release",
            "cvx_format_alignment", "cvx_format_batch", "cvx_score_batch",
            "cvx_genome_encoded_bytes", "cvx_genome_encode", "cvx_genome_upload", "cvx_genome_free",
-           "cvx_genome_decode", "cvx_submit_windows")
+           "cvx_genome_decode", "cvx_submit_windows", "cvx_job_text")
 
 
 class CvxParams(C.Structure):
@@ -129,6 +129,8 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_genome_free.restype = None
     lib.cvx_genome_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cvx_submit_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(CvxTile), C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.cvx_job_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CvxAlignmentText), C.c_void_p,
+                                 C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     lib.cvx_score_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p]
     lib.cvx_format_alignment.argtypes = [C.POINTER(CvxResult), C.c_void_p, C.c_char_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,

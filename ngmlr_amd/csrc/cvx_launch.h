@@ -27,6 +27,10 @@ hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scr
 hipError_t launch_decode_windows(const uint8_t *bin, const uint64_t *starts, int n_starts,
 		const WindowDesc *win, int n, uint8_t *dst, hipStream_t st);
 
+/* device-side text stage (cvx_text.hip): lengths + fields + offsets, then the strings */
+hipError_t launch_text_size(const TextArgs &a, hipStream_t st);
+hipError_t launch_text_write(const TextArgs &a, hipStream_t st);
+
 /* catch-all kernel (cvx_generic.hip): any ring size, state in a global scratch */
 size_t generic_scratch_bytes(int ring);
 /* sse_variant: the reference's SSE-path semantics for scoring outside the scalar-equivalent regime */

@@ -172,6 +172,12 @@ struct cvx_batch_s {
 	DevBuf<uint8_t> d_gscratch;      /* slot state of tiles taken by the catch-all kernel */
 	DevBuf<uint64_t> d_gscratch_off;
 	/* chained tiles (row blocks) */
+	/* device-side text stage (cvx_job_text) */
+	PinBuf h_ext, h_trec, h_toff, h_text;
+	DevBuf<int32_t> d_ext;
+	DevBuf<TextRec> d_trec;
+	DevBuf<unsigned long long> d_tlen;   /* lengths, offsets, total */
+	DevBuf<uint8_t> d_text;
 	PinBuf h_win;                    /* WindowDesc[n]: reference windows decoded on the device (cvx_submit_windows) */
 	DevBuf<WindowDesc> d_win;
 	PinBuf h_chain;                  /* ChainTask[] of all chain classes, ChainBlk[], tile lists */
@@ -206,6 +212,8 @@ struct cvx_batch_s {
 		d_counters.release(); d_dstoff.release(); d_dense.release(); d_res.release();
 		d_gscratch.release(); d_gscratch_off.release();
 		h_win.release(); d_win.release();
+		h_ext.release(); h_trec.release(); h_toff.release(); h_text.release();
+		d_ext.release(); d_trec.release(); d_tlen.release(); d_text.release();
 		h_chain.release(); d_chain.release(); d_progress.release(); d_bnd.release(); d_chain_out.release();
 		if (ev_in) { (void) hipEventDestroy(ev_in); ev_in = nullptr; }
 		if (ev_res) { (void) hipEventDestroy(ev_res); ev_res = nullptr; }
@@ -1001,6 +1009,68 @@ void cvx_job_release(cvx_handle h, cvx_job j) {
 		if (j->state >= kPlanned && j->state < kFinished) (void) hipDeviceSynchronize();   /* released without waiting */
 	}
 	recycle_batch(h, j);
+}
+
+/* ------------------------------------------------------------------ device-side text stage */
+
+int cvx_job_text(cvx_handle h, cvx_job j, const int32_t *ext_qstart, const int32_t *ext_qend,
+		cvx_alignment_text *out, uint64_t *text_off, const char **text, uint64_t *text_bytes) {
+	ABI_GUARD_BEGIN
+	static_assert(sizeof(TextRec) == sizeof(cvx_alignment_text), "TextRec mirrors cvx_alignment_text");
+	if (!h || !j || j->state < kFinished) { set_err("cvx_job_text: job not finished (call cvx_wait first)"); return CVX_ERR_ARG; }
+	const int n = j->n;
+	if (n > 0 && (!out || !text_off || !text)) { set_err("cvx_job_text: NULL output"); return CVX_ERR_ARG; }
+	if (text_bytes) *text_bytes = 0;
+	if (n == 0) { if (text) *text = ""; return CVX_OK; }
+	HIP_TRY(hipSetDevice(h->device));
+	hipStream_t st = h->s_main;
+	const size_t n1 = (size_t) n;
+	TextArgs a;
+	a.ext_qstart = a.ext_qend = nullptr;
+	if (ext_qstart || ext_qend) {
+		RC_TRY(j->h_ext.ensure(2 * n1 * sizeof(int32_t)));
+		RC_TRY(j->d_ext.ensure(2 * n1));
+		int32_t *he = j->h_ext.as<int32_t>();
+		for (int i = 0; i < n; ++i) { he[i] = ext_qstart ? ext_qstart[i] : 0; he[n1 + (size_t) i] = ext_qend ? ext_qend[i] : 0; }
+		HIP_TRY(hipMemcpyAsync(j->d_ext.p, he, 2 * n1 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+		a.ext_qstart = j->d_ext.p;
+		a.ext_qend = j->d_ext.p + n1;
+	}
+	RC_TRY(j->d_trec.ensure(n1));
+	RC_TRY(j->d_tlen.ensure(2 * n1 + 8));
+	RC_TRY(j->h_trec.ensure(n1 * sizeof(TextRec)));
+	RC_TRY(j->h_toff.ensure((n1 + 1) * sizeof(unsigned long long)));
+	a.seq = j->d_seq.p;
+	a.tin = j->d_tin.p;
+	a.trun = j->d_trun.p;
+	a.tout = j->d_tout.p;
+	a.ops = j->d_regions.p;
+	a.recs = j->d_trec.p;
+	a.text_len = j->d_tlen.p;
+	a.text_off = j->d_tlen.p + n1;
+	a.text_total = j->d_tlen.p + 2 * n1;
+	a.text = nullptr;
+	a.n_tiles = n;
+	/* pass 1: lengths, fields, offsets; the total comes back with the offsets */
+	HIP_TRY(launch_text_size(a, st));
+	unsigned long long *hoff = j->h_toff.as<unsigned long long>();
+	HIP_TRY(hipMemcpyAsync(hoff, a.text_off, (n1 + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(j->h_trec.p, j->d_trec.p, n1 * sizeof(TextRec), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const unsigned long long total = hoff[n1];
+	/* pass 2: the strings */
+	RC_TRY(j->d_text.ensure((size_t) total + 64));
+	RC_TRY(j->h_text.ensure((size_t) total + 64));
+	a.text = j->d_text.p;
+	HIP_TRY(launch_text_write(a, st));
+	HIP_TRY(hipMemcpyAsync(j->h_text.p, j->d_text.p, (size_t) ((total + 255) / 256 * 256 <= j->d_text.cap ? (total + 255) / 256 * 256 : total), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	memcpy(out, j->h_trec.p, n1 * sizeof(TextRec));
+	for (int i = 0; i < n; ++i) text_off[i] = hoff[i];
+	*text = j->h_text.as<char>();
+	if (text_bytes) *text_bytes = total;
+	return CVX_OK;
+	ABI_GUARD_END
 }
 
 /* ------------------------------------------------------------------ resident genome (decode half) */

@@ -162,6 +162,32 @@ struct WindowDesc {        /* one reference window to decode from the resident g
 	int64_t n_chars;       /* characters to write = the reference call's sequenceLength - 1 (its NUL is not stored) */
 };
 
+struct TextRec {           /* same layout as cvx_alignment_text (include/cvx_align.h), written by text_kernel */
+	int32_t ret;
+	float score;
+	int32_t position_offset, qstart, qend, nm;
+	float identity;
+	int32_t alignment_length, cigar_op_count, sv_type;
+	int32_t first_ref, first_read, last_ref, last_read;
+	int32_t nm_count, cigar_len, md_len;
+};
+
+struct TextArgs {          /* device-side text stage (cvx_text.hip) */
+	const uint8_t *seq;
+	const TileIn *tin;
+	const TileRun *trun;
+	const TileOut *tout;
+	const int32_t *ops;            /* per-tile op regions */
+	const int32_t *ext_qstart;     /* per tile, or NULL for zeros */
+	const int32_t *ext_qend;
+	TextRec *recs;
+	unsigned long long *text_len;  /* bytes of tile t's two strings incl. their NULs */
+	unsigned long long *text_off;  /* exclusive prefix sum of text_len */
+	unsigned long long *text_total;
+	uint8_t *text;                 /* [cigar NUL md NUL] per tile, dense */
+	int32_t n_tiles;
+};
+
 struct FillArgs {
 	const uint8_t *seq;
 	const RowDesc2 *rows;

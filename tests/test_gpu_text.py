@@ -1,0 +1,66 @@
+"""GPU (-m gpu): the device-side text stage (cvx_job_text) against the host form
+(cvx_format_alignment, itself pinned to the reference's convertCigar by tests/test_host_format_cpu.py and
+the golden tiles): every cvx_alignment_text field, the identity bits, and the CIGAR / MD strings byte by
+byte -- over every corridor kind, external clips, long deletions and insertions, invalid tiles, tiles with
+hundreds of ops per 64-op step boundary, and full-size PacBio tiles."""
+import numpy as np
+import pytest
+
+from ngmlr_amd import capi
+from ngmlr_amd.aligner import format_alignment
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("ret", "score_bits", "position_offset", "qstart", "qend", "nm", "alignment_length", "cigar_op_count",
+          "sv_type", "first_ref", "first_read", "last_ref", "last_read", "nm_count", "cigar_len", "md_len", "cigar", "md")
+
+
+def _compare(al, tiles):
+    job = al.submit(tiles)
+    res, ops = job.wait()
+    eqs = np.array([t.ext_qstart for t in tiles], dtype=np.int32)
+    eqe = np.array([t.ext_qend for t in tiles], dtype=np.int32)
+    dev = job.text(eqs, eqe)
+    bad = []
+    n_valid = 0
+    for i, t in enumerate(tiles):
+        r = capi.CvxResult.from_buffer_copy(res[i].tobytes())
+        host = format_alignment(al.lib, r, ops, t)
+        d = dev[i]
+        n_valid += host["ret"] >= 0
+        for k in FIELDS:
+            if host[k] != d[k]:
+                bad.append((t.tag, k, str(host[k])[:60], str(d[k])[:60]))
+                break
+        else:
+            if np.float32(host["identity"]).view(np.uint32) != np.float32(d["identity"]).view(np.uint32):
+                bad.append((t.tag, "identity", host["identity"], d["identity"]))
+    job.release()
+    assert not bad, bad[:5]
+    return n_valid
+
+
+def test_text_stage_equals_host_form_on_the_zoo(hip_aligner):
+    assert _compare(hip_aligner, util.tile_zoo(seed=64, n=180, max_w=3000) + util.edge_tiles()) > 100
+
+
+def test_text_stage_on_golden_tiles(hip_aligner):
+    tiles = [t for name in ("ref_test_2.npz", "ref_test_4.npz", "ref_test_3.npz") for t, _ in util.load_golden(name)]
+    assert _compare(hip_aligner, tiles) > 40
+
+
+def test_text_stage_long_gaps_and_full_size(hip_aligner):
+    from ngmlr_amd import synth
+    rng = np.random.default_rng(21)
+    tiles = synth.workload_pacbio(6, seed=5) + synth.workload_ont(20, seed=6, max_len=9000)
+    from tests.test_gpu_parity import _sv_tile
+    # deletions / insertions of 70..400 bases: single ops whose MD text is hundreds of characters
+    tiles.append(_sv_tile(rng, 900, [70, 130], [65, 200], "full"))
+    tiles.append(_sv_tile(rng, 1300, [400], [257], "full"))
+    tiles.append(_sv_tile(rng, 700, [1, 2, 3, 33], [1, 2, 64], "endpoints"))
+    tiles.append(util.wrap16_tile(pre=3000, ins=400, post=2500, w=300))
+    for i, t in enumerate(tiles):
+        if i % 3 == 0:
+            t.ext_qstart, t.ext_qend = int(rng.integers(0, 5000)), int(rng.integers(0, 5000))
+    assert _compare(hip_aligner, tiles) > 20
