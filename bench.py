@@ -388,7 +388,7 @@ def main() -> int:
                 "corridor_width_max": int(wd.max()),
                 "cells_per_gpu_per_step": ts.cells,
                 "batches_in_flight_per_gpu": args.depth,
-                "h2d_bytes_per_gpu_per_step": int(ts.ref.nbytes + ts.qry.nbytes + ts.row_offset.nbytes + ts.row_length.nbytes),
+                "h2d_bytes_per_gpu_per_step": int(ts.ref.nbytes + ts.qry.nbytes + ts.row_offset.size),   # sequences + one step byte per corridor row
                 "launch": "torch.distributed.run, one rank per device" if under_launcher else "one process, one host thread + handle per device",
                 "sharding": "reads sharded across devices, no collective on the data path",
             },

@@ -80,6 +80,8 @@ struct UploadLayout {
 	uint64_t pad = 0;               /* zeroed bytes before the first and after the last sequence */
 	uint64_t seq_total = 0;         /* bytes of the seq arena */
 	uint64_t n_rows = 0;            /* entries of the rows arena */
+	uint64_t delta_total = 0;       /* bytes of the row-step stream (every tile's H bytes, 4-byte aligned) */
+	std::vector<RowSrc> rsrc;       /* per tile: where its rows come from (src_off = offset into the step stream until packed) */
 	bool windows = false;           /* references decoded on the device: [pad][qry...][pad][ref...][pad] */
 	uint64_t upload_bytes = 0;      /* leading part of the seq arena that is packed on the host and uploaded */
 	std::vector<uint64_t> wprefix;  /* packing work per tile (bytes moved), prefix sums */
@@ -114,8 +116,9 @@ inline int upload_layout(int n, const cvx_tile *tiles, std::vector<TileIn> &tin,
 	L.upload_bytes = windows ? (L.pad + qry_bytes + L.pad) : L.seq_total;
 	if (L.seq_total >= 0xFFFF0000ull) return kLayoutTooLarge;
 	tin.resize((size_t) n);
+	L.rsrc.assign((size_t) n, RowSrc());
 	L.wprefix.assign((size_t) n + 1, 0);
-	uint64_t so = L.pad, ro = 0;
+	uint64_t so = L.pad, ro = 0, dof = 0;
 	uint64_t rso = L.pad + qry_bytes + L.pad;       /* windows: where the decoded references start */
 	for (int i = 0; i < n; ++i) {
 		const cvx_tile &t = tiles[i];
@@ -134,8 +137,12 @@ inline int upload_layout(int n, const cvx_tile *tiles, std::vector<TileIn> &tin,
 		ti.row_off = ro;
 		ti.reserved = 0;
 		ro += (uint64_t) t.qry_len;
+		RowSrc &rs = L.rsrc[(size_t) i];
+		rs.src_off = dof; rs.off0 = 0; rs.width = 0; rs.fmt = kRowsDelta8; rs.pad = 0;
+		dof += ((uint64_t) t.qry_len + 3) / 4 * 4;
 		L.wprefix[(size_t) i + 1] = L.wprefix[(size_t) i] + (windows ? 0 : (uint64_t) t.ref_len) + 9ull * (uint64_t) t.qry_len + 64;
 	}
+	L.delta_total = dof;
 	return kLayoutOk;
 }
 
@@ -146,24 +153,75 @@ inline void upload_zero_pads(const UploadLayout &L, uint8_t *hseq) {
 	else memset(hseq + (size_t) (L.seq_total - L.pad - 64), 0, (size_t) L.pad + 64);
 }
 
-/* copies tiles [begin, end) into the staging arenas (callable from several threads at once) */
+/* Rows of the tiles that do not fit the one-byte form, collected by one packing thread. */
+struct RowOverflow {
+	std::vector<int32_t> tiles;        /* tile indices, in packing order */
+	std::vector<RowDesc> rows;         /* their rows, back to back */
+};
+
+/* copies tiles [begin, end) into the staging arenas (callable from several threads at once).  Rows go
+ * to the step stream `hdelta` (one byte per row: offset[y] - offset[y-1]; rsrc[i] gets row 0's offset and
+ * the common width); a tile whose width changes or whose offset jumps by more than a byte is marked
+ * kRowsExplicit and its rows are appended to `ovf` instead. */
 inline void upload_pack(int begin, int end, const cvx_tile *tiles, const std::vector<TileIn> &tin,
-		uint8_t *hseq, RowDesc *hrows, bool windows = false) {
+		uint8_t *hseq, uint8_t *hdelta, std::vector<RowSrc> &rsrc, RowOverflow &ovf, bool windows = false) {
 	for (int i = begin; i < end; ++i) {
 		const cvx_tile &t = tiles[i];
 		const TileIn &ti = tin[(size_t) i];
 		if (t.ref_len && !windows) memcpy(hseq + ti.ref_off, t.ref, (size_t) t.ref_len);
 		if (t.qry_len) memcpy(hseq + ti.qry_off, t.qry, (size_t) t.qry_len);
-		RowDesc *dst = hrows + ti.row_off;
+		RowSrc &rs = rsrc[(size_t) i];
 		const char *po = (const char *) t.row_offset;
 		const char *pl = (const char *) t.row_length;
 		const size_t stride = (size_t) t.row_stride_bytes;
-		for (int y = 0; y < t.qry_len; ++y) {
-			RowDesc rd;
-			memcpy(&rd.off, po + (size_t) y * stride, 4);
-			memcpy(&rd.len, pl + (size_t) y * stride, 4);
-			dst[y] = rd;
+		const int H = t.qry_len;
+		rs.fmt = kRowsDelta8;
+		if (H <= 0) continue;
+		int8_t *dst = reinterpret_cast<int8_t *>(hdelta + rs.src_off);
+		int32_t prev, w0;
+		memcpy(&prev, po, 4);
+		memcpy(&w0, pl, 4);
+		rs.off0 = prev;
+		rs.width = w0;
+		dst[0] = 0;
+		bool fits = true;
+		for (int y = 1; y < H; ++y) {
+			int32_t o, l;
+			memcpy(&o, po + (size_t) y * stride, 4);
+			memcpy(&l, pl + (size_t) y * stride, 4);
+			const int64_t d = (int64_t) o - (int64_t) prev;
+			if (l != w0 || d < -128 || d > 127) { fits = false; break; }
+			dst[y] = (int8_t) d;
+			prev = o;
 		}
+		if (!fits) {
+			rs.fmt = kRowsExplicit;
+			ovf.tiles.push_back(i);
+			const size_t at = ovf.rows.size();
+			ovf.rows.resize(at + (size_t) H);
+			for (int y = 0; y < H; ++y) {
+				RowDesc rd;
+				memcpy(&rd.off, po + (size_t) y * stride, 4);
+				memcpy(&rd.len, pl + (size_t) y * stride, 4);
+				ovf.rows[at + (size_t) y] = rd;
+			}
+		}
+	}
+}
+
+/* what expand_rows_kernel does on the device, for the host's own needs (chain planning, tests):
+ * the (offset, length) rows of tile i.  hrowsx: the explicit-rows buffer (rsrc[i].src_off indexes it). */
+inline void expand_rows_host(const RowSrc &rs, int H, const uint8_t *hdelta, const RowDesc *hrowsx, RowDesc *out) {
+	if (rs.fmt == kRowsExplicit) {
+		if (H > 0) memcpy(out, hrowsx + rs.src_off, (size_t) H * sizeof(RowDesc));
+		return;
+	}
+	const int8_t *d = reinterpret_cast<const int8_t *>(hdelta + rs.src_off);
+	int32_t o = rs.off0;
+	for (int y = 0; y < H; ++y) {
+		if (y > 0) o += (int32_t) d[y];
+		out[y].off = o;
+		out[y].len = rs.width;
 	}
 }
 
@@ -289,7 +347,18 @@ struct PlanTuning {
 	int force_generic = 0; /* every tile to the catch-all kernel (scoring that needs its SSE-variant instantiation) */
 };
 
+/* rows_of(i, tmp) -> the (offset, length) rows of tile i (may fill and return tmp), or an empty function /
+ * nullptr result when the host has none (then nothing is chained). */
+template <typename RowsOf>
+inline void host_plan_rows(int n, const TilePlan *plan, const TileIn *tin, RowsOf rows_of, bool have_rows, const PlanTuning &tune, HostPlan &hp);
+
 inline void host_plan(int n, const TilePlan *plan, const TileIn *tin, const RowDesc *rows, const PlanTuning &tune, HostPlan &hp) {
+	/* rows: one arena indexed by TileIn::row_off (tests), or NULL */
+	host_plan_rows(n, plan, tin, [&](int i, std::vector<RowDesc> &) { return rows + tin[(size_t) i].row_off; }, rows != nullptr, tune, hp);
+}
+
+template <typename RowsOf>
+inline void host_plan_rows(int n, const TilePlan *plan, const TileIn *tin, RowsOf rows_of, bool have_rows, const PlanTuning &tune, HostPlan &hp) {
 	const int tune_min_slots = tune.min_slots, tune_force_wrap = tune.force_wrap;
 	hp.trun.assign((size_t) n, TileRun());
 	hp.tout.assign((size_t) n, TileOut());
@@ -333,14 +402,15 @@ inline void host_plan(int n, const TilePlan *plan, const TileIn *tin, const RowD
 		hp.ops_ints += (uint64_t) r.ops_cap;
 		hp.active += p.active;
 		const bool long_tile = small_batch && p.need >= 128 && (p.rend - p.r0) >= kLongTileSteps;
-		if ((k < 0 || long_tile) && regular && rows && tune_min_slots == 0 && !tune.force_generic) {
+		if ((k < 0 || long_tile) && regular && have_rows && tune_min_slots == 0 && !tune.force_generic) {
 			/* more live rows than any ring (or one very long tile in a batch too small to fill the
 			 * device with whole tiles): row blocks chained through boundary streams */
 			int cc = chain_class_for(p.need, small_batch);
 			for (int q = 0; q < kNumChainClasses; ++q) if (kChainClasses[q] == tune.chain_m) cc = q;
 			const size_t slot = (size_t) cc * 2 + (wrap ? 1 : 0);
 			per_tile[slot].emplace_back();
-			plan_chain_tile(i, kChainClasses[cc], p, tin[(size_t) i], rows + tin[(size_t) i].row_off, hp, r, per_tile[slot].back());
+			std::vector<RowDesc> tmp_rows;
+			plan_chain_tile(i, kChainClasses[cc], p, tin[(size_t) i], rows_of(i, tmp_rows), hp, r, per_tile[slot].back());
 			hp.chain_tiles[slot].push_back(i);
 			hp.n_chained++;
 			continue;

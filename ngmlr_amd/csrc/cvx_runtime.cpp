@@ -28,6 +28,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -144,20 +145,25 @@ struct cvx_batch_s {
 	int n = 0;
 	int state = kEmpty;
 	bool in_flight = false;          /* submitted through the streaming API and not yet released */
-	uint64_t seq_total = 0, n_rows = 0;
+	uint64_t seq_total = 0, n_rows = 0, n_rowsx = 0;
 	uint64_t ops_total = 0;          /* valid after the compute stage has been waited for */
 	uint64_t dense_cap = 0;
 	bool have_ops = false;           /* dense ops are in h_ops */
 
 	/* host side, page-locked */
-	PinBuf h_seq, h_rows, h_tin;     /* upload staging (owned by the batch: no wait before reuse by another batch) */
+	PinBuf h_seq, h_delta, h_rsrc, h_rowsx, h_tin;     /* upload staging (owned by the batch: no wait before reuse by another batch):
+	                                                    * sequences, one step byte per corridor row, RowSrc[n], rows that need the verbatim form */
+	std::vector<RowDesc> chain_rows;                   /* scratch: expanded rows of a tile being chained */
 	PinBuf h_plan;                   /* TilePlan[n] */
 	PinBuf h_trun, h_tout, h_lists, h_goff;   /* what the host planning produces */
 	PinBuf h_res;                    /* ResultRec[n] + BatchSummary */
 	PinBuf h_ops;                    /* dense ops */
 
 	DevBuf<uint8_t> d_seq;
-	DevBuf<RowDesc> d_rows;
+	DevBuf<RowDesc> d_rows;          /* the expanded rows arena (expand_rows_kernel) */
+	DevBuf<uint8_t> d_delta;
+	DevBuf<RowSrc> d_rsrc;
+	DevBuf<RowDesc> d_rowsx;
 	DevBuf<TileIn> d_tin;
 	DevBuf<TilePlan> d_plan;
 	DevBuf<TileRun> d_trun;
@@ -205,7 +211,8 @@ struct cvx_batch_s {
 		return CVX_OK;
 	}
 	void release() {
-		h_seq.release(); h_rows.release(); h_tin.release(); h_plan.release(); h_trun.release(); h_tout.release();
+		h_seq.release(); h_delta.release(); h_rsrc.release(); h_rowsx.release(); h_tin.release();
+		d_delta.release(); d_rsrc.release(); d_rowsx.release(); h_plan.release(); h_trun.release(); h_tout.release();
 		h_lists.release(); h_goff.release(); h_res.release(); h_ops.release();
 		d_seq.release(); d_rows.release(); d_tin.release(); d_plan.release(); d_trun.release();
 		d_tout.release(); d_dirs.release(); d_regions.release(); d_lists.release();
@@ -326,7 +333,10 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	const size_t n1 = (size_t) std::max(n, 1);
 	const size_t rows1 = (size_t) std::max<uint64_t>(L.n_rows, 1);
 	RC_TRY(b->h_seq.ensure((size_t) L.seq_total + 256));
-	RC_TRY(b->h_rows.ensure(rows1 * sizeof(RowDesc)));
+	RC_TRY(b->h_delta.ensure((size_t) L.delta_total + 256));
+	RC_TRY(b->h_rsrc.ensure(n1 * sizeof(RowSrc)));
+	RC_TRY(b->d_delta.ensure((size_t) L.delta_total + 256));
+	RC_TRY(b->d_rsrc.ensure(n1));
 	RC_TRY(b->h_tin.ensure(n1 * sizeof(TileIn)));
 	RC_TRY(b->h_plan.ensure(n1 * sizeof(TilePlan)));
 	RC_TRY(b->h_res.ensure(n1 * sizeof(ResultRec) + sizeof(BatchSummary)));
@@ -346,7 +356,8 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	if (n) memcpy(b->h_tin.p, tin.data(), (size_t) n * sizeof(TileIn));
 
 	uint8_t *hseq = b->h_seq.as<uint8_t>();
-	RowDesc *hrows = b->h_rows.as<RowDesc>();
+	uint8_t *hdelta = b->h_delta.as<uint8_t>();
+	std::vector<RowOverflow> overflow;
 	upload_zero_pads(L, hseq);
 	const std::vector<uint64_t> &wprefix = L.wprefix;
 	int threads = std::max(1, h->pack_threads);
@@ -354,7 +365,7 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	hipStream_t st = h->s_io;
 	const int pieces = threads > 1 ? 8 : 1;
 	int t0 = 0;
-	uint64_t seq_done = 0;                   /* bytes of hseq already on their way */
+	uint64_t seq_done = 0, delta_done = 0;   /* bytes of hseq / hdelta already on their way */
 	for (int pc = 1; pc <= pieces; ++pc) {
 		int t1 = n;
 		if (pc < pieces) {
@@ -366,28 +377,58 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 			std::vector<uint64_t> wp((size_t) (t1 - t0) + 1);
 			for (int i = t0; i <= t1; ++i) wp[(size_t) (i - t0)] = wprefix[(size_t) i] - wprefix[(size_t) t0];
 			const int base = t0;
-			parallel_ranges(t1 - t0, wp, threads, [&](int bg, int en) { upload_pack(base + bg, base + en, tiles, tin, hseq, hrows, windows); });
+			/* every packing thread of the piece collects the rows of its misfits in its own list */
+			const size_t first = overflow.size();
+			overflow.resize(first + (size_t) threads + 1);
+			std::atomic<int> slot(0);
+			parallel_ranges(t1 - t0, wp, threads, [&](int bg, int en) {
+				upload_pack(base + bg, base + en, tiles, tin, hseq, hdelta, L.rsrc, overflow[first + (size_t) slot.fetch_add(1)], windows);
+			});
 		}
 		/* Copy boundaries are multiples of 256 bytes: a host-to-device copy whose address or size is
-		 * not dword-aligned is not handed to the SDMA engines but to a blit kernel
-		 * (__amd_rocclr_copyBuffer) that pulls the bytes over PCIe with compute units the fill needs --
-		 * measured: 0.5 GB of sequence pieces per step at odd offsets cost the pipelined step ~7 ms.
-		 * The bytes below the rounded-down end are all packed; the remainder travels with the next
-		 * piece, and the last piece runs to the (256-aligned) end of the arena. */
-		/* (with device-decoded references only [pad][reads][pad] is uploaded; tiles are laid out in
+		 * not dword-aligned is not handed to the SDMA engines but to a blit kernel that pulls the bytes
+		 * over PCIe with compute units the fill needs.  The bytes below the rounded-down end are all
+		 * packed; the remainder travels with the next piece, the last piece runs to the aligned end.
+		 * (with device-decoded references only [pad][reads][pad] is uploaded; tiles are laid out in
 		 * order, so everything below tile t1's first byte is packed) */
 		uint64_t seq_end = (t1 == n) ? L.upload_bytes : (uint64_t) (windows ? tin[(size_t) t1].qry_off : tin[(size_t) t1].ref_off);
 		seq_end = (t1 == n) ? (seq_end + 255) / 256 * 256 : seq_end / 256 * 256;
 		if (seq_end > seq_done)
 			HIP_TRY(hipMemcpyAsync(b->d_seq.p + seq_done, hseq + seq_done, (size_t) (seq_end - seq_done), hipMemcpyHostToDevice, st));
 		seq_done = std::max(seq_done, seq_end);
-		const uint64_t r0 = (t0 < n) ? tin[(size_t) t0].row_off : L.n_rows;
-		const uint64_t r1 = (t1 < n) ? tin[(size_t) t1].row_off : L.n_rows;
-		if (r1 > r0)
-			HIP_TRY(hipMemcpyAsync(b->d_rows.p + r0, hrows + r0, (size_t) (r1 - r0) * sizeof(RowDesc), hipMemcpyHostToDevice, st));
+		uint64_t del_end = (t1 == n) ? L.delta_total : L.rsrc[(size_t) t1].src_off;       /* (src_off = step-stream offset until the misfits are renumbered below) */
+		del_end = (t1 == n) ? (del_end + 255) / 256 * 256 : del_end / 256 * 256;
+		if (del_end > delta_done)
+			HIP_TRY(hipMemcpyAsync(b->d_delta.p + delta_done, hdelta + delta_done, (size_t) (del_end - delta_done), hipMemcpyHostToDevice, st));
+		delta_done = std::max(delta_done, del_end);
 		t0 = t1;
 	}
 	if (n) HIP_TRY(hipMemcpyAsync(b->d_tin.p, b->h_tin.p, (size_t) n * sizeof(TileIn), hipMemcpyHostToDevice, st));
+	if (n) {
+		/* the misfits' rows (none in any corridor the reference builds), then the rows arena on the device */
+		uint64_t n_x = 0;
+		for (const RowOverflow &o : overflow) n_x += o.rows.size();
+		b->n_rowsx = n_x;
+		if (n_x) {
+			RC_TRY(b->h_rowsx.ensure((size_t) n_x * sizeof(RowDesc)));
+			RC_TRY(b->d_rowsx.ensure((size_t) n_x));
+			RowDesc *hx = b->h_rowsx.as<RowDesc>();
+			uint64_t at = 0;
+			for (const RowOverflow &o : overflow) {
+				uint64_t r = 0;
+				for (int32_t ti : o.tiles) {
+					L.rsrc[(size_t) ti].src_off = at + r;
+					r += (uint64_t) tin[(size_t) ti].H;
+				}
+				if (!o.rows.empty()) memcpy(hx + at, o.rows.data(), o.rows.size() * sizeof(RowDesc));
+				at += o.rows.size();
+			}
+			HIP_TRY(hipMemcpyAsync(b->d_rowsx.p, hx, (size_t) n_x * sizeof(RowDesc), hipMemcpyHostToDevice, st));
+		}
+		memcpy(b->h_rsrc.p, L.rsrc.data(), (size_t) n * sizeof(RowSrc));
+		HIP_TRY(hipMemcpyAsync(b->d_rsrc.p, b->h_rsrc.p, (size_t) n * sizeof(RowSrc), hipMemcpyHostToDevice, st));
+		HIP_TRY(launch_expand_rows(b->d_rsrc.p, b->d_tin.p, b->d_delta.p, b->d_rowsx.p, b->d_rows.p, n, st));
+	}
 	if (windows && n) {
 		/* the references: decoded from the resident genome straight into the arena (and its last pad cleared) */
 		RC_TRY(b->h_win.ensure((size_t) n * sizeof(WindowDesc)));
@@ -444,7 +485,13 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	PlanTuning tune;
 	tune.min_slots = h->tune_min_slots; tune.max_slots = h->tune_max_slots; tune.force_wrap = h->tune_force_wrap; tune.chain_m = h->tune_chain_m;
 	tune.force_generic = h->sse_variant ? 1 : 0;
-	host_plan(n, b->plan(), b->tin(), b->h_rows.as<RowDesc>(), tune, hp);
+	/* (a tile that gets chained needs its rows on the host: rebuilt from the step stream the batch still owns) */
+	const RowSrc *rsrc = b->h_rsrc.as<RowSrc>();
+	host_plan_rows(n, b->plan(), b->tin(), [&](int i, std::vector<RowDesc> &tmp) -> const RowDesc * {
+		tmp.resize((size_t) std::max(b->tin()[(size_t) i].H, 1));
+		expand_rows_host(rsrc[(size_t) i], b->tin()[(size_t) i].H, b->h_delta.as<uint8_t>(), b->h_rowsx.as<RowDesc>(), tmp.data());
+		return tmp.data();
+	}, true, tune, hp);
 	std::vector<std::vector<int32_t>> &cls = hp.cls;
 	std::vector<int32_t> &generic = hp.generic;
 	RC_TRY(b->d_dirs.ensure((size_t) hp.dir_dwords + 64));

@@ -57,6 +57,20 @@ struct ScoreParams {
 	float mat, mis, go, ge, gem, decay;
 };
 
+/* How a tile's corridor rows travel to the device (expand_rows_kernel rebuilds the int2 rows arena):
+ * every corridor the reference builds has one width for all rows and row offsets that move by a
+ * few columns per row, so a row is one signed byte -- the offset's step from the row above -- instead
+ * of eight; anything else (a width that changes, a step outside -128..127) goes verbatim. */
+enum RowFormat { kRowsDelta8 = 0, kRowsExplicit = 1 };
+struct RowSrc {
+	uint64_t src_off;      /* kRowsDelta8: byte offset of the tile's H step bytes (byte 0 unused) in the delta stream;
+	                        * kRowsExplicit: index of its first RowDesc in the explicit-rows buffer */
+	int32_t off0;          /* offset of row 0 */
+	int32_t width;         /* the common row length (kRowsDelta8) */
+	int32_t fmt;
+	int32_t pad;
+};
+
 struct TileIn {            /* written by the host at upload */
 	uint32_t ref_off;      /* byte offset of ref[0] in the seq arena */
 	uint32_t qry_off;      /* byte offset of qry[0] */

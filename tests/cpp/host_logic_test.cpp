@@ -32,8 +32,10 @@ int main() {
 		for (auto &c : qrys[i]) c = "ACGT"[rng() % 4];
 		off[i].resize(H); len[i].resize(H); lines[i].resize(H);
 		for (int y = 0; y < H; ++y) {
-			off[i][y] = (int32_t) (y - 150 + (int) (rng() % 7));
-			len[i][y] = (int32_t) (300 + rng() % 70);
+			// two thirds of the tiles look like the reference's corridors (one width, offsets creeping along);
+			// the others change width from row to row or jump by more than a byte
+			off[i][y] = (int32_t) (y - 150 + (int) (rng() % 7)) + ((i % 11 == 5 && y > H / 2) ? 500 : 0) - ((i % 7 == 3) ? 2 * y : 0);
+			len[i][y] = (i % 3 == 0) ? (int32_t) (300 + rng() % 70) : 340;
 			lines[i][y] = {off[i][y], len[i][y], 0xdeadbeefull};
 		}
 		cvx_tile &t = tiles[i];
@@ -64,23 +66,48 @@ int main() {
 	CHECK(so + L.pad + 64 == L.seq_total && ro == L.n_rows);
 	CHECK(L.wprefix.size() == (size_t) n + 1 && L.wprefix[0] == 0);
 
+	CHECK(L.rsrc.size() == (size_t) n && L.delta_total >= L.n_rows);
 	std::vector<uint8_t> a(L.seq_total, 0xAA), b(L.seq_total, 0x55);
-	std::vector<RowDesc> ra(L.n_rows + 1), rb(L.n_rows + 1);
+	std::vector<uint8_t> da(L.delta_total + 4, 0x11), db(L.delta_total + 4, 0x22);
+	std::vector<RowSrc> sa = L.rsrc, sb = L.rsrc;
 	upload_zero_pads(L, a.data());
 	upload_zero_pads(L, b.data());
-	upload_pack(0, n, tiles.data(), tin, a.data(), ra.data());                      // one thread
-	parallel_ranges(n, L.wprefix, 7, [&](int bg, int en) { upload_pack(bg, en, tiles.data(), tin, b.data(), rb.data()); });
+	RowOverflow oa;
+	upload_pack(0, n, tiles.data(), tin, a.data(), da.data(), sa, oa);              // one thread
+	std::vector<RowOverflow> ob(8);
+	std::atomic<int> oslot{0};
+	parallel_ranges(n, L.wprefix, 7, [&](int bg, int en) { upload_pack(bg, en, tiles.data(), tin, b.data(), db.data(), sb, ob[oslot++]); });
 	CHECK(a == b);                                                                   // every byte defined, same result
-	CHECK(memcmp(ra.data(), rb.data(), L.n_rows * sizeof(RowDesc)) == 0);
 	for (uint64_t k = 0; k < L.pad; ++k) if (a[k] != 0 || a[L.seq_total - 1 - k] != 0) { CHECK(!"pads zeroed"); break; }
+	// the misfits' rows get their place in the verbatim buffer (what stage_upload does after the parallel phase)
+	auto place = [&](std::vector<RowOverflow> &lists, std::vector<RowSrc> &rs, std::vector<RowDesc> &rowsx) {
+		uint64_t at = 0;
+		for (RowOverflow &o : lists) {
+			uint64_t r = 0;
+			for (int32_t ti : o.tiles) { rs[ti].src_off = at + r; r += (uint64_t) tin[ti].H; }
+			rowsx.insert(rowsx.end(), o.rows.begin(), o.rows.end());
+			at += o.rows.size();
+		}
+	};
+	std::vector<RowDesc> xa, xb;
+	std::vector<RowOverflow> la(1, oa);
+	place(la, sa, xa);
+	place(ob, sb, xb);
+	int n_explicit = 0, n_delta = 0;
 	for (int i = 0; i < n; ++i) {
 		CHECK(memcmp(a.data() + tin[i].ref_off, refs[i].data(), refs[i].size()) == 0);
 		CHECK(memcmp(a.data() + tin[i].qry_off, qrys[i].data(), qrys[i].size()) == 0);
-		for (int y = 0; y < tiles[i].qry_len; ++y) {
-			const RowDesc &rd = ra[tin[i].row_off + y];
-			if (rd.off != off[i][y] || rd.len != len[i][y]) { CHECK(!"row copied"); break; }
+		CHECK(sa[i].fmt == sb[i].fmt);
+		(sa[i].fmt == kRowsExplicit ? n_explicit : n_delta) += 1;
+		const int H = tiles[i].qry_len;
+		std::vector<RowDesc> ra((size_t) H + 1), rb((size_t) H + 1);
+		expand_rows_host(sa[i], H, da.data(), xa.data(), ra.data());                 // = expand_rows_kernel
+		expand_rows_host(sb[i], H, db.data(), xb.data(), rb.data());
+		for (int y = 0; y < H; ++y) {
+			if (ra[y].off != off[i][y] || ra[y].len != len[i][y] || rb[y].off != off[i][y] || rb[y].len != len[i][y]) { CHECK(!"rows survive the one-byte form"); break; }
 		}
 	}
+	CHECK(n_delta > 0 && n_explicit > 0);                                            // both forms exercised
 	// ranges handed to the threads tile [0, n) exactly once
 	{
 		std::vector<int> seen(n, 0);
