@@ -117,6 +117,50 @@ def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
     return cpu, parity, detail
 
 
+def subread_scoring_rates(lib, dev, n=32768):
+    from ngmlr_amd import synth
+    from ngmlr_amd.aligner import StrippedSWHip
+    from oracle.pyoracle import ScoreOracle, have_score_ref
+    rng = np.random.default_rng(1)
+    refs, qrys = [], []
+    for _ in range(n):
+        w = synth.random_ref(rng, 308)
+        a = int(rng.integers(0, 50))
+        qrys.append(synth.mutate(rng, w[a:a + 256], 0.15)[:256].tobytes())
+        refs.append(w.tobytes())
+    cells = sum((len(r) + 1) * (len(q) + 1) for r, q in zip(refs, qrys))
+    sw = StrippedSWHip(device=dev)
+    sw.batch_score(refs[:1024], qrys[:1024])
+    c0 = time.perf_counter()
+    got = sw.batch_score(refs, qrys)
+    dt_gpu = time.perf_counter() - c0
+    c0 = time.perf_counter()
+    for lo in range(0, n, 1024):
+        sw.batch_score(refs[lo:lo + 1024], qrys[lo:lo + 1024])
+    dt_1k = time.perf_counter() - c0
+    sw.close()
+    kind = "reference" if have_score_ref() else "port"
+    threads = os.cpu_count() or 1
+    want = np.zeros(n, dtype=np.float32)
+    step = (n + threads - 1) // threads
+
+    def work(k):
+        lo, hi = k * step, min(n, (k + 1) * step)
+        if lo < hi:
+            want[lo:hi] = ScoreOracle(kind).scores(refs[lo:hi], qrys[lo:hi])
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    c0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    dt_cpu = time.perf_counter() - c0
+    return {"pairs": n, "gpu_pairs_per_s": n / dt_gpu, "gpu_cell_updates_per_s": cells / dt_gpu,
+            "gpu_pairs_per_s_in_1024_pair_calls": n / dt_1k, "cpu_pairs_per_s": n / dt_cpu, "cpu_kind": kind, "cpu_threads": threads,
+            "parity": "%d/%d" % (int((got == want).sum()), n),
+            "what": "cvx_score_batch (host strings in -> scores out, incl. the python marshalling of this bench) vs StrippedSW + ssw.c"}
+
+
 class Worker:
     """One device: a handle, its own tiles, a pipelined stream of steps."""
 
@@ -347,6 +391,16 @@ def main() -> int:
         except Exception as e:
             resident = {"error": str(e)}
 
+        # sub-read scoring, the reference's batch shape (1024 pairs of a 256-base sub-read against a
+        # ~300-base window, src/ScoreBuffer.cpp:87-168): cvx_score_batch against the reference's own StrippedSW
+        # on all host threads, same pairs, every score compared
+        subread = None
+        if not args.no_cpu_baseline and args.gpus == 1:
+            try:
+                subread = subread_scoring_rates(w0.al.lib, devs[0])
+            except Exception as e:
+                subread = {"error": str(e)}
+
         value = bases * args.steps / dt * 3600.0 / 1e9
         launch_ms, launch_meta = w0.launch_ms, w0.launch_meta
         # dominant kernel = the fill launch that carries most of the work (classes run concurrently)
@@ -420,6 +474,7 @@ def main() -> int:
             "cpu_baseline": cpu,
             "text_stage_host": text_stage,
             "text_stage_device": text_dev,
+            "subread_scoring": subread,
             "tile_generation_s": t_gen,
         }
     for w in workers:
