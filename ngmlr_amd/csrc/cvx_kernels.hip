@@ -1036,6 +1036,9 @@ CVX_DEV void backtrack_walk_grp(const Group<G> g, const bool has_tile, const boo
 			elem_len = n;
 		}
 	};
+	int c_gb = -1;             /* chained tiles: block whose record c_cb holds (per lane) */
+	ChainBlk c_cb;
+	c_cb.dir_off = 0; c_cb.tblk0 = 0; c_cb.nblk32 = 1;
 
 	while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
 		if (act) {
@@ -1053,11 +1056,13 @@ CVX_DEV void backtrack_walk_grp(const Group<G> g, const bool has_tile, const boo
 				const int2 ol = rows[ly];
 				size_t widx = (size_t) (ttc >> 5) * N + sl;
 				if (chained) {
+					/* the block record of this lane's row: kept from the previous probe while the row stays in
+					 * the same 64-row block, so that most probes cost one memory round trip, not two */
 					const int gb = ly / N;
-					const ChainBlk cb = blk[gb];
-					int wr = (ttc >> 5) - cb.tblk0;
-					wr = wr < 0 ? 0 : (wr >= cb.nblk32 ? cb.nblk32 - 1 : wr);
-					widx = cb.dir_off + (size_t) wr * N + (size_t) (ly - gb * N);
+					if (gb != c_gb) { c_cb = blk[gb]; c_gb = gb; }
+					int wr = (ttc >> 5) - c_cb.tblk0;
+					wr = wr < 0 ? 0 : (wr >= c_cb.nblk32 ? c_cb.nblk32 - 1 : wr);
+					widx = c_cb.dir_off + (size_t) wr * N + (size_t) (ly - gb * N);
 				}
 				const uint2 w = dirs[widx];
 				const int rc = ref[lx], qc = qry[ly];
