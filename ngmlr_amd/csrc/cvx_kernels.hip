@@ -999,7 +999,7 @@ struct Group {
 	int base;      /* first lane of the group */
 	CVX_DEV unsigned ballot(bool p) const {
 		const u64 b = __builtin_amdgcn_ballot_w64(p);
-		return (unsigned) (b >> base) & ((1u << G) - 1u);
+		return (unsigned) (b >> base) & (G == 32 ? 0xffffffffu : ((1u << (G & 31)) - 1u));
 	}
 	CVX_DEV int bcast(int v, int l) const { return __shfl(v, base + l, 64); }
 };
@@ -1073,7 +1073,7 @@ CVX_DEV void backtrack_walk_grp(const Group<G> g, const bool has_tile, const boo
 				int minC, maxC;
 				valid_bounds(ol.x, ol.y, minC, maxC);
 
-				const unsigned full = (1u << G) - 1u;
+				const unsigned full = (G == 32) ? 0xffffffffu : ((1u << (G & 31)) - 1u);
 				const unsigned run = g.ballot(code == want);
 				const int L = (run == full) ? G : __builtin_ctz(~run);
 				const unsigned low = (L == G) ? full : ((1u << L) - 1u);
@@ -1156,8 +1156,8 @@ CVX_DEV void backtrack_walk_grp(const Group<G> g, const bool has_tile, const boo
 								unsigned c2 = plane_code(w.x, w.y, 31 - (tn & 31));
 								if (!col_in) c2 = 0u;
 								const unsigned im = g.ballot(have && c2 == 1u) >> L;      /* bit k: cell (x, y - k) is I; bit 0 is set */
-								const int Li = __builtin_ctz(~im);                          /* <= G - L */
-								const unsigned ilow = (1u << Li) - 1u;
+								const int Li = (~im == 0u) ? 32 : __builtin_ctz(~im);       /* <= G - L */
+								const unsigned ilow = (Li >= 32) ? 0xffffffffu : ((1u << Li) - 1u);
 								const unsigned vpi = g.ballot(x > minC && x < maxC) >> L;
 								if ((~vpi & ilow) != 0u) { status = 2; go_on = false; }
 								else {
@@ -1451,6 +1451,12 @@ hipError_t launch_backtrack(const BacktrackArgs &a, const int32_t *order, int n_
 	if (group == 16 && order != nullptr) {
 		if (n_order <= 0) return hipSuccess;
 		hipLaunchKernelGGL(backtrack_grp_kernel<16>, dim3((n_order + 3) / 4), dim3(64), 0, st, a, order, n_order);   /* four tiles per wave */
+	} else if (group == 8 && order != nullptr) {
+		if (n_order <= 0) return hipSuccess;
+		hipLaunchKernelGGL(backtrack_grp_kernel<8>, dim3((n_order + 7) / 8), dim3(64), 0, st, a, order, n_order);    /* eight tiles per wave */
+	} else if (group == 32 && order != nullptr) {
+		if (n_order <= 0) return hipSuccess;
+		hipLaunchKernelGGL(backtrack_grp_kernel<32>, dim3((n_order + 1) / 2), dim3(64), 0, st, a, order, n_order);   /* two tiles per wave */
 	} else {
 		hipLaunchKernelGGL(backtrack_kernel, dim3(a.n_tiles), dim3(64), 0, st, a);   /* one wave per tile */
 	}

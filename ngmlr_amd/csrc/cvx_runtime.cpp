@@ -192,6 +192,7 @@ struct cvx_batch_s {
 	DevBuf<BoundaryRec> d_bnd;
 	DevBuf<ChainOut> d_chain_out;
 
+	hipEvent_t ev_bt0 = nullptr, ev_bt1 = nullptr;   /* fork / join of the long-read backtrack launch */
 	hipEvent_t ev_in = nullptr;      /* upload + plan records on the host */
 	hipEvent_t ev_res = nullptr;     /* result records on the host */
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   /* timing: plan begin/end, fills done, all done, fills may start */
@@ -207,6 +208,8 @@ struct cvx_batch_s {
 	int make_events() {
 		if (!ev_in) HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
 		if (!ev_res) HIP_TRY(hipEventCreateWithFlags(&ev_res, hipEventDisableTiming));
+		if (!ev_bt0) HIP_TRY(hipEventCreateWithFlags(&ev_bt0, hipEventDisableTiming));
+		if (!ev_bt1) HIP_TRY(hipEventCreateWithFlags(&ev_bt1, hipEventDisableTiming));
 		for (auto &e : ev) if (!e) HIP_TRY(hipEventCreate(&e));
 		return CVX_OK;
 	}
@@ -224,6 +227,8 @@ struct cvx_batch_s {
 		h_chain.release(); d_chain.release(); d_progress.release(); d_bnd.release(); d_chain_out.release();
 		if (ev_in) { (void) hipEventDestroy(ev_in); ev_in = nullptr; }
 		if (ev_res) { (void) hipEventDestroy(ev_res); ev_res = nullptr; }
+		if (ev_bt0) { (void) hipEventDestroy(ev_bt0); ev_bt0 = nullptr; }
+		if (ev_bt1) { (void) hipEventDestroy(ev_bt1); ev_bt1 = nullptr; }
 		for (auto &e : ev) if (e) { (void) hipEventDestroy(e); e = nullptr; }
 		for (auto &e : lev) if (e) (void) hipEventDestroy(e);
 		lev.clear();
@@ -246,7 +251,8 @@ struct cvx_context {
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
-	int bt_group = 16;         /* lanes per tile in the backtrack (16: four tiles per wave; 64: the one-wave-per-tile walk; env CVX_TUNE_BT_GROUP) */
+	int bt_group = 0;          /* lanes per tile in the backtrack: 0 = auto (8 for the bulk, 32 for the much-longer-than-average
+	                            * reads), 8 / 16 / 32 = that many for all, 64 = the one-wave-per-tile walk (env CVX_TUNE_BT_GROUP) */
 	bool overlap_post = false; /* tuning knob (env CVX_TUNE_OVERLAP_POST): backtrack/finalize/compaction of batch k on their own stream, beside the fills of batch k+1 */
 	bool sse_variant = false; /* scoring outside the regime where the reference's SSE path equals the scalar recurrence:
 	                           * every tile goes to the catch-all kernel's SSE-variant instantiation */
@@ -705,8 +711,29 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	ba.n_tiles = n;
 	/* few tiles: the walk is latency-bound and 64 probing lanes per tile take the long diagonal runs in
 	 * a quarter of the probes; many tiles: it is issue-bound and four tiles share a wave */
-	const int bt_group = (h->bt_group == 16 && n_walk < 4096) ? 64 : h->bt_group;
-	HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin, n_walk, bt_group, st));
+	if (n_walk < 4096) {
+		HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin, n_walk, 64, st));
+	} else if (h->bt_group != 0) {
+		HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin, n_walk, h->bt_group, st));
+	} else {
+		/* auto: the bulk of a batch is issue-bound and walks fastest eight tiles to a wave; the few
+		 * reads much longer than the rest (the list is sorted by length) are a latency-bound tail
+		 * -- a serial chain of H / 7 probes each -- and get 32 lanes per tile, on a second stream
+		 * beside the bulk (measured: PacBio 5.4 -> 4.9 ms with 8 lanes, ONT mix 8.2 -> 6.6 with 32) */
+		const TileIn *tin = b->tin();
+		const uint64_t mean_h = b->n_rows / (uint64_t) std::max(n, 1);
+		int n_long = 0;
+		while (n_long < n_walk && (uint64_t) tin[(size_t) lists[bt_begin + (size_t) n_long]].H > 3 * mean_h) n_long++;
+		if (n_long > 0) {
+			hipStream_t ls = h->aux[0];
+			HIP_TRY(hipEventRecord(b->ev_bt0, st));
+			HIP_TRY(hipStreamWaitEvent(ls, b->ev_bt0, 0));
+			HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin, n_long, 32, ls));
+			HIP_TRY(hipEventRecord(b->ev_bt1, ls));
+		}
+		HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin + n_long, n_walk - n_long, 8, st));
+		if (n_long > 0) HIP_TRY(hipStreamWaitEvent(st, b->ev_bt1, 0));
+	}
 	ResultRec *d_rec = reinterpret_cast<ResultRec *>(b->d_res.p);
 	BatchSummary *d_sum = reinterpret_cast<BatchSummary *>(b->d_res.p + (size_t) n * sizeof(ResultRec));
 	HIP_TRY(launch_finalize(b->d_tout.p, b->d_plan.p, b->d_dstoff.p, d_rec, d_sum, b->d_counters.p, n, b->dense_cap, st));
