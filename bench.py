@@ -212,7 +212,10 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tiles", type=int, default=24576, help="tiles per GPU per step (~21 GB of direction words per batch in flight)")
+    ap.add_argument("--tiles", type=int, default=49152,
+                    help="tiles per GPU per step: eight rounds of the 6144 resident fill waves, ~45 GB of direction words per batch, "
+                         "~195 GB of the 288 GB of HBM with three batches in flight (batches are sized for the memory: the fixed ~5 ms "
+                         "of ramp and ragged end per fill launch is 4 %% of it instead of 8 %% at 24576)")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight per device")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--seed", type=int, default=7)
