@@ -43,78 +43,129 @@ PARITY_KEYS = ("ret", "score_bits", "position_offset", "qstart", "qend", "nm", "
 
 
 def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
-    """The step's tiles through the CPU checker on the host cores of this box (bounded sample),
-    and every one of those alignments compared with the GPU's.  Prefers the reference's own
-    ConvexAlignFast (oracle/_ref, kind "reference"), else the C restatement (kind "port")."""
+    """The step's tiles through the CPU checker on the host cores of this box (bounded sample), and
+    every one of those alignments compared with the GPU's.  The reference's own ConvexAlignFast
+    (oracle/_ref, kind "reference") runs inside ONE C call on a C++ thread per core (oracle_align_many:
+    python threads around the per-tile call serialise on the interpreter lock and stop scaling at ~16
+    threads); without oracle/_ref the C restatement (kind "port") runs on python threads."""
+    import ctypes as C
     from ngmlr_amd.aligner import format_tileset
-    from oracle.pyoracle import Oracle, have_ref, same_alignment
+    from oracle import pyoracle
+    from oracle.pyoracle import Oracle, have_ref
     kind = "reference" if have_ref() else "port"
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, 256))
-    oracles = [Oracle(kind) for _ in range(threads)]
-    # calibrate under load (all threads busy: the fill is memory-bound on the host, one tile alone is
-    # several times faster than one tile per core), then size the sample to ~seconds_budget of wall time
-    n_cal = min(len(ts), threads)
-    cal = [threading.Thread(target=lambda k=k: oracles[k].align(ts.tile(k), want_nm=False)) for k in range(n_cal)]
-    t0 = time.perf_counter()
-    for th in cal:
-        th.start()
-    for th in cal:
-        th.join()
-    per_round = max(time.perf_counter() - t0, 1e-3)
-    per_thread = int(max(1, min(len(ts) // threads if len(ts) >= threads else 1, seconds_budget / per_round)))
-    n_sample = min(len(ts), per_thread * threads)
-    # GPU side of the comparison: text stage of the sampled tiles (all host threads, C)
+    n = len(ts)
+
+    def run_reference(idx, threads):
+        """-> (seconds wall, busy seconds summed, outs, cigar list, md list) for tiles idx (C++ threads)."""
+        lib = C.CDLL(pyoracle.REF_SO)
+        m = len(idx)
+        tab = ts.table()[idx]
+        caps = (4 * ts.H[idx] + 4 * ts.W[idx] + 256).astype(np.int32)
+        toff = np.concatenate([[0], np.cumsum(2 * caps.astype(np.int64))]).astype(np.uint64)
+        text = np.zeros(int(toff[-1]) + 16, dtype=np.uint8)
+        outs = (pyoracle.OracleOut * m)()
+        busy = np.zeros(threads, dtype=np.float64)
+        params = (C.c_float * 6)(*pyoracle.DEFAULT_PARAMS)
+        arr = lambda a: np.ascontiguousarray(a)  # noqa: E731
+        refp, qryp, rop, rlp = arr(tab["ref"]), arr(tab["qry"]), arr(tab["row_offset"]), arr(tab["row_length"])
+        rl, ql = arr(tab["ref_len"]), arr(tab["qry_len"])
+        lib.oracle_align_many.restype = C.c_int
+        lib.oracle_align_many.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 11
+        toff_in = np.ascontiguousarray(toff[:-1])          # (kept in a variable: the call must not outlive a temporary)
+        c0 = time.perf_counter()
+        threw = lib.oracle_align_many(params, threads, m, refp.ctypes.data, rl.ctypes.data, qryp.ctypes.data, ql.ctypes.data,
+                                      rop.ctypes.data, rlp.ctypes.data, C.addressof(outs), text.ctypes.data, toff_in.ctypes.data,
+                                      caps.ctypes.data, busy.ctypes.data)
+        dt = time.perf_counter() - c0
+        assert threw == 0, "the reference threw on %d tiles" % threw
+        raw = text.tobytes()
+        cig = [raw[int(toff[k]):int(toff[k]) + outs[k].cigar_len].decode() for k in range(m)]
+        md = [raw[int(toff[k]) + int(caps[k]):int(toff[k]) + int(caps[k]) + outs[k].md_len].decode() for k in range(m)]
+        return dt, float(busy.sum()), outs, cig, md
+
+    scan = None
+    if kind == "reference":
+        # How many threads serve the reference best on this host?  (Measured on the bench box, 2 x 64 cores with
+        # SMT: linear to 32 threads -- 35 Gbp/h --, HALF of that on 64 and less on 256: the job does not get all
+        # the cores it can see.)  A short scan, then the bounded sample on the best count.
+        scan = {}
+        for tc in [c for c in (8, 16, 32, 64, 128, 256) if c <= cores] or [cores]:
+            m = min(n, 2 * tc)
+            sdt = run_reference(np.arange(m), tc)[0]
+            scan[tc] = float(ts.H[:m].sum()) / sdt * 3.6e-6
+        threads = max(scan, key=scan.get)
+        per_round = float(ts.H[:min(n, threads)].sum()) / (scan[threads] / 3.6e-6)
+        n_sample = int(min(n, max(threads, threads * int(seconds_budget / max(per_round, 1e-3)))))
+        idx = np.arange(n_sample)
+        dt, busy_sum, outs, cigs, mds = run_reference(idx, threads)
+        want = []
+        for k in range(n_sample):
+            o = outs[k]
+            d = {f: getattr(o, f) for f, _ in pyoracle.OracleOut._fields_}
+            d["score_bits"] = int(np.float32(o.score).view(np.uint32))
+            d["cigar"], d["md"] = cigs[k], mds[k]
+            want.append(d)
+    else:
+        oracles = [Oracle(kind) for _ in range(threads)]
+        n_cal = min(n, threads)
+        cal = [threading.Thread(target=lambda k=k: oracles[k].align(ts.tile(k), want_nm=False)) for k in range(n_cal)]
+        t0 = time.perf_counter()
+        for th in cal:
+            th.start()
+        for th in cal:
+            th.join()
+        per_round = max(time.perf_counter() - t0, 1e-3)
+        per_thread = int(max(1, min(n // threads if n >= threads else 1, seconds_budget / per_round)))
+        n_sample = min(n, per_thread * threads)
+        want = [None] * n_sample
+        busy = [0.0] * threads
+
+        def work(k):
+            for i in range(k, n_sample, threads):
+                c0 = time.perf_counter()
+                want[i] = oracles[k].align(ts.tile(i), want_nm=False)
+                busy[k] += time.perf_counter() - c0
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t0
+        busy_sum = sum(busy)
+        for o in oracles:
+            o.close()
+    # GPU side of the comparison: text stage of the sampled tiles (all host threads, C), outside the CPU timing
     gpu_txt = format_tileset(al.lib, ts, np.arange(n_sample), results, ops)
-    bad = [0] * threads
-    first_bad = [None] * threads
-    busy = [0.0] * threads
-
-    def work(k):
-        for i in range(k, n_sample, threads):
-            t = ts.tile(i)
-            c0 = time.perf_counter()
-            want = oracles[k].align(t, want_nm=False)
-            busy[k] += time.perf_counter() - c0
-            got = gpu_txt[i]
-            got["identity"] = got.get("identity", 0.0)
-            diff = None
-            if not (want["ret"] < 0 and got["ret"] < 0):
-                for key in PARITY_KEYS:
-                    if want[key] != got[key]:
-                        diff = key
-                        break
-                if diff is None and np.float32(want["identity"]).view(np.uint32) != np.float32(got["identity"]).view(np.uint32):
-                    diff = "identity"
-            if diff is not None:
-                bad[k] += 1
-                if first_bad[k] is None:
-                    first_bad[k] = "tile %d: %s" % (i, diff)
-
-    ths = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
-    t0 = time.perf_counter()
-    for th in ths:
-        th.start()
-    for th in ths:
-        th.join()
-    dt = time.perf_counter() - t0
-    for o in oracles:
-        o.close()
+    n_bad, detail = 0, None
+    for i in range(n_sample):
+        w, got = want[i], gpu_txt[i]
+        diff = None
+        if not (w["ret"] < 0 and got["ret"] < 0):
+            for key in PARITY_KEYS:
+                if w[key] != got[key]:
+                    diff = key
+                    break
+            if diff is None and np.float32(w["identity"]).view(np.uint32) != np.float32(got["identity"]).view(np.uint32):
+                diff = "identity"
+        if diff is not None:
+            n_bad += 1
+            detail = detail or "tile %d: %s" % (i, diff)
     bases = int(ts.H[:n_sample].sum())
     cells = int(sum(int(ts.row_length[ts.qry_off[i]:ts.qry_off[i + 1]].astype(np.int64).sum()) for i in range(n_sample)))
-    n_bad = sum(bad)
     cpu = {
         "value": bases / dt * 3600.0 / 1e9,
         "unit": "Gbp/h",
         "cores": threads,
         "kind": kind,
-        "sample": "%d of the step's tiles (%.2f Mbp, %.2e cells) in %.1f s wall on %d threads (%d host cores)" % (
-            n_sample, bases / 1e6, cells, dt, threads, cores),
-        "cells_per_s_per_core": cells / max(sum(busy), 1e-9),
+        "sample": "%d of the step's tiles (%.2f Mbp, %.2e cells) in %.1f s wall on %d %s threads (%d host cores)" % (
+            n_sample, bases / 1e6, cells, dt, threads, "C++ (best of a thread-count scan)" if kind == "reference" else "python", cores),
+        "cells_per_s_per_core": cells / max(busy_sum, 1e-9),
+        "thread_scan_Gbp_per_h": scan,
     }
-    parity = "%d/%d" % (n_sample - n_bad, n_sample)
-    detail = next((f for f in first_bad if f), None)
-    return cpu, parity, detail
+    return cpu, "%d/%d" % (n_sample - n_bad, n_sample), detail
 
 
 def subread_scoring_rates(lib, dev, n=32768):

@@ -54,6 +54,19 @@ int oracle_align(void *h, const char *ref, const char *qry,
 		int32_t ext_qstart, int32_t ext_qend, oracle_align_out *out,
 		char *cigar, char *md, int32_t text_cap, int32_t *nm_triples, int32_t nm_cap);
 
+/* Many alignments on `n_threads` host threads inside ONE call (the CPU-baseline leg of bench.py: python threads
+ * around oracle_align share the interpreter lock for their buffer handling and stop scaling at ~16 threads).
+ * Tile i: ref[i] / qry[i] need not be NUL-terminated (ref_len / qry_len given; each thread makes the terminated
+ * copies the reference's strlen needs), rows at row_offset[i] / row_length[i] (qry_len[i] entries).  One aligner
+ * instance per thread, tiles dealt round-robin.  outs[i] as oracle_align fills it; cigar / md of tile i go to
+ * text + text_off[i] and text + text_off[i] + text_cap[i] (two buffers of text_cap[i] bytes each).
+ * busy_seconds[t]: time thread t spent inside SingleAlign.  Returns the number of tiles whose call threw.
+ * Only the reference build exports this symbol. */
+int oracle_align_many(const float params[6], int32_t n_threads, int32_t n,
+		const char *const *ref, const int32_t *ref_len, const char *const *qry, const int32_t *qry_len,
+		const int32_t *const *row_offset, const int32_t *const *row_length,
+		oracle_align_out *outs, char *text, const uint64_t *text_off, const int32_t *text_cap, double *busy_seconds);
+
 /* Which implementation is this: "reference" or "port". */
 const char *oracle_kind(void);
 

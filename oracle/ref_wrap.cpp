@@ -6,8 +6,12 @@
  * (/root/reference/src/ConvexAlignFast.cpp, AlignmentMatrixFast.cpp); nothing is
  * copied into this repository and the output goes to oracle/_ref/ (git-ignored).
  */
+#include <chrono>
 #include <cstring>
 #include <cstdio>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "ConvexAlignFast.h"   /* -I/root/reference/src */
 #include "IConfig.h"
@@ -103,6 +107,40 @@ int oracle_align(void *h, const char *ref, const char *qry,
 	a.clearNmPerPosition();
 	delete[] lines;
 	return rc;
+}
+
+
+int oracle_align_many(const float params[6], int32_t n_threads, int32_t n,
+		const char *const *ref, const int32_t *ref_len, const char *const *qry, const int32_t *qry_len,
+		const int32_t *const *row_offset, const int32_t *const *row_length,
+		oracle_align_out *outs, char *text, const uint64_t *text_off, const int32_t *text_cap, double *busy_seconds) {
+	if (n_threads < 1) n_threads = 1;
+	std::vector<int> threw((size_t) n_threads, 0);
+	auto work = [&](int t) {
+		void *h = oracle_create(params);
+		std::string r, q;
+		double busy = 0.0;
+		for (int i = t; i < n; i += n_threads) {
+			r.assign(ref[i], (size_t) ref_len[i]);
+			q.assign(qry[i], (size_t) qry_len[i]);
+			char *cig = text + text_off[i];
+			char *md = cig + text_cap[i];
+			auto t0 = std::chrono::steady_clock::now();
+			int rc = oracle_align(h, r.c_str(), q.c_str(), row_offset[i], row_length[i], qry_len[i], 0, 0, &outs[i],
+					cig, md, text_cap[i], 0, 0);
+			busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			if (rc != 0) threw[(size_t) t]++;
+		}
+		if (busy_seconds) busy_seconds[t] = busy;
+		oracle_destroy(h);
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+	work(0);
+	for (auto &x : th) x.join();
+	int bad = 0;
+	for (int v : threw) bad += v;
+	return bad;
 }
 
 }
