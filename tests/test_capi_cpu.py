@@ -83,3 +83,18 @@ def test_any_finite_scoring_is_accepted(built):
     p = capi.CvxParams(2, float("nan"), -5, -5, -1, 0.15)
     assert lib.cvx_create(0, C.byref(p), 0, C.byref(h)) == -2
     assert b"not finite" in lib.cvx_last_error()
+
+
+def test_bench_fails_loudly_when_devices_are_missing(built):
+    """`python bench.py --gpus N` launched directly must drive N devices or refuse before doing any work
+    (it used to report n_gpus 1 whatever N was)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert res.returncode == 2
+    assert "needs 2 visible MI355X device(s)" in res.stderr and res.stdout.strip() == ""
