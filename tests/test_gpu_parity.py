@@ -243,6 +243,35 @@ def test_sse_variant_kernel_equals_ring_kernels_under_default_scoring(built, por
     al.close()
 
 
+@pytest.mark.parametrize("env", [{"CVX_TUNE_BT_GROUP": "8"}, {"CVX_TUNE_BT_GROUP": "16"}, {"CVX_TUNE_BT_GROUP": "32"},
+                                 {"CVX_TUNE_BT_GROUP": "64"}, {"CVX_TUNE_OVERLAP_POST": "1"}])
+def test_runtime_knobs_do_not_change_results(built, port_oracle, monkeypatch, env):
+    """Every lanes-per-tile setting of the backtrack (the default picks 8 / 32 / 64 by batch shape) and the
+    post-fill overlap: same alignments.  A batch of > 4096 tiles so that the grouped kernels really run,
+    chained and whole tiles mixed, a few reads much longer than the rest."""
+    from ngmlr_amd import synth
+    from ngmlr_amd.aligner import ConvexAlignHip
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(404)
+    tiles = util.tile_zoo(seed=91, n=48, max_w=1500) + util.edge_tiles()
+    tiles.append(synth.make_tile(rng, 9000, err=0.2, ratio=(4, 4, 2), corridor="anchors", tag="long"))
+    tiles.append(synth.make_tile(rng, 2500, err=0.18, ratio=(4, 4, 2), corridor="endpoints", width=1400, realign=True, tag="chained"))
+    want = [port_oracle.align(t) for t in tiles]
+    filler = [synth.make_tile(rng, int(rng.integers(40, 120)), err=0.1, corridor="linear", ref_pad=60, tag="filler") for _ in range(64)]
+    batch = tiles + filler * 66                        # 4224 + len(tiles) tiles
+    al = ConvexAlignHip(device=0)
+    got = al.batch_align(batch, want_nm=False)
+    al.close()
+    bad = [(t.tag, same_alignment(w, g, keys=("ret", "score_bits", "position_offset", "qstart", "qend", "nm", "cigar", "md")))
+           for t, w, g in zip(tiles, want, got)]
+    bad = [b for b in bad if b[1] is not None and b[1] != "nm_per_position"]
+    assert not bad, bad[:5]
+    fill_want = [port_oracle.align(t) for t in filler[:8]]
+    for t, w, g in zip(filler[:8], fill_want, got[len(tiles):len(tiles) + 8]):
+        assert (w["ret"], w["cigar"]) == (g["ret"], g["cigar"]) or (w["ret"] < 0 and g["ret"] < 0), t.tag
+
+
 def test_irregular_corridors_take_the_catch_all_kernel(hip_aligner, port_oracle):
     """CorridorLine[] shapes no reference caller builds (row starts that do not increase):
     computed on the device by the catch-all kernel, never on the CPU, still bit-exact."""
