@@ -243,6 +243,44 @@ def test_sse_variant_kernel_equals_ring_kernels_under_default_scoring(built, por
     al.close()
 
 
+def _early_best_tiles(rng, n=24):
+    """Reads whose alignment ends long before the read does (a clean prefix, then junk): the best cell lies in
+    the first 30-60 % of the anti-diagonals, outside the exactly tracked tail of the two-phase fill."""
+    from ngmlr_amd import synth
+    tiles = []
+    for k in range(n):
+        W = int(rng.integers(2500, 7000))
+        ref = synth.random_ref(rng, W)
+        good = int(W * float(rng.uniform(0.3, 0.6)))
+        qry = np.concatenate([synth.mutate(rng, ref[:good], 0.1), synth.random_ref(rng, W - good)])
+        off, ln = synth.corridor_anchors(len(qry), W)
+        tiles.append(synth.Tile(ref.tobytes(), qry.tobytes(), off, ln, tag="early-best%d" % k))
+    return tiles
+
+
+@pytest.mark.parametrize("late_min", [None, "1", "1000000"])
+def test_two_phase_tracking_redo_path(built, port_oracle, monkeypatch, late_min):
+    """The two-phase fill only tracks the best cell exactly in the last groups of a tile and redoes a tile
+    with the exact instantiation when an earlier score is at least as large (cvx_kernels.hip).  Tiles whose
+    best cell is early MUST take that second pass and still equal the oracle (argmax cell included); a
+    one-group tail (CVX_TUNE_LATE_MIN=1) sends almost everything through it, a huge one nothing."""
+    from ngmlr_amd.aligner import ConvexAlignHip
+    if late_min is not None:
+        monkeypatch.setenv("CVX_TUNE_LATE_MIN", late_min)
+    rng = np.random.default_rng(77)
+    tiles = _early_best_tiles(rng) + util.tile_zoo(seed=12, n=36, max_w=3000)
+    al = ConvexAlignHip(device=0)
+    _check(al, port_oracle, tiles, need_valid=False)
+    batch = al.upload(tiles)
+    tm = batch.run()
+    batch.free()
+    al.close()
+    if late_min == "1000000":
+        assert tm.n_tiles_redone == 0
+    else:
+        assert tm.n_tiles_redone >= 12, tm.n_tiles_redone      # at least the engineered ones (some end in row 0: invalid, but still redone)
+
+
 @pytest.mark.parametrize("env", [{"CVX_TUNE_BT_GROUP": "8"}, {"CVX_TUNE_BT_GROUP": "16"}, {"CVX_TUNE_BT_GROUP": "32"},
                                  {"CVX_TUNE_BT_GROUP": "64"}, {"CVX_TUNE_OVERLAP_POST": "1"}])
 def test_runtime_knobs_do_not_change_results(built, port_oracle, monkeypatch, env):
