@@ -100,3 +100,30 @@ def test_corridorline_stride_is_accepted(hip_aligner, port_oracle):
     capi.check(lib.cvx_align_batch(hip_aligner.h, 1, C.byref(tile), res, ops.ctypes.data, len(ops), C.byref(used)))
     got = format_alignment(lib, res[0], ops, t)
     assert same_alignment(port_oracle.align(t), got) is None
+
+
+def test_more_ops_than_the_dense_arena_was_sized_for(built):
+    """The dense ops arena is sized for a third of H + W per tile; with a mild mismatch penalty an alignment
+    can alternate match / mismatch base by base (one op per base).  The batch summary then reports the
+    overflow and the ops are compacted again into a larger arena (cvx_runtime.cpp stage_ops) -- same results."""
+    from ngmlr_amd import synth
+    from ngmlr_amd.aligner import ConvexAlignHip
+    from oracle.pyoracle import Oracle, same_alignment
+    sc = dict(match=2.0, mismatch=-1.0, gap_open=-5.0, gap_extend=-5.0, gap_extend_min=-1.0, gap_decay=0.15)
+    rng = np.random.default_rng(3)
+    comp = np.frombuffer(bytes.maketrans(b"ACGT", b"CATG"), dtype=np.uint8)
+    tiles = []
+    for k in range(6):
+        ref = synth.random_ref(rng, 2500)
+        qry = ref.copy()
+        qry[1::2] = comp[qry[1::2]]                      # every other base substituted
+        off, ln = synth.corridor_anchors(len(qry), len(ref))
+        tiles.append(synth.Tile(ref.tobytes(), qry.tobytes(), off, ln, tag="alternating%d" % k))
+    al = ConvexAlignHip(device=0, **sc)
+    got = al.batch_align(tiles)
+    al.close()
+    orc = Oracle("port", (sc["match"], sc["mismatch"], sc["gap_open"], sc["gap_extend"], sc["gap_extend_min"], sc["gap_decay"]))
+    for t, g in zip(tiles, got):
+        w = orc.align(t)
+        assert same_alignment(w, g) is None, (t.tag, same_alignment(w, g))
+        assert g["ret"] == t.H and g["cigar"] in ("%dM" % t.H, "%dM1S" % (t.H - 1)) and g["nm"] > 1000      # ~2500 ops each: 15 000 > the 10 400 the arena was sized for
