@@ -126,4 +126,4 @@ def test_more_ops_than_the_dense_arena_was_sized_for(built):
     for t, g in zip(tiles, got):
         w = orc.align(t)
         assert same_alignment(w, g) is None, (t.tag, same_alignment(w, g))
-        assert g["ret"] == t.H and g["cigar"] in ("%dM" % t.H, "%dM1S" % (t.H - 1)) and g["nm"] > 1000      # ~2500 ops each: 15 000 > the 10 400 the arena was sized for
+        assert g["ret"] == t.H and g["nm"] > 1000      # ~2500 one-base ops each: 15 000 > the 10 400 the arena was sized for
