@@ -127,3 +127,30 @@ def test_more_ops_than_the_dense_arena_was_sized_for(built):
         w = orc.align(t)
         assert same_alignment(w, g) is None, (t.tag, same_alignment(w, g))
         assert g["ret"] == t.H and g["nm"] > 1000      # ~2500 one-base ops each: 15 000 > the 10 400 the arena was sized for
+
+
+def test_streaming_jobs_waited_out_of_order_and_released_unwaited(hip_aligner, port_oracle):
+    """cvx_submit / cvx_wait / cvx_job_release: several jobs in flight on one handle; waiting for a later job
+    first, and releasing one that was never waited for, must neither hang nor disturb the others."""
+    from ngmlr_amd import capi
+    from ngmlr_amd.aligner import format_alignment
+    from oracle.pyoracle import same_alignment
+    sets = [util.tile_zoo(seed=200 + k, n=20, max_w=1500) for k in range(4)]
+    jobs = [hip_aligner.submit(ts) for ts in sets]
+
+    def check(job, tiles):
+        res, ops = job.wait()
+        for i, t in enumerate(tiles):
+            r = capi.CvxResult.from_buffer_copy(res[i].tobytes())
+            assert same_alignment(port_oracle.align(t), format_alignment(hip_aligner.lib, r, ops, t)) is None, t.tag
+    check(jobs[2], sets[2])
+    check(jobs[0], sets[0])
+    jobs[1].release()                      # never waited for
+    check(jobs[3], sets[3])
+    jobs[2].wait()                         # waiting twice is harmless
+    for j in (jobs[0], jobs[2], jobs[3]):
+        j.release()
+    # the handle is still good
+    got = hip_aligner.batch_align(sets[1][:5])
+    for t, g in zip(sets[1][:5], got):
+        assert same_alignment(port_oracle.align(t), g) is None
