@@ -153,6 +153,37 @@ inline void upload_zero_pads(const UploadLayout &L, uint8_t *hseq) {
 	else memset(hseq + (size_t) (L.seq_total - L.pad - 64), 0, (size_t) L.pad + 64);
 }
 
+/* Step bytes of rows [1, H) of a tile whose (offset, length) arrays are plain int32 arrays (stride 4), eight
+ * rows per iteration.  Returns the first row it did not finish (H when all rows fit the one-byte form; a row
+ * whose width differs or whose step is outside -128..127 stops it, and the scalar loop decides). */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) inline int pack_steps_avx2(const int32_t *off, const int32_t *len, int H, int32_t w0, int8_t *dst) {
+	const __m256i vw = _mm256_set1_epi32(w0);
+	const __m256i lo = _mm256_set1_epi32(-129), hi = _mm256_set1_epi32(128);
+	const __m256i big = _mm256_set1_epi32(1 << 30), nbig = _mm256_set1_epi32(-(1 << 30));
+	const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+			0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+	int y = 1;
+	for (; y + 8 <= H; y += 8) {
+		const __m256i cur = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(off + y));
+		const __m256i prv = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(off + y - 1));
+		const __m256i l = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(len + y));
+		/* with both offsets inside (-2^30, 2^30) the 32-bit difference cannot wrap (anything else: scalar loop) */
+		const __m256i d = _mm256_sub_epi32(cur, prv);
+		const __m256i inr = _mm256_and_si256(_mm256_and_si256(_mm256_cmpgt_epi32(cur, nbig), _mm256_cmpgt_epi32(big, cur)),
+				_mm256_and_si256(_mm256_cmpgt_epi32(prv, nbig), _mm256_cmpgt_epi32(big, prv)));
+		const __m256i ok = _mm256_and_si256(_mm256_and_si256(_mm256_and_si256(_mm256_cmpgt_epi32(d, lo), _mm256_cmpgt_epi32(hi, d)), _mm256_cmpeq_epi32(l, vw)), inr);
+		if (_mm256_movemask_epi8(ok) != -1) break;
+		const __m256i b = _mm256_shuffle_epi8(d, pick);
+		const uint32_t b0 = (uint32_t) _mm256_extract_epi32(b, 0), b1 = (uint32_t) _mm256_extract_epi32(b, 4);
+		memcpy(dst + y, &b0, 4);
+		memcpy(dst + y + 4, &b1, 4);
+	}
+	return y;
+}
+#endif
+
 /* Rows of the tiles that do not fit the one-byte form, collected by one packing thread. */
 struct RowOverflow {
 	std::vector<int32_t> tiles;        /* tile indices, in packing order */
@@ -185,7 +216,17 @@ inline void upload_pack(int begin, int end, const cvx_tile *tiles, const std::ve
 		rs.width = w0;
 		dst[0] = 0;
 		bool fits = true;
-		for (int y = 1; y < H; ++y) {
+		int y_from = 1;
+#if defined(__x86_64__)
+		/* plain int32 arrays with in-range first offset: eight rows per iteration (the scalar loop below finishes
+		 * the tail and is the judge of any row the vector loop stopped at) */
+		static const bool have_avx2 = __builtin_cpu_supports("avx2");
+		if (have_avx2 && stride == 4 && H > 16) {
+			y_from = pack_steps_avx2(reinterpret_cast<const int32_t *>(po), reinterpret_cast<const int32_t *>(pl), H, w0, dst);
+			if (y_from > 1) memcpy(&prev, po + (size_t) (y_from - 1) * stride, 4);
+		}
+#endif
+		for (int y = y_from; y < H; ++y) {
 			int32_t o, l;
 			memcpy(&o, po + (size_t) y * stride, 4);
 			memcpy(&l, pl + (size_t) y * stride, 4);

@@ -2,6 +2,7 @@
 // packing (ragged, empty and strided tiles, multi-threaded == single-threaded), kernel-class choice,
 // arena offsets and the LPT work lists.  Built with plain g++ by tests/test_host_logic_cpu.py.
 #include <atomic>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -32,10 +33,12 @@ int main() {
 		for (auto &c : qrys[i]) c = "ACGT"[rng() % 4];
 		off[i].resize(H); len[i].resize(H); lines[i].resize(H);
 		for (int y = 0; y < H; ++y) {
+			// (one tile has offsets next to INT32_MIN / INT32_MAX: the 32-bit difference of the vector path would wrap)
 			// two thirds of the tiles look like the reference's corridors (one width, offsets creeping along);
 			// the others change width from row to row or jump by more than a byte
 			off[i][y] = (int32_t) (y - 150 + (int) (rng() % 7)) + ((i % 11 == 5 && y > H / 2) ? 500 : 0) - ((i % 7 == 3) ? 2 * y : 0);
 			len[i][y] = (i % 3 == 0) ? (int32_t) (300 + rng() % 70) : 340;
+			if (i == 44) off[i][y] = (y & 1) ? INT32_MAX - y : INT32_MIN + y;
 			lines[i][y] = {off[i][y], len[i][y], 0xdeadbeefull};
 		}
 		cvx_tile &t = tiles[i];
