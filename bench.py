@@ -471,8 +471,9 @@ def main() -> int:
             ent = pm.get("fill_ring_kernel<M=%d,NW=%d,wrap16=%d>" % dom)
             if ent:
                 traffic = ent["hbm_bytes"] * (meta["alg_bytes"] / ent["alg_bytes"])
-                traffic_src = ("SCALED, not measured in this run: profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE "
-                               "of %d tiles) x algorithmic-byte ratio" % ent.get("tiles", 0))
+                traffic_src = ("not measured in this run: profiles/r02_pmc.json (separate rocprofv3 --pmc FETCH_SIZE x2 / --pmc WRITE_SIZE passes of "
+                               "the same bench command, %d tiles in the launch) x algorithmic-byte ratio %.3f" % (
+                                   ent.get("tiles", 0), meta["alg_bytes"] / ent["alg_bytes"]))
         except Exception:
             pass
         out = {

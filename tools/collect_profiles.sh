@@ -11,8 +11,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 400 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o p -- python $R/bench.py --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
-timeout -s KILL 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o p -- python $R/bench.py --tiles 4096 --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_fetch.log 2>&1
-timeout -s KILL 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o p -- python $R/bench.py --tiles 4096 --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_write.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o p -- python $R/bench.py --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o p -- python $R/bench.py --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_write.log 2>&1
 # issue-side counters: instructions, wave cycles, and the three disjoint wave states (parked / issue-stalled / issuing)
 timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/${TAG}_sq -o p -- python $R/bench.py --tiles 12288 --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_sq.log 2>&1
 # VALU pipe occupancy proper (cycles the VALU is executing, not instruction counts), if this rocprofv3 has the counters
