@@ -99,39 +99,55 @@ int BatchingAligner::SingleAlign(int const mode, CorridorLine * corridor, int co
 /* ------------------------------------------------------------------ SharedAligner */
 
 namespace {
+/* one (backend, batching aligner) pair per device; workers are dealt round-robin over the devices in the
+ * order they construct their aligner, so ngmlr's -t N reads shard over every MI355X of the node (all tiles
+ * of a read stay with its worker, hence on one device) */
+const int kMaxDevices = 64;
 std::mutex g_sharedMtx;
-ConvexAlignHip * g_backend = 0;
-BatchingAligner * g_shared = 0;
+ConvexAlignHip * g_backend[kMaxDevices] = {0};
+BatchingAligner * g_shared[kMaxDevices] = {0};
+int g_deviceUsers[kMaxDevices] = {0};
 int g_users = 0;
+long g_joined = 0;
 long g_lastLaunches = 0, g_lastRequests = 0;
 }
 
 SharedAligner::SharedAligner(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
-		float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId) : shared(0) {
+		float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId) : shared(0), device(0) {
 	std::lock_guard<std::mutex> g(g_sharedMtx);
-	if (g_shared == 0) {
+	int nDev = cvx_device_count();
+	if (const char * e = getenv("CVX_DEVICES")) nDev = atoi(e) < nDev ? atoi(e) : nDev;      /* use only the first k devices */
+	if (nDev > kMaxDevices) nDev = kMaxDevices;
+	/* deviceId >= 0 pins the worker; the default spreads them */
+	device = (deviceId >= 0 && nDev > 0) ? deviceId % nDev : (nDev > 0 ? (int) (g_joined % nDev) : 0);
+	g_joined += 1;
+	if (g_shared[device] == 0) {
 		int maxBatch = 4096, timeoutUs = 2000;
 		if (const char * e = getenv("CVX_BATCH_MAX")) maxBatch = atoi(e);
 		if (const char * e = getenv("CVX_BATCH_TIMEOUT_US")) timeoutUs = atoi(e);
-		g_backend = new ConvexAlignHip(stdOutMode, match, mismatch, gapOpen, gapExtend, gapExtendMin, gapDecay, deviceId);
-		g_shared = new BatchingAligner(g_backend, 0, maxBatch, timeoutUs);   /* workers join one by one */
+		g_backend[device] = new ConvexAlignHip(stdOutMode, match, mismatch, gapOpen, gapExtend, gapExtendMin, gapDecay, device);   /* throws without a usable device */
+		g_shared[device] = new BatchingAligner(g_backend[device], 0, maxBatch, timeoutUs);   /* workers join one by one */
 	}
-	g_shared->WorkerJoined();
+	g_shared[device]->WorkerJoined();
+	g_deviceUsers[device] += 1;
 	g_users += 1;
-	shared = g_shared;
+	shared = g_shared[device];
 }
 
 SharedAligner::~SharedAligner() {
 	std::lock_guard<std::mutex> g(g_sharedMtx);
 	shared->WorkerDone();
+	g_deviceUsers[device] -= 1;
 	g_users -= 1;
+	if (g_deviceUsers[device] == 0) {
+		g_lastLaunches += g_shared[device]->Launches();
+		g_lastRequests += g_shared[device]->Requests();
+		delete g_shared[device]; g_shared[device] = 0;
+		delete g_backend[device]; g_backend[device] = 0;
+	}
 	if (g_users == 0) {
-		g_lastLaunches = g_shared->Launches();
-		g_lastRequests = g_shared->Requests();
 		fprintf(stderr, "SharedAligner: %ld alignments in %ld device launches (%.1f per launch)\n", g_lastRequests,
 				g_lastLaunches, g_lastLaunches ? (double) g_lastRequests / (double) g_lastLaunches : 0.0);
-		delete g_shared; g_shared = 0;
-		delete g_backend; g_backend = 0;
 	}
 }
 
@@ -141,7 +157,17 @@ int SharedAligner::SingleAlign(int const mode, CorridorLine * corridor, int cons
 	return shared->SingleAlign(mode, corridor, corridorHeight, refSeq, qrySeq, result, externalQStart, externalQEnd, extData);
 }
 
-long SharedAligner::Launches() { std::lock_guard<std::mutex> g(g_sharedMtx); return g_shared ? g_shared->Launches() : g_lastLaunches; }
-long SharedAligner::Requests() { std::lock_guard<std::mutex> g(g_sharedMtx); return g_shared ? g_shared->Requests() : g_lastRequests; }
+long SharedAligner::Launches() {
+	std::lock_guard<std::mutex> g(g_sharedMtx);
+	long n = g_lastLaunches;
+	for (int d = 0; d < kMaxDevices; ++d) if (g_shared[d]) n += g_shared[d]->Launches();
+	return n;
+}
+long SharedAligner::Requests() {
+	std::lock_guard<std::mutex> g(g_sharedMtx);
+	long n = g_lastRequests;
+	for (int d = 0; d < kMaxDevices; ++d) if (g_shared[d]) n += g_shared[d]->Requests();
+	return n;
+}
 
 }  // namespace Convex

@@ -79,15 +79,16 @@ private:
  * AlignmentBuffer (one per CS worker thread, reference src/CS.cpp:412-418) constructs "its"
  * aligner at src/AlignmentBuffer.h:355 and deletes it in its destructor (:375).  Constructing a
  * SharedAligner there instead gives each worker a thin IAlignment whose SingleAlign parks in ONE
- * process-wide BatchingAligner over ONE ConvexAlignHip per device: with `-t N` up to N tiles
- * travel per device launch.  The first SharedAligner creates the shared pair, the last one to be
- * destroyed prints the launch statistics and deletes it.  Scoring parameters are those of the
+ * BatchingAligner per device (one ConvexAlignHip each): with `-t N` up to N tiles travel per device
+ * launch, and on a node with several MI355X the workers -- hence the reads -- are dealt round-robin over
+ * the devices (CVX_DEVICES=k limits that to the first k).  The first SharedAligner of a device creates
+ * its pair, the last one to go deletes it; the very last one prints the launch statistics.  Scoring parameters are those of the
  * first construction (every worker passes the same Config values).
  */
 class SharedAligner: public IAlignment {
 public:
 	SharedAligner(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
-			float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId = 0);
+			float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId = -1 /* -1: workers are dealt over all devices */);
 	virtual ~SharedAligner();
 
 	virtual int GetScoreBatchSize() const { return 0; }
@@ -109,6 +110,7 @@ public:
 
 private:
 	BatchingAligner * shared;
+	int device;
 };
 
 }  // namespace Convex
