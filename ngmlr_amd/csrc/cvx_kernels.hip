@@ -108,6 +108,10 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 			int pgs, pge;
 			row_span(r[y - 1], W, y - 1, pgs, pge);
 			if (gs <= pgs) flags |= kPlanIrregular;  /* ring schedule needs increasing row starts */
+			/* ... and rows that end in order: the fill hands slots over in row order (its staged row
+			 * records are overwritten on that assumption).  True for every corridor the reference builds
+			 * (one width, offsets that never decrease); a corridor whose rows shrink goes to the catch-all kernel. */
+			if (ge < pge) flags |= kPlanIrregular;
 		}
 		/* first row y' > y that starts at or after ge + margin (gs is increasing): gallop out from
 		 * a guess -- row starts advance by about two anti-diagonals per row in a sloped corridor --
@@ -511,9 +515,13 @@ fill_ring_kernel(const FillArgs a) {
 	float vmat = a.sp.mat, vmis = a.sp.mis;
 	asm volatile("" : "+v"(vmat), "+v"(vmis));
 
-	/* rarely touched per-slot state lives in LDS to keep VGPRs for occupancy: the read
-	 * row a slot holds and the row of its best cell (both only change at a row switch) */
-	__shared__ int s_y[M][64];
+	/* The row a slot takes over next is a 16-byte record in LDS, written 16*M rows at a time by the whole
+	 * wave long before the hand-over (stage_rows below): the hand-over itself is one ds_read_b128 and two
+	 * adds for the few lanes whose row just ended, instead of two dependent trips to HBM (corridor row, then
+	 * reference characters) and ~25 VALU instructions executed by the whole wave for one or two lanes --
+	 * round 2's counters had the wave parked on s_waitcnt for a quarter of its time, most of it here.
+	 * The row of a slot's best cell (changes only at a hand-over) lives in LDS too, to keep VGPRs for occupancy. */
+	__shared__ int4 s_rec[CHAIN ? 1 : M][64];
 	__shared__ int s_besty[M][64];
 	__shared__ BoundaryRec s_bnd[CHAIN ? kChainChunk : 1];      /* the predecessor's boundary records of the current chunk of steps */
 
@@ -567,40 +575,74 @@ fill_ring_kernel(const FillArgs a) {
 	u64 mD[M];         /* latest cell is a deletion (run > 0)  */
 	u64 mI[M];         /* latest cell is an insertion          */
 
-	/* (re)bind slot j to its row y[j]; rnext = index of the next step.  Leaves the
-	 * reference characters of the group starting at rnext in cwn[j]. */
-	auto bind_row = [&](int j, int rnext) {
-		const int yy = s_y[j][tid];
+	/* Row record: what a slot needs to take row yy (block-local index) over at any later step rnext:
+	 *   x = first anti-diagonal of the row (cnt = rnext - x is the column index inside the row, < 0 before it starts)
+	 *   y = row length after clipping to [0, W)          z = read character of the row
+	 *   w = arena offset of the reference character of anti-diagonal 0 in this row (= ref_off - row index);
+	 *       also identifies the row: yy = ref_base - w.
+	 * Rows at and beyond H (the ring outlives the tile) get a record that never starts. */
+	const unsigned ref_base = ti.ref_off - (unsigned) y0;
+	auto make_rec = [&](const int yy) {
+		int4 rec;
+		rec.w = (int) (ref_base - (unsigned) yy);
 		if (yy < H) {
 			const int2 ol = rows[yy];
 			long long lo = ol.x > 0 ? ol.x : 0;
 			long long hi = (long long) ol.x + (long long) ol.y;
 			if (hi > W) hi = W;
 			if (hi < lo) hi = lo;
-			cnt[j] = rnext - (yy + y0 + (int) lo);
-			len[j] = (int) (hi - lo);
-			qch[j] = seq[qry_off + (unsigned) yy];
-			xa[j] = ti.ref_off + (unsigned) (rnext - (yy + y0));
+			rec.x = yy + y0 + (int) lo;
+			rec.y = (int) (hi - lo);
+			rec.z = seq[qry_off + (unsigned) yy];
 		} else {
-			cnt[j] = -(1 << 30);
-			len[j] = 0;
-			qch[j] = 0;
-			xa[j] = ti.ref_off;
+			rec.x = yy + y0 + (1 << 30);
+			rec.y = 0;
+			rec.z = 0;
 		}
-		cwn[j] = *reinterpret_cast<const unsigned *>(seq + xa[j]);
-		xa[j] += 4u;
+		return rec;
+	};
+	/* slot j takes the row of `rec` over; rnext = index of the next step.  Invariant between groups:
+	 * xa[j] = rec.w + r + 4, the address of the characters of the group after next. */
+	auto take_row = [&](const int j, const int4 rec, const int rnext, const bool fetch_now) {
+		cnt[j] = rnext - rec.x;
+		len[j] = rec.y;
+		qch[j] = rec.z;
+		xa[j] = (unsigned) rec.w + (unsigned) rnext + 4u;
+		/* The characters of the group starting at rnext: whatever cwn[j] holds will do when the row starts
+		 * no earlier than the group after (cells outside a row are forced to the empty element whatever
+		 * they compare); the regular prefetch at the top of the next group then picks the row up.  Only a
+		 * ring without slack hands a slot over less than a group before its row starts. */
+		if (fetch_now || cnt[j] > -4) cwn[j] = *reinterpret_cast<const unsigned *>(seq + (xa[j] - 4u));
+	};
+	/* the wave writes the records of rows [Y, Y + 16 M) to their slots (sY = Y mod N, wave-uniform) */
+	constexpr int kStage = 16 * M;
+	auto stage_rows = [&](const int Y, const int sY) {
+		if (lane < kStage) {
+			const int4 rec = make_rec(Y + lane);
+			const int sl = sY + lane;
+			s_rec[CHAIN ? 0 : sl % M][sl / M] = rec;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      /* one wave: LDS write -> read order across lanes */
 	};
 
 #pragma unroll
 	for (int j = 0; j < M; ++j) {
-		s_y[j][tid] = tid * M + j;
 		s_besty[j][tid] = 0;
 		S[j] = 0.0f; Hc[j] = go; V[j] = go; dg[j] = 0.0f;
 		drun[j] = 0; irun[j] = 0;
 		best[j] = 0.0f; best_r[j] = 0;
 		accA[j] = accB[j] = 0u;
 		mD[j] = 0; mI[j] = 0;
-		bind_row(j, r0);
+		cwn[j] = 0u;
+		take_row(j, make_rec(tid * M + j), r0, true);
+	}
+	/* rows [N, 2N - 16 M) are staged up front; from then on the hand-over of every row that is a multiple
+	 * of 16 M (slot 0 of lanes 0, 16, 32, 48) stages the 16 M rows that end one ring further on: their slots
+	 * were all handed over before it (rows end in order), and the first of them is needed only when the row
+	 * 16 M above the triggering one ends, N - 16 M row ends later. */
+	int stage_next = N, stage_slot = 0;
+	if (!CHAIN) {
+		for (; stage_next < 2 * N - kStage; stage_next += kStage, stage_slot += kStage) stage_rows(stage_next, stage_slot);
 	}
 
 	const int ngroups = (nsteps + 3) >> 2;
@@ -837,16 +879,23 @@ fill_ring_kernel(const FillArgs a) {
 		/* hand finished slots to their next row (y + N): a row's last cell is consumed
 		 * by the row below one step after it was computed, so wait for cnt > len
 		 * (a chained block has at most N rows: nothing is ever handed on) */
+		/* (wave-uniform: a row that is a multiple of 16 M is handed over in this group) */
+		const bool stage_now = !CHAIN && (ballot(cnt[0] > len[0]) & 0x0001000100010001ull) != 0ull;
 #pragma unroll
 		for (int j = 0; j < M; ++j) {
-			if (!CHAIN && cnt[j] > len[j]) {     /* finished a real row (unbound slots count up from -2^30) */
-				const int yy = s_y[j][tid];
+			if (!CHAIN && cnt[j] > len[j]) {     /* finished a real row (slots beyond the tile count up from -2^30) */
 				if (TRACK) {
+					const int yy = (int) (ref_base - (xa[j] - (unsigned) r - 4u));
 					if (best_r[j] >= r - cnt[j]) s_besty[j][tid] = yy;
 				}
-				s_y[j][tid] = yy + N;
-				bind_row(j, r);
+				take_row(j, s_rec[CHAIN ? 0 : j][tid], r, false);
 			}
+		}
+		if (stage_now) {
+			stage_rows(stage_next, stage_slot);
+			stage_next += kStage;
+			stage_slot += kStage;
+			if (stage_slot >= N) stage_slot = 0;
 		}
 	};
 
@@ -870,7 +919,8 @@ fill_ring_kernel(const FillArgs a) {
 #pragma unroll
 	for (int j = 0; j < M; ++j) {
 		int vy = s_besty[j][tid];
-		if (s_y[j][tid] < H && best_r[j] >= r - cnt[j]) vy = s_y[j][tid];
+		const int ycur = (int) (ref_base - (xa[j] - (unsigned) r - 4u));      /* the row the slot holds now */
+		if (ycur < H && best_r[j] >= r - cnt[j]) vy = ycur;
 		const float v = best[j];
 		const int vx = best_r[j] - vy;
 		if (v > 0.0f) {     /* best[] starts at 0: a slot that never saw a positive score has no candidate */
