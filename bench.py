@@ -24,6 +24,7 @@ the same tiles, every one of which is also compared with the GPU result (`parity
 from __future__ import annotations
 
 import argparse
+from ctypes import c_char_p as C_char_p
 import json
 import multiprocessing as mp
 import os
@@ -61,7 +62,6 @@ def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
         """-> (seconds wall, busy seconds summed, outs, cigar list, md list) for tiles idx (C++ threads)."""
         lib = C.CDLL(pyoracle.REF_SO)
         m = len(idx)
-        tab = ts.table()[idx]
         caps = (4 * ts.H[idx] + 4 * ts.W[idx] + 256).astype(np.int32)
         toff = np.concatenate([[0], np.cumsum(2 * caps.astype(np.int64))]).astype(np.uint64)
         text = np.zeros(int(toff[-1]) + 16, dtype=np.uint8)
@@ -69,8 +69,12 @@ def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
         busy = np.zeros(threads, dtype=np.float64)
         params = (C.c_float * 6)(*pyoracle.DEFAULT_PARAMS)
         arr = lambda a: np.ascontiguousarray(a)  # noqa: E731
-        refp, qryp, rop, rlp = arr(tab["ref"]), arr(tab["qry"]), arr(tab["row_offset"]), arr(tab["row_length"])
-        rl, ql = arr(tab["ref_len"]), arr(tab["qry_len"])
+        # (the reference takes the corridor ROWS: pointers into the tile set's arrays, whatever form the GPU side was handed)
+        refp = arr((ts.ref.ctypes.data + ts.ref_off[:-1][idx]).astype(np.uint64))
+        qryp = arr((ts.qry.ctypes.data + ts.qry_off[:-1][idx]).astype(np.uint64))
+        rop = arr((ts.row_offset.ctypes.data + 4 * ts.qry_off[:-1][idx]).astype(np.uint64))
+        rlp = arr((ts.row_length.ctypes.data + 4 * ts.qry_off[:-1][idx]).astype(np.uint64))
+        rl, ql = arr(ts.W[idx].astype(np.int32)), arr(ts.H[idx].astype(np.int32))
         lib.oracle_align_many.restype = C.c_int
         lib.oracle_align_many.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 11
         toff_in = np.ascontiguousarray(toff[:-1])          # (kept in a variable: the call must not outlive a temporary)
@@ -165,7 +169,80 @@ def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
         "cells_per_s_per_core": cells / max(busy_sum, 1e-9),
         "thread_scan_Gbp_per_h": scan,
     }
+    # the same reference as independent processes, one per visible core (and at the thread scan's best count): its best foot
+    try:
+        if kind == "reference":
+            per_tile_s = dt * threads / max(n_sample, 1)            # ~ one core's seconds per tile
+            best = None
+            for pc in sorted({min(cores, 128), threads}):
+                m = int(min(n, max(pc, pc * int(max(1.0, seconds_budget / 2.0 / max(per_tile_s, 1e-3))))))
+                r = cpu_baseline_processes(ts, m, pc, seconds_budget)
+                if r is not None:
+                    cpu.setdefault("as_processes", []).append(r)
+                    if best is None or r["value"] > best["value"]:
+                        best = r
+            if best is not None and best["value"] > cpu["value"]:
+                cpu["threads_in_one_process"] = {"value": cpu["value"], "cores": cpu["cores"]}
+                cpu["value"], cpu["cores"] = best["value"], best["processes"]
+                cpu["sample"] = ("%d of the step's tiles on %d single-threaded processes in %.1f s wall (the best of: one process with the best thread "
+                                 "count -- %.1f Gbp/h on %d threads, every tile of that run compared with the GPU --, and 1 process per core); %d host cores"
+                                 % (best["tiles"], best["processes"], best["seconds"], cpu["threads_in_one_process"]["value"], threads, cores))
+    except Exception as e:        # the extra measurement must not break the contract line
+        cpu["as_processes_error"] = str(e)
     return cpu, "%d/%d" % (n_sample - n_bad, n_sample), detail
+
+
+def cpu_baseline_processes(ts, n_sample, procs, seconds_budget):
+    """The reference as independent single-threaded PROCESSES (how BASELINE.md section 2 measured it; the reference's
+    threads inside one process stop scaling at ~32 on the bench host): `procs` workers (oracle/ref_proc_worker.py),
+    started together, each with every procs-th tile of the sample.  -> dict or None.  Outputs are not collected here
+    (parity is checked on the threaded run)."""
+    import subprocess
+    import tempfile
+    from oracle import pyoracle
+    if not pyoracle.have_ref():
+        return None
+    # bounded: at most 4096 tiles (~0.5 GB of arrays, written once and memory-mapped by every worker) and 128 processes
+    procs = int(max(1, min(procs, 128)))
+    n_sample = int(min(len(ts), 4096, max(procs, n_sample)))
+    sub = ts.subset(np.arange(n_sample))
+    d = tempfile.mkdtemp(prefix="cvx_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    path, go = d, os.path.join(d, "go")
+    files = []
+    for k_, a_ in (("ref", sub.ref), ("qry", sub.qry), ("row_offset", sub.row_offset), ("row_length", sub.row_length),
+                   ("ref_off", sub.ref_off), ("qry_off", sub.qry_off)):
+        np.save(os.path.join(d, k_ + ".npy"), np.ascontiguousarray(a_))
+        files.append(os.path.join(d, k_ + ".npy"))
+    worker = os.path.join(ROOT, "oracle", "ref_proc_worker.py")
+    ps = [subprocess.Popen([sys.executable, worker, path, str(k), str(procs), go], stdout=subprocess.PIPE, text=True) for k in range(procs)]
+    try:
+        for q in ps:
+            if q.stdout.readline().strip() != "ready":
+                raise RuntimeError("worker did not start")
+        t0 = time.perf_counter()
+        open(go, "w").close()
+        outs = [q.stdout.readline().split() for q in ps]
+        dt = time.perf_counter() - t0
+        for q in ps:
+            q.wait(timeout=60)
+        bases = sum(int(o[1]) for o in outs)
+        cells = sum(int(o[2]) for o in outs)
+        busy = sum(float(o[0]) for o in outs)
+        return {"value": bases / dt * 3600.0 / 1e9, "unit": "Gbp/h", "processes": procs, "tiles": n_sample, "seconds": dt,
+                "cells_per_s_per_process": cells / max(busy, 1e-9), "threw": sum(int(o[3]) for o in outs)}
+    finally:
+        for q in ps:
+            if q.poll() is None:
+                q.kill()
+        for f in files + [go]:
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+        try:
+            os.rmdir(d)
+        except OSError:
+            pass
 
 
 def subread_scoring_rates(lib, dev, n=32768):
@@ -271,6 +348,11 @@ def main() -> int:
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--resident-steps", type=int, default=3, help="extra untimed-for-`value` steps with inputs resident in HBM")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (SURVEY 8e, config C4): ONE list of --tiles tiles, partitioned over the devices by the sum of "
+                         "their cells (LPT, ngmlr_amd.shard), results restored to list order; default: weak, --tiles per device")
+    ap.add_argument("--row-arrays", action="store_true", help="hand over corridor row arrays instead of the builders' closed forms")
+    ap.add_argument("--no-pin", action="store_true", help="keep the sequences in ordinary (pageable) memory: cvx_submit packs them into its own staging")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -307,9 +389,19 @@ def main() -> int:
     from ngmlr_amd import synth
     t_gen = time.perf_counter()
     procs = max(1, min((os.cpu_count() or 1) // (world if under_launcher else 1), 64))
+    strong_parts = None
     with ProcessPoolExecutor(procs, mp_context=mp.get_context("fork")) as pool:
-        tilesets = [synth.pacbio_tileset(args.tiles, seed=args.seed + 1000 * (rank + d), read_len=args.read_len, pool=pool)
-                    for d in range(n_local)]
+        if args.strong:
+            # one list for the whole job (every rank generates the same one from the same seed), partitioned by cells
+            from ngmlr_amd.shard import shard_tiles
+            whole = synth.pacbio_tileset(args.tiles, seed=args.seed, read_len=args.read_len, pool=pool)
+            cells = np.add.reduceat(whole.row_length.astype(np.int64), whole.qry_off[:-1]) if len(whole) else np.zeros(0, np.int64)
+            strong_parts = shard_tiles(cells.tolist(), args.gpus)
+            mine = [rank] if under_launcher else list(range(n_local))
+            tilesets = [whole.subset(strong_parts[d]) for d in mine]
+        else:
+            tilesets = [synth.pacbio_tileset(args.tiles, seed=args.seed + 1000 * (rank + d), read_len=args.read_len, pool=pool)
+                        for d in range(n_local)]
     t_gen = time.perf_counter() - t_gen
 
     from ngmlr_amd import capi
@@ -328,6 +420,13 @@ def main() -> int:
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     devs = [local_rank] if under_launcher else list(range(n_local))
     workers = [Worker(d, ts, args.depth) for d, ts in zip(devs, tilesets)]
+    # corridors travel as the closed forms of the reference's builders (the device generates the rows), sequences sit
+    # in page-locked arenas the device pulls from directly: cvx_submit touches no base and no row
+    pinned = []
+    for ts in tilesets:
+        if not args.row_arrays:
+            ts.use_closed_form()
+        pinned.append((not args.no_pin) and ts.pin(lib))
 
     def sync_all():
         # every device this process drives is idle: hipDeviceSynchronize behind the C ABI (what
@@ -467,15 +566,24 @@ def main() -> int:
         # committed rocprofv3 passes of this round are scaled to this launch by algorithmic bytes
         traffic, traffic_src = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-            ent = pm.get("fill_ring_kernel<M=%d,NW=%d,wrap16=%d>" % dom)
-            if ent:
-                traffic = ent["hbm_bytes"] * (meta["alg_bytes"] / ent["alg_bytes"])
-                traffic_src = ("not measured in this run: profiles/r02_pmc.json (separate rocprofv3 --pmc FETCH_SIZE x2 / --pmc WRITE_SIZE passes of "
-                               "the same bench command, %d tiles in the launch) x algorithmic-byte ratio %.3f" % (
-                                   ent.get("tiles", 0), meta["alg_bytes"] / ent["alg_bytes"]))
-        except Exception:
-            pass
+            import glob
+            lib.cvx_build_id.restype = C_char_p
+            build_id = lib.cvx_build_id().decode()
+            for pm_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+                pm = json.load(open(pm_path))
+                if pm.get("build_id") != build_id:
+                    continue                                   # counters of another build of the kernels: not this launch's traffic
+                ent = pm.get("fill_ring_kernel<M=%d,NW=%d,wrap16=%d>" % dom)
+                if ent:
+                    traffic = ent["hbm_bytes"] * (meta["alg_bytes"] / ent["alg_bytes"])
+                    traffic_src = ("not measured in this run: %s (separate rocprofv3 --pmc FETCH_SIZE x2 / --pmc WRITE_SIZE passes of the same bench "
+                                   "command on the same build %s, %d tiles in the launch) x algorithmic-byte ratio %.3f" % (
+                                       os.path.relpath(pm_path, ROOT), build_id, ent.get("tiles", 0), meta["alg_bytes"] / ent["alg_bytes"]))
+                    break
+            if traffic is None:
+                traffic_src = "no profiles/r*_pmc.json was collected on this build of the kernels (%s): null rather than a stale number" % build_id
+        except Exception as e:
+            traffic_src = "unavailable: %s" % e
         out = {
             "metric": "aligned Gbp/hour (PacBio 10kb synthetic, convex-gap SW hot path, host buffers in -> results out, CIGAR bit-exact)",
             "value": value,
@@ -485,7 +593,7 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -497,7 +605,11 @@ def main() -> int:
                 "corridor_width_max": int(wd.max()),
                 "cells_per_gpu_per_step": ts.cells,
                 "batches_in_flight_per_gpu": args.depth,
-                "h2d_bytes_per_gpu_per_step": int(ts.ref.nbytes + ts.qry.nbytes + ts.row_offset.size),   # sequences + one step byte per corridor row
+                "h2d_bytes_per_gpu_per_step": int(ts.ref.nbytes + ts.qry.nbytes + (ts.row_offset.size if args.row_arrays else 32 * len(ts))),   # sequences + one step byte per corridor row, or a 32-byte closed form per tile
+                "corridors": "row arrays (one step byte per row uploaded)" if args.row_arrays else "closed forms of the reference's builders (cvx_tile.corridor_kind), rows generated on the device",
+                "sequences": "page-locked arena (cvx_host_alloc), pulled by the device without host packing" if pinned and pinned[0] else "pageable memory, packed into the job's pinned staging by cvx_submit",
+                "strong_scaling_partition": ({"tiles_total": args.tiles, "tiles_per_device": [len(p_) for p_ in strong_parts], "by": "sum of corridor cells (LPT)",
+                                              "order_restored": sorted(i_ for p_ in strong_parts for i_ in p_) == list(range(args.tiles))} if strong_parts is not None else None),
                 "launch": "torch.distributed.run, one rank per device" if under_launcher else "one process, one host thread + handle per device",
                 "sharding": "reads sharded across devices, no collective on the data path",
             },
@@ -522,7 +634,8 @@ def main() -> int:
                                   if resident and "fill_ms" in resident else None),
             "device_resident": resident,
             "host_ms_per_step": {"cvx_submit": float(w0.host_s[0]) / args.steps * 1e3, "cvx_wait": float(w0.host_s[1]) / args.steps * 1e3,
-                                 "what": "wall time the device's host thread spends inside the two calls (packing + queueing / blocked on results)"},
+                                 "what": "wall time the device's host thread spends inside the two calls (packing + queueing / blocked on results)",
+                                 "pack_threads_shared_by_the_process": int(os.environ.get("CVX_PACK_THREADS", "0")) or min(os.cpu_count() or 1, 16)},
             "valid_alignments": "%d/%d" % (valid, len(ts)),
             "parity": parity,
             "parity_detail": parity_detail,
@@ -534,6 +647,8 @@ def main() -> int:
         }
     for w in workers:
         w.al.close()
+    for ts in tilesets:
+        ts.unpin()
     if out is not None:
         print(json.dumps(out))
     if dist is not None:

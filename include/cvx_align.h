@@ -27,6 +27,8 @@
  *                             upload / kernels / download of neighbouring batches overlapped
  *                             (what a batching host driver needs, SURVEY.md 8 f1;
  *                              reference src/AlignmentBuffer.cpp:3361-3406)
+ * cvx_tile.corridor_kind      the corridor builders' closed forms, rows generated on the device
+ *                             src/AlignmentBuffer.cpp:68-197 (a8: the builders stay in ngmlr, their output need not travel)
  * cvx_format_alignment        convertCigar + N-clip flags    src/ConvexAlignFast.cpp:112-333,493-528
  * cvx_job_text                the same for a whole finished job, on the device (next-row f3)
  * cvx_score_batch             StrippedSW::BatchScore/SingleScore  src/StrippedSW.cpp:118-203 (next-row f2)
@@ -49,7 +51,7 @@
 extern "C" {
 #endif
 
-#define CVX_ABI_VERSION 3
+#define CVX_ABI_VERSION 4
 
 /* return codes */
 enum {
@@ -91,10 +93,29 @@ typedef struct {
 
 /* One SingleAlign call.  ref/qry need not be NUL-terminated (lengths are explicit;
  * the reference takes strlen).  Row y of the corridor covers reference columns
- * [row_offset[y], row_offset[y]+row_length[y]) clipped to [0, ref_len); the two
- * arrays are read with a byte stride so that &CorridorLine[0].offset /
- * &CorridorLine[0].length with stride sizeof(CorridorLine)=16 can be passed
- * directly (src/IAlignment.h:29-33). */
+ * [offset[y], offset[y]+length[y]) clipped to [0, ref_len).
+ *
+ * corridor_kind says where the rows come from:
+ *   CVX_CORRIDOR_ROWS    the caller's arrays: row_offset / row_length are read with a byte stride so
+ *                        that &CorridorLine[0].offset / &CorridorLine[0].length with stride
+ *                        sizeof(CorridorLine)=16 can be passed directly (src/IAlignment.h:29-33).
+ *   CVX_CORRIDOR_AFFINE  the closed form of the reference's own corridor builders: every row has
+ *                        corridor_width columns and
+ *                            offset[y] = (int) (((float) y - corridor_d) / corridor_k - corridor_right)
+ *                        evaluated in binary32 exactly as the reference does (float subtract, correctly
+ *                        rounded divide, float subtract, truncation), on the device -- no row array is
+ *                        read, packed or uploaded:
+ *                          getCorridorEndpointsWithAnchors  src/AlignmentBuffer.cpp:178-191
+ *                              k = qryLen * 1.0f / refLen, d = 0, right = corridorRight, width = (int)(left + right)
+ *                          getCorridorEndpoints             src/AlignmentBuffer.cpp:107-127
+ *                              k = qryLen * 1.0f / refLen, d = width / 2.0f, right = 0
+ *                          getCorridorLinear                src/AlignmentBuffer.cpp:68-82
+ *                              k = 1, d = width / 2 (integer division), right = 0      (exact below 2^24 rows)
+ *   CVX_CORRIDOR_CONST   every row is (corridor_offset, corridor_width):
+ *                          getCorridorFull                  src/AlignmentBuffer.cpp:84-105
+ * row_offset / row_length / row_stride_bytes are ignored for the closed forms. */
+enum { CVX_CORRIDOR_ROWS = 0, CVX_CORRIDOR_AFFINE = 1, CVX_CORRIDOR_CONST = 2 };
+
 typedef struct {
 	const char *ref;
 	const char *qry;
@@ -103,6 +124,12 @@ typedef struct {
 	int32_t ref_len;
 	int32_t qry_len;          /* = corridor height; every caller passes them equal */
 	int32_t row_stride_bytes; /* 4 for packed int32 arrays, 16 for CorridorLine[] */
+	int32_t corridor_kind;    /* CVX_CORRIDOR_* (0 = the row arrays) */
+	float corridor_k;
+	float corridor_d;
+	float corridor_right;
+	int32_t corridor_offset;
+	int32_t corridor_width;
 	int32_t reserved;
 } cvx_tile;
 
@@ -155,6 +182,9 @@ typedef struct {
 const char *cvx_last_error(void);
 int cvx_abi_version(void);
 int cvx_device_count(void);
+/* identifies the build of the device kernels (a hash of their source): profiles/ records it with the counters it
+ * collects, and bench.py reports counter-derived figures only for the build they were collected on */
+const char *cvx_build_id(void);
 /* Blocks until everything queued on `device_id` (by any handle of this process) has finished:
  * hipDeviceSynchronize behind the C ABI, for callers that bracket a timed region. */
 int cvx_device_synchronize(int device_id);
@@ -198,6 +228,26 @@ int cvx_wait(cvx_handle h, cvx_job job, const cvx_result **results, const uint32
 int cvx_job_timing(cvx_job job, cvx_timing *t);                        /* after cvx_wait */
 int cvx_job_launch_info(cvx_job job, int32_t i, cvx_launch_info *info); /* after cvx_wait */
 void cvx_job_release(cvx_handle h, cvx_job job);
+
+/* Page-locked host memory for sequences.  When all reads of a batch lie back to back (tile i+1's qry
+ * starts where tile i's ends) inside memory from cvx_host_alloc, and so do all its references, cvx_submit
+ * does not touch a single base: the device pulls both blocks straight out of the caller's arena.  Such
+ * memory must stay unchanged until cvx_wait has returned for every job that references it (ordinary
+ * memory is copied into the job's own staging before cvx_submit returns, as before). */
+int cvx_host_alloc(uint64_t bytes, void **out);
+void cvx_host_free(void *p);
+
+/* The corridor rows the device uses for a tile (its closed form evaluated by the device kernel, or the
+ * caller's arrays as they arrive there): offset[qry_len], length[qry_len].  A checking aid -- the
+ * reference's builders restated on the device must reproduce their arrays bit for bit. */
+int cvx_corridor_rows(cvx_handle h, const cvx_tile *tile, int32_t *offset, int32_t *length);
+
+/* Host-side cost of cvx_submit without a device: lays the batch out and packs it into ordinary memory
+ * `iters` times on the calling thread (plus the shared pack threads), no HIP call, nothing computed.
+ * assume_page_locked != 0: blocks of sequences that lie back to back count as page-locked (they would travel
+ * without packing).  *ms_per_iter = wall time per pass; *bytes_touched = bytes the host read + wrote per pass.  For sizing
+ * the host side of an N-device node on a box without devices (tools/host_scale.py). */
+int cvx_pack_probe(int32_t n_tiles, const cvx_tile *tiles, int32_t iters, int32_t assume_page_locked, double *ms_per_iter, uint64_t *bytes_touched);
 
 /* Reference genome resident in HBM (decode half).
  *

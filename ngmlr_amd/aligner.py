@@ -49,25 +49,42 @@ class ConvexAlignHip:
         return 1 << 20
 
     # ------------------------------------------------------------------ staged API
-    def _pack(self, tiles: Sequence):
+    def _pack(self, tiles: Sequence, closed_form: bool = False):
+        """cvx_tile[] for per-tile objects.  closed_form: tiles that carry a corridor descriptor (Tile.desc) hand
+        over that instead of their row arrays."""
         n = len(tiles)
         arr = (capi.CvxTile * max(n, 1))()
         keep = []
         for i, t in enumerate(tiles):
+            arr[i].ref = t.ref
+            arr[i].qry = t.qry
+            arr[i].ref_len = len(t.ref)
+            arr[i].qry_len = len(t.qry)
+            desc = getattr(t, "desc", None) if closed_form else None
+            if desc is not None:
+                (arr[i].corridor_kind, arr[i].corridor_k, arr[i].corridor_d, arr[i].corridor_right,
+                 arr[i].corridor_offset, arr[i].corridor_width) = desc
+                keep.append((t.ref, t.qry))
+                continue
             off = np.ascontiguousarray(t.row_offset, dtype=np.int32)
             ln = np.ascontiguousarray(t.row_length, dtype=np.int32)
             keep.append((off, ln, t.ref, t.qry))
-            arr[i].ref = t.ref
-            arr[i].qry = t.qry
             arr[i].row_offset = off.ctypes.data
             arr[i].row_length = ln.ctypes.data
-            arr[i].ref_len = len(t.ref)
-            arr[i].qry_len = len(t.qry)
             arr[i].row_stride_bytes = 4
         return arr, keep
 
-    def upload(self, tiles: Sequence) -> "DeviceBatch":
-        arr, keep = self._pack(tiles)
+    def corridor_rows(self, tile):
+        """cvx_corridor_rows: the (offset, length) rows the DEVICE derives from the tile's closed form."""
+        arr, keep = self._pack([tile], closed_form=True)
+        H = len(tile.qry)
+        off = np.zeros(max(H, 1), dtype=np.int32)
+        ln = np.zeros(max(H, 1), dtype=np.int32)
+        capi.check(self.lib.cvx_corridor_rows(self.h, arr, off.ctypes.data, ln.ctypes.data))
+        return off[:H], ln[:H]
+
+    def upload(self, tiles: Sequence, closed_form: bool = False) -> "DeviceBatch":
+        arr, keep = self._pack(tiles, closed_form)
         b = C.c_void_p()
         capi.check(self.lib.cvx_batch_upload(self.h, len(tiles), arr, C.byref(b)))
         return DeviceBatch(self, b, list(tiles))
@@ -109,9 +126,9 @@ class ConvexAlignHip:
         return Job(self, j, n, keep)
 
     # ------------------------------------------------------------------ reference-shaped API
-    def batch_align(self, tiles: Sequence, want_nm: bool = True) -> List[dict]:
+    def batch_align(self, tiles: Sequence, want_nm: bool = True, closed_form: bool = False) -> List[dict]:
         """N x SingleAlign: returns one Align-like dict per tile (keys = the Align fields)."""
-        batch = self.upload(tiles)
+        batch = self.upload(tiles, closed_form)
         try:
             batch.run()
             return batch.alignments(want_nm=want_nm)

@@ -24,7 +24,8 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_submit", "cvx_wait", "cvx_job_timing", "cvx_job_launch_info", "cvx_job_release",
            "cvx_format_alignment", "cvx_format_batch", "cvx_score_batch",
            "cvx_genome_encoded_bytes", "cvx_genome_encode", "cvx_genome_upload", "cvx_genome_free",
-           "cvx_genome_decode", "cvx_submit_windows", "cvx_job_text")
+           "cvx_genome_decode", "cvx_submit_windows", "cvx_job_text",
+           "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id")
 
 
 class CvxParams(C.Structure):
@@ -35,7 +36,13 @@ class CvxParams(C.Structure):
 class CvxTile(C.Structure):
     _fields_ = [("ref", C.c_char_p), ("qry", C.c_char_p), ("row_offset", C.c_void_p),
                 ("row_length", C.c_void_p), ("ref_len", C.c_int32), ("qry_len", C.c_int32),
-                ("row_stride_bytes", C.c_int32), ("reserved", C.c_int32)]
+                ("row_stride_bytes", C.c_int32), ("corridor_kind", C.c_int32),
+                ("corridor_k", C.c_float), ("corridor_d", C.c_float), ("corridor_right", C.c_float),
+                ("corridor_offset", C.c_int32), ("corridor_width", C.c_int32), ("reserved", C.c_int32)]
+
+
+CORRIDOR_ROWS, CORRIDOR_AFFINE, CORRIDOR_CONST = 0, 1, 2
+assert C.sizeof(CvxTile) == 72
 
 
 class CvxResult(C.Structure):
@@ -95,6 +102,7 @@ def load(path: str = None) -> C.CDLL:
     lib = C.CDLL(path)
     lib.cvx_last_error.restype = C.c_char_p
     lib.cvx_abi_version.restype = C.c_int
+    lib.cvx_build_id.restype = C.c_char_p
     lib.cvx_device_count.restype = C.c_int
     lib.cvx_device_synchronize.argtypes = [C.c_int]
     lib.cvx_create.argtypes = [C.c_int, C.POINTER(CvxParams), C.c_uint64, C.POINTER(C.c_void_p)]
@@ -131,6 +139,11 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_submit_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(CvxTile), C.c_void_p, C.POINTER(C.c_void_p)]
     lib.cvx_job_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CvxAlignmentText), C.c_void_p,
                                  C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    lib.cvx_host_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.cvx_host_free.argtypes = [C.c_void_p]
+    lib.cvx_host_free.restype = None
+    lib.cvx_corridor_rows.argtypes = [C.c_void_p, C.POINTER(CvxTile), C.c_void_p, C.c_void_p]
+    lib.cvx_pack_probe.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.cvx_score_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p]
     lib.cvx_format_alignment.argtypes = [C.POINTER(CvxResult), C.c_void_p, C.c_char_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,

@@ -94,6 +94,11 @@ void ConvexAlignHip::AlignTiles(Tile * tiles, int n) {
 		c.row_offset = &t.corridor[0].offset;
 		c.row_length = &t.corridor[0].length;
 		c.row_stride_bytes = (int32_t) sizeof(CorridorLine);
+		/* ngmlr hands over the rows its corridor builders produced (src/AlignmentBuffer.cpp:68-197); a caller that
+		 * knows which builder made them can pass its closed form instead (cvx_tile.corridor_kind) and skip the arrays */
+		c.corridor_kind = CVX_CORRIDOR_ROWS;
+		c.corridor_k = c.corridor_d = c.corridor_right = 0.0f;
+		c.corridor_offset = c.corridor_width = 0;
 		c.reserved = 0;
 		/* caller-visible side effect of AlignmentMatrixFast::prepare (src/AlignmentMatrixFast.cpp:39-44) */
 		unsigned long acc = 0;

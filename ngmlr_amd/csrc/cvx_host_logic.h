@@ -8,7 +8,12 @@
 #define CVX_HOST_LOGIC_H
 
 #include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -52,13 +57,90 @@ inline int chain_class_for(int need, bool small_batch) {
 
 /* ------------------------------------------------------------------ host threads */
 
-/* fn(begin, end) over [0, n) on up to `threads` host threads; ranges balanced by the work
- * prefix sums (prefix[i] = work of items < i, n + 1 entries) */
+/* The process's pack threads: one persistent pool shared by every handle (eight handles on an 8-device node
+ * used to spawn 24 fresh threads each per call -- 192 threads on a host that behaves like ~32 cores).  Size:
+ * CVX_PACK_THREADS, else min(hardware threads, 16); the calling thread works too, so a pool of size 1 has no
+ * worker threads at all.  Handles that pack at the same time share the workers task by task. */
+class PackPool {
+public:
+	static PackPool &get() {
+		static PackPool pool;
+		return pool;
+	}
+	int size() const { return n_threads_; }
+	/* runs fn(0) ... fn(n_tasks - 1), returns when all are done */
+	void run(int n_tasks, const std::function<void(int)> &fn) {
+		if (n_tasks <= 0) return;
+		if (n_tasks == 1 || n_threads_ <= 1) { for (int i = 0; i < n_tasks; ++i) fn(i); return; }
+		Group g;
+		g.left = n_tasks;
+		{
+			std::lock_guard<std::mutex> lk(m_);
+			for (int i = 0; i < n_tasks; ++i) q_.push_back(Task{&g, &fn, i});
+		}
+		cv_.notify_all();
+		/* the caller takes tasks as well (its own or another caller's: whatever is at the front) */
+		for (;;) {
+			Task t;
+			{
+				std::unique_lock<std::mutex> lk(m_);
+				if (g.left == 0) break;
+				if (q_.empty()) { done_.wait(lk, [&] { return g.left == 0 || !q_.empty(); }); continue; }
+				t = q_.front();
+				q_.pop_front();
+			}
+			execute(t);
+		}
+	}
+private:
+	struct Group { int left = 0; };
+	struct Task { Group *g; const std::function<void(int)> *fn; int i; };
+	PackPool() {
+		int hw = (int) std::thread::hardware_concurrency();
+		n_threads_ = std::max(1, std::min(hw > 0 ? hw : 1, 16));
+		if (const char *e = getenv("CVX_PACK_THREADS")) n_threads_ = std::max(1, atoi(e));
+		for (int i = 1; i < n_threads_; ++i) workers_.emplace_back([this] { loop(); });
+	}
+	~PackPool() {
+		{ std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+		cv_.notify_all();
+		for (auto &t : workers_) t.join();
+	}
+	void execute(const Task &t) {
+		(*t.fn)(t.i);
+		bool last;
+		{ std::lock_guard<std::mutex> lk(m_); last = (--t.g->left == 0); }
+		if (last) done_.notify_all();
+	}
+	void loop() {
+		for (;;) {
+			Task t;
+			{
+				std::unique_lock<std::mutex> lk(m_);
+				cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+				if (stop_ && q_.empty()) return;
+				t = q_.front();
+				q_.pop_front();
+			}
+			execute(t);
+			done_.notify_all();      /* a caller waiting for work to help with */
+		}
+	}
+	std::mutex m_;
+	std::condition_variable cv_, done_;
+	std::deque<Task> q_;
+	std::vector<std::thread> workers_;
+	bool stop_ = false;
+	int n_threads_ = 1;
+};
+
+/* fn(begin, end) over [0, n) in up to `threads` ranges balanced by the work prefix sums
+ * (prefix[i] = work of items < i, n + 1 entries), on the process's pack threads */
 template <typename F>
 void parallel_ranges(int n, const std::vector<uint64_t> &prefix, int threads, F fn) {
 	if (threads <= 1 || n < 2 * threads) { fn(0, n); return; }
 	const uint64_t total = prefix[(size_t) n];
-	std::vector<std::thread> th;
+	std::vector<std::pair<int, int>> ranges;
 	int begin = 0;
 	for (int k = 1; k <= threads && begin < n; ++k) {
 		int end = n;
@@ -68,89 +150,109 @@ void parallel_ranges(int n, const std::vector<uint64_t> &prefix, int threads, F 
 			if (end <= begin) end = begin + 1;
 			if (end > n) end = n;
 		}
-		th.emplace_back(fn, begin, end);
+		ranges.emplace_back(begin, end);
 		begin = end;
 	}
-	for (auto &t : th) t.join();
+	PackPool::get().run((int) ranges.size(), [&](int i) { fn(ranges[(size_t) i].first, ranges[(size_t) i].second); });
 }
 
 /* ------------------------------------------------------------------ upload layout + packing */
 
 struct UploadLayout {
-	uint64_t pad = 0;               /* zeroed bytes before the first and after the last sequence */
-	uint64_t seq_total = 0;         /* bytes of the seq arena */
+	uint64_t pad = 0;               /* defined bytes before the first, between the two blocks and after the last sequence (multiple of 256) */
+	uint64_t seq_total = 0;         /* bytes of the seq arena: [pad][every read][pad][every reference][pad] */
+	uint64_t qry_base = 0, qry_bytes = 0;   /* arena offset / size of the block of reads */
+	uint64_t ref_base = 0, ref_bytes = 0;   /* ... of the block of references (ref_base is a multiple of 256) */
 	uint64_t n_rows = 0;            /* entries of the rows arena */
-	uint64_t delta_total = 0;       /* bytes of the row-step stream (every tile's H bytes, 4-byte aligned) */
+	uint64_t delta_total = 0;       /* bytes of the row-step stream (H bytes, 4-byte aligned, per tile whose rows come as arrays) */
 	std::vector<RowSrc> rsrc;       /* per tile: where its rows come from (src_off = offset into the step stream until packed) */
-	bool windows = false;           /* references decoded on the device: [pad][qry...][pad][ref...][pad] */
-	uint64_t upload_bytes = 0;      /* leading part of the seq arena that is packed on the host and uploaded */
-	std::vector<uint64_t> wprefix;  /* packing work per tile (bytes moved), prefix sums */
+	bool windows = false;           /* references decoded on the device from the resident genome: their block is not uploaded */
+	/* the caller's reads (references) lie back to back in tile order: the block can travel as it is, without
+	 * packing, when the runtime finds it in page-locked memory (cvx_host_alloc) */
+	bool qry_contig = false, ref_contig = false;
+	std::vector<uint64_t> wprefix;  /* packing work per tile (bytes moved if everything is packed), prefix sums */
 };
 
 enum { kLayoutOk = 0, kLayoutMalformed = 1, kLayoutTooLarge = 2 };
 
 /* Validates the tiles and assigns arena offsets (TileIn).  On kLayoutMalformed *bad is the
  * offending tile; kLayoutTooLarge: more than 4 GiB of bases (32-bit sequence offsets). */
-/* windows: the tiles' references are decoded on the device from the resident genome (cvx_genome.hip):
- * tile.ref is ignored, the arena becomes [pad][every qry][pad][every ref][pad] and only the part up to
- * L.upload_bytes travels over PCIe. */
 inline int upload_layout(int n, const cvx_tile *tiles, std::vector<TileIn> &tin, UploadLayout &L, int *bad, bool windows = false) {
-	uint64_t seq_bytes = 0, n_rows = 0, qry_bytes = 0;
+	uint64_t ref_bytes = 0, n_rows = 0, qry_bytes = 0;
 	int64_t max_hw = 0;
+	bool qc = n > 0, rc = n > 0 && !windows;
 	for (int i = 0; i < n; ++i) {
 		const cvx_tile &t = tiles[i];
+		const bool rows_given = t.corridor_kind == CVX_CORRIDOR_ROWS;
 		if (t.ref_len < 0 || t.qry_len < 0 || (t.ref_len > 0 && !t.ref && !windows) || (t.qry_len > 0 && !t.qry) ||
-				(t.qry_len > 0 && (!t.row_offset || !t.row_length)) || (t.row_stride_bytes & 3) || t.row_stride_bytes < 4) {
+				(rows_given && t.qry_len > 0 && (!t.row_offset || !t.row_length)) ||
+				(rows_given && ((t.row_stride_bytes & 3) || t.row_stride_bytes < 4)) ||
+				t.corridor_kind < CVX_CORRIDOR_ROWS || t.corridor_kind > CVX_CORRIDOR_CONST ||
+				(t.corridor_kind == CVX_CORRIDOR_AFFINE && !(t.corridor_k > 0.0f && t.corridor_k < 3.0e38f &&
+					t.corridor_d == t.corridor_d && t.corridor_right == t.corridor_right)) ||
+				(!rows_given && t.corridor_width < 0)) {
 			if (bad) *bad = i;
 			return kLayoutMalformed;
 		}
-		seq_bytes += (uint64_t) t.ref_len + (uint64_t) t.qry_len;
+		if (i > 0) {
+			if (tiles[i - 1].qry + tiles[i - 1].qry_len != t.qry) qc = false;
+			if (!windows && tiles[i - 1].ref + tiles[i - 1].ref_len != t.ref) rc = false;
+		}
+		ref_bytes += (uint64_t) t.ref_len;
 		qry_bytes += (uint64_t) t.qry_len;
 		n_rows += (uint64_t) t.qry_len;
 		max_hw = std::max<int64_t>(max_hw, (int64_t) t.ref_len + t.qry_len);
 	}
-	L.pad = (uint64_t) max_hw + kRingMax + 256;
-	L.seq_total = seq_bytes + (windows ? 3 : 2) * L.pad + 64;
+	L.pad = ((uint64_t) max_hw + kRingMax + 256 + 255) / 256 * 256;
+	L.qry_base = L.pad;
+	L.qry_bytes = qry_bytes;
+	L.ref_base = (L.qry_base + qry_bytes + L.pad + 255) / 256 * 256;
+	L.ref_bytes = ref_bytes;
+	L.seq_total = L.ref_base + ref_bytes + L.pad + 64;
 	L.n_rows = n_rows;
 	L.windows = windows;
-	L.upload_bytes = windows ? (L.pad + qry_bytes + L.pad) : L.seq_total;
+	L.qry_contig = qc;
+	L.ref_contig = rc;
 	if (L.seq_total >= 0xFFFF0000ull) return kLayoutTooLarge;
 	tin.resize((size_t) n);
 	L.rsrc.assign((size_t) n, RowSrc());
 	L.wprefix.assign((size_t) n + 1, 0);
-	uint64_t so = L.pad, ro = 0, dof = 0;
-	uint64_t rso = L.pad + qry_bytes + L.pad;       /* windows: where the decoded references start */
+	uint64_t qo = L.qry_base, ro = 0, dof = 0, rso = L.ref_base;
 	for (int i = 0; i < n; ++i) {
 		const cvx_tile &t = tiles[i];
 		TileIn &ti = tin[(size_t) i];
-		if (windows) {
-			ti.ref_off = (uint32_t) rso;
-			rso += (uint64_t) t.ref_len;
-		} else {
-			ti.ref_off = (uint32_t) so;
-			so += (uint64_t) t.ref_len;
-		}
-		ti.qry_off = (uint32_t) so;
-		so += (uint64_t) t.qry_len;
+		ti.ref_off = (uint32_t) rso;
+		rso += (uint64_t) t.ref_len;
+		ti.qry_off = (uint32_t) qo;
+		qo += (uint64_t) t.qry_len;
 		ti.W = t.ref_len;
 		ti.H = t.qry_len;
 		ti.row_off = ro;
 		ti.reserved = 0;
 		ro += (uint64_t) t.qry_len;
 		RowSrc &rs = L.rsrc[(size_t) i];
-		rs.src_off = dof; rs.off0 = 0; rs.width = 0; rs.fmt = kRowsDelta8; rs.pad = 0;
-		dof += ((uint64_t) t.qry_len + 3) / 4 * 4;
-		L.wprefix[(size_t) i + 1] = L.wprefix[(size_t) i] + (windows ? 0 : (uint64_t) t.ref_len) + 9ull * (uint64_t) t.qry_len + 64;
+		memset(&rs, 0, sizeof(rs));
+		uint64_t row_work = 0;
+		if (t.corridor_kind == CVX_CORRIDOR_AFFINE) {
+			rs.fmt = kRowsAffine; rs.width = t.corridor_width; rs.k = t.corridor_k; rs.d = t.corridor_d; rs.right = t.corridor_right;
+		} else if (t.corridor_kind == CVX_CORRIDOR_CONST) {
+			rs.fmt = kRowsConst; rs.width = t.corridor_width; rs.off0 = t.corridor_offset;
+		} else {
+			rs.src_off = dof; rs.fmt = kRowsDelta8;
+			dof += ((uint64_t) t.qry_len + 3) / 4 * 4;
+			row_work = 9ull * (uint64_t) t.qry_len;
+		}
+		L.wprefix[(size_t) i + 1] = L.wprefix[(size_t) i] + (windows ? 0 : (uint64_t) t.ref_len) + (uint64_t) t.qry_len + row_work + 64;
 	}
 	L.delta_total = dof;
 	return kLayoutOk;
 }
 
-/* the kernels prefetch a little past either end of a tile: both pads must be defined */
+/* the kernels prefetch a little past either end of a tile: all three pads must be defined (host staging form) */
 inline void upload_zero_pads(const UploadLayout &L, uint8_t *hseq) {
-	memset(hseq, 0, (size_t) L.pad);
-	if (L.windows) memset(hseq + (size_t) (L.upload_bytes - L.pad), 0, (size_t) L.pad);   /* the pad between reads and references */
-	else memset(hseq + (size_t) (L.seq_total - L.pad - 64), 0, (size_t) L.pad + 64);
+	memset(hseq, 0, (size_t) L.qry_base);
+	memset(hseq + (size_t) (L.qry_base + L.qry_bytes), 0, (size_t) (L.ref_base - L.qry_base - L.qry_bytes));
+	if (!L.windows) memset(hseq + (size_t) (L.ref_base + L.ref_bytes), 0, (size_t) (L.seq_total - L.ref_base - L.ref_bytes));
 }
 
 /* Step bytes of rows [1, H) of a tile whose (offset, length) arrays are plain int32 arrays (stride 4), eight
@@ -190,23 +292,24 @@ struct RowOverflow {
 	std::vector<RowDesc> rows;         /* their rows, back to back */
 };
 
-/* copies tiles [begin, end) into the staging arenas (callable from several threads at once).  Rows go
- * to the step stream `hdelta` (one byte per row: offset[y] - offset[y-1]; rsrc[i] gets row 0's offset and
- * the common width); a tile whose width changes or whose offset jumps by more than a byte is marked
- * kRowsExplicit and its rows are appended to `ovf` instead. */
+/* copies tiles [begin, end) into the staging arenas (callable from several threads at once).  Rows that
+ * come as arrays go to the step stream `hdelta` (one byte per row: offset[y] - offset[y-1]; rsrc[i] gets row
+ * 0's offset and the common width); a tile whose width changes or whose offset jumps by more than a byte is
+ * marked kRowsExplicit and its rows are appended to `ovf` instead.  Closed-form corridors have nothing to
+ * pack.  copy_qry / copy_ref = false: that block travels straight from the caller's page-locked memory. */
 inline void upload_pack(int begin, int end, const cvx_tile *tiles, const std::vector<TileIn> &tin,
-		uint8_t *hseq, uint8_t *hdelta, std::vector<RowSrc> &rsrc, RowOverflow &ovf, bool windows = false) {
+		uint8_t *hseq, uint8_t *hdelta, std::vector<RowSrc> &rsrc, RowOverflow &ovf, bool copy_qry = true, bool copy_ref = true) {
 	for (int i = begin; i < end; ++i) {
 		const cvx_tile &t = tiles[i];
 		const TileIn &ti = tin[(size_t) i];
-		if (t.ref_len && !windows) memcpy(hseq + ti.ref_off, t.ref, (size_t) t.ref_len);
-		if (t.qry_len) memcpy(hseq + ti.qry_off, t.qry, (size_t) t.qry_len);
+		if (t.ref_len && copy_ref) memcpy(hseq + ti.ref_off, t.ref, (size_t) t.ref_len);
+		if (t.qry_len && copy_qry) memcpy(hseq + ti.qry_off, t.qry, (size_t) t.qry_len);
 		RowSrc &rs = rsrc[(size_t) i];
+		if (rs.fmt != kRowsDelta8) continue;       /* closed form: generated on the device */
 		const char *po = (const char *) t.row_offset;
 		const char *pl = (const char *) t.row_length;
 		const size_t stride = (size_t) t.row_stride_bytes;
 		const int H = t.qry_len;
-		rs.fmt = kRowsDelta8;
 		if (H <= 0) continue;
 		int8_t *dst = reinterpret_cast<int8_t *>(hdelta + rs.src_off);
 		int32_t prev, w0;
@@ -255,6 +358,13 @@ inline void upload_pack(int begin, int end, const cvx_tile *tiles, const std::ve
 inline void expand_rows_host(const RowSrc &rs, int H, const uint8_t *hdelta, const RowDesc *hrowsx, RowDesc *out) {
 	if (rs.fmt == kRowsExplicit) {
 		if (H > 0) memcpy(out, hrowsx + rs.src_off, (size_t) H * sizeof(RowDesc));
+		return;
+	}
+	if (rs.fmt == kRowsAffine || rs.fmt == kRowsConst) {
+		for (int y = 0; y < H; ++y) {
+			out[y].off = rs.fmt == kRowsConst ? rs.off0 : affine_row_offset(y, rs.d, rs.k, rs.right);
+			out[y].len = rs.width;
+		}
 		return;
 	}
 	const int8_t *d = reinterpret_cast<const int8_t *>(hdelta + rs.src_off);

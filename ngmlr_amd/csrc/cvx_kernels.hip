@@ -201,6 +201,16 @@ expand_rows_kernel(const RowSrc *rsrc, const TileIn *tin, const uint8_t *delta, 
 		for (int y = lane; y < H; y += 64) out[y] = src[y];
 		return;
 	}
+	if (rs.fmt == kRowsAffine) {
+		/* the reference's corridor builders in closed form (cvx_types.h affine_row_offset; src/AlignmentBuffer.cpp:107-127,
+		 * 178-191, 68-82): binary32 subtract, correctly rounded divide, subtract, truncation -- row by row, no carried state */
+		for (int y = lane; y < H; y += 64) out[y] = make_int2(affine_row_offset(y, rs.d, rs.k, rs.right), rs.width);
+		return;
+	}
+	if (rs.fmt == kRowsConst) {
+		for (int y = lane; y < H; y += 64) out[y] = make_int2(rs.off0, rs.width);
+		return;
+	}
 	const int8_t *d = reinterpret_cast<const int8_t *>(delta + rs.src_off);
 	int carry = rs.off0;
 	for (int y0 = 0; y0 < H; y0 += 64) {

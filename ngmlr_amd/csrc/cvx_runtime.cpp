@@ -29,11 +29,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -130,6 +132,18 @@ struct PinBuf {
 	template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
+/* page-locked blocks handed out by cvx_host_alloc: sequences found inside one travel without packing */
+std::mutex g_pin_mtx;
+std::vector<std::pair<const char *, size_t>> g_pin_blocks;
+
+bool in_pinned_block(const void *p, uint64_t bytes) {
+	const char *c = static_cast<const char *>(p);
+	std::lock_guard<std::mutex> lk(g_pin_mtx);
+	for (const auto &b : g_pin_blocks)
+		if (c >= b.first && c + bytes <= b.first + b.second) return true;
+	return false;
+}
+
 }  // namespace
 
 /* Four streams per handle (io, main, post, one aux) and not more: the ROCm runtime multiplexes the streams of a process onto
@@ -146,6 +160,7 @@ struct cvx_batch_s {
 	int state = kEmpty;
 	bool in_flight = false;          /* submitted through the streaming API and not yet released */
 	uint64_t seq_total = 0, n_rows = 0, n_rowsx = 0;
+	uint64_t zero_copy_bytes = 0;    /* sequence bytes of the last upload that travelled straight from the caller's page-locked arena */
 	uint64_t ops_total = 0;          /* valid after the compute stage has been waited for */
 	uint64_t dense_cap = 0;
 	bool have_ops = false;           /* dense ops are in h_ops */
@@ -338,7 +353,6 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	RC_TRY(b->make_events());
 	const size_t n1 = (size_t) std::max(n, 1);
 	const size_t rows1 = (size_t) std::max<uint64_t>(L.n_rows, 1);
-	RC_TRY(b->h_seq.ensure((size_t) L.seq_total + 256));
 	RC_TRY(b->h_delta.ensure((size_t) L.delta_total + 256));
 	RC_TRY(b->h_rsrc.ensure(n1 * sizeof(RowSrc)));
 	RC_TRY(b->d_delta.ensure((size_t) L.delta_total + 256));
@@ -361,17 +375,39 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	RC_TRY(b->d_res.ensure(n1 * sizeof(ResultRec) + sizeof(BatchSummary)));
 	if (n) memcpy(b->h_tin.p, tin.data(), (size_t) n * sizeof(TileIn));
 
+	/* a block of sequences that already lies back to back in page-locked memory is not packed: the
+	 * device pulls it out of the caller's arena (the job's staging then holds only what the host wrote) */
+	const bool zc_qry = n > 0 && L.qry_contig && L.qry_bytes > 0 && in_pinned_block(tiles[0].qry, L.qry_bytes);
+	const bool zc_ref = n > 0 && !windows && L.ref_contig && L.ref_bytes > 0 && in_pinned_block(tiles[0].ref, L.ref_bytes);
+	b->zero_copy_bytes = (zc_qry ? L.qry_bytes : 0) + (zc_ref ? L.ref_bytes : 0);
+	const bool pack_seq = !(zc_qry && (zc_ref || windows));      /* anything left for the host to copy? */
+	if (pack_seq) RC_TRY(b->h_seq.ensure((size_t) L.seq_total + 256));
 	uint8_t *hseq = b->h_seq.as<uint8_t>();
 	uint8_t *hdelta = b->h_delta.as<uint8_t>();
 	std::vector<RowOverflow> overflow;
-	upload_zero_pads(L, hseq);
-	const std::vector<uint64_t> &wprefix = L.wprefix;
-	int threads = std::max(1, h->pack_threads);
-	if (wprefix[(size_t) n] < (8u << 20)) threads = 1;      /* not worth a thread below ~8 MB */
 	hipStream_t st = h->s_io;
+	/* the three pads: uploaded with the packed blocks, or cleared on the device around the blocks that travel as they are
+	 * (queued behind those copies: a copy rounded up to whole dwords may spill a few bytes into the pad that follows) */
+	if (pack_seq) upload_zero_pads(L, hseq);
+	if (zc_qry) HIP_TRY(hipMemcpyAsync(b->d_seq.p + L.qry_base, tiles[0].qry, (size_t) L.qry_bytes, hipMemcpyHostToDevice, st));
+	if (zc_ref) HIP_TRY(hipMemcpyAsync(b->d_seq.p + L.ref_base, tiles[0].ref, (size_t) L.ref_bytes, hipMemcpyHostToDevice, st));
+	if (zc_qry) {
+		HIP_TRY(hipMemsetAsync(b->d_seq.p, 0, (size_t) L.qry_base, st));
+		HIP_TRY(hipMemsetAsync(b->d_seq.p + L.qry_base + L.qry_bytes, 0, (size_t) (L.ref_base - L.qry_base - L.qry_bytes), st));
+	}
+	if (zc_ref) HIP_TRY(hipMemsetAsync(b->d_seq.p + L.ref_base + L.ref_bytes, 0, (size_t) (L.seq_total - L.ref_base - L.ref_bytes), st));
+	/* what the host still moves per tile decides whether packing is worth threads and pieces */
+	uint64_t pack_work = L.delta_total * 9ull;
+	if (!zc_qry) pack_work += L.qry_bytes;
+	if (!zc_ref && !windows) pack_work += L.ref_bytes;
+	const std::vector<uint64_t> &wprefix = L.wprefix;
+	int threads = std::max(1, std::min(h->pack_threads, PackPool::get().size()));
+	if (pack_work < (8u << 20)) threads = 1;      /* not worth a thread below ~8 MB */
 	const int pieces = threads > 1 ? 8 : 1;
 	int t0 = 0;
-	uint64_t seq_done = 0, delta_done = 0;   /* bytes of hseq / hdelta already on their way */
+	/* bytes of the two blocks of hseq / of hdelta already on their way (block A = [pad][reads][pad], block B = [references][pad]) */
+	uint64_t a_done = 0, b_done = L.ref_base, delta_done = 0;
+	const uint64_t a_end_all = L.ref_base, b_end_all = (L.seq_total + 255) / 256 * 256;
 	for (int pc = 1; pc <= pieces; ++pc) {
 		int t1 = n;
 		if (pc < pieces) {
@@ -379,34 +415,45 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 			t1 = (int) (std::upper_bound(wprefix.begin(), wprefix.end(), target) - wprefix.begin());
 			t1 = std::min(std::max(t1, t0), n);
 		}
-		if (t1 > t0) {
+		if (t1 > t0 && pack_work > 0) {
 			std::vector<uint64_t> wp((size_t) (t1 - t0) + 1);
 			for (int i = t0; i <= t1; ++i) wp[(size_t) (i - t0)] = wprefix[(size_t) i] - wprefix[(size_t) t0];
 			const int base = t0;
-			/* every packing thread of the piece collects the rows of its misfits in its own list */
+			/* every packing range of the piece collects the rows of its misfits in its own list */
 			const size_t first = overflow.size();
 			overflow.resize(first + (size_t) threads + 1);
 			std::atomic<int> slot(0);
 			parallel_ranges(t1 - t0, wp, threads, [&](int bg, int en) {
-				upload_pack(base + bg, base + en, tiles, tin, hseq, hdelta, L.rsrc, overflow[first + (size_t) slot.fetch_add(1)], windows);
+				upload_pack(base + bg, base + en, tiles, tin, hseq, hdelta, L.rsrc, overflow[first + (size_t) slot.fetch_add(1)], !zc_qry, !zc_ref && !windows);
 			});
 		}
 		/* Copy boundaries are multiples of 256 bytes: a host-to-device copy whose address or size is
 		 * not dword-aligned is not handed to the SDMA engines but to a blit kernel that pulls the bytes
 		 * over PCIe with compute units the fill needs.  The bytes below the rounded-down end are all
-		 * packed; the remainder travels with the next piece, the last piece runs to the aligned end.
-		 * (with device-decoded references only [pad][reads][pad] is uploaded; tiles are laid out in
-		 * order, so everything below tile t1's first byte is packed) */
-		uint64_t seq_end = (t1 == n) ? L.upload_bytes : (uint64_t) (windows ? tin[(size_t) t1].qry_off : tin[(size_t) t1].ref_off);
-		seq_end = (t1 == n) ? (seq_end + 255) / 256 * 256 : seq_end / 256 * 256;
-		if (seq_end > seq_done)
-			HIP_TRY(hipMemcpyAsync(b->d_seq.p + seq_done, hseq + seq_done, (size_t) (seq_end - seq_done), hipMemcpyHostToDevice, st));
-		seq_done = std::max(seq_done, seq_end);
-		uint64_t del_end = (t1 == n) ? L.delta_total : L.rsrc[(size_t) t1].src_off;       /* (src_off = step-stream offset until the misfits are renumbered below) */
-		del_end = (t1 == n) ? (del_end + 255) / 256 * 256 : del_end / 256 * 256;
-		if (del_end > delta_done)
-			HIP_TRY(hipMemcpyAsync(b->d_delta.p + delta_done, hdelta + delta_done, (size_t) (del_end - delta_done), hipMemcpyHostToDevice, st));
-		delta_done = std::max(delta_done, del_end);
+		 * packed (tiles are laid out in order inside either block); the remainder travels with the next
+		 * piece, the last piece runs to the aligned end. */
+		if (!zc_qry) {
+			const uint64_t a_end = (t1 == n) ? a_end_all : (uint64_t) tin[(size_t) t1].qry_off / 256 * 256;
+			if (a_end > a_done) HIP_TRY(hipMemcpyAsync(b->d_seq.p + a_done, hseq + a_done, (size_t) (a_end - a_done), hipMemcpyHostToDevice, st));
+			a_done = std::max(a_done, a_end);
+		}
+		if (!zc_ref && !windows) {
+			const uint64_t b_end = (t1 == n) ? b_end_all : (uint64_t) tin[(size_t) t1].ref_off / 256 * 256;
+			if (b_end > b_done) HIP_TRY(hipMemcpyAsync(b->d_seq.p + b_done, hseq + b_done, (size_t) (b_end - b_done), hipMemcpyHostToDevice, st));
+			b_done = std::max(b_done, b_end);
+		}
+		if (L.delta_total) {
+			uint64_t del_end = L.delta_total;
+			if (t1 < n) {        /* first tile at or after t1 whose rows travel as steps (src_off = step-stream offset until the misfits are renumbered below) */
+				int q = t1;
+				while (q < n && L.rsrc[(size_t) q].fmt != kRowsDelta8 && L.rsrc[(size_t) q].fmt != kRowsExplicit) q++;
+				if (q < n) del_end = L.rsrc[(size_t) q].src_off;
+			}
+			del_end = (t1 == n) ? (del_end + 255) / 256 * 256 : del_end / 256 * 256;
+			if (del_end > delta_done)
+				HIP_TRY(hipMemcpyAsync(b->d_delta.p + delta_done, hdelta + delta_done, (size_t) (del_end - delta_done), hipMemcpyHostToDevice, st));
+			delta_done = std::max(delta_done, del_end);
+		}
 		t0 = t1;
 	}
 	if (n) HIP_TRY(hipMemcpyAsync(b->d_tin.p, b->h_tin.p, (size_t) n * sizeof(TileIn), hipMemcpyHostToDevice, st));
@@ -446,7 +493,7 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 			hw[i].n_chars = tiles[i].ref_len;
 		}
 		HIP_TRY(hipMemcpyAsync(b->d_win.p, hw, (size_t) n * sizeof(WindowDesc), hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemsetAsync(b->d_seq.p + (L.seq_total - L.pad - 64), 0, (size_t) L.pad + 64, st));
+		HIP_TRY(hipMemsetAsync(b->d_seq.p + L.ref_base + L.ref_bytes, 0, (size_t) (L.seq_total - L.ref_base - L.ref_bytes), st));
 		HIP_TRY(launch_decode_windows(genome->d_bin.p, genome->d_starts.p, genome->n_starts, b->d_win.p, n, b->d_seq.p, st));
 	}
 	b->state = kUploaded;
@@ -816,6 +863,11 @@ const char *cvx_last_error(void) { return g_err.c_str(); }
 
 int cvx_abi_version(void) { return CVX_ABI_VERSION; }
 
+#ifndef CVX_BUILD_ID
+#define CVX_BUILD_ID "unknown"
+#endif
+const char *cvx_build_id(void) { return CVX_BUILD_ID; }
+
 int cvx_device_count(void) {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -878,9 +930,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_BT_GROUP")) c->bt_group = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_OVERLAP_POST")) c->overlap_post = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_SSE_VARIANT")) c->sse_variant = c->sse_variant || atoi(e) != 0;   /* test knob */
-	const int hw = (int) std::thread::hardware_concurrency();
-	c->pack_threads = std::max(1, std::min(hw > 0 ? hw : 1, 24));
-	if (const char *e = getenv("CVX_PACK_THREADS")) c->pack_threads = std::max(1, atoi(e));
+	c->pack_threads = PackPool::get().size();      /* the process's shared pack threads (CVX_PACK_THREADS) */
 	if (const char *e = getenv("CVX_TUNE_MIN_M")) c->tune_min_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_FORCE_WRAP16")) c->tune_force_wrap = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
@@ -1083,6 +1133,126 @@ void cvx_job_release(cvx_handle h, cvx_job j) {
 		if (j->state >= kPlanned && j->state < kFinished) (void) hipDeviceSynchronize();   /* released without waiting */
 	}
 	recycle_batch(h, j);
+}
+
+/* ------------------------------------------------------------------ page-locked arenas, corridor rows, host-side probe */
+
+int cvx_host_alloc(uint64_t bytes, void **out) {
+	ABI_GUARD_BEGIN
+	if (!out) { set_err("cvx_host_alloc: NULL argument"); return CVX_ERR_ARG; }
+	*out = nullptr;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void) hipGetLastError(); set_err("cvx_host_alloc: no HIP device"); return CVX_ERR_NO_DEVICE; }
+	void *p = nullptr;
+	const size_t want = (size_t) bytes + 4096;        /* slack: block copies are rounded up to whole dwords */
+	hipError_t e = hipHostMalloc(&p, want, hipHostMallocPortable);
+	if (e != hipSuccess) { (void) hipGetLastError(); set_err("hipHostMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e)); return CVX_ERR_OOM; }
+	{
+		std::lock_guard<std::mutex> lk(g_pin_mtx);
+		g_pin_blocks.emplace_back(static_cast<const char *>(p), want);
+	}
+	*out = p;
+	return CVX_OK;
+	ABI_GUARD_END
+}
+
+void cvx_host_free(void *p) {
+	if (!p) return;
+	{
+		std::lock_guard<std::mutex> lk(g_pin_mtx);
+		for (size_t i = 0; i < g_pin_blocks.size(); ++i)
+			if (g_pin_blocks[i].first == p) { g_pin_blocks.erase(g_pin_blocks.begin() + (long) i); break; }
+	}
+	(void) hipHostFree(p);
+}
+
+int cvx_corridor_rows(cvx_handle h, const cvx_tile *tile, int32_t *offset, int32_t *length) {
+	ABI_GUARD_BEGIN
+	if (!h || !tile || tile->qry_len < 0 || (tile->qry_len > 0 && (!offset || !length))) { set_err("cvx_corridor_rows: bad argument"); return CVX_ERR_ARG; }
+	const int H = tile->qry_len;
+	if (H == 0) return CVX_OK;
+	if (tile->corridor_kind == CVX_CORRIDOR_ROWS) {
+		if (!tile->row_offset || !tile->row_length || (tile->row_stride_bytes & 3) || tile->row_stride_bytes < 4) { set_err("cvx_corridor_rows: bad row arrays"); return CVX_ERR_ARG; }
+		for (int y = 0; y < H; ++y) {
+			memcpy(&offset[y], (const char *) tile->row_offset + (size_t) y * (size_t) tile->row_stride_bytes, 4);
+			memcpy(&length[y], (const char *) tile->row_length + (size_t) y * (size_t) tile->row_stride_bytes, 4);
+		}
+		return CVX_OK;
+	}
+	/* the closed forms are evaluated where the product evaluates them: by expand_rows_kernel */
+	cvx_tile t = *tile;
+	static const char dummy[1] = {0};
+	t.ref = t.qry = dummy;      /* only the corridor matters here */
+	t.ref_len = 0;
+	std::vector<TileIn> tin;
+	UploadLayout L;
+	int bad = -1;
+	{
+		cvx_tile probe = t;
+		probe.qry_len = 0;       /* validate the descriptor without sequences */
+		if (upload_layout(1, &probe, tin, L, &bad, false) != kLayoutOk) { set_err("cvx_corridor_rows: malformed corridor descriptor"); return CVX_ERR_ARG; }
+	}
+	HIP_TRY(hipSetDevice(h->device));
+	RowSrc rs = L.rsrc[0];
+	TileIn ti;
+	memset(&ti, 0, sizeof(ti));
+	ti.H = H;
+	DevBuf<RowSrc> d_rs;
+	DevBuf<TileIn> d_ti;
+	DevBuf<RowDesc> d_rows;
+	int rc = d_rs.ensure(1);
+	if (rc == CVX_OK) rc = d_ti.ensure(1);
+	if (rc == CVX_OK) rc = d_rows.ensure((size_t) H);
+	std::vector<RowDesc> rows((size_t) H);
+	hipError_t e = hipSuccess;
+	if (rc == CVX_OK) {
+		e = hipMemcpy(d_rs.p, &rs, sizeof(rs), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(d_ti.p, &ti, sizeof(ti), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = launch_expand_rows(d_rs.p, d_ti.p, nullptr, nullptr, d_rows.p, 1, h->s_main);
+		if (e == hipSuccess) e = hipStreamSynchronize(h->s_main);
+		if (e == hipSuccess) e = hipMemcpy(rows.data(), d_rows.p, (size_t) H * sizeof(RowDesc), hipMemcpyDeviceToHost);
+	}
+	d_rs.release(); d_ti.release(); d_rows.release();
+	if (rc != CVX_OK) return rc;
+	if (e != hipSuccess) { set_err("cvx_corridor_rows: %s", hipGetErrorString(e)); return CVX_ERR_HIP; }
+	for (int y = 0; y < H; ++y) { offset[y] = rows[(size_t) y].off; length[y] = rows[(size_t) y].len; }
+	return CVX_OK;
+	ABI_GUARD_END
+}
+
+int cvx_pack_probe(int32_t n, const cvx_tile *tiles, int32_t iters, int32_t assume_page_locked, double *ms_per_iter, uint64_t *bytes_touched) {
+	ABI_GUARD_BEGIN
+	if (n < 0 || (n > 0 && !tiles) || iters <= 0 || !ms_per_iter) { set_err("cvx_pack_probe: bad argument"); return CVX_ERR_ARG; }
+	/* what stage_upload does on the host, minus every HIP call: layout, packing into (ordinary) staging on the
+	 * process's pack threads.  Nothing is aligned -- this measures the submit side, it computes nothing. */
+	std::vector<uint8_t> hseq, hdelta;
+	uint64_t touched = 0;
+	const auto c0 = std::chrono::steady_clock::now();
+	for (int it = 0; it < iters; ++it) {
+		UploadLayout L;
+		std::vector<TileIn> tin;
+		int bad = -1;
+		const int lrc = upload_layout(n, tiles, tin, L, &bad, false);
+		if (lrc != kLayoutOk) { set_err("cvx_pack_probe: tile %d malformed / batch too large", bad); return CVX_ERR_ARG; }
+		const bool zc_qry = assume_page_locked && L.qry_contig, zc_ref = assume_page_locked && L.ref_contig;
+		if (hseq.size() < L.seq_total + 256) hseq.resize((size_t) L.seq_total + 256);
+		if (hdelta.size() < L.delta_total + 256) hdelta.resize((size_t) L.delta_total + 256);
+		uint64_t pack_work = L.delta_total * 9ull + (zc_qry ? 0 : L.qry_bytes) + (zc_ref ? 0 : L.ref_bytes);
+		int threads = PackPool::get().size();
+		if (pack_work < (8u << 20)) threads = 1;
+		std::vector<RowOverflow> overflow((size_t) threads + 1);
+		std::atomic<int> slot(0);
+		if (pack_work > 0)
+			parallel_ranges(n, L.wprefix, threads, [&](int bg, int en) {
+				upload_pack(bg, en, tiles, tin, hseq.data(), hdelta.data(), L.rsrc, overflow[(size_t) slot.fetch_add(1)], !zc_qry, !zc_ref);
+			});
+		touched = 2 * ((zc_qry ? 0 : L.qry_bytes) + (zc_ref ? 0 : L.ref_bytes)) + L.delta_total * 9ull + (uint64_t) n * (sizeof(TileIn) + sizeof(RowSrc) + sizeof(cvx_tile));
+	}
+	const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+	*ms_per_iter = dt * 1e3 / iters;
+	if (bytes_touched) *bytes_touched = touched;
+	return CVX_OK;
+	ABI_GUARD_END
 }
 
 /* ------------------------------------------------------------------ device-side text stage */

@@ -61,15 +61,31 @@ struct ScoreParams {
  * every corridor the reference builds has one width for all rows and row offsets that move by a
  * few columns per row, so a row is one signed byte -- the offset's step from the row above -- instead
  * of eight; anything else (a width that changes, a step outside -128..127) goes verbatim. */
-enum RowFormat { kRowsDelta8 = 0, kRowsExplicit = 1 };
+enum RowFormat { kRowsDelta8 = 0, kRowsExplicit = 1, kRowsAffine = 2, kRowsConst = 3 };
 struct RowSrc {
 	uint64_t src_off;      /* kRowsDelta8: byte offset of the tile's H step bytes (byte 0 unused) in the delta stream;
 	                        * kRowsExplicit: index of its first RowDesc in the explicit-rows buffer */
-	int32_t off0;          /* offset of row 0 */
-	int32_t width;         /* the common row length (kRowsDelta8) */
+	int32_t off0;          /* offset of row 0 (kRowsDelta8), of every row (kRowsConst) */
+	int32_t width;         /* the common row length (all but kRowsExplicit) */
 	int32_t fmt;
-	int32_t pad;
+	/* kRowsAffine (cvx_tile.corridor_kind == CVX_CORRIDOR_AFFINE): offset[y] = (int) (((float) y - d) / k - right),
+	 * the closed form of the reference's corridor builders (src/AlignmentBuffer.cpp:107-127, 178-191, 68-82);
+	 * nothing of such a tile's rows crosses PCIe */
+	float k, d, right;
 };
+
+/* The closed form, shared by the device kernel and the host's chain planning: binary32 throughout, every
+ * operation rounded on its own (the files that include this are compiled with -ffp-contract=off), the
+ * divide correctly rounded on both sides, C truncation. */
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline int32_t affine_row_offset(int y, float d, float k, float right) {
+	const float a = (float) y - d;
+	const float q = a / k;
+	const float r = q - right;
+	return (int32_t) r;
+}
 
 struct TileIn {            /* written by the host at upload */
 	uint32_t ref_off;      /* byte offset of ref[0] in the seq arena */

@@ -41,6 +41,9 @@ class Tile:
     ext_qstart: int = 0
     ext_qend: int = 0
     tag: str = ""
+    # closed form of the corridor when the builder that made the rows is known (cvx_tile.corridor_kind):
+    # (kind, k, d, right, offset, width) with kind 1 = affine, 2 = constant; None = only the arrays
+    desc: Optional[tuple] = None
 
     @property
     def H(self) -> int:
@@ -67,10 +70,17 @@ def _trunc_i32(a: np.ndarray) -> np.ndarray:
     return np.trunc(a).astype(np.int64).astype(np.int32)
 
 
-def corridor_anchors(H: int, W: int, mult: int = 1, scatter_left: float = 0.0,
-                     scatter_right: float = 0.0) -> Tuple[np.ndarray, np.ndarray]:
+def affine_rows(H: int, k, d, right, width: int) -> Tuple[np.ndarray, np.ndarray]:
+    """offset[y] = (int) (((float) y - d) / k - right) in binary32 with C truncation: the common closed form of the
+    reference's corridor builders (cvx_tile.corridor_kind = CVX_CORRIDOR_AFFINE; the device evaluates the same)."""
+    i = np.arange(H, dtype=np.int64).astype(F32)
+    off = _trunc_i32(F32(F32(F32(i - F32(d)) / F32(k)) - F32(right)))
+    return off, np.full(H, width, dtype=np.int32)
+
+
+def anchors_desc(H: int, W: int, mult: int = 1, scatter_left: float = 0.0, scatter_right: float = 0.0) -> tuple:
     """src/AlignmentBuffer.cpp:140-192 with the anchor scatter given directly
-    (max positive / negative deviation of anchors from the k-line)."""
+    (max positive / negative deviation of anchors from the k-line) -> closed form (kind, k, d, right, offset, width)."""
     k = F32(H) * F32(1.0) / F32(W)
     left = F32(scatter_left)
     right = F32(scatter_right)
@@ -81,31 +91,45 @@ def corridor_anchors(H: int, W: int, mult: int = 1, scatter_left: float = 0.0,
     left = F32(left * F32(mult))
     right = F32(right * F32(mult))
     width = int(np.trunc(F32(left + right)))
-    i = np.arange(H, dtype=np.int64).astype(F32)
-    off = _trunc_i32((i - F32(0)) / k - right)
-    return off, np.full(H, width, dtype=np.int32)
+    return (1, float(k), 0.0, float(right), 0, width)
 
 
-def corridor_endpoints(H: int, W: int, corridor: int, realign: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+def corridor_anchors(H: int, W: int, mult: int = 1, scatter_left: float = 0.0,
+                     scatter_right: float = 0.0) -> Tuple[np.ndarray, np.ndarray]:
+    _, k, d, right, _, width = anchors_desc(H, W, mult, scatter_left, scatter_right)
+    return affine_rows(H, k, d, right, width)
+
+
+def endpoints_desc(H: int, W: int, corridor: int, realign: bool = False) -> tuple:
     """src/AlignmentBuffer.cpp:110-124; ``corridor`` is corridor*corridorMultiplier."""
     width = corridor // (1 if realign else 4)
     k = F32(H) * F32(1.0) / F32(W)
     d = F32(width) / F32(2.0)
-    i = np.arange(H, dtype=np.int64).astype(F32)
-    off = _trunc_i32((i - d) / k)
-    return off, np.full(H, width, dtype=np.int32)
+    return (1, float(k), float(d), 0.0, 0, width)
+
+
+def corridor_endpoints(H: int, W: int, corridor: int, realign: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    _, k, d, right, _, width = endpoints_desc(H, W, corridor, realign)
+    return affine_rows(H, k, d, right, width)
+
+
+def linear_desc(H: int, width: int) -> tuple:
+    """src/AlignmentBuffer.cpp:77-80 (short reads): offset = i - width / 2 (integer)."""
+    return (1, 1.0, float(width // 2), 0.0, 0, width)
 
 
 def corridor_linear(H: int, width: int) -> Tuple[np.ndarray, np.ndarray]:
-    """src/AlignmentBuffer.cpp:77-80 (short reads)."""
     off = (np.arange(H, dtype=np.int64) - width // 2).astype(np.int32)
     return off, np.full(H, width, dtype=np.int32)
 
 
-def corridor_full(H: int, W: int) -> Tuple[np.ndarray, np.ndarray]:
+def full_desc(H: int, W: int) -> tuple:
     """src/AlignmentBuffer.cpp:93-103: every row spans the whole window plus 20%."""
-    off = int(W * -0.2)
-    length = W + int(W * 0.2)
+    return (2, 0.0, 0.0, 0.0, int(W * -0.2), W + int(W * 0.2))
+
+
+def corridor_full(H: int, W: int) -> Tuple[np.ndarray, np.ndarray]:
+    _, _, _, _, off, length = full_desc(H, W)
     return np.full(H, off, dtype=np.int32), np.full(H, length, dtype=np.int32)
 
 
@@ -184,18 +208,22 @@ def make_tile(rng: np.random.Generator, W: int, err: float = 0.15,
     if corridor == "anchors":
         sl = float(rng.random() * scatter)
         sr = float(rng.random() * scatter)
-        off, ln = corridor_anchors(H, W, mult=mult, scatter_left=sl, scatter_right=sr)
+        desc = anchors_desc(H, W, mult=mult, scatter_left=sl, scatter_right=sr)
+        off, ln = affine_rows(H, desc[1], desc[2], desc[3], desc[5])
     elif corridor == "endpoints":
         c = width if width is not None else estimate_corridor(H, W, W)
-        off, ln = corridor_endpoints(H, W, c * mult, realign=realign)
+        desc = endpoints_desc(H, W, c * mult, realign=realign)
+        off, ln = affine_rows(H, desc[1], desc[2], desc[3], desc[5])
     elif corridor == "linear":
         w = width if width is not None else 256 + 2 * int(F32(0.15) * F32(H))
+        desc = linear_desc(H, w * mult)
         off, ln = corridor_linear(H, w * mult)
     elif corridor == "full":
+        desc = full_desc(H, W)
         off, ln = corridor_full(H, W)
     else:
         raise ValueError(corridor)
-    return Tile(ref=ref.tobytes(), qry=qry.tobytes(), row_offset=off, row_length=ln, tag=tag or corridor)
+    return Tile(ref=ref.tobytes(), qry=qry.tobytes(), row_offset=off, row_length=ln, tag=tag or corridor, desc=desc)
 
 
 def workload_pacbio(n_tiles: int, seed: int = 7, read_len: int = 10000, err: float = 0.15,
@@ -261,18 +289,33 @@ def workload_short(n_tiles: int, seed: int = 17) -> List[Tile]:
 # batch in four flat arrays (chunks of it can be generated on worker processes) and hands the C ABI
 # a tile table that points straight into those arrays.
 
-class TileSet:
-    """n tiles in flat arrays: ref / qry bytes, one (offset, length) per read row."""
+TILE_DTYPE = np.dtype([("ref", np.uint64), ("qry", np.uint64), ("row_offset", np.uint64), ("row_length", np.uint64),
+                       ("ref_len", np.int32), ("qry_len", np.int32), ("row_stride_bytes", np.int32), ("corridor_kind", np.int32),
+                       ("corridor_k", np.float32), ("corridor_d", np.float32), ("corridor_right", np.float32),
+                       ("corridor_offset", np.int32), ("corridor_width", np.int32), ("reserved", np.int32)])
+assert TILE_DTYPE.itemsize == 72
+DESC_DTYPE = np.dtype([("kind", np.int32), ("k", np.float32), ("d", np.float32), ("right", np.float32),
+                       ("offset", np.int32), ("width", np.int32)])
 
-    def __init__(self, ref, ref_off, qry, qry_off, row_offset, row_length, tag=""):
+
+class TileSet:
+    """n tiles in flat arrays: ref / qry bytes back to back in tile order, one (offset, length) per read row, and
+    (optionally) the closed form of every corridor.  `closed_form`: the tile table hands the C ABI the closed forms
+    instead of the row arrays.  pin(lib): the sequences move into page-locked memory (cvx_host_alloc), from where the
+    device pulls them without any packing on the host."""
+
+    def __init__(self, ref, ref_off, qry, qry_off, row_offset, row_length, tag="", desc=None):
         self.ref, self.ref_off = ref, ref_off
         self.qry, self.qry_off = qry, qry_off
         self.row_offset, self.row_length = row_offset, row_length
         self.tag = tag
+        self.desc = desc                      # DESC_DTYPE[n] or None
+        self.closed_form = False
         self.n = len(ref_off) - 1
         self.H = np.diff(qry_off).astype(np.int64)
         self.W = np.diff(ref_off).astype(np.int64)
         self._table = None
+        self._pinned = None
 
     def __len__(self) -> int:
         return self.n
@@ -292,33 +335,100 @@ class TileSet:
         """Tile i as the per-tile object the oracle wrapper and the tests take (copies)."""
         r0, r1 = int(self.ref_off[i]), int(self.ref_off[i + 1])
         q0, q1 = int(self.qry_off[i]), int(self.qry_off[i + 1])
+        d = self.desc[i] if self.desc is not None else None
         return Tile(ref=self.ref[r0:r1].tobytes(), qry=self.qry[q0:q1].tobytes(),
-                    row_offset=self.row_offset[q0:q1], row_length=self.row_length[q0:q1], tag=self.tag)
+                    row_offset=self.row_offset[q0:q1], row_length=self.row_length[q0:q1], tag=self.tag,
+                    desc=None if d is None else (int(d["kind"]), float(d["k"]), float(d["d"]), float(d["right"]), int(d["offset"]), int(d["width"])))
+
+    def use_closed_form(self, on: bool = True) -> "TileSet":
+        if on and self.desc is None:
+            raise ValueError("this TileSet carries no corridor descriptors")
+        self.closed_form, self._table = bool(on), None
+        return self
+
+    def pin(self, lib) -> bool:
+        """Moves ref / qry into page-locked arenas from cvx_host_alloc (False, nothing changed, when that fails: no device)."""
+        import ctypes as C
+        if self._pinned is not None:
+            return True
+        ptrs = []
+        for arr in (self.ref, self.qry):
+            p = C.c_void_p()
+            if lib.cvx_host_alloc(max(int(arr.nbytes), 1), C.byref(p)) != 0:
+                for q in ptrs:
+                    lib.cvx_host_free(q)
+                return False
+            ptrs.append(p)
+        views = []
+        for p, arr in zip(ptrs, (self.ref, self.qry)):
+            v = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(int(arr.nbytes), 1),))[:arr.nbytes]
+            v[:] = arr
+            views.append(v)
+        self.ref, self.qry = views
+        self._pinned = (lib, ptrs)
+        self._table = None
+        return True
+
+    def unpin(self) -> None:
+        if self._pinned is not None:
+            lib, ptrs = self._pinned
+            self.ref, self.qry = self.ref.copy(), self.qry.copy()
+            for p in ptrs:
+                lib.cvx_host_free(p)
+            self._pinned, self._table = None, None
+
+    def subset(self, idx) -> "TileSet":
+        """The tiles idx (in that order) as a new TileSet (copies)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        gather = lambda data, off: (np.concatenate([data[int(off[i]):int(off[i + 1])] for i in idx]) if len(idx) else data[:0].copy())  # noqa: E731
+        W, H = self.W[idx], self.H[idx]
+        out = TileSet(gather(self.ref, self.ref_off), np.concatenate([[0], np.cumsum(W)]).astype(np.int64),
+                      gather(self.qry, self.qry_off), np.concatenate([[0], np.cumsum(H)]).astype(np.int64),
+                      gather(self.row_offset, self.qry_off), gather(self.row_length, self.qry_off), tag=self.tag,
+                      desc=None if self.desc is None else self.desc[idx].copy())
+        out.closed_form = self.closed_form
+        return out
 
     def table(self) -> np.ndarray:
         """cvx_tile[n] (include/cvx_align.h) as a structured array whose pointers reference this
         object's arrays -- keep the TileSet alive while the table is in use."""
         if self._table is None:
-            dt = np.dtype([("ref", np.uint64), ("qry", np.uint64), ("row_offset", np.uint64), ("row_length", np.uint64),
-                           ("ref_len", np.int32), ("qry_len", np.int32), ("row_stride_bytes", np.int32), ("reserved", np.int32)])
-            assert dt.itemsize == 48
-            t = np.zeros(self.n, dtype=dt)
+            t = np.zeros(self.n, dtype=TILE_DTYPE)
             t["ref"] = self.ref.ctypes.data + self.ref_off[:-1].astype(np.uint64)
             t["qry"] = self.qry.ctypes.data + self.qry_off[:-1].astype(np.uint64)
-            t["row_offset"] = self.row_offset.ctypes.data + 4 * self.qry_off[:-1].astype(np.uint64)
-            t["row_length"] = self.row_length.ctypes.data + 4 * self.qry_off[:-1].astype(np.uint64)
             t["ref_len"] = self.W
             t["qry_len"] = self.H
-            t["row_stride_bytes"] = 4
+            if self.closed_form:
+                t["corridor_kind"] = self.desc["kind"]
+                t["corridor_k"], t["corridor_d"], t["corridor_right"] = self.desc["k"], self.desc["d"], self.desc["right"]
+                t["corridor_offset"], t["corridor_width"] = self.desc["offset"], self.desc["width"]
+            else:
+                t["row_offset"] = self.row_offset.ctypes.data + 4 * self.qry_off[:-1].astype(np.uint64)
+                t["row_length"] = self.row_length.ctypes.data + 4 * self.qry_off[:-1].astype(np.uint64)
+                t["row_stride_bytes"] = 4
             self._table = t
         return self._table
+
+
+def tileset_from_tiles(tiles: Sequence[Tile], tag: str = "") -> TileSet:
+    """Per-tile objects -> flat arrays (descriptors kept when every tile has one)."""
+    W = np.array([t.W for t in tiles], dtype=np.int64)
+    H = np.array([t.H for t in tiles], dtype=np.int64)
+    cat = lambda parts, dt: (np.concatenate(parts) if len(parts) else np.zeros(0, dt))  # noqa: E731
+    desc = None
+    if tiles and all(t.desc is not None for t in tiles):
+        desc = np.array([t.desc for t in tiles], dtype=DESC_DTYPE)
+    return TileSet(cat([np.frombuffer(t.ref, dtype=np.uint8) for t in tiles], np.uint8), np.concatenate([[0], np.cumsum(W)]).astype(np.int64),
+                   cat([np.frombuffer(t.qry, dtype=np.uint8) for t in tiles], np.uint8), np.concatenate([[0], np.cumsum(H)]).astype(np.int64),
+                   cat([np.asarray(t.row_offset, dtype=np.int32) for t in tiles], np.int32),
+                   cat([np.asarray(t.row_length, dtype=np.int32) for t in tiles], np.int32), tag=tag, desc=desc)
 
 
 def _pacbio_chunk(args):
     """`m` PacBio-like tiles (config C2, see workload_pacbio) as flat arrays; one process-pool task."""
     seed, m, read_len, err, scatter = args
     rng = np.random.default_rng(seed)
-    refs, qrys, offs, lens = [], [], [], []
+    refs, qrys, offs, lens, descs = [], [], [], [], []
     for _ in range(m):
         W = int(read_len * (0.9 + 0.2 * rng.random()))
         t = make_tile(rng, W, err=err, ratio=(6, 3, 1), corridor="anchors", scatter=scatter)
@@ -326,9 +436,10 @@ def _pacbio_chunk(args):
         qrys.append(np.frombuffer(t.qry, dtype=np.uint8))
         offs.append(t.row_offset)
         lens.append(t.row_length)
+        descs.append(t.desc)
     W = np.array([len(r) for r in refs], dtype=np.int64)
     H = np.array([len(q) for q in qrys], dtype=np.int64)
-    return np.concatenate(refs), np.concatenate(qrys), np.concatenate(offs), np.concatenate(lens), W, H
+    return np.concatenate(refs), np.concatenate(qrys), np.concatenate(offs), np.concatenate(lens), W, H, np.array(descs, dtype=DESC_DTYPE)
 
 
 def pacbio_tileset(n_tiles: int, seed: int = 7, read_len: int = 10000, err: float = 0.15,
@@ -343,4 +454,4 @@ def pacbio_tileset(n_tiles: int, seed: int = 7, read_len: int = 10000, err: floa
     cat = lambda k, dt: np.concatenate([p[k] for p in parts]) if parts else np.zeros(0, dt)  # noqa: E731
     return TileSet(cat(0, np.uint8), np.concatenate([[0], np.cumsum(W)]).astype(np.int64),
                    cat(1, np.uint8), np.concatenate([[0], np.cumsum(H)]).astype(np.int64),
-                   cat(2, np.int32), cat(3, np.int32), tag="pacbio")
+                   cat(2, np.int32), cat(3, np.int32), tag="pacbio", desc=cat(6, DESC_DTYPE))

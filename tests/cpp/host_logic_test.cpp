@@ -25,6 +25,7 @@ int main() {
 	std::vector<std::vector<int32_t>> off(n), len(n);
 	std::vector<std::vector<CorridorLine16>> lines(n);
 	std::vector<cvx_tile> tiles(n);
+	uint64_t n_closed_rows = 0;
 	for (int i = 0; i < n; ++i) {
 		const int W = (i % 17 == 0) ? 0 : (int) (rng() % 5000);
 		const int H = (i % 13 == 0) ? 0 : (int) (rng() % 4000);
@@ -45,7 +46,25 @@ int main() {
 		memset(&t, 0, sizeof(t));
 		t.ref = refs[i].data(); t.qry = qrys[i].data();
 		t.ref_len = W; t.qry_len = H;
-		if (i & 1) {       // CorridorLine[] passed directly, stride 16
+		if (i % 9 == 4 || i % 10 == 7) {
+			// closed-form corridor: no row arrays; the rows the device would generate replace off / len for the checks below
+			n_closed_rows += (uint64_t) H;
+			t.corridor_width = 309 + i % 60;
+			if (i % 9 == 4) {
+				t.corridor_kind = CVX_CORRIDOR_AFFINE;
+				t.corridor_k = (float) std::max(H, 1) * 1.0f / (float) std::max(W, 1);
+				t.corridor_d = (i & 2) ? (float) t.corridor_width / 2.0f : 0.0f;
+				t.corridor_right = (i & 2) ? 0.0f : 156.16f + (float) (i % 5);
+			} else {
+				t.corridor_kind = CVX_CORRIDOR_CONST;
+				t.corridor_offset = (int) (W * -0.2);
+			}
+			for (int y = 0; y < H; ++y) {
+				off[i][y] = t.corridor_kind == CVX_CORRIDOR_CONST ? t.corridor_offset
+						: (int32_t) (((float) y - t.corridor_d) / t.corridor_k - t.corridor_right);
+				len[i][y] = t.corridor_width;
+			}
+		} else if (i & 1) {       // CorridorLine[] passed directly, stride 16
 			t.row_offset = H ? &lines[i][0].offset : nullptr;
 			t.row_length = H ? &lines[i][0].length : nullptr;
 			t.row_stride_bytes = 16;
@@ -59,17 +78,20 @@ int main() {
 	int bad = -1;
 	CHECK(upload_layout(n, tiles.data(), tin, L, &bad) == kLayoutOk);
 	CHECK(L.pad >= (uint64_t) kRingMax + 256);
-	uint64_t so = L.pad, ro = 0;
+	// arena = [pad][every read][pad][every reference][pad]: two blocks in tile order
+	uint64_t qo = L.qry_base, so = L.ref_base, ro = 0;
+	CHECK(L.qry_base == L.pad && L.pad % 256 == 0 && L.ref_base % 256 == 0 && L.ref_base >= L.qry_base + L.qry_bytes + L.pad);
 	for (int i = 0; i < n; ++i) {
 		CHECK(tin[i].ref_off == so); so += tiles[i].ref_len;
-		CHECK(tin[i].qry_off == so); so += tiles[i].qry_len;
+		CHECK(tin[i].qry_off == qo); qo += tiles[i].qry_len;
 		CHECK(tin[i].row_off == ro); ro += tiles[i].qry_len;
 		CHECK(tin[i].H == tiles[i].qry_len && tin[i].W == tiles[i].ref_len);
 	}
-	CHECK(so + L.pad + 64 == L.seq_total && ro == L.n_rows);
+	CHECK(qo == L.qry_base + L.qry_bytes && so == L.ref_base + L.ref_bytes && so + L.pad + 64 == L.seq_total && ro == L.n_rows);
+	CHECK(!L.qry_contig && !L.ref_contig);                                           // every tile has its own std::string
 	CHECK(L.wprefix.size() == (size_t) n + 1 && L.wprefix[0] == 0);
 
-	CHECK(L.rsrc.size() == (size_t) n && L.delta_total >= L.n_rows);
+	CHECK(L.rsrc.size() == (size_t) n && L.delta_total >= L.n_rows - n_closed_rows);
 	std::vector<uint8_t> a(L.seq_total, 0xAA), b(L.seq_total, 0x55);
 	std::vector<uint8_t> da(L.delta_total + 4, 0x11), db(L.delta_total + 4, 0x22);
 	std::vector<RowSrc> sa = L.rsrc, sb = L.rsrc;
@@ -96,12 +118,13 @@ int main() {
 	std::vector<RowOverflow> la(1, oa);
 	place(la, sa, xa);
 	place(ob, sb, xb);
-	int n_explicit = 0, n_delta = 0;
+	int n_explicit = 0, n_delta = 0, n_closed = 0;
 	for (int i = 0; i < n; ++i) {
 		CHECK(memcmp(a.data() + tin[i].ref_off, refs[i].data(), refs[i].size()) == 0);
 		CHECK(memcmp(a.data() + tin[i].qry_off, qrys[i].data(), qrys[i].size()) == 0);
 		CHECK(sa[i].fmt == sb[i].fmt);
-		(sa[i].fmt == kRowsExplicit ? n_explicit : n_delta) += 1;
+		if (tiles[i].corridor_kind != CVX_CORRIDOR_ROWS) { CHECK(sa[i].fmt == (tiles[i].corridor_kind == CVX_CORRIDOR_AFFINE ? kRowsAffine : kRowsConst)); n_closed++; }
+		else (sa[i].fmt == kRowsExplicit ? n_explicit : n_delta) += 1;
 		const int H = tiles[i].qry_len;
 		std::vector<RowDesc> ra((size_t) H + 1), rb((size_t) H + 1);
 		expand_rows_host(sa[i], H, da.data(), xa.data(), ra.data());                 // = expand_rows_kernel
@@ -110,7 +133,7 @@ int main() {
 			if (ra[y].off != off[i][y] || ra[y].len != len[i][y] || rb[y].off != off[i][y] || rb[y].len != len[i][y]) { CHECK(!"rows survive the one-byte form"); break; }
 		}
 	}
-	CHECK(n_delta > 0 && n_explicit > 0);                                            // both forms exercised
+	CHECK(n_delta > 0 && n_explicit > 0 && n_closed > 10);                           // every form exercised
 	// ranges handed to the threads tile [0, n) exactly once
 	{
 		std::vector<int> seen(n, 0);
@@ -127,7 +150,34 @@ int main() {
 		CHECK(upload_layout(5, t2.data(), tin, L, &bad) == kLayoutMalformed && bad == 3);
 		t2[3].row_stride_bytes = 4; t2[2].qry_len = 10; t2[2].row_offset = nullptr;
 		CHECK(upload_layout(5, t2.data(), tin, L, &bad) == kLayoutMalformed && bad == 2);
-		CHECK(upload_layout(0, nullptr, tin, L, &bad) == kLayoutOk && L.n_rows == 0 && L.seq_total == 2 * L.pad + 64);
+		CHECK(upload_layout(0, nullptr, tin, L, &bad) == kLayoutOk && L.n_rows == 0 && L.seq_total == L.ref_base + L.pad + 64);
+		// a malformed closed form, and sequences that do lie back to back (one arena, tile order)
+		std::vector<cvx_tile> t3(tiles.begin(), tiles.begin() + 3);
+		t3[1].corridor_kind = CVX_CORRIDOR_AFFINE; t3[1].corridor_k = 0.0f; t3[1].corridor_width = 300;
+		CHECK(upload_layout(3, t3.data(), tin, L, &bad) == kLayoutMalformed && bad == 1);
+		std::string arena_q, arena_r;
+		for (int i = 0; i < 3; ++i) { arena_q += qrys[i]; arena_r += refs[i]; }
+		size_t aq = 0, ar = 0;
+		for (int i = 0; i < 3; ++i) { t3[i] = tiles[i]; t3[i].qry = arena_q.data() + aq; t3[i].ref = arena_r.data() + ar; aq += qrys[i].size(); ar += refs[i].size(); }
+		CHECK(upload_layout(3, t3.data(), tin, L, &bad) == kLayoutOk && L.qry_contig && L.ref_contig);
+		// nothing is copied for a block that travels from the caller's page-locked arena
+		std::vector<uint8_t> z(L.seq_total, 0xEE), dz(L.delta_total + 4, 0);
+		RowOverflow oz;
+		upload_pack(0, 3, t3.data(), tin, z.data(), dz.data(), L.rsrc, oz, false, false);
+		bool untouched = true;
+		for (uint8_t c : z) if (c != 0xEE) untouched = false;
+		CHECK(untouched);
+	}
+	// the pool: many callers at once, every task exactly once
+	{
+		std::vector<std::atomic<int>> hits(64 * 50);
+		for (auto &h : hits) h = 0;
+		std::vector<std::thread> callers;
+		for (int c = 0; c < 8; ++c) callers.emplace_back([&, c] { for (int r = 0; r < 8; ++r) PackPool::get().run(50, [&](int i) { hits[(size_t) ((c * 8 + r) * 50 + i)]++; }); });
+		for (auto &t : callers) t.join();
+		bool once = true;
+		for (auto &h : hits) if (h != 1) once = false;
+		CHECK(once);
 	}
 
 	// ---------------------------------------------------------------- host planning

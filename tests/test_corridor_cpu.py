@@ -1,0 +1,88 @@
+"""CPU: the closed forms of the reference's corridor builders (cvx_tile.corridor_kind, restated in
+ngmlr_amd/synth.py for the generators and in cvx_types.h for the device / host planning) reproduce every corridor
+the unmodified reference was recorded building -- the committed golden tiles of test_2 / test_3 / test_4 and, when
+generated, all 985 SingleAlign calls of test_3 -- bit for bit; tests/util.fit_corridor recovers the builder and its
+parameters from the recorded rows.  (The device's own evaluation is checked in tests/test_gpu_corridor.py.)"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ngmlr_amd import capi, synth
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rows_of(desc, H):
+    if desc[0] == capi.CORRIDOR_AFFINE:
+        return synth.affine_rows(H, desc[1], desc[2], desc[3], desc[5])
+    return np.full(H, desc[4], np.int32), np.full(H, desc[5], np.int32)
+
+
+@pytest.mark.parametrize("name", ["ref_test_2.npz", "ref_test_4.npz", "ref_test_3.npz", "full"])
+def test_recorded_corridors_have_a_closed_form(name):
+    if name == "full":
+        name = util.full_golden_path()
+        if name is None:
+            pytest.skip("oracle/_ref/golden_full not generated")
+    kinds = {}
+    for t, _ in util.load_golden(name):
+        d = util.fit_corridor(t.row_offset, t.row_length, t.H, t.W)
+        assert d is not None, t.tag
+        off, ln = _rows_of(d, t.H)
+        assert np.array_equal(off, t.row_offset) and np.array_equal(ln, t.row_length), t.tag
+        kinds[d[0]] = kinds.get(d[0], 0) + 1
+    assert kinds.get(capi.CORRIDOR_AFFINE, 0) > 0
+
+
+def test_generators_carry_their_closed_form():
+    for t in util.tile_zoo(n=48) + synth.workload_short(20) + synth.workload_ultralong_sv(4, read_len=3000):
+        assert t.desc is not None
+        off, ln = _rows_of(t.desc, t.H)
+        assert np.array_equal(off, t.row_offset) and np.array_equal(ln, t.row_length), (t.tag, t.desc)
+        d = util.fit_corridor(t.row_offset, t.row_length, t.H, t.W)
+        assert d is not None
+        off, ln = _rows_of(d, t.H)
+        assert np.array_equal(off, t.row_offset) and np.array_equal(ln, t.row_length), (t.tag, d)
+
+
+def test_host_side_closed_form_matches_numpy(tmp_path):
+    """affine_row_offset of cvx_types.h compiled for the host (what the chain planning uses) against numpy float32."""
+    src = tmp_path / "aff.cpp"
+    src.write_text('#include "cvx_types.h"\nextern "C" void rows(int H, float d, float k, float r, int *out) '
+                   '{ for (int y = 0; y < H; ++y) out[y] = cvx::affine_row_offset(y, d, k, r); }\n')
+    so = tmp_path / "aff.so"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "ngmlr_amd", "csrc"),
+                    str(src), "-o", str(so)], check=True)
+    lib = C.CDLL(str(so))
+    lib.rows.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        H = int(rng.integers(1, 30000))
+        W = int(rng.integers(1, 30000))
+        k = np.float32(H) * np.float32(1.0) / np.float32(W)
+        d = np.float32(rng.choice([0.0, 154.5, 1024.0]))
+        r = np.float32(rng.choice([0.0, 156.16, 312.32, 901.7]))
+        out = np.zeros(H, dtype=np.int32)
+        lib.rows(H, float(d), float(k), float(r), out.ctypes.data)
+        want, _ = synth.affine_rows(H, k, d, r, 1)
+        assert np.array_equal(out, want)
+
+
+def test_tileset_table_layout_and_subset():
+    tiles = util.tile_zoo(n=12)
+    ts = synth.tileset_from_tiles(tiles)
+    assert ts.desc is not None and len(ts) == 12
+    tab = ts.table()
+    assert tab.dtype.itemsize == C.sizeof(capi.CvxTile) and np.all(tab["corridor_kind"] == 0) and np.all(tab["row_stride_bytes"] == 4)
+    ts.use_closed_form()
+    tab = ts.table()
+    assert np.all(tab["corridor_kind"] > 0) and np.all(tab["row_offset"] == 0)
+    sub = ts.subset([5, 2, 9])
+    for k, i in enumerate([5, 2, 9]):
+        a, b = sub.tile(k), tiles[i]
+        assert a.ref == b.ref and a.qry == b.qry and np.array_equal(a.row_offset, b.row_offset) and a.desc[0] == b.desc[0]
+        assert abs(a.desc[1] - np.float32(b.desc[1])) == 0 and a.desc[5] == b.desc[5]

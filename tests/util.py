@@ -135,3 +135,63 @@ def edge_tiles():
     ln = (200 + (np.arange(H) % 7) * 3).astype(np.int32)
     out.append(synth.Tile(d.tobytes(), q.tobytes(), off, ln, tag="ragged"))
     return out
+
+
+# --------------------------------------------------------------------------- corridor closed forms
+
+def _f32_from_ord(o):
+    """ordered int64 -> float32 (monotone bijection between float32 values and integers)"""
+    o = np.asarray(o, dtype=np.int64)
+    bits = np.where(o >= 0, o, (-(o + 1)) | np.int64(0x80000000))
+    return bits.astype(np.uint32).view(np.float32)
+
+
+def _ord_from_f32(x):
+    b = np.asarray(np.float32(x)).view(np.uint32).astype(np.int64)
+    return np.where(b & 0x80000000, -(b & 0x7fffffff) - 1, b)
+
+
+def fit_corridor(off, ln, H, W):
+    """Closed form (kind, k, d, right, offset, width) that reproduces the recorded rows of one of the reference's
+    corridor builders bit for bit, or None.  Test infrastructure: the recorder sees only the CorridorLine[] a
+    SingleAlign call received, not which builder made it (src/AlignmentBuffer.cpp:68-197), so the builder and --
+    for the anchors corridor -- a `corridorRight` consistent with every row are recovered here.  k is always
+    qryLen * 1.0f / refLen (:117, :141); the endpoints corridor has d = width / 2.0f and no shift (:118-124); the
+    anchors corridor has d = 0 and offset = (int)(i / k - right) (:190): every row bounds `right` from both sides
+    (the expression is monotone in it), and any float32 inside the intersection generates identical rows."""
+    off = np.asarray(off, dtype=np.int32)
+    ln = np.asarray(ln, dtype=np.int32)
+    if H == 0:
+        return (2, 0.0, 0.0, 0.0, 0, 0)
+    w = int(ln[0])
+    if not np.all(ln == w):
+        return None
+    if np.all(off == off[0]):
+        return (2, 0.0, 0.0, 0.0, int(off[0]), w)
+    y = np.arange(H, dtype=np.int64)
+    if np.array_equal(off.astype(np.int64), y + int(off[0])) and abs(int(off[0])) < (1 << 23) and H < (1 << 23):
+        return (1, 1.0, float(-int(off[0])), 0.0, 0, w)          # getCorridorLinear: i - width / 2
+    F32 = np.float32
+    k = F32(H) * F32(1.0) / F32(max(W, 1))
+    d = F32(w) / F32(2.0)
+    o2, _ = synth.affine_rows(H, k, d, 0.0, w)
+    if np.array_equal(o2, off):
+        return (1, float(k), float(d), 0.0, 0, w)                  # getCorridorEndpoints
+    q = (y.astype(F32) - F32(0)) / k
+
+    def g(right):
+        return np.trunc(F32(q - F32(right))).astype(np.int64)
+    # smallest `right` with g <= off everywhere (g falls as right grows), largest with g >= off everywhere
+    lo, hi = int(_ord_from_f32(-3.0e6)), int(_ord_from_f32(3.0e6))
+    a_lo, a_hi = lo, hi
+    while a_lo < a_hi:
+        m = (a_lo + a_hi) // 2
+        if np.all(g(_f32_from_ord(m)) <= off):
+            a_hi = m
+        else:
+            a_lo = m + 1
+    right = float(_f32_from_ord(a_lo))
+    o3, _ = synth.affine_rows(H, k, 0.0, right, w)
+    if np.array_equal(o3, off):
+        return (1, float(k), 0.0, right, 0, w)                     # getCorridorEndpointsWithAnchors
+    return None

@@ -28,3 +28,4 @@ for p in stats fetch write sq sq2; do
 	[ -n "$db" ] && python $R/tools/rocpd_summary.py $db > $OUT/${TAG}_$p.txt 2>&1
 done
 ls -la $OUT | tail -30
+python $R/tools/make_pmc_json.py $TAG $OUT/${TAG}_pmc.json > /dev/null 2>&1 && echo "wrote $OUT/${TAG}_pmc.json (build $(python -c "import sys; sys.path.insert(0,'$R'); from ngmlr_amd import capi; print(capi.load().cvx_build_id().decode())"))"

@@ -37,7 +37,10 @@ def main():
     fetch, write = counters(g("fetch.txt")), counters(g("write.txt"))
     tiles, alg = bench_meta(g("fetch.log"))
     hbm = int((2.0 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024)
-    d = {"_comment": "rocprofv3 --pmc passes of tools/collect_profiles.sh %s (separate runs, --kernel-trace only); largest dispatch of "
+    sys.path.insert(0, ROOT)
+    from ngmlr_amd import capi
+    build_id = capi.load().cvx_build_id().decode()      # the library the passes ran on (same snapshot)
+    d = {"build_id": build_id, "_comment": "rocprofv3 --pmc passes of tools/collect_profiles.sh %s (separate runs, --kernel-trace only); largest dispatch of "
                      "the dominant fill kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); hbm_bytes = 2*FETCH + WRITE. "
                      "bench.py scales hbm_bytes to its own launch by algorithmic bytes and says so." % tag,
          "fill_ring_kernel<M=3,NW=1,wrap16=0>": {"tiles": tiles, "alg_bytes": alg, "fetch_size_kib": fetch["FETCH_SIZE"],
