@@ -220,11 +220,20 @@ void cvx_batch_free(cvx_handle h, cvx_batch b);
  *               cvx_job_release.  Jobs complete in submission order.
  *   cvx_job_release  returns the job's arenas to the handle (they are reused by the next submit).
  *
+ * Errors belong to their job: if something fails while a job's kernels are queued (say a multi-GB arena does not
+ * fit beside the batches in flight), that job's cvx_wait -- and only it -- returns the error, every time it is
+ * called; the job handle stays valid until cvx_job_release.  cvx_submit reports only what happens to the batch
+ * being submitted.  cvx_destroy frees whatever jobs were never released (their handles die with the context).
+ *
  * With two or three jobs in flight (submit k+1, then wait k-1) the upload of batch k+1 and the
  * download of batch k-1 run under the kernels of batch k.  A handle is not re-entrant: one host
  * thread per handle (one handle per device and thread, like the reference's aligner instances). */
 int cvx_submit(cvx_handle h, int32_t n_tiles, const cvx_tile *tiles, cvx_job *out);
 int cvx_wait(cvx_handle h, cvx_job job, const cvx_result **results, const uint32_t **ops, uint64_t *n_ops);
+/* Non-blocking: *done = 1 when cvx_wait on the job would return without waiting for the device (finished or failed).
+ * Also hands the device the kernels of any job whose corridor analysis has come back meanwhile -- a driver that polls
+ * instead of blocking in cvx_wait (batching_aligner.cpp) keeps the pipeline moving with it. */
+int cvx_job_poll(cvx_handle h, cvx_job job, int32_t *done);
 int cvx_job_timing(cvx_job job, cvx_timing *t);                        /* after cvx_wait */
 int cvx_job_launch_info(cvx_job job, int32_t i, cvx_launch_info *info); /* after cvx_wait */
 void cvx_job_release(cvx_handle h, cvx_job job);

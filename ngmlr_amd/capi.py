@@ -25,7 +25,7 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_format_alignment", "cvx_format_batch", "cvx_score_batch",
            "cvx_genome_encoded_bytes", "cvx_genome_encode", "cvx_genome_upload", "cvx_genome_free",
            "cvx_genome_decode", "cvx_submit_windows", "cvx_job_text",
-           "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id")
+           "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id", "cvx_job_poll")
 
 
 class CvxParams(C.Structure):
@@ -122,6 +122,7 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_submit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CvxTile), C.POINTER(C.c_void_p)]
     lib.cvx_wait.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.POINTER(CvxResult)), C.POINTER(C.POINTER(C.c_uint32)),
                              C.POINTER(C.c_uint64)]
+    lib.cvx_job_poll.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     lib.cvx_job_timing.argtypes = [C.c_void_p, C.POINTER(CvxTiming)]
     lib.cvx_job_launch_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CvxLaunchInfo)]
     lib.cvx_job_release.argtypes = [C.c_void_p, C.c_void_p]

@@ -1,6 +1,7 @@
 /* batching_aligner.cpp -- see batching_aligner.h */
 #include "batching_aligner.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -8,50 +9,121 @@
 namespace Convex {
 
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
-		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0), leaderActive(false),
-		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), launches(0), requests(0) {
+		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0),
+		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), stop(false), launches(0), requests(0), maxInFlight(0) {
+	dispatcher = std::thread([this] { dispatchLoop(); });
 }
 
 BatchingAligner::~BatchingAligner() {
+	{
+		std::lock_guard<std::mutex> lk(mtx);
+		stop = true;
+	}
+	cvDispatch.notify_all();
+	dispatcher.join();
 }
 
 void BatchingAligner::WorkerDone() {
-	std::unique_lock<std::mutex> lk(mtx);
-	workers -= 1;
-	/* the remaining workers may all be parked now */
-	if (!leaderActive && !queue.empty() && parked >= workers) flushLocked(lk);
+	{
+		std::lock_guard<std::mutex> lk(mtx);
+		workers -= 1;
+	}
+	cvDispatch.notify_all();      /* the remaining workers may all be parked now */
 }
 
 void BatchingAligner::WorkerJoined() {
-	std::unique_lock<std::mutex> lk(mtx);
+	std::lock_guard<std::mutex> lk(mtx);
 	workers += 1;
 }
 
-/* called with the lock held by a parked thread: run everything that is queued */
-void BatchingAligner::flushLocked(std::unique_lock<std::mutex> & lk) {
-	leaderActive = true;
-	std::vector<Request *> batch;
-	batch.swap(queue);
-	lk.unlock();
+/* called with the lock held */
+bool BatchingAligner::shouldCut(bool deviceIdle) const {
+	if (queue.empty()) return false;
+	if ((int) queue.size() >= maxBatch) return true;
+	if (parked >= workers) return true;                      /* nobody left who could add to the launch */
+	if (deviceIdle) return true;                             /* nothing to overlap with: latency first */
+	if (timeoutUs > 0 && std::chrono::steady_clock::now() - oldest >= std::chrono::microseconds(timeoutUs)) return true;
+	return false;
+}
 
-	std::vector<ConvexAlignHip::Tile> tiles(batch.size());
-	for (size_t i = 0; i < batch.size(); ++i) { tiles[i] = batch[i]->tile; batch[i]->queued = false; }
-	bool failed = false;
-	try {
-		backend->AlignTiles(tiles.data(), (int) tiles.size());
-	} catch (...) {
-		failed = true;   /* every waiter rethrows in its own thread, like the reference's hard errors */
+/* The one thread that owns the device handle.  Up to two launches in flight: the upload and corridor analysis of the
+ * younger run under the kernels of the older; requests that arrive meanwhile form the launch after that. */
+void BatchingAligner::dispatchLoop() {
+	std::unique_lock<std::mutex> lk(mtx);
+	for (;;) {
+		/* buffers of launches whose workers have all finished writing */
+		while (!retired.empty()) {
+			Launch * l = retired.back();
+			retired.pop_back();
+			lk.unlock();
+			if (l->job) backend->Release(l->job);
+			delete l;
+			lk.lock();
+		}
+		if (stop && queue.empty() && inFlight.empty()) break;
+		bool const canSubmit = inFlight.size() < 2;
+		if (canSubmit && shouldCut(inFlight.empty())) {
+			Launch * l = new Launch();
+			l->job = 0; l->results = 0; l->ops = 0; l->failed = false;
+			size_t const take = std::min(queue.size(), (size_t) maxBatch);
+			l->reqs.assign(queue.begin(), queue.begin() + (long) take);
+			queue.erase(queue.begin(), queue.begin() + (long) take);
+			if (!queue.empty()) oldest = std::chrono::steady_clock::now();
+			l->unfinished = (int) l->reqs.size();
+			for (Request * r : l->reqs) r->launch = l;
+			launches += 1;
+			lk.unlock();
+			std::vector<ConvexAlignHip::Tile> tiles(l->reqs.size());
+			for (size_t i = 0; i < tiles.size(); ++i) tiles[i] = l->reqs[i]->tile;
+			try {
+				l->job = backend->Submit(tiles.data(), (int) tiles.size());
+			} catch (...) {
+				l->failed = true;
+			}
+			lk.lock();
+			inFlight.push_back(l);
+			if ((long) inFlight.size() > maxInFlight) maxInFlight = (long) inFlight.size();
+			continue;                                        /* maybe a second launch right away */
+		}
+		if (!inFlight.empty()) {
+			/* Block in Wait only when nothing else can happen meanwhile (two launches in flight, or nobody left to
+			 * add requests).  Otherwise poll the oldest launch at a few kHz: requests that arrive while it runs are cut
+			 * into the second launch -- whose upload and corridor analysis then run under its kernels -- as soon as
+			 * one of the rules fires. */
+			Launch * l = inFlight.front();
+			bool const block = l->failed || inFlight.size() >= 2 || parked >= workers;
+			if (!block) {
+				lk.unlock();
+				bool const done = backend->Poll(l->job);
+				lk.lock();
+				if (!done) {
+					cvDispatch.wait_for(lk, std::chrono::microseconds(200));
+					continue;
+				}
+			}
+			inFlight.pop_front();
+			lk.unlock();
+			if (!l->failed) {
+				try {
+					backend->Wait(l->job, &l->results, &l->ops);
+				} catch (...) {
+					l->failed = true;
+				}
+			}
+			lk.lock();
+			for (size_t i = 0; i < l->reqs.size(); ++i) {
+				Request * r = l->reqs[i];
+				r->failed = l->failed;
+				r->result = l->failed ? 0 : &l->results[i];
+				r->done = true;
+			}
+			cvWorkers.notify_all();
+			continue;
+		}
+		/* idle: nothing in flight, nothing to cut yet */
+		if (!queue.empty() && timeoutUs > 0) cvDispatch.wait_until(lk, oldest + std::chrono::microseconds(timeoutUs));
+		else cvDispatch.wait(lk);
 	}
-
-	lk.lock();
-	for (size_t i = 0; i < batch.size(); ++i) {
-		batch[i]->tile.ret = tiles[i].ret;
-		batch[i]->failed = failed;
-		batch[i]->done = true;
-	}
-	launches += 1;
-	leaderActive = false;
-	cv.notify_all();
 }
 
 int BatchingAligner::SingleAlign(int const mode, CorridorLine * corridor, int const corridorHeight,
@@ -61,38 +133,40 @@ int BatchingAligner::SingleAlign(int const mode, CorridorLine * corridor, int co
 	Request req;
 	req.tile.corridor = corridor; req.tile.corridorHeight = corridorHeight;
 	req.tile.refSeq = refSeq; req.tile.qrySeq = qrySeq; req.tile.result = &result;
-	req.tile.externalQStart = externalQStart; req.tile.externalQEnd = externalQEnd; req.tile.ret = -1;
-	req.done = false; req.failed = false;
+	req.tile.externalQStart = externalQStart; req.tile.externalQEnd = externalQEnd; req.tile.ret = -1; req.tile.failed = false;
+	req.launch = 0; req.result = 0; req.done = false; req.failed = false;
+	ConvexAlignHip::Prepare(req.tile);       /* in the caller's thread; throws like the reference for a malformed call */
 
 	std::unique_lock<std::mutex> lk(mtx);
+	if (queue.empty()) oldest = std::chrono::steady_clock::now();
 	queue.push_back(&req);
-	req.queued = true;
 	requests += 1;
 	parked += 1;
-	std::chrono::microseconds const patience(timeoutUs > 0 ? timeoutUs : 1000000);
-	std::chrono::steady_clock::time_point deadline = std::chrono::steady_clock::now() + patience;
-	while (!req.done) {
-		bool const expired = timeoutUs > 0 && std::chrono::steady_clock::now() >= deadline;
-		bool const mine = !leaderActive && !queue.empty() &&
-				((int) queue.size() >= maxBatch || parked >= workers || expired);
-		if (mine) {
-			flushLocked(lk);      /* may or may not contain my own request */
-			continue;
-		}
-		/* The timed wait only makes sense while this request still sits in the queue and nobody is
-		 * flushing: once a leader has taken it (or is busy with an earlier batch) the only event to
-		 * wait for is the leader's notify_all -- a deadline that has already passed would turn
-		 * wait_until into a spin on the mutex the leader needs. */
-		if (timeoutUs > 0 && req.queued && !leaderActive) {
-			if (expired) deadline = std::chrono::steady_clock::now() + patience;   /* re-arm */
-			cv.wait_until(lk, deadline);
-		} else {
-			cv.wait(lk);
+	cvDispatch.notify_one();
+	while (!req.done) cvWorkers.wait(lk);
+	parked -= 1;
+	Launch * l = req.launch;
+	bool const failed = req.failed;
+	cvx_result const * r = req.result;
+	uint32_t const * ops = l->ops;
+	lk.unlock();
+
+	/* the text stage of this request, in this worker's thread, out of the launch's buffers */
+	bool threw = failed;
+	if (!failed) {
+		try {
+			backend->Finish(req.tile, *r, ops);
+		} catch (...) {
+			threw = true;
 		}
 	}
-	parked -= 1;
+	lk.lock();
+	if (--l->unfinished == 0) {
+		retired.push_back(l);
+		cvDispatch.notify_one();
+	}
 	lk.unlock();
-	if (req.failed) throw 1;
+	if (threw) throw 1;
 	return req.tile.ret;
 }
 
@@ -135,8 +209,8 @@ SharedAligner::SharedAligner(int const stdOutMode, float const match, float cons
 }
 
 SharedAligner::~SharedAligner() {
+	shared->WorkerDone();        /* (outside the process-wide lock: it only touches this device's aligner) */
 	std::lock_guard<std::mutex> g(g_sharedMtx);
-	shared->WorkerDone();
 	g_deviceUsers[device] -= 1;
 	g_users -= 1;
 	if (g_deviceUsers[device] == 0) {

@@ -4,19 +4,38 @@
  * ngmlr calls SingleAlign once per interval from each worker thread and needs the result
  * before it can trim the next interval (reference src/AlignmentBuffer.cpp:3361-3406,
  * :291-425), so one worker can never keep a GPU busy.  BatchingAligner is an IAlignment
- * that many worker threads share: each SingleAlign parks its request in a queue; when the
- * queue is full, or every registered worker is parked, or a deadline passes, ONE of the
- * parked threads takes the whole queue to ConvexAlignHip::AlignTiles (one device launch)
- * and wakes the others.  No extra thread, no change to the callers.
+ * that many worker threads share.  Each SingleAlign prepares its request (string lengths,
+ * the offsetInMatrix side effect) in the caller's thread, parks it in a queue and sleeps.
+ * ONE dispatcher thread per BatchingAligner -- the only thread that talks to the device
+ * handle -- cuts the queue into launches and keeps up to two of them in flight through the
+ * streaming ABI (cvx_submit / cvx_wait): while launch k runs, the requests that arrive form
+ * launch k+1, whose upload and corridor analysis overlap launch k's kernels.  When a launch
+ * has finished, the dispatcher hands every parked worker its result record and wakes it; the
+ * worker writes its own CIGAR / MD / NM into its own Align (the text stage runs on as many
+ * threads as there are workers), and the last one returns the launch's buffers.
+ *
+ * A launch is cut when   the queue holds maxBatch requests,
+ *                   or   every registered worker is parked (nobody else can add to it),
+ *                   or   the oldest request has waited timeoutUs,
+ *                   or   the device is idle and something is queued (latency before batch size
+ *                        when there is nothing to overlap with).
+ *
+ * Errors stay with their request: a hard error of one tile (corridor no kernel covers, CIGAR
+ * that does not fit) is thrown in that worker's thread only -- the reference's caller drops
+ * exactly that alignment (src/AlignmentBuffer.cpp:454-463); only a failure of a whole launch
+ * fails all of its requests.
  *
  * Usage in ngmlr: one BatchingAligner per device, handed to every AlignmentBuffer in place
- * of its private aligner; `workers` = number of CS threads (-t).
+ * of its private aligner (SharedAligner below does that without touching the pipeline).
  */
 #ifndef BATCHING_ALIGNER_H
 #define BATCHING_ALIGNER_H
 
+#include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "convex_align_hip.h"
@@ -25,8 +44,8 @@ namespace Convex {
 
 class BatchingAligner: public IAlignment {
 public:
-	/* backend is owned by the caller.  maxBatch: flush when this many requests wait;
-	 * timeoutUs: flush after the oldest request waited this long (0 = only the other rules). */
+	/* backend is owned by the caller.  maxBatch: cut a launch when this many requests wait;
+	 * timeoutUs: cut one when the oldest request has waited this long (0 = only the other rules). */
 	BatchingAligner(ConvexAlignHip * backend, int workers, int maxBatch = 4096, int timeoutUs = 2000);
 	virtual ~BatchingAligner();
 
@@ -52,26 +71,43 @@ public:
 	/* statistics */
 	long Launches() const { return launches; }
 	long Requests() const { return requests; }
+	long MaxInFlight() const { return maxInFlight; }
 
 private:
+	struct Launch;
 	struct Request {
 		ConvexAlignHip::Tile tile;
+		Launch * launch;                   /* set when the dispatcher has taken the request */
+		cvx_result const * result;         /* set when the launch is done */
 		bool done;
+		bool failed;                       /* the whole launch failed */
+	};
+	struct Launch {
+		cvx_job job;
+		std::vector<Request *> reqs;
+		cvx_result const * results;
+		uint32_t const * ops;
+		int unfinished;                    /* workers still writing their text out of this launch's buffers */
 		bool failed;
-		bool queued;           /* still in the queue (no leader has taken it yet) */
 	};
 	ConvexAlignHip * backend;
 	std::mutex mtx;
-	std::condition_variable cv;
+	std::condition_variable cvWorkers;     /* results are ready */
+	std::condition_variable cvDispatch;    /* something to do for the dispatcher */
 	std::vector<Request *> queue;
+	std::chrono::steady_clock::time_point oldest;
+	std::deque<Launch *> inFlight;         /* submitted, not yet waited for (dispatcher only) */
+	std::vector<Launch *> retired;         /* all workers done: buffers to give back (by the dispatcher) */
 	int workers;
 	int parked;
-	bool leaderActive;
 	int maxBatch;
 	int timeoutUs;
-	long launches, requests;
+	bool stop;
+	long launches, requests, maxInFlight;
+	std::thread dispatcher;
 
-	void flushLocked(std::unique_lock<std::mutex> & lk);
+	void dispatchLoop();
+	bool shouldCut(bool deviceIdle) const;
 };
 
 /*

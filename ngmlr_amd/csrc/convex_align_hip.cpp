@@ -64,33 +64,43 @@ int ConvexAlignHip::SingleAlign(int const mode, CorridorLine * corridor, int con
 	Tile t;
 	t.corridor = corridor; t.corridorHeight = corridorHeight;
 	t.refSeq = refSeq; t.qrySeq = qrySeq; t.result = &result;
-	t.externalQStart = externalQStart; t.externalQEnd = externalQEnd; t.ret = -1;
+	t.externalQStart = externalQStart; t.externalQEnd = externalQEnd; t.ret = -1; t.failed = false;
 	AlignTiles(&t, 1);
+	if (t.failed) throw 1;
 	return t.ret;
 }
 
-void ConvexAlignHip::AlignTiles(Tile * tiles, int n) {
-	if (n <= 0) return;
-	packed.resize((size_t) n);
-	results.resize((size_t) n);
-	uint64_t ops_need = 0;
+void ConvexAlignHip::Prepare(Tile & t) {
+	Align & a = *t.result;
+	a.svType = 0;               /* the reference reads it as a debug id, then clears it */
+	a.Score = -1.0f;
+	t.ret = -1;
+	t.failed = false;
+	t.refLen = (int) strlen(t.refSeq);
+	t.qryLen = (int) strlen(t.qrySeq);
+	if (t.corridorHeight != t.qryLen) {
+		/* every reference caller passes corridorHeight == strlen(qry); anything else
+		 * indexes the corridor out of bounds in the reference itself */
+		fprintf(stderr, "ConvexAlignHip: corridorHeight %d != read length %d\n", t.corridorHeight, t.qryLen);
+		throw 1;
+	}
+	/* caller-visible side effect of AlignmentMatrixFast::prepare (src/AlignmentMatrixFast.cpp:39-44) */
+	unsigned long acc = 0;
+	for (int y = 0; y < t.corridorHeight; ++y) {
+		t.corridor[y].offsetInMatrix = acc;
+		acc += (unsigned long) (long) t.corridor[y].length;
+	}
+}
+
+cvx_job ConvexAlignHip::Submit(Tile const * tiles, int n) {
+	packed.resize((size_t) (n > 0 ? n : 1));
 	for (int i = 0; i < n; ++i) {
-		Tile & t = tiles[i];
-		Align & a = *t.result;
-		a.svType = 0;               /* the reference reads it as a debug id, then clears it */
-		a.Score = -1.0f;
-		t.ret = -1;
+		Tile const & t = tiles[i];
 		cvx_tile & c = packed[(size_t) i];
 		c.ref = t.refSeq;
 		c.qry = t.qrySeq;
-		c.ref_len = (int32_t) strlen(t.refSeq);
-		c.qry_len = (int32_t) strlen(t.qrySeq);
-		if (t.corridorHeight != c.qry_len) {
-			/* every reference caller passes corridorHeight == strlen(qry); anything else
-			 * indexes the corridor out of bounds in the reference itself */
-			fprintf(stderr, "ConvexAlignHip: corridorHeight %d != read length %d\n", t.corridorHeight, c.qry_len);
-			throw 1;
-		}
+		c.ref_len = t.refLen;
+		c.qry_len = t.qryLen;
 		c.row_offset = &t.corridor[0].offset;
 		c.row_length = &t.corridor[0].length;
 		c.row_stride_bytes = (int32_t) sizeof(CorridorLine);
@@ -100,33 +110,66 @@ void ConvexAlignHip::AlignTiles(Tile * tiles, int n) {
 		c.corridor_k = c.corridor_d = c.corridor_right = 0.0f;
 		c.corridor_offset = c.corridor_width = 0;
 		c.reserved = 0;
-		/* caller-visible side effect of AlignmentMatrixFast::prepare (src/AlignmentMatrixFast.cpp:39-44) */
-		unsigned long acc = 0;
-		for (int y = 0; y < t.corridorHeight; ++y) {
-			t.corridor[y].offsetInMatrix = acc;
-			acc += (unsigned long) (long) t.corridor[y].length;
-		}
-		ops_need += (uint64_t) c.ref_len + (uint64_t) c.qry_len + 8;
 	}
-	if (ops.size() < ops_need) ops.resize((size_t) ops_need);
-	uint64_t used = 0;
-	int rc = cvx_align_batch(handle, n, packed.data(), results.data(), ops.data(), ops.size(), &used);
-	if (rc != CVX_OK) {
+	cvx_job job = 0;
+	if (cvx_submit(handle, n, packed.data(), &job) != CVX_OK) {
 		fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
 		throw 1;
 	}
-	for (int i = 0; i < n; ++i) {
-		if (results[(size_t) i].status == CVX_TILE_UNSUPPORTED) {
-			fprintf(stderr, "ConvexAlignHip: corridor shape not covered by any device kernel\n");
-			throw 1;
-		}
-		finish(tiles[i], results[(size_t) i], packed[(size_t) i].ref_len, packed[(size_t) i].qry_len);
+	return job;
+}
+
+bool ConvexAlignHip::Poll(cvx_job job) {
+	int32_t done = 0;
+	if (cvx_job_poll(handle, job, &done) != CVX_OK) return true;      /* let Wait report it */
+	return done != 0;
+}
+
+void ConvexAlignHip::Wait(cvx_job job, cvx_result const ** results, uint32_t const ** ops) {
+	uint64_t nOps = 0;
+	if (cvx_wait(handle, job, results, ops, &nOps) != CVX_OK) {
+		fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
+		throw 1;
 	}
 }
 
+void ConvexAlignHip::Release(cvx_job job) {
+	cvx_job_release(handle, job);
+}
+
+void ConvexAlignHip::AlignTiles(Tile * tiles, int n) {
+	if (n <= 0) return;
+	for (int i = 0; i < n; ++i) Prepare(tiles[i]);
+	cvx_job job = Submit(tiles, n);
+	cvx_result const * res = 0;
+	uint32_t const * ops = 0;
+	try {
+		Wait(job, &res, &ops);
+	} catch (...) {
+		Release(job);
+		throw;
+	}
+	for (int i = 0; i < n; ++i) {
+		try {
+			Finish(tiles[i], res[i], ops);
+		} catch (...) {
+			/* this tile's own hard error: the caller drops this alignment and no other (src/AlignmentBuffer.cpp:454-463) */
+			tiles[i].failed = true;
+			tiles[i].ret = -1;
+			tiles[i].result->Score = -1.0f;
+		}
+	}
+	Release(job);
+}
+
 /* convertCigar + flags into the caller's Align (src/ConvexAlignFast.cpp:488-539) */
-void ConvexAlignHip::finish(Tile & t, cvx_result const & r, int refLen, int qryLen) {
+void ConvexAlignHip::Finish(Tile & t, cvx_result const & r, uint32_t const * ops) const {
 	Align & a = *t.result;
+	int const refLen = t.refLen, qryLen = t.qryLen;
+	if (r.status == CVX_TILE_UNSUPPORTED) {
+		fprintf(stderr, "ConvexAlignHip: corridor shape not covered by any device kernel\n");
+		throw 1;
+	}
 	if (r.status != CVX_TILE_OK) {
 		if (r.status == CVX_TILE_TOO_LARGE) {
 			/* the reference's message (src/AlignmentMatrixFast.cpp:56), same float arithmetic for the size */
@@ -141,7 +184,7 @@ void ConvexAlignHip::finish(Tile & t, cvx_result const & r, int refLen, int qryL
 	}
 	cvx_alignment_text txt;
 	for (;;) {
-		int rc = cvx_format_alignment(&r, ops.data(), t.refSeq, refLen, qryLen, t.externalQStart,
+		int rc = cvx_format_alignment(&r, ops, t.refSeq, refLen, qryLen, t.externalQStart,
 				t.externalQEnd, a.pBuffer1, a.maxBufferLength, a.pBuffer2, a.maxMdBufferLength,
 				(int32_t *) a.nmPerPosition, a.nmPerPostionLength, &txt);
 		if (rc != CVX_OK) throw 1;

@@ -12,7 +12,9 @@
  *     errors (reference src/ConvexAlignFast.cpp:452-559);
  *   - BatchScore / corridor-less SingleAlign throw like the reference's do.
  * Extra: AlignTiles() -- many corridor alignments in one launch (the shape the
- * reference's BatchAlign slot lacks a corridor argument for).
+ * reference's BatchAlign slot lacks a corridor argument for) -- and its split form
+ * Submit() / Wait() / Finish() / Release(), which keeps several launches in flight
+ * (batching_aligner.h drives it from one dispatcher thread per device).
  */
 #ifndef CONVEX_ALIGN_HIP_H
 #define CONVEX_ALIGN_HIP_H
@@ -55,18 +57,34 @@ public:
 		int externalQStart;
 		int externalQEnd;
 		int ret;               /* out: what SingleAlign would have returned */
+		bool failed;           /* out (AlignTiles): this tile hit a hard error -- the reference would have thrown for it alone */
+		int refLen, qryLen;    /* filled by Prepare() */
 	};
-	/* n independent corridor alignments in one device launch. */
+	/* n independent corridor alignments in one device launch.  A hard error that belongs to one tile (a corridor no
+	 * kernel covers, a CIGAR that does not fit the caller's buffer) marks that tile `failed` and leaves the others
+	 * alone -- the reference's caller drops exactly one alignment in that case (src/AlignmentBuffer.cpp:454-463);
+	 * a failure of the launch itself throws. */
 	void AlignTiles(Tile * tiles, int n);
+
+	/* The same in stages, for a driver that keeps launches in flight.  Prepare / Finish may run on any thread (they
+	 * touch only the tile and the caller's Align); Submit / Wait / Release belong to the ONE thread that owns this
+	 * aligner's device handle.
+	 *   Prepare  strlen + height check + the caller-visible offsetInMatrix side effect (throws like SingleAlign)
+	 *   Submit   queues a launch for n prepared tiles, returns its job (throws on a hard error of the launch)
+	 *   Poll     non-blocking "is it done"; Wait  blocks until the job is done: result records and run-length ops, valid until Release
+	 *   Finish   convertCigar + flags of ONE tile into its Align (throws 1 for that tile's hard errors)
+	 *   Release  gives the job's buffers back */
+	static void Prepare(Tile & t);
+	cvx_job Submit(Tile const * tiles, int n);
+	bool Poll(cvx_job job);       /* true: Wait would not block (also keeps queued launches moving) */
+	void Wait(cvx_job job, cvx_result const ** results, uint32_t const ** ops);
+	void Finish(Tile & t, cvx_result const & r, uint32_t const * ops) const;
+	void Release(cvx_job job);
 
 private:
 	cvx_handle handle;
 	unsigned long maxMatrixMB;
 	std::vector<cvx_tile> packed;
-	std::vector<cvx_result> results;
-	std::vector<uint32_t> ops;
-
-	void finish(Tile & t, cvx_result const & r, int refLen, int qryLen);
 };
 
 }  // namespace Convex

@@ -153,12 +153,14 @@ bool in_pinned_block(const void *p, uint64_t bytes) {
 static const int kAuxStreams = 1;
 static const size_t kPoolBatches = 4;
 
-enum BatchState { kEmpty = 0, kUploaded = 1, kPlanned = 2, kComputed = 3, kFinished = 4 };
+enum BatchState { kFailed = -1, kEmpty = 0, kUploaded = 1, kPlanned = 2, kComputed = 3, kFinished = 4 };
 
 struct cvx_batch_s {
 	int n = 0;
 	int state = kEmpty;
 	bool in_flight = false;          /* submitted through the streaming API and not yet released */
+	int fail_rc = CVX_OK;            /* state == kFailed: what went wrong with THIS job (cvx_wait returns it) */
+	std::string fail_msg;
 	uint64_t seq_total = 0, n_rows = 0, n_rowsx = 0;
 	uint64_t zero_copy_bytes = 0;    /* sequence bytes of the last upload that travelled straight from the caller's page-locked arena */
 	uint64_t ops_total = 0;          /* valid after the compute stage has been waited for */
@@ -166,6 +168,8 @@ struct cvx_batch_s {
 	bool have_ops = false;           /* dense ops are in h_ops */
 
 	/* host side, page-locked */
+	PinBuf h_zero;                   /* zeros for the pads around blocks that travel straight from the caller's arena */
+	size_t zero_cap = 0;
 	PinBuf h_seq, h_delta, h_rsrc, h_rowsx, h_tin;     /* upload staging (owned by the batch: no wait before reuse by another batch):
 	                                                    * sequences, one step byte per corridor row, RowSrc[n], rows that need the verbatim form */
 	std::vector<RowDesc> chain_rows;                   /* scratch: expanded rows of a tile being chained */
@@ -210,6 +214,7 @@ struct cvx_batch_s {
 	hipEvent_t ev_bt0 = nullptr, ev_bt1 = nullptr;   /* fork / join of the long-read backtrack launch */
 	hipEvent_t ev_in = nullptr;      /* upload + plan records on the host */
 	hipEvent_t ev_res = nullptr;     /* result records on the host */
+	hipEvent_t ev_ops = nullptr;     /* dense ops on the host */
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   /* timing: plan begin/end, fills done, all done, fills may start */
 	std::vector<hipEvent_t> lev;     /* 3 events per fill class: start, two-phase pass done, exact pass done */
 	std::vector<cvx_launch_info> launches;
@@ -223,12 +228,14 @@ struct cvx_batch_s {
 	int make_events() {
 		if (!ev_in) HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
 		if (!ev_res) HIP_TRY(hipEventCreateWithFlags(&ev_res, hipEventDisableTiming));
+		if (!ev_ops) HIP_TRY(hipEventCreateWithFlags(&ev_ops, hipEventDisableTiming));
 		if (!ev_bt0) HIP_TRY(hipEventCreateWithFlags(&ev_bt0, hipEventDisableTiming));
 		if (!ev_bt1) HIP_TRY(hipEventCreateWithFlags(&ev_bt1, hipEventDisableTiming));
 		for (auto &e : ev) if (!e) HIP_TRY(hipEventCreate(&e));
 		return CVX_OK;
 	}
 	void release() {
+		h_zero.release(); zero_cap = 0;
 		h_seq.release(); h_delta.release(); h_rsrc.release(); h_rowsx.release(); h_tin.release();
 		d_delta.release(); d_rsrc.release(); d_rowsx.release(); h_plan.release(); h_trun.release(); h_tout.release();
 		h_lists.release(); h_goff.release(); h_res.release(); h_ops.release();
@@ -242,6 +249,7 @@ struct cvx_batch_s {
 		h_chain.release(); d_chain.release(); d_progress.release(); d_bnd.release(); d_chain_out.release();
 		if (ev_in) { (void) hipEventDestroy(ev_in); ev_in = nullptr; }
 		if (ev_res) { (void) hipEventDestroy(ev_res); ev_res = nullptr; }
+		if (ev_ops) { (void) hipEventDestroy(ev_ops); ev_ops = nullptr; }
 		if (ev_bt0) { (void) hipEventDestroy(ev_bt0); ev_bt0 = nullptr; }
 		if (ev_bt1) { (void) hipEventDestroy(ev_bt1); ev_bt1 = nullptr; }
 		for (auto &e : ev) if (e) { (void) hipEventDestroy(e); e = nullptr; }
@@ -266,6 +274,7 @@ struct cvx_context {
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
+	int test_fail_compute = 0; /* test knob (env CVX_TUNE_FAIL_COMPUTE = k): the k-th compute stage of this handle fails (error-path tests) */
 	int bt_group = 0;          /* lanes per tile in the backtrack: 0 = auto (8 for the bulk, 32 for the much-longer-than-average
 	                            * reads), 8 / 16 / 32 = that many for all, 64 = the one-wave-per-tile walk (env CVX_TUNE_BT_GROUP) */
 	bool overlap_post = false; /* tuning knob (env CVX_TUNE_OVERLAP_POST): backtrack/finalize/compaction of batch k on their own stream, beside the fills of batch k+1 */
@@ -276,6 +285,7 @@ struct cvx_context {
 	 * synchronises the whole device, which would serialise handles that work side by side */
 	std::vector<cvx_batch_s *> pool;
 	std::vector<cvx_batch_s *> pending;      /* streaming jobs whose compute stage is not queued yet */
+	std::vector<cvx_batch_s *> live;         /* every streaming job the caller has not released yet (cvx_destroy frees what is left) */
 	/* sub-read scoring (cvx_score_batch): persistent staging and device buffers */
 	PinBuf sc_hseq, sc_hpairs, sc_hout;
 	DevBuf<uint8_t> sc_seq;
@@ -304,10 +314,18 @@ cvx_batch_s *acquire_batch(cvx_context *h) {
 }
 
 void recycle_batch(cvx_context *h, cvx_batch_s *b) {
+	const bool failed = b->state == kFailed;
 	b->state = kEmpty;
 	b->in_flight = false;
 	b->have_ops = false;
-	if (h && h->pool.size() < kPoolBatches) { h->pool.push_back(b); return; }
+	b->fail_rc = CVX_OK;
+	b->fail_msg.clear();
+	if (h) {
+		auto it = std::find(h->live.begin(), h->live.end(), b);
+		if (it != h->live.end()) h->live.erase(it);
+	}
+	/* (a job that failed half-way keeps nothing worth pooling: its arenas go back to the allocator) */
+	if (h && !failed && h->pool.size() < kPoolBatches) { h->pool.push_back(b); return; }
 	b->release();
 	delete b;
 }
@@ -319,9 +337,21 @@ void discard_batch(cvx_context *h, cvx_batch_s *b) {
 	if (h) {
 		auto it = std::find(h->pending.begin(), h->pending.end(), b);
 		if (it != h->pending.end()) h->pending.erase(it);
+		it = std::find(h->live.begin(), h->live.end(), b);
+		if (it != h->live.end()) h->live.erase(it);
 	}
 	b->release();
 	delete b;
+}
+
+/* A streaming job whose stage failed stays alive (the caller still holds its handle) and remembers why:
+ * cvx_wait on it returns this code, cvx_job_release frees it.  Whatever was queued for it is drained first. */
+int fail_job(cvx_batch_s *b, int rc) {
+	(void) hipDeviceSynchronize();
+	b->state = kFailed;
+	b->fail_rc = rc;
+	b->fail_msg = g_err;
+	return rc;
 }
 
 float ev_ms(hipEvent_t a, hipEvent_t b) {
@@ -377,8 +407,8 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 
 	/* a block of sequences that already lies back to back in page-locked memory is not packed: the
 	 * device pulls it out of the caller's arena (the job's staging then holds only what the host wrote) */
-	const bool zc_qry = n > 0 && L.qry_contig && L.qry_bytes > 0 && in_pinned_block(tiles[0].qry, L.qry_bytes);
-	const bool zc_ref = n > 0 && !windows && L.ref_contig && L.ref_bytes > 0 && in_pinned_block(tiles[0].ref, L.ref_bytes);
+	const bool zc_qry = n > 0 && L.qry_contig && L.qry_bytes > 0 && in_pinned_block(tiles[0].qry, L.qry_bytes + 4);
+	const bool zc_ref = n > 0 && !windows && L.ref_contig && L.ref_bytes > 0 && in_pinned_block(tiles[0].ref, L.ref_bytes + 4);
 	b->zero_copy_bytes = (zc_qry ? L.qry_bytes : 0) + (zc_ref ? L.ref_bytes : 0);
 	const bool pack_seq = !(zc_qry && (zc_ref || windows));      /* anything left for the host to copy? */
 	if (pack_seq) RC_TRY(b->h_seq.ensure((size_t) L.seq_total + 256));
@@ -389,13 +419,34 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	/* the three pads: uploaded with the packed blocks, or cleared on the device around the blocks that travel as they are
 	 * (queued behind those copies: a copy rounded up to whole dwords may spill a few bytes into the pad that follows) */
 	if (pack_seq) upload_zero_pads(L, hseq);
-	if (zc_qry) HIP_TRY(hipMemcpyAsync(b->d_seq.p + L.qry_base, tiles[0].qry, (size_t) L.qry_bytes, hipMemcpyHostToDevice, st));
-	if (zc_ref) HIP_TRY(hipMemcpyAsync(b->d_seq.p + L.ref_base, tiles[0].ref, (size_t) L.ref_bytes, hipMemcpyHostToDevice, st));
-	if (zc_qry) {
-		HIP_TRY(hipMemsetAsync(b->d_seq.p, 0, (size_t) L.qry_base, st));
-		HIP_TRY(hipMemsetAsync(b->d_seq.p + L.qry_base + L.qry_bytes, 0, (size_t) (L.ref_base - L.qry_base - L.qry_bytes), st));
+	if (zc_qry || zc_ref) {
+		/* Pads around blocks that travel as they are: copied from a page-locked block of zeros, whole 256-byte
+		 * units (SDMA engines; a memset would be a kernel that has to find wave slots beside the fill), queued
+		 * BEFORE the blocks, which then overwrite the few bytes of overlap.  A block's own copy is rounded up to
+		 * whole dwords: up to three bytes of whatever follows it in the caller's arena land in the pad behind it --
+		 * pads only have to be readable (every cell outside a tile is forced to the empty element), not zero. */
+		const uint64_t zmax = L.pad + 1024;
+		RC_TRY(b->h_zero.ensure((size_t) zmax));
+		if (b->zero_cap != b->h_zero.cap) { memset(b->h_zero.p, 0, b->h_zero.cap); b->zero_cap = b->h_zero.cap; }
+		auto zero_range = [&](uint64_t lo, uint64_t hi) -> int {      /* [lo, hi) widened to 256-byte units, inside the arena */
+			lo = lo / 256 * 256;
+			hi = std::min<uint64_t>((hi + 255) / 256 * 256, (L.seq_total + 255) / 256 * 256);
+			for (uint64_t at = lo; at < hi; at += zmax / 256 * 256) {
+				const uint64_t len = std::min<uint64_t>(hi - at, zmax / 256 * 256);
+				HIP_TRY(hipMemcpyAsync(b->d_seq.p + at, b->h_zero.p, (size_t) len, hipMemcpyHostToDevice, st));
+			}
+			return CVX_OK;
+		};
+		if (zc_qry) {
+			RC_TRY(zero_range(0, L.qry_base));
+			RC_TRY(zero_range(L.qry_base + L.qry_bytes, L.ref_base));
+			HIP_TRY(hipMemcpyAsync(b->d_seq.p + L.qry_base, tiles[0].qry, (size_t) ((L.qry_bytes + 3) / 4 * 4), hipMemcpyHostToDevice, st));
+		}
+		if (zc_ref) {
+			RC_TRY(zero_range(L.ref_base + L.ref_bytes, L.seq_total));
+			HIP_TRY(hipMemcpyAsync(b->d_seq.p + L.ref_base, tiles[0].ref, (size_t) ((L.ref_bytes + 3) / 4 * 4), hipMemcpyHostToDevice, st));
+		}
 	}
-	if (zc_ref) HIP_TRY(hipMemsetAsync(b->d_seq.p + L.ref_base + L.ref_bytes, 0, (size_t) (L.seq_total - L.ref_base - L.ref_bytes), st));
 	/* what the host still moves per tile decides whether packing is worth threads and pieces */
 	uint64_t pack_work = L.delta_total * 9ull;
 	if (!zc_qry) pack_work += L.qry_bytes;
@@ -517,6 +568,10 @@ int stage_plan(cvx_context *h, cvx_batch_s *b, hipStream_t st) {
 /* ---- stage 3: host planning, then every kernel of the batch on `main` (+ aux); nothing waits */
 int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	const int n = b->n;
+	if (h->test_fail_compute > 0 && --h->test_fail_compute == 0) {      /* test knob: this job fails before anything is queued for it */
+		set_err("stage_compute: failure injected by CVX_TUNE_FAIL_COMPUTE");
+		return CVX_ERR_OOM;
+	}
 	hipStream_t st = h->s_main;
 	HIP_TRY(hipEventSynchronize(b->ev_in));        /* queued a whole batch ago in the streaming case */
 	b->launches.clear();
@@ -802,6 +857,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 /* ---- wait for the result records; timing of the batch */
 int stage_results(cvx_context *h, cvx_batch_s *b) {
 	(void) h;
+	if (b->state < kComputed) { set_err("internal: results requested from a batch whose kernels were never queued (state %d)", b->state); return CVX_ERR_ARG; }
 	HIP_TRY(hipEventSynchronize(b->ev_res));
 	if (b->n == 0) { b->ops_total = 0; b->state = kFinished; return CVX_OK; }
 	const BatchSummary *s = b->summary();
@@ -831,8 +887,11 @@ int stage_ops(cvx_context *h, cvx_batch_s *b) {
 	}
 	if (b->ops_total) {
 		RC_TRY(b->h_ops.ensure((size_t) b->ops_total * sizeof(uint32_t)));
+		/* (an event right behind the copy: the io stream may already carry the upload and corridor analysis of
+		 * later jobs, which this job's caller has no reason to wait for) */
 		HIP_TRY(hipMemcpyAsync(b->h_ops.p, b->d_dense.p, (size_t) b->ops_total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s_io));
-		HIP_TRY(hipStreamSynchronize(h->s_io));
+		HIP_TRY(hipEventRecord(b->ev_ops, h->s_io));
+		HIP_TRY(hipEventSynchronize(b->ev_ops));
 	}
 	b->have_ops = true;
 	return CVX_OK;
@@ -846,10 +905,13 @@ int pump(cvx_context *h, bool block, const cvx_batch_s *upto) {
 		if (!block) {
 			hipError_t q = hipEventQuery(b->ev_in);
 			if (q == hipErrorNotReady) { (void) hipGetLastError(); break; }
-			if (q != hipSuccess) { set_err("hipEventQuery: %s", hipGetErrorString(q)); return CVX_ERR_HIP; }
+			if (q != hipSuccess) { set_err("hipEventQuery: %s", hipGetErrorString(q)); h->pending.erase(h->pending.begin()); (void) fail_job(b, CVX_ERR_HIP); continue; }
 		}
 		h->pending.erase(h->pending.begin());
-		RC_TRY(stage_compute(h, b));
+		/* a failure (say, the direction arena of a multi-GB batch does not fit beside the batches in flight) belongs
+		 * to THIS job: it is recorded on it and reported by its own cvx_wait, never against another job's call */
+		const int rc = stage_compute(h, b);
+		if (rc != CVX_OK) (void) fail_job(b, rc);
 		if (upto && b == upto) break;
 	}
 	return CVX_OK;
@@ -933,6 +995,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	c->pack_threads = PackPool::get().size();      /* the process's shared pack threads (CVX_PACK_THREADS) */
 	if (const char *e = getenv("CVX_TUNE_MIN_M")) c->tune_min_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_FORCE_WRAP16")) c->tune_force_wrap = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_FAIL_COMPUTE")) c->test_fail_compute = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_M")) c->tune_chain_m = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
@@ -962,6 +1025,11 @@ void cvx_destroy(cvx_handle h) {
 	for (auto &a : h->aux) if (a) (void) hipStreamDestroy(a);
 	for (cvx_batch_s *b : h->pool) { b->release(); delete b; }
 	h->pool.clear();
+	/* jobs the caller never released (submitted, maybe waited for): the device is idle, free them too --
+	 * their handles are dead from here on, like everything else that belonged to this context */
+	for (cvx_batch_s *b : h->live) { b->release(); delete b; }
+	h->live.clear();
+	h->pending.clear();
 	h->sc_hseq.release(); h->sc_hpairs.release(); h->sc_hout.release();
 	h->sc_seq.release(); h->sc_pairs.release(); h->sc_rows.release(); h->sc_out.release();
 	delete h;
@@ -1080,8 +1148,9 @@ static int submit_common(cvx_handle h, int32_t n, const cvx_tile *tiles, const c
 	*out = nullptr;
 	if (genome && genome->device != h->device) { set_err("cvx_submit_windows: the genome lives on device %d, the handle on %d", genome->device, h->device); return CVX_ERR_ARG; }
 	HIP_TRY(hipSetDevice(h->device));
-	/* first hand the device whatever is ready to run, then spend host time on packing */
-	RC_TRY(pump(h, false, nullptr));
+	/* first hand the device whatever is ready to run, then spend host time on packing (a job that fails there keeps
+	 * its own error; this call reports only what happens to the batch being submitted) */
+	(void) pump(h, false, nullptr);
 	cvx_batch_s *b = acquire_batch(h);
 	if (!b) return CVX_ERR_OOM;
 	int rc = stage_upload(h, b, n, tiles, genome, ref_position);
@@ -1089,6 +1158,7 @@ static int submit_common(cvx_handle h, int32_t n, const cvx_tile *tiles, const c
 	if (rc != CVX_OK) { discard_batch(h, b); return rc; }
 	b->in_flight = true;
 	h->pending.push_back(b);
+	h->live.push_back(b);
 	(void) pump(h, false, nullptr);
 	*out = b;
 	return CVX_OK;
@@ -1108,15 +1178,33 @@ int cvx_wait(cvx_handle h, cvx_job j, const cvx_result **results, const uint32_t
 	ABI_GUARD_BEGIN
 	if (!h || !j || !j->in_flight) { set_err("cvx_wait: not a submitted job"); return CVX_ERR_ARG; }
 	HIP_TRY(hipSetDevice(h->device));
-	int rc = CVX_OK;
-	if (j->state < kComputed) rc = pump(h, true, j);
-	if (rc == CVX_OK && j->state < kFinished) rc = stage_results(h, j);
-	if (rc == CVX_OK) rc = stage_ops(h, j);
-	if (rc != CVX_OK) { discard_batch(h, j); return rc; }
+	/* A job that failed (now or in an earlier call) stays valid until cvx_job_release and keeps answering with its
+	 * own error; nothing of another job is ever returned in its place. */
+	if (j->state != kFailed && j->state < kComputed) (void) pump(h, true, j);
+	if (j->state != kFailed && j->state < kFinished) { const int rc = stage_results(h, j); if (rc != CVX_OK) (void) fail_job(j, rc); }
+	if (j->state != kFailed) { const int rc = stage_ops(h, j); if (rc != CVX_OK) (void) fail_job(j, rc); }
+	if (j->state == kFailed) { g_err = j->fail_msg; return j->fail_rc; }
 	(void) pump(h, false, nullptr);      /* later jobs whose inputs have arrived meanwhile */
 	if (results) *results = reinterpret_cast<const cvx_result *>(j->res());
 	if (ops) *ops = j->h_ops.as<uint32_t>();
 	if (n_ops) *n_ops = j->ops_total;
+	return CVX_OK;
+	ABI_GUARD_END
+}
+
+int cvx_job_poll(cvx_handle h, cvx_job j, int32_t *done) {
+	ABI_GUARD_BEGIN
+	if (!h || !j || !j->in_flight || !done) { set_err("cvx_job_poll: not a submitted job"); return CVX_ERR_ARG; }
+	HIP_TRY(hipSetDevice(h->device));
+	(void) pump(h, false, nullptr);          /* queue the kernels of whatever has its corridor plans back */
+	*done = 0;
+	if (j->state == kFailed || j->state >= kFinished) { *done = 1; return CVX_OK; }
+	if (j->state >= kComputed) {
+		hipError_t q = hipEventQuery(j->ev_res);
+		if (q == hipSuccess) *done = 1;
+		else if (q == hipErrorNotReady) (void) hipGetLastError();
+		else { set_err("hipEventQuery: %s", hipGetErrorString(q)); return CVX_ERR_HIP; }
+	}
 	return CVX_OK;
 	ABI_GUARD_END
 }
@@ -1130,7 +1218,7 @@ void cvx_job_release(cvx_handle h, cvx_job j) {
 		(void) hipSetDevice(h->device);
 		auto it = std::find(h->pending.begin(), h->pending.end(), j);
 		if (it != h->pending.end()) h->pending.erase(it);
-		if (j->state >= kPlanned && j->state < kFinished) (void) hipDeviceSynchronize();   /* released without waiting */
+		if ((j->state >= kPlanned && j->state < kFinished) || j->state == kFailed) (void) hipDeviceSynchronize();   /* released without waiting */
 	}
 	recycle_batch(h, j);
 }

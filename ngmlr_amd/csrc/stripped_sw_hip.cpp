@@ -3,23 +3,44 @@
 
 #include <cstdio>
 
-StrippedSWHip::StrippedSWHip(int const deviceId) : handle(0) {
-	/* the scoring kernel has fixed weights; the handle only needs a valid scoring triple */
-	cvx_params p = { 2.0f, -5.0f, -5.0f, -5.0f, -1.0f, 0.15f };
-	if (cvx_create(deviceId, &p, 0, &handle) != CVX_OK) {
-		fprintf(stderr, "StrippedSWHip: %s\n", cvx_last_error());
-		throw "StrippedSWHip: no usable MI355X";
+#include <mutex>
+
+namespace {
+const int kMaxDevices = 64;
+std::mutex g_mtx[kMaxDevices];
+std::mutex g_tableMtx;
+cvx_handle g_handle[kMaxDevices] = {0};
+int g_users[kMaxDevices] = {0};
+}
+
+StrippedSWHip::StrippedSWHip(int const deviceId) : device(deviceId >= 0 && deviceId < kMaxDevices ? deviceId : 0) {
+	std::lock_guard<std::mutex> g(g_tableMtx);
+	if (g_handle[device] == 0) {
+		/* the scoring kernel has fixed weights; the handle only needs a valid scoring triple */
+		cvx_params p = { 2.0f, -5.0f, -5.0f, -5.0f, -1.0f, 0.15f };
+		if (cvx_create(device, &p, 0, &g_handle[device]) != CVX_OK) {
+			fprintf(stderr, "StrippedSWHip: %s\n", cvx_last_error());
+			g_handle[device] = 0;
+			throw "StrippedSWHip: no usable MI355X";
+		}
 	}
+	g_users[device] += 1;
 }
 
 StrippedSWHip::~StrippedSWHip() {
-	cvx_destroy(handle);
+	std::lock_guard<std::mutex> g(g_tableMtx);
+	if (--g_users[device] == 0) {
+		std::lock_guard<std::mutex> d(g_mtx[device]);
+		cvx_destroy(g_handle[device]);
+		g_handle[device] = 0;
+	}
 }
 
 int StrippedSWHip::BatchScore(int const mode, int const batchSize, char const * const * const refSeqList,
 		char const * const * const qrySeqList, float * const results, void * extData) {
 	(void) mode; (void) extData;
-	if (cvx_score_batch(handle, batchSize, refSeqList, qrySeqList, results) != CVX_OK) {
+	std::lock_guard<std::mutex> d(g_mtx[device]);
+	if (cvx_score_batch(g_handle[device], batchSize, refSeqList, qrySeqList, results) != CVX_OK) {
 		fprintf(stderr, "StrippedSWHip: %s\n", cvx_last_error());
 		throw 1;
 	}

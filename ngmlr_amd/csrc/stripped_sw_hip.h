@@ -6,6 +6,11 @@
  * (src/AlignmentBuffer.cpp:1224-1225, :2538, src/ScoreBuffer.cpp:267).  Same return values as
  * StrippedSW::BatchScore / SingleScore (src/StrippedSW.cpp:118-203); the alignment entry
  * points throw, as this backend is score-only.
+ *
+ * ngmlr creates one scoring aligner per worker thread (NGM::CreateAlignment, src/NGM.cpp:350-361, called
+ * from src/CS.cpp:416); all StrippedSWHip instances of a process share ONE device handle per device (its
+ * staging buffers are reused call after call, so calls are serialised by a mutex: a 1024-pair batch is
+ * well under a millisecond of device time, the workers spend theirs elsewhere).
  */
 #ifndef STRIPPED_SW_HIP_H
 #define STRIPPED_SW_HIP_H
@@ -32,7 +37,7 @@ public:
 	}
 
 private:
-	cvx_handle handle;
+	int device;
 };
 
 #endif

@@ -154,3 +154,51 @@ def test_streaming_jobs_waited_out_of_order_and_released_unwaited(hip_aligner, p
     got = hip_aligner.batch_align(sets[1][:5])
     for t, g in zip(sets[1][:5], got):
         assert same_alignment(port_oracle.align(t), g) is None
+
+
+def test_a_failed_job_keeps_its_own_error(built):
+    """a failure while a job's kernels are being queued belongs to that job -- its cvx_wait returns the
+    error (every time), its handle stays valid until cvx_job_release, and the jobs around it deliver their own,
+    correct results.  CVX_TUNE_FAIL_COMPUTE=2 makes the second compute stage of a handle fail before anything is queued."""
+    import ctypes as C
+    import os
+    import numpy as np
+    from ngmlr_amd import capi, synth
+    from ngmlr_amd.aligner import ConvexAlignHip
+    rng = np.random.default_rng(11)
+    tiles = [synth.make_tile(rng, 900, corridor="anchors", scatter=10.0) for _ in range(6)]
+    ref = ConvexAlignHip(device=0)
+    want = ref.batch_align(tiles, want_nm=False)
+    ref.close()
+    os.environ["CVX_TUNE_FAIL_COMPUTE"] = "2"
+    try:
+        al = ConvexAlignHip(device=0)
+    finally:
+        del os.environ["CVX_TUNE_FAIL_COMPUTE"]
+    jobs = [al.submit(tiles) for _ in range(3)]
+    res0, _ = jobs[0].wait()
+    for _ in range(2):                                   # the failed job answers with its own error, twice, and stays valid
+        with pytest.raises(capi.CvxError) as e:
+            jobs[1].wait()
+        assert e.value.code == -4 and "CVX_TUNE_FAIL_COMPUTE" in str(e.value)
+    res2, _ = jobs[2].wait()
+    for res in (res0, res2):
+        for i, w in enumerate(want):
+            assert int(res[i]["status"]) == w["status"]
+            assert int(np.float32(res[i]["score"]).view(np.uint32)) == w["fwd_score_bits"]
+    # a polled job: done flips to 1 without blocking in cvx_wait
+    j3 = al.submit(tiles)
+    done = C.c_int32(0)
+    for _ in range(20000):
+        capi.check(al.lib.cvx_job_poll(al.h, j3.j, C.byref(done)))
+        if done.value:
+            break
+    assert done.value == 1
+    r3, _ = j3.wait()
+    assert int(r3[0]["status"]) == want[0]["status"]
+    for j in jobs + [j3]:
+        j.release()
+    # destroy with a job the caller never released: nothing leaks, nothing crashes
+    j4 = al.submit(tiles)
+    al.close()
+    j4.j = None

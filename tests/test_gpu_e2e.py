@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip")
 BIN_BATCHED = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_batched")
+BIN_FULL = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_full")
 E2E = os.path.join(ROOT, "tests", "golden", "e2e")
 
 
@@ -82,6 +83,19 @@ def test_test_3_batched_pipeline_sam_identical(built, tmp_path, threads):
     assert requests == 985
     assert launches < requests          # batching happened
     print("test_3 -t %d: %d alignments in %d launches (%.1f per launch)" % (threads, requests, launches, requests / launches))
+
+
+def test_test_3_both_plugins_on_the_device(built, tmp_path):
+    """Alignment (Convex::SharedAligner at src/AlignmentBuffer.h:355) AND sub-read scoring (StrippedSWHip at
+    NGM::CreateAlignment, src/NGM.cpp:355, i.e. ScoreBuffer's BatchScore of 1024-pair batches) on the MI355X: the
+    reference's pipeline around them unchanged, SAM records identical to the unmodified reference."""
+    import re
+    got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_FULL)
+    assert sorted(got) == _test_3_want()
+    m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", err)
+    assert m and int(m.group(1)) == 985, err[-2000:]
+    syms = subprocess.run(["nm", "-C", BIN_FULL], stdout=subprocess.PIPE, text=True).stdout
+    assert "StrippedSWHip::BatchScore" in syms
 
 
 def test_binary_links_the_device_library(built):

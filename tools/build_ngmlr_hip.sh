@@ -17,15 +17,25 @@ mkdir -p "$REPO/oracle/_ref"
 # build_variant OUT_NAME ALIGNER_CLASS: the class constructed at src/AlignmentBuffer.h:355
 #   ngmlr_hip          Convex::ConvexAlignHip  one private aligner per worker, one tile per launch
 #   ngmlr_hip_batched  Convex::SharedAligner   all -t N workers share one BatchingAligner per device
+#   ngmlr_hip_full     Convex::SharedAligner + StrippedSWHip at NGM::CreateAlignment (src/NGM.cpp:355): alignment AND
+#                      sub-read scoring on the device
 #   ngmlr_ref          (nothing changed)       the unmodified reference, for wall-clock comparison only
 build_variant() {
-local OUT_NAME=$1 CLASS=$2
+local OUT_NAME=$1 CLASS=$2 SCORER=${3:-}
 local T="$WORK/$OUT_NAME"
 cp -r /root/reference "$T"
 if [ "$CLASS" != "unmodified" ]; then
-python3 - "$T" "$REPO" "$CLASS" <<'PY'
+python3 - "$T" "$REPO" "$CLASS" "$SCORER" <<'PY'
 import re, sys
-T, REPO, CLASS = sys.argv[1], sys.argv[2], sys.argv[3]
+T, REPO, CLASS, SCORER = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+if SCORER:
+    p = T + '/src/NGM.cpp'
+    s = open(p).read()
+    assert s.count('instance = new StrippedSW();') == 1
+    s = s.replace('instance = new StrippedSW();', 'instance = new %s();' % SCORER, 1)
+    s = s.replace('#include "StrippedSW.h"', '#include "StrippedSW.h"\n#include "stripped_sw_hip.h"', 1)
+    assert 'stripped_sw_hip.h' in s
+    open(p, 'w').write(s)
 p = T + '/src/AlignmentBuffer.h'
 s = open(p).read()
 s = s.replace('#include "ConvexAlignFast.h"', '#include "ConvexAlignFast.h"\n#include "convex_align_hip.h"\n#include "batching_aligner.h"', 1)
@@ -35,7 +45,7 @@ s = pat.sub('aligner = new %s(' % CLASS, s)
 open(p, 'w').write(s)
 p = T + '/src/CMakeLists.txt'
 c = open(p).read()
-c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp\n%s/ngmlr_amd/csrc/batching_aligner.cpp' % (REPO, REPO, REPO, REPO), 1)
+c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp\n%s/ngmlr_amd/csrc/batching_aligner.cpp\n%s/ngmlr_amd/csrc/stripped_sw_hip.cpp' % (REPO, REPO, REPO, REPO, REPO), 1)
 c = c.replace('TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})', 'TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})\nTARGET_LINK_LIBRARIES(ngmlr %s/ngmlr_amd/libcvxalign.so)\nset_target_properties(ngmlr PROPERTIES BUILD_RPATH "\\$ORIGIN/../../ngmlr_amd;/opt/rocm/lib" SKIP_BUILD_RPATH FALSE)' % REPO, 1)
 open(p, 'w').write(c)
 PY
@@ -49,8 +59,9 @@ echo "built $REPO/oracle/_ref/$OUT_NAME"
 }
 build_variant ngmlr_hip Convex::ConvexAlignHip &
 build_variant ngmlr_hip_batched Convex::SharedAligner &
+build_variant ngmlr_hip_full Convex::SharedAligner StrippedSWHip &
 build_variant ngmlr_ref unmodified &     # the reference as it is: wall-clock yardstick of tools/e2e_rates.py
 wait
-test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched"
+test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched" && test -x "$REPO/oracle/_ref/ngmlr_hip_full"
 readelf -d "$REPO/oracle/_ref/ngmlr_hip" | grep -E "RPATH|RUNPATH|NEEDED" | head
 rm -rf "$WORK"

@@ -1,9 +1,17 @@
-"""Dev tool (GPU box): the reference's ngmlr end to end on test/test_3.sh's reads (142 PacBio reads, 985
-convex alignments) -- unmodified (CPU ConvexAlignFast), with a private ConvexAlignHip per worker, and with
-all workers sharing one BatchingAligner -- wall clock, alignments per device launch, and
-whether the sorted SAM records are identical.  The run is dominated by ngmlr's start-up (reference
-encoding + index of a 130 kb genome) and its candidate search; it says how the drop-in behaves inside
-the real pipeline, not how fast the kernels are."""
+"""Dev tool (GPU box): the reference's ngmlr end to end, unmodified against the drop-ins.
+
+    e2e_rates.py [threads...]              test/test_3.sh's reads (142 PacBio reads, 985 convex alignments): unmodified
+                                           (CPU ConvexAlignFast), a private ConvexAlignHip per worker, all workers sharing
+                                           one BatchingAligner, and that plus the scoring plugin on the device;
+                                           SAM compared with the recorded output of the unmodified reference.
+    e2e_rates.py --synthetic N [threads]   BASELINE.md section 2's workload: N synthetic PacBio-like 10 kb reads (15 % error,
+                                           ins:del:sub 6:3:1, half of them reverse-complemented) on a 2 Mbp random reference;
+                                           ngmlr_ref at -t nproc' (best of a few thread counts) against the batched drop-ins with
+                                           many more workers than cores (reads in flight are what fills a launch); SAM of the
+                                           drop-in compared with the SAM ngmlr_ref produced in this very run.
+
+Wall clock includes ngmlr's start-up (reference encoding + index); `map` is the mapping phase alone as ngmlr itself
+reports it.  Says how the drop-in behaves inside the real pipeline, not how fast the kernels are."""
 import gzip
 import os
 import re
@@ -12,26 +20,107 @@ import sys
 import tempfile
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 E2E = os.path.join(ROOT, "tests", "golden", "e2e")
 tmp = tempfile.mkdtemp()
-fq = os.path.join(tmp, "test_3.fq")
-open(fq, "wb").write(gzip.open(os.path.join(E2E, "test_3_reads.fq.gz"), "rb").read())
-want = [l.rstrip("\n") for l in gzip.open(os.path.join(ROOT, "tests", "golden", "test_3.sorted.sam.gz"), "rt") if l.strip()]
-threads = [int(x) for x in sys.argv[1:]] or [1, 16, 64]
-for name in ("ngmlr_ref", "ngmlr_hip", "ngmlr_hip_batched"):
+
+
+def run(name, t, ref, fq, extra_env=None):
     binary = os.path.join(ROOT, "oracle", "_ref", name)
     if not os.path.exists(binary):
-        print("%-18s not built" % name)
-        continue
-    for t in threads:
-        ref_copy = os.path.join(tmp, "%s_%d.fasta.gz" % (name, t))      # own copy: every run encodes its reference afresh
-        open(ref_copy, "wb").write(open(os.path.join(E2E, "test_3_reference.fasta.gz"), "rb").read())
-        t0 = time.perf_counter()
-        res = subprocess.run([binary, "--skip-write", "-x", "pacbio", "-t", str(t), "-R", "0.01", "--no-progress", "-r", ref_copy, "-q", fq],
-                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=900)
-        dt = time.perf_counter() - t0
-        got = sorted(l for l in res.stdout.splitlines() if l and not l.startswith("@"))
-        m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", res.stderr)
-        extra = "  %s alignments in %s launches" % (m.group(1), m.group(2)) if m else ""
-        print("%-18s -t %-3d wall %6.2f s  rc %d  SAM %s%s" % (name, t, dt, res.returncode, "identical" if got == want else "DIFFERENT (%d records)" % len(got), extra), flush=True)
+        return None
+    ref_copy = os.path.join(tmp, "%s_%d_%s" % (name, t, os.path.basename(ref)))      # own copy: every run encodes its reference afresh
+    open(ref_copy, "wb").write(open(ref, "rb").read())
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    t0 = time.perf_counter()
+    res = subprocess.run([binary, "--skip-write", "-x", "pacbio", "-t", str(t), "-R", "0.01", "--no-progress", "-r", ref_copy, "-q", fq],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=3000, env=env)
+    dt = time.perf_counter() - t0
+    recs = sorted(l for l in res.stdout.splitlines() if l and not l.startswith("@"))
+    m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", res.stderr)
+    mp = re.search(r"Done \(\d+ reads mapped \([^)]*\), \d+ reads not mapped, \d+ lines written\)\(elapsed: ([0-9.]+)", res.stderr)
+    return {"wall": dt, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None,
+            "map_s": float(mp.group(1)) if mp else None, "err": res.stderr[-400:]}
+
+
+def line(name, t, r, same):
+    l = r["launch"]
+    print("%-18s -t %-4d wall %7.2f s%s  rc %d  SAM %s%s" % (
+        name, t, r["wall"], ("  map %6.2f s" % r["map_s"]) if r["map_s"] is not None else "", r["rc"], same,
+        ("  %d alignments in %d launches (%.1f per launch)" % (l[0], l[1], l[0] / max(l[1], 1))) if l else ""), flush=True)
+
+
+def synthetic(n_reads, threads):
+    from ngmlr_amd import synth
+    rng = np.random.default_rng(2025)
+    L = 2_000_000
+    ref = synth.random_ref(rng, L)
+    fa = os.path.join(tmp, "synth_ref.fa")
+    with open(fa, "w") as f:
+        f.write(">synth2M\n")
+        s = ref.tobytes().decode()
+        for i in range(0, L, 80):
+            f.write(s[i:i + 80] + "\n")
+    fq = os.path.join(tmp, "synth_reads.fq")
+    bases = 0
+    with open(fq, "w") as f:
+        for i in range(n_reads):
+            a = int(rng.integers(0, L - 11000))
+            w = ref[a:a + int(rng.integers(9000, 11000))]
+            q = synth.mutate(rng, w, 0.15, (6, 3, 1))
+            if rng.random() < 0.5:
+                q = synth.revcomp(q)
+            bases += len(q)
+            f.write("@r%d_%d\n%s\n+\n%s\n" % (i, a, q.tobytes().decode(), "I" * len(q)))
+    print("synthetic: %d reads, %.1f Mbp, reference %d bp; host has %d hardware threads" % (n_reads, bases / 1e6, L, os.cpu_count()))
+    cores = os.cpu_count() or 8
+    base = None
+    best = None
+    for t in sorted({min(cores, 32), min(cores, 64), cores}):
+        r = run("ngmlr_ref", t, fa, fq)
+        if r is None:
+            print("ngmlr_ref not built")
+            return
+        if base is None:
+            base = r["recs"]
+        line("ngmlr_ref", t, r, "reference" if r["recs"] == base else "DIFFERS from the first ngmlr_ref run")
+        if best is None or r["wall"] < best[1]["wall"]:
+            best = (t, r)
+    for name in ("ngmlr_hip_batched", "ngmlr_hip_full"):
+        for t in threads:
+            r = run(name, t, fa, fq)
+            if r is None:
+                print("%-18s not built" % name)
+                break
+            line(name, t, r, "identical" if r["recs"] == base else "DIFFERENT (%d vs %d records)" % (len(r["recs"]), len(base)))
+            if r["rc"] != 0:
+                print(r["err"])
+            else:
+                print("    wall / best ngmlr_ref (-t %d): %.2f   mapped bases per hour (wall): %.1f Gbp/h vs %.1f Gbp/h" % (
+                    best[0], r["wall"] / best[1]["wall"], bases / r["wall"] * 3.6e-6, bases / best[1]["wall"] * 3.6e-6))
+
+
+def test_3(threads):
+    fq = os.path.join(tmp, "test_3.fq")
+    open(fq, "wb").write(gzip.open(os.path.join(E2E, "test_3_reads.fq.gz"), "rb").read())
+    want = [l.rstrip("\n") for l in gzip.open(os.path.join(ROOT, "tests", "golden", "test_3.sorted.sam.gz"), "rt") if l.strip()]
+    for name in ("ngmlr_ref", "ngmlr_hip", "ngmlr_hip_batched", "ngmlr_hip_full"):
+        for t in threads:
+            r = run(name, t, os.path.join(E2E, "test_3_reference.fasta.gz"), fq)
+            if r is None:
+                print("%-18s not built" % name)
+                break
+            line(name, t, r, "identical" if r["recs"] == want else "DIFFERENT (%d records)" % len(r["recs"]))
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    if args and args[0] == "--synthetic":
+        n = int(args[1]) if len(args) > 1 else 2000
+        synthetic(n, [int(x) for x in args[2:]] or [64, 256, 512])
+    else:
+        test_3([int(x) for x in args] or [1, 16, 64])
