@@ -245,6 +245,44 @@ def cpu_baseline_processes(ts, n_sample, procs, seconds_budget):
             pass
 
 
+def other_config(al, tiles, what, parity_n, parity_max_cells=3.0e8):
+    """One of the other BASELINE configs: device rate with inputs resident in HBM (best of three runs), per fill class,
+    and a bounded sample of its tiles compared field by field with the reference's own ConvexAlignFast (oracle/_ref)."""
+    from ngmlr_amd.aligner import format_alignment
+    from oracle.pyoracle import Oracle, have_ref, same_alignment
+    bases = float(sum(t.H for t in tiles))
+    batch = al.upload(tiles, closed_form=True)
+    try:
+        batch.run()
+        best = None
+        for _ in range(3):
+            tm = batch.run()
+            if best is None or tm.total_ms < best.total_ms:
+                best = tm
+        classes = [{"M": li["slots_per_lane"], "tasks_or_waves": li["waves"], "int16_runs": li["wrap16"], "tiles": li["n_tiles"],
+                    "ms": li["ms"], "G_cells_per_s": li["cells"] / max(li["ms"], 1e-6) * 1e-6} for li in batch.launches()]
+        res, ops = batch.download()
+        n_valid = sum(1 for i in range(len(tiles)) if res[i].status == 0)
+        kind = "reference" if have_ref() else "port"
+        orc = Oracle(kind)
+        # bounded sample: spread over the list, tiles whose CPU cost stays small (the 8192-column 100 kb tiles take the CPU ~10 s each)
+        cand = [i for i in range(0, len(tiles), max(1, len(tiles) // (4 * parity_n))) if tiles[i].cells <= parity_max_cells][:parity_n]
+        bad, first = 0, None
+        for i in cand:
+            d = same_alignment(orc.align(tiles[i]), format_alignment(al.lib, res[i], ops, tiles[i]))
+            if d is not None:
+                bad += 1
+                first = first or "tile %d (%s): %s" % (i, tiles[i].tag, d)
+        orc.close()
+        return {"what": what, "tiles": len(tiles), "read_bases": int(bases), "Gbp_per_h": bases / best.total_ms * 3.6e-3,
+                "ms": {"plan": best.plan_ms, "fill": best.fill_ms, "backtrack": best.backtrack_ms, "total": best.total_ms},
+                "G_cells_per_s": best.cells / best.total_ms * 1e-6, "fill_classes": classes, "valid_alignments": "%d/%d" % (n_valid, len(tiles)),
+                "parity": "%d/%d vs oracle/_ref (%s)" % (len(cand) - bad, len(cand), kind), "parity_detail": first,
+                "measured": "device rate, inputs resident in HBM (cvx_batch_run, best of 3), closed-form corridors"}
+    finally:
+        batch.free()
+
+
 def subread_scoring_rates(lib, dev, n=32768):
     from ngmlr_amd import synth
     from ngmlr_amd.aligner import StrippedSWHip
@@ -353,6 +391,7 @@ def main() -> int:
                          "their cells (LPT, ngmlr_amd.shard), results restored to list order; default: weak, --tiles per device")
     ap.add_argument("--row-arrays", action="store_true", help="hand over corridor row arrays instead of the builders' closed forms")
     ap.add_argument("--no-pin", action="store_true", help="keep the sequences in ordinary (pageable) memory: cvx_submit packs them into its own staging")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs (ONT mix, ultra-long + SV, short reads) reported beside the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -402,6 +441,12 @@ def main() -> int:
         else:
             tilesets = [synth.pacbio_tileset(args.tiles, seed=args.seed + 1000 * (rank + d), read_len=args.read_len, pool=pool)
                         for d in range(n_local)]
+        extra_tiles = {}
+        if rank == 0 and args.gpus == 1 and not args.no_extras and not args.no_cpu_baseline:
+            # the other BASELINE configs (parity cases with a rate, outside the timed region): generated here, before HIP exists
+            extra_tiles["ont"] = synth.parallel_workload("ont", 24000, 11, pool)
+            extra_tiles["ultralong_sv"] = synth.parallel_workload("ultralong_mix", 2048, 19, pool, chunk=16)
+            extra_tiles["short"] = synth.parallel_workload("short", 60000, 17, pool, chunk=2048)
     t_gen = time.perf_counter() - t_gen
 
     from ngmlr_amd import capi
@@ -554,6 +599,18 @@ def main() -> int:
             except Exception as e:
                 subread = {"error": str(e)}
 
+        # the other BASELINE configs (C3 ONT mix, C5 ultra-long + SV, short reads): rate + parity, outside the timed region
+        others = None
+        if extra_tiles:
+            others = {}
+            for name_, what_, pn_ in (("ont", "configs[2]: ONT-like reads, 25 % error 4:4:2, tile mix median 1.3 kb up to 20 kb, widths 309-463, 10 % retries at 2x", 96),
+                                      ("ultralong_sv", "configs[4]: 100 kb reads, 95 % first-attempt anchors corridors (309+), 5 % widened to 2048 / 8192 columns or full-matrix inversion tiles", 6),
+                                      ("short", "short reads (<= 256 bp) on the linear corridor (src/AlignmentBuffer.cpp:2576-2594)", 256)):
+                try:
+                    others[name_] = other_config(w0.al, extra_tiles[name_], what_, pn_)
+                except Exception as e:
+                    others[name_] = {"error": str(e)}
+
         value = bases * args.steps / dt * 3600.0 / 1e9
         launch_ms, launch_meta = w0.launch_ms, w0.launch_meta
         # dominant kernel = the fill launch that carries most of the work (classes run concurrently)
@@ -643,6 +700,7 @@ def main() -> int:
             "text_stage_host": text_stage,
             "text_stage_device": text_dev,
             "subread_scoring": subread,
+            "other_configs": others,
             "tile_generation_s": t_gen,
         }
     for w in workers:

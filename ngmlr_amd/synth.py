@@ -273,6 +273,36 @@ def workload_ultralong_sv(n_tiles: int, seed: int = 13, read_len: int = 100000) 
     return tiles
 
 
+def workload_ultralong_mix(n_tiles: int, seed: int = 19, read_len: int = 100000, wide_frac: float = 0.05) -> List[Tile]:
+    """Config C5 as a THROUGHPUT batch: thousands of 100 kb tiles, 95 % of them on the anchors corridor of the first
+    alignment attempt (width 309+), `wide_frac` of them retries on widened corridors (2048 / 8192 columns, the
+    endpoints corridor of attempts >= 3, src/AlignmentBuffer.cpp:291-294, 1454-1467) or full-matrix inversion checks."""
+    rng = np.random.default_rng(seed)
+    tiles = []
+    for i in range(n_tiles):
+        u = rng.random()
+        if u >= wide_frac:
+            tiles.append(make_tile(rng, read_len, err=0.2, ratio=(4, 4, 2), corridor="anchors", scatter=40.0, tag="ul-309"))
+        elif u < wide_frac * 0.4:
+            tiles.append(make_tile(rng, int(rng.integers(500, 5000)), err=0.2, ratio=(4, 4, 2), corridor="full", tag="sv-full"))
+        else:
+            width = 2048 if u < wide_frac * 0.8 else 8192
+            tiles.append(make_tile(rng, read_len, err=0.2, ratio=(4, 4, 2), corridor="endpoints", width=width, realign=True, tag="ul-%d" % width))
+    return tiles
+
+
+def _workload_chunk(args):
+    name, n, seed, kw = args
+    return globals()["workload_" + name](n, seed=seed, **kw)
+
+
+def parallel_workload(name: str, n_tiles: int, seed: int, pool=None, chunk: int = 256, **kw) -> List[Tile]:
+    """workload_<name>(n_tiles) generated `chunk` tiles at a time (own seed per chunk) on `pool`'s worker processes."""
+    tasks = [(name, min(chunk, n_tiles - c0), seed * 1009 + c0, kw) for c0 in range(0, n_tiles, chunk)]
+    parts = list(pool.map(_workload_chunk, tasks)) if pool is not None else [_workload_chunk(t) for t in tasks]
+    return [t for p in parts for t in p]
+
+
 def workload_short(n_tiles: int, seed: int = 17) -> List[Tile]:
     """Short reads (<= 256 bp) through getCorridorLinear (src/AlignmentBuffer.cpp:2576-2594)."""
     rng = np.random.default_rng(seed)

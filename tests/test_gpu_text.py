@@ -64,3 +64,58 @@ def test_text_stage_long_gaps_and_full_size(hip_aligner):
         if i % 3 == 0:
             t.ext_qstart, t.ext_qend = int(rng.integers(0, 5000)), int(rng.integers(0, 5000))
     assert _compare(hip_aligner, tiles) > 20
+
+
+def _device_text_vs(al, tiles, expect):
+    """device text of `tiles` against expect(i) -> dict with the reference's fields (ret, score_bits, cigar, md, ...)"""
+    job = al.submit(tiles)
+    job.wait()
+    eqs = np.array([t.ext_qstart for t in tiles], dtype=np.int32)
+    eqe = np.array([t.ext_qend for t in tiles], dtype=np.int32)
+    dev = job.text(eqs, eqe)
+    job.release()
+    bad = []
+    for i, t in enumerate(tiles):
+        w, d = expect(i), dev[i]
+        if w["ret"] < 0:
+            if d["ret"] >= 0:
+                bad.append((t.tag, "ret", w["ret"], d["ret"]))
+            continue
+        for k in ("ret", "score_bits", "cigar", "md", "position_offset", "qstart", "qend", "nm", "alignment_length",
+                  "cigar_op_count", "sv_type", "first_ref", "first_read", "last_ref", "last_read"):
+            if w[k] != d[k]:
+                bad.append((t.tag, k, str(w[k])[:50], str(d[k])[:50]))
+                break
+        else:
+            wi = w["identity_bits"] if "identity_bits" in w else int(np.float32(w["identity"]).view(np.uint32))
+            if wi != int(np.float32(d["identity"]).view(np.uint32)):
+                bad.append((t.tag, "identity"))
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("name", ["ref_test_2.npz", "ref_test_4.npz", "ref_test_3.npz"])
+def test_device_text_equals_recorded_reference_output(hip_aligner, name):
+    """Directly against what the unmodified reference wrote for its own SingleAlign calls (not through the host form)."""
+    pairs = util.load_golden(name)
+    _device_text_vs(hip_aligner, [t for t, _ in pairs], lambda i: pairs[i][1])
+
+
+def test_device_text_equals_reference_aligner(hip_aligner, ref_oracle):
+    """... and against the reference's own ConvexAlignFast (oracle/_ref) on the zoo, the edge cases and the N-clip tiles
+    (svType 0x1 fires in both directions, src/ConvexAlignFast.cpp:493-528)."""
+    nclip = util.nclip_tiles()
+    tiles = util.tile_zoo(seed=66, n=60, max_w=2000) + util.edge_tiles() + [t for t, _ in nclip]
+    want = [ref_oracle.align(t, want_nm=False) for t in tiles]
+    _device_text_vs(hip_aligner, tiles, lambda i: want[i])
+    base = len(tiles) - len(nclip)
+    assert sum(want[base + k]["sv_type"] for k in range(len(nclip))) == sum(f for _, f in nclip) >= 4
+
+
+def test_n_clip_flags_through_the_host_form(hip_aligner, ref_oracle):
+    from oracle.pyoracle import same_alignment
+    nclip = util.nclip_tiles()
+    got = hip_aligner.batch_align([t for t, _ in nclip])
+    for (t, flag), g in zip(nclip, got):
+        want = ref_oracle.align(t)
+        assert same_alignment(want, g) is None, (t.tag, same_alignment(want, g))
+        assert g["sv_type"] == flag == want["sv_type"]

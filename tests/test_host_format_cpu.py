@@ -122,3 +122,20 @@ def test_threaded_batch_text_stage_equals_single_calls(port_oracle):
             assert out[i].nm == w["nm"] and out[i].position_offset == w["position_offset"]
             n = w["alignment_length"]
             assert np.array_equal(keep[i][2][:n], w["nm_per_position"])
+
+
+def test_n_clip_flags_fire_like_the_reference(port_oracle, ref_oracle):
+    """svType |= 0x1 when an alignment ends next to a run of 'X' in the reference window (src/ConvexAlignFast.cpp:493-528):
+    positive and negative cases around the 80 % threshold -- the reference itself, the C restatement, and the product's host
+    text stage (cvx_format_alignment) fed with the restatement's ops."""
+    n_pos = 0
+    for t, flag in util.nclip_tiles():
+        want = ref_oracle.align(t)
+        assert want["ret"] >= 0 and want["sv_type"] == flag, (t.tag, want["sv_type"])
+        port = port_oracle.align(t)
+        assert same_alignment(want, port) is None, (t.tag, same_alignment(want, port))
+        _, got = _format_from_oracle(port_oracle, t)
+        assert got is not None and same_alignment(want, got) is None, (t.tag, same_alignment(want, got))
+        assert got["sv_type"] == flag
+        n_pos += flag
+    assert n_pos >= 4

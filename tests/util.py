@@ -195,3 +195,36 @@ def fit_corridor(off, ln, H, W):
     if np.array_equal(o3, off):
         return (1, float(k), 0.0, right, 0, w)                     # getCorridorEndpointsWithAnchors
     return None
+
+
+# --------------------------------------------------------------------------- N-clip flags
+
+def nclip_tiles(seed=31):
+    """Tiles whose alignment ends next to runs of 'X' in the reference window: the reference sets svType |= 0x1 when
+    more than 80 % of (up to) 100 reference characters before the alignment start / after its end are 'X'
+    (src/ConvexAlignFast.cpp:493-528).  -> list of (tile, expected flag).  'X' never matches a read base, so the local
+    alignment clips exactly at the run."""
+    rng = np.random.default_rng(seed)
+    out = []
+
+    def tile(lead, trail, core=700, tag=""):
+        mid = synth.random_ref(rng, core)
+        ref = np.concatenate([lead, mid, trail]).astype(np.uint8)
+        qry = synth.mutate(rng, mid, 0.08)
+        off, ln = synth.corridor_full(len(qry), len(ref))
+        return synth.Tile(ref.tobytes(), qry.tobytes(), off, ln, tag=tag, desc=synth.full_desc(len(qry), len(ref)))
+    X = lambda n: np.full(n, ord("X"), np.uint8)  # noqa: E731
+    acgt = lambda n: synth.random_ref(rng, n)  # noqa: E731
+    out.append((tile(X(150), acgt(0), tag="x-before"), 1))
+    out.append((tile(acgt(0), X(150), tag="x-after"), 1))
+    out.append((tile(X(120), X(130), tag="x-both"), 1))
+    out.append((tile(X(30), acgt(0), tag="x-before-short-window"), 1))            # fewer than 100 characters to probe
+    out.append((tile(np.concatenate([X(60), acgt(45)]), acgt(0), tag="x-too-far"), 0))     # 55 of 100 probes
+    mixed = X(100).copy()
+    mixed[::4] = ord("A")                                                          # 75 % X: below the threshold
+    out.append((tile(mixed, acgt(0), tag="x-75-percent"), 0))
+    mixed2 = X(100).copy()
+    mixed2[::8] = ord("N")                                                         # 87 % X, 'N' does not count
+    out.append((tile(mixed2, acgt(0), tag="x-87-percent"), 1))
+    out.append((tile(np.full(150, ord("N"), np.uint8), acgt(0), tag="n-not-x"), 0))   # the decoder's 'N' is not what the test looks for
+    return out

@@ -10,8 +10,8 @@
                                            many more workers than cores (reads in flight are what fills a launch); SAM of the
                                            drop-in compared with the SAM ngmlr_ref produced in this very run.
 
-Wall clock includes ngmlr's start-up (reference encoding + index); `map` is the mapping phase alone as ngmlr itself
-reports it.  Says how the drop-in behaves inside the real pipeline, not how fast the kernels are."""
+Wall clock includes ngmlr's start-up (reference encoding + index); `map` is the wall clock minus the
+index construction time ngmlr reports (thread start-up + mapping + exit).  Says how the drop-in behaves inside the real pipeline, not how fast the kernels are."""
 import gzip
 import os
 import re
@@ -42,9 +42,9 @@ def run(name, t, ref, fq, extra_env=None):
     dt = time.perf_counter() - t0
     recs = sorted(l for l in res.stdout.splitlines() if l and not l.startswith("@"))
     m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", res.stderr)
-    mp = re.search(r"Done \(\d+ reads mapped \([^)]*\), \d+ reads not mapped, \d+ lines written\)\(elapsed: ([0-9.]+)", res.stderr)
+    mp = re.search(r"Overall time for creating RefTable: ([0-9.]+)s", res.stderr)
     return {"wall": dt, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None,
-            "map_s": float(mp.group(1)) if mp else None, "err": res.stderr[-400:]}
+            "map_s": dt - float(mp.group(1)) if mp else None, "err": res.stderr[-400:]}
 
 
 def line(name, t, r, same):
@@ -80,7 +80,7 @@ def synthetic(n_reads, threads):
     cores = os.cpu_count() or 8
     base = None
     best = None
-    for t in sorted({min(cores, 32), min(cores, 64), cores}):
+    for t in sorted({min(cores, 32), min(cores, 64)}):
         r = run("ngmlr_ref", t, fa, fq)
         if r is None:
             print("ngmlr_ref not built")
@@ -100,8 +100,9 @@ def synthetic(n_reads, threads):
             if r["rc"] != 0:
                 print(r["err"])
             else:
-                print("    wall / best ngmlr_ref (-t %d): %.2f   mapped bases per hour (wall): %.1f Gbp/h vs %.1f Gbp/h" % (
-                    best[0], r["wall"] / best[1]["wall"], bases / r["wall"] * 3.6e-6, bases / best[1]["wall"] * 3.6e-6))
+                print("    wall / best ngmlr_ref (-t %d): %.2f   map / map: %.2f   mapped bases per hour of `map`: %.1f Gbp/h vs %.1f Gbp/h" % (
+                    best[0], r["wall"] / best[1]["wall"], (r["map_s"] or r["wall"]) / (best[1]["map_s"] or best[1]["wall"]),
+                    bases / (r["map_s"] or r["wall"]) * 3.6e-6, bases / (best[1]["map_s"] or best[1]["wall"]) * 3.6e-6))
 
 
 def test_3(threads):
