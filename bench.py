@@ -297,12 +297,21 @@ def subread_scoring_rates(lib, dev, n=32768):
     cells = sum((len(r) + 1) * (len(q) + 1) for r, q in zip(refs, qrys))
     sw = StrippedSWHip(device=dev)
     sw.batch_score(refs[:1024], qrys[:1024])
+    import ctypes as C
+
+    def kernel_ms():
+        ms = C.c_float()
+        sw.lib.cvx_score_kernel_ms(sw._al.h, C.byref(ms))
+        return float(ms.value)
     c0 = time.perf_counter()
     got = sw.batch_score(refs, qrys)
     dt_gpu = time.perf_counter() - c0
+    k_all = kernel_ms() * 1e-3                     # the kernel alone (HIP events on its stream), inputs resident in HBM
     c0 = time.perf_counter()
+    k_1k = 0.0
     for lo in range(0, n, 1024):
         sw.batch_score(refs[lo:lo + 1024], qrys[lo:lo + 1024])
+        k_1k += kernel_ms() * 1e-3
     dt_1k = time.perf_counter() - c0
     sw.close()
     kind = "reference" if have_score_ref() else "port"
@@ -322,6 +331,10 @@ def subread_scoring_rates(lib, dev, n=32768):
         th.join()
     dt_cpu = time.perf_counter() - c0
     return {"pairs": n, "gpu_pairs_per_s": n / dt_gpu, "gpu_cell_updates_per_s": cells / dt_gpu,
+            "device_resident": {"pairs_per_s": n / max(k_all, 1e-9), "cell_updates_per_s": cells / max(k_all, 1e-9), "kernel_ms": k_all * 1e3,
+                                "in_1024_pair_launches_pairs_per_s": n / max(k_1k, 1e-9),
+                                "bound": "integer VALU issue: ~10 instructions per cell, one lane per diagonal, sequences as codes in LDS (score_diag_kernel); no HBM traffic to speak of",
+                                "what": "the scoring kernel alone, HIP events on its stream (cvx_score_kernel_ms)"},
             "gpu_pairs_per_s_in_1024_pair_calls": n / dt_1k, "cpu_pairs_per_s": n / dt_cpu, "cpu_kind": kind, "cpu_threads": threads,
             "parity": "%d/%d" % (int((got == want).sum()), n),
             "what": "cvx_score_batch (host strings in -> scores out, incl. the python marshalling of this bench) vs StrippedSW + ssw.c"}

@@ -299,6 +299,9 @@ int cvx_submit_windows(cvx_handle h, cvx_genome g, int32_t n_tiles, const cvx_ti
  * reference passes -1 into ssw's uint8_t gap weights) or -1.0f for sequences of 100000
  * characters or more.  Exact for scores below 32767. */
 int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char *const *qrys, float *scores);
+/* duration of the scoring kernel of the handle's last cvx_score_batch (HIP events on its stream): the device-resident
+ * rate, beside the rate of the whole call (strings in host memory in, scores out) */
+int cvx_score_kernel_ms(cvx_handle h, float *ms);
 
 /* Host-side text stage (convertCigar, src/ConvexAlignFast.cpp:112-333, and the
  * N-clip flags of :493-528).  Pure host code, no device needed. */

@@ -22,6 +22,8 @@ struct ScorePair {
 };
 /* max_ref_len: longest reference string of the batch incl. its NUL (<= 512: rows in registers, four pairs per workgroup) */
 hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scratch, float *out, int n, int max_ref_len, hipStream_t st);
+/* every pair has qry_len <= 512 and ref_len <= 2048 (NULs included): diagonal kernel, no serial dependency (cvx_score.hip) */
+hipError_t launch_score_diag(const uint8_t *seq, const ScorePair *pairs, float *out, int n, hipStream_t st);
 
 /* reference windows from the 4-bit genome resident in HBM (cvx_genome.hip) */
 hipError_t launch_decode_windows(const uint8_t *bin, const uint64_t *starts, int n_starts,

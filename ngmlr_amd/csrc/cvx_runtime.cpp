@@ -292,6 +292,9 @@ struct cvx_context {
 	DevBuf<ScorePair> sc_pairs;
 	DevBuf<int32_t> sc_rows;
 	DevBuf<float> sc_out;
+	hipEvent_t sc_ev0 = nullptr, sc_ev1 = nullptr;
+	float sc_kernel_ms = 0.0f;
+	bool score_no_diag = false;   /* test knob (env CVX_TUNE_SCORE_NO_DIAG): always the row-by-row kernels */
 };
 
 struct cvx_genome_s {            /* an encoded reference genome resident in HBM (cvx_genome.hip) */
@@ -1004,6 +1007,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_MIN_M")) c->tune_min_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_FORCE_WRAP16")) c->tune_force_wrap = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_FAIL_COMPUTE")) c->test_fail_compute = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_SCORE_NO_DIAG")) c->score_no_diag = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_M")) c->tune_chain_m = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
@@ -1040,6 +1044,8 @@ void cvx_destroy(cvx_handle h) {
 	h->pending.clear();
 	h->sc_hseq.release(); h->sc_hpairs.release(); h->sc_hout.release();
 	h->sc_seq.release(); h->sc_pairs.release(); h->sc_rows.release(); h->sc_out.release();
+	if (h->sc_ev0) (void) hipEventDestroy(h->sc_ev0);
+	if (h->sc_ev1) (void) hipEventDestroy(h->sc_ev1);
 	delete h;
 }
 
@@ -1500,11 +1506,12 @@ int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char
 	RC_TRY(h->sc_hout.ensure((size_t) n * sizeof(float)));
 	ScorePair *pairs = h->sc_hpairs.as<ScorePair>();
 	uint64_t bytes = 0, rows = 0;
-	size_t max_rl = 0;
+	size_t max_rl = 0, max_ql = 0;
 	for (int i = 0; i < n; ++i) {
 		if (!refs[i] || !qrys[i]) { set_err("cvx_score_batch: NULL sequence %d", i); return CVX_ERR_ARG; }
 		const size_t rl = strlen(refs[i]) + 1, ql = strlen(qrys[i]) + 1;
 		max_rl = std::max(max_rl, rl);
+		max_ql = std::max(max_ql, ql);
 		ScorePair &p = pairs[i];
 		p.ref_off = bytes; bytes += rl;
 		p.qry_off = bytes; bytes += ql;
@@ -1526,12 +1533,26 @@ int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char
 	hipStream_t st = h->s_main;
 	HIP_TRY(hipMemcpyAsync(h->sc_seq.p, hseq, (size_t) ((bytes + 255) / 256 * 256), hipMemcpyHostToDevice, st));   /* dword-aligned size: SDMA, not a blit kernel */
 	HIP_TRY(hipMemcpyAsync(h->sc_pairs.p, pairs, (size_t) n * sizeof(ScorePair), hipMemcpyHostToDevice, st));
-	HIP_TRY(launch_score(h->sc_seq.p, h->sc_pairs.p, h->sc_rows.p, h->sc_out.p, n, (int) std::min<size_t>(max_rl, 0x7fffffff), st));
+	/* the kernel alone, on the stream it runs on (cvx_score_kernel_ms: the device-resident rate beside the marshalled one) */
+	if (!h->sc_ev0) { HIP_TRY(hipEventCreate(&h->sc_ev0)); HIP_TRY(hipEventCreate(&h->sc_ev1)); }
+	HIP_TRY(hipEventRecord(h->sc_ev0, st));
+	if (max_ql <= 512 && max_rl <= 2048 && !h->score_no_diag)
+		HIP_TRY(launch_score_diag(h->sc_seq.p, h->sc_pairs.p, h->sc_out.p, n, st));      /* the batched shape (256-base sub-read x ~300-base window) */
+	else
+		HIP_TRY(launch_score(h->sc_seq.p, h->sc_pairs.p, h->sc_rows.p, h->sc_out.p, n, (int) std::min<size_t>(max_rl, 0x7fffffff), st));
+	HIP_TRY(hipEventRecord(h->sc_ev1, st));
 	HIP_TRY(hipMemcpyAsync(h->sc_hout.p, h->sc_out.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	memcpy(scores, h->sc_hout.p, (size_t) n * sizeof(float));
+	h->sc_kernel_ms = ev_ms(h->sc_ev0, h->sc_ev1);
 	return CVX_OK;
 	ABI_GUARD_END
+}
+
+int cvx_score_kernel_ms(cvx_handle h, float *ms) {
+	if (!h || !ms) { set_err("cvx_score_kernel_ms: NULL argument"); return CVX_ERR_ARG; }
+	*ms = h->sc_kernel_ms;
+	return CVX_OK;
 }
 
 }  /* extern "C" */

@@ -148,6 +148,61 @@ score_reg_kernel(const uint8_t *seq, const ScorePair *pairs, float *out, int n) 
 	if (lane == 0) out[p] = (float) best;
 }
 
+/*
+ * score_diag_kernel -- the batched shape without any serial dependency.  A gap costs 255 per base, so an alignment
+ * with g >= 1 gaps scores sum(segments) - 255 g (or less), where the ungapped segments together consume at most
+ * min(Q, R) bases of the shorter sequence: with min(Q, R) <= 511 the segments other than the best one total at most
+ * 511 g / (g + 1) <= 255 g (g = 1: the smaller of two segments is <= 255), hence no gapped path beats the best
+ * ungapped one -- the matrix maximum is the maximum over all diagonals of the best contiguous run (Kadane:
+ * h = max(0, h + s)), which is what H[i][j] = max(0, H[i-1][j-1] + s, ...) computes along a diagonal when the gap
+ * terms never win.  Every lane walks its own diagonal, 64 diagonals at a time, both sequences as codes in LDS; no
+ * shuffles, no row state.  Exact for the same reason the 8-bit ssw kernel's answer is (scores <= 511 here).
+ * One wave per pair, four pairs per workgroup; windows up to kDiagMaxRef columns.
+ */
+static const int kDiagMaxQry = 512, kDiagMaxRef = 2048;
+
+__global__ void __launch_bounds__(256)
+score_diag_kernel(const uint8_t *seq, const ScorePair *pairs, float *out, int n) {
+	__shared__ uint8_t s_q[4][kDiagMaxQry];
+	__shared__ uint8_t s_r[4][kDiagMaxRef + 64];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int p = blockIdx.x * 4 + w;
+	const bool live = p < n;                             /* wave-uniform */
+	ScorePair pr;
+	pr.ref_off = pr.qry_off = 0; pr.ref_len = pr.qry_len = 0; pr.scratch_off = 0;
+	if (live) pr = pairs[p];
+	const int R = pr.ref_len, Q = pr.qry_len;            /* lengths include the NUL (:131-132) */
+	for (int j = lane; j < R; j += 64) s_r[w][j] = (uint8_t) nt_code(seq[pr.ref_off + (unsigned) j]);
+	for (int i = lane; i < Q; i += 64) s_q[w][i] = (uint8_t) nt_code(seq[pr.qry_off + (unsigned) i]);
+	__syncthreads();
+	if (!live) return;
+	int best = 0;
+	for (int d0 = -(Q - 1); d0 < R; d0 += 64) {
+		const int d = d0 + lane;                         /* this lane's diagonal: column j = i + d */
+		const int i_lo = d < 0 ? -d : 0;
+		const int i_hi = d < R ? min(Q, R - d) : 0;      /* rows [i_lo, i_hi) */
+		const int w_lo = max(0, -(d0 + 63)), w_hi = min(Q, R - d0);       /* the wave's union of row ranges */
+		int h = 0;
+		for (int i = w_lo; i < w_hi; ++i) {
+			const int qc = s_q[w][i];
+			const bool act = i >= i_lo && i < i_hi;
+			const int rc = act ? (int) s_r[w][i + d] : 4;
+			const int s = (qc == 4 || rc == 4) ? 0 : (qc == rc ? 1 : -1);
+			h = act ? max(h + s, 0) : 0;
+			best = max(best, h);
+		}
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
+	if (lane == 0) out[p] = (float) best;
+}
+
+hipError_t launch_score_diag(const uint8_t *seq, const ScorePair *pairs, float *out, int n, hipStream_t st) {
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(score_diag_kernel, dim3((n + 3) / 4), dim3(256), 0, st, seq, pairs, out, n);
+	return hipGetLastError();
+}
+
 hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scratch, float *out, int n, int max_ref_len, hipStream_t st) {
 	if (n <= 0) return hipSuccess;
 	const int blocks = (n + 3) / 4;

@@ -94,3 +94,46 @@ def test_hundred_thousand_pairs_including_the_255_switch(built):
     for lo in range(0, 8192, 1024):
         assert np.array_equal(sw.batch_score(refs[lo:lo + 1024], qrys[lo:lo + 1024]), want[lo:lo + 1024])
     sw.close()
+
+
+def test_diagonal_kernel_equals_row_kernels_and_oracle(built):
+    """The batched shape goes to score_diag_kernel (one lane per diagonal: with a 255-per-base gap no gapped path can win
+    while the shorter sequence has at most 511 characters); the row-by-row kernels (CVX_TUNE_SCORE_NO_DIAG=1) and the CPU
+    checker must agree with it pair by pair -- including scores far above 255, N / x, empty strings, a window of 2047
+    columns -- and long-by-long pairs (both sides >= 512) still take the row kernels, where a gap CAN pay."""
+    import os
+    from ngmlr_amd import synth
+    from ngmlr_amd.aligner import StrippedSWHip
+    rng = np.random.default_rng(88)
+    refs, qrys = [], []
+    for i in range(3000):
+        k = i % 6
+        if k == 0:
+            w = synth.random_ref(rng, 308); a = int(rng.integers(0, 50)); q = synth.mutate(rng, w[a:a + 256], 0.15)[:256]
+        elif k == 1:                                    # read of up to 510 bases, near-identical: score ~ 500
+            L = int(rng.integers(400, 511)); w = synth.random_ref(rng, L + 30); q = synth.mutate(rng, w[15:15 + L], 0.003)[:510]
+        elif k == 2:                                    # two long matching blocks separated by junk in the read: a gap would join them if it were cheap
+            w = synth.random_ref(rng, 700); q = np.concatenate([w[50:290], synth.random_ref(rng, 12), w[290:520]])
+        elif k == 3:
+            w = synth.random_ref(rng, int(rng.integers(1500, 2047)), n_frac=0.02, x_frac=0.02); q = synth.mutate(rng, w[700:1100], 0.1)
+        elif k == 4:
+            w = synth.random_ref(rng, int(rng.integers(0, 40))); q = synth.random_ref(rng, int(rng.integers(0, 40)))
+        else:                                           # long by long: the row kernels' territory (a 255-per-base gap can pay)
+            w = synth.random_ref(rng, 1400); q = np.concatenate([w[100:600], w[601:1200]])
+        refs.append(w.tobytes()); qrys.append(q.tobytes())
+    want = _oracle_scores_threaded(refs, qrys)
+    sw = StrippedSWHip(device=0)
+    got = sw.batch_score(refs, qrys)
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
+    short = [i for i in range(3000) if i % 6 != 5]
+    got_s = sw.batch_score([refs[i] for i in short], [qrys[i] for i in short])      # a batch the diagonal kernel takes whole
+    assert np.array_equal(got_s, want[short])
+    sw.close()
+    os.environ["CVX_TUNE_SCORE_NO_DIAG"] = "1"
+    try:
+        sw2 = StrippedSWHip(device=0)
+    finally:
+        del os.environ["CVX_TUNE_SCORE_NO_DIAG"]
+    assert np.array_equal(sw2.batch_score([refs[i] for i in short], [qrys[i] for i in short]), want[short])
+    sw2.close()
+    assert want[[i for i in range(3000) if i % 6 == 5]].min() > 700          # the gap did pay there: 500 + 599 - 255
