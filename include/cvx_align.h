@@ -34,6 +34,8 @@
  * cvx_score_batch             StrippedSW::BatchScore/SingleScore  src/StrippedSW.cpp:118-203 (next-row f2)
  * cvx_genome_* / cvx_submit_windows  SequenceProvider's 4-bit genome + DecodeRefSequenceExact
  *                             src/SequenceProvider.cpp:333-386,475-565 (next-row f4, decode half)
+ * cvx_index_upload / cvx_search_batch  CS::RunRead's k-mer vote over the CompactPrefixTable
+ *                             src/CS.cpp:57-149,219-268,324-398, src/CSstatic.cpp:23-73, src/PrefixTable.cpp:476-532 (f4, search half)
  *
  * The binding a maintainer adds on the ngmlr side is in INTEGRATION.md
  * (ngmlr_amd/csrc/convex_align_hip.{h,cpp}: an IAlignment subclass over this ABI).
@@ -292,6 +294,35 @@ int cvx_genome_decode(cvx_handle h, cvx_genome g, int32_t n, const uint64_t *pos
 		const uint64_t *out_offset, char *out);
 int cvx_submit_windows(cvx_handle h, cvx_genome g, int32_t n_tiles, const cvx_tile *tiles,
 		const uint64_t *ref_position, cvx_job *out);
+
+/* Candidate search (search half): the k-mer vote of CS::RunRead (src/CS.cpp:324-398: PrefixIteration
+ * src/CSstatic.cpp:23-73, PrefixSearch / AddLocationStd src/CS.cpp:57-149, CollectResultsStd :219-268) for a batch of
+ * (sub-)reads over the reference's k-mer table resident in HBM.
+ *
+ *   cvx_index_upload   puts one unit of ngmlr's CompactPrefixTable into HBM as it lies in host memory: `ref_table_index` =
+ *                      TableUnit::RefTableIndex, 4^kmer_len + 2 entries of the packed 5-byte Index (uint m_TabIndex; char
+ *                      m_RevCompIndex: src/PrefixTable.h:15-31), `ref_table` = TableUnit::RefTable (uint32 locations,
+ *                      src/IRefProvider.h:10-16), `unit_offset` = TableUnit::Offset.  What GetRefEntry reads
+ *                      (src/PrefixTable.cpp:476-532) and nothing else.  Genomes of one table unit (< 4 Gbp).
+ *   cvx_search_batch   n reads (NUL-terminated strings; lens[i] = MappedRead::length): for read i the LocationScore list
+ *                      CollectResultsStd hands to AllocScores -- same entries, same order (a bin enters the list when one of its
+ *                      scores first reaches the growing threshold, so the order depends on the order of the votes, which is
+ *                      kept) -- in cands[cand_begin[i] .. + n_candidates[i]); n_candidates[i] = -1 where the reference gives up
+ *                      ("too many candidates": every table size of the retry ladder 2^16 / 2^18 / 2^19 / 2^20 overflowed its
+ *                      probe budget).  sensitivity = Config.getSensitivity() (0.8), min_kmer_hits = getMinKmerHits() (0),
+ *                      bin_shift = getBinSize() (4).  CVX_ERR_CAPACITY with *cand_used = the need when cands is too small. */
+typedef struct cvx_index_s *cvx_index;
+typedef struct {
+	uint64_t location;       /* LocationScore::Location.m_Location = ResolveBin(bin) */
+	float score;             /* LocationScore::Score.f: votes of that strand */
+	int32_t reverse;         /* Location.isReverse() */
+} cvx_candidate;
+int cvx_index_upload(cvx_handle h, int32_t kmer_len, const void *ref_table_index, const uint32_t *ref_table, uint32_t n_locations,
+		uint64_t unit_offset, cvx_index *out);
+void cvx_index_free(cvx_handle h, cvx_index ix);
+int cvx_search_batch(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
+		float sensitivity, float min_kmer_hits, int32_t bin_shift,
+		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used);
 
 /* Sub-read scoring: what StrippedSW::BatchScore / SingleScore return
  * (reference src/StrippedSW.cpp:118-203 over ssw.c): refs/qrys are NUL-terminated strings,

@@ -305,6 +305,47 @@ class Genome:
             self.g = None
 
 
+CANDIDATE_DTYPE = np.dtype([("location", np.uint64), ("score", np.float32), ("reverse", np.int32)])
+
+
+class KmerIndex:
+    """One unit of ngmlr's CompactPrefixTable resident in HBM, and CS::RunRead's candidate search over it for batches of
+    (sub-)reads (search half; reference src/CS.cpp:57-149, 219-268, 324-398)."""
+
+    def __init__(self, aligner: ConvexAlignHip, kmer_len: int, index_records: np.ndarray, locations: np.ndarray, unit_offset: int = 0):
+        self.al = aligner
+        self.ix = C.c_void_p()
+        idx = np.ascontiguousarray(index_records)
+        assert idx.dtype.itemsize == 5 and len(idx) == (1 << (2 * kmer_len)) + 2, "Index[4^k + 2], 5 packed bytes each"
+        loc = np.ascontiguousarray(locations, dtype=np.uint32)
+        capi.check(aligner.lib.cvx_index_upload(aligner.h, kmer_len, idx.ctypes.data, loc.ctypes.data, len(loc), unit_offset, C.byref(self.ix)))
+
+    def search(self, reads: Sequence[bytes], sensitivity: float = 0.8, min_kmer_hits: float = 0.0, bin_shift: int = 4):
+        """-> list (one per read) of CANDIDATE_DTYPE arrays in the reference's list order; None where the reference gives up."""
+        n = len(reads)
+        arr = (C.c_char_p * max(n, 1))(*reads)
+        lens = np.array([len(r) for r in reads], dtype=np.int32)
+        ncand = np.zeros(max(n, 1), dtype=np.int32)
+        begin = np.zeros(max(n, 1), dtype=np.uint64)
+        used = C.c_uint64()
+        cap = 1 << 16
+        while True:
+            cands = np.zeros(cap, dtype=CANDIDATE_DTYPE)
+            rc = self.al.lib.cvx_search_batch(self.al.h, self.ix, n, arr, lens.ctypes.data, sensitivity, min_kmer_hits, bin_shift,
+                                             ncand.ctypes.data, begin.ctypes.data, cands.ctypes.data, cap, C.byref(used))
+            if rc == -6 and used.value > cap:
+                cap = int(used.value) + 64
+                continue
+            capi.check(rc)
+            break
+        return [None if ncand[i] < 0 else cands[int(begin[i]):int(begin[i]) + int(ncand[i])].copy() for i in range(n)]
+
+    def free(self) -> None:
+        if self.ix:
+            self.al.lib.cvx_index_free(self.al.h, self.ix)
+            self.ix = None
+
+
 class StrippedSWHip:
     """Mirror of the reference's StrippedSW for the scoring calls (src/StrippedSW.cpp:118-203):
     batch_score == BatchScore, single_score == SingleScore; alignment calls are not part of

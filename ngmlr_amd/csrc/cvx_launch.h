@@ -25,6 +25,44 @@ hipError_t launch_score(const uint8_t *seq, const ScorePair *pairs, int32_t *scr
 /* every pair has qry_len <= 512 and ref_len <= 2048 (NULs included): diagonal kernel, no serial dependency (cvx_score.hip) */
 hipError_t launch_score_diag(const uint8_t *seq, const ScorePair *pairs, float *out, int n, hipStream_t st);
 
+/* candidate search (cvx_search.hip): k-mer vote of a batch of reads over the resident k-mer table */
+struct SearchCandidate {         /* same layout as cvx_candidate (include/cvx_align.h) */
+	uint64_t location;
+	float score;
+	int32_t reverse;
+};
+struct SearchArgs {
+	/* the table: m_TabIndex per prefix (4^k + 2 entries), used flags, RefTable */
+	const uint32_t *tab;
+	const uint8_t *used;
+	const uint32_t *locs;
+	unsigned long long unit_offset;
+	int32_t k;
+	/* the reads: bytes with a NUL behind each */
+	const uint8_t *seq;
+	const uint64_t *seq_off;
+	const int32_t *seq_len;
+	int32_t n;
+	/* per read */
+	unsigned long long *events;      /* votes it will cast (search_count_kernel) */
+	const uint64_t *list_off;        /* exclusive prefix sum of events: rList region; candidates at twice that */
+	uint32_t *rlist;
+	SearchCandidate *cand;
+	int32_t *n_cand;                 /* -1: the probe budget ran out at this table size */
+	float *max_hit;
+	/* this attempt */
+	const int32_t *work;             /* read indices (NULL: all n) */
+	int32_t n_work;
+	int32_t bits;                    /* vote table of 2^bits entries per read in flight */
+	float hpoc_factor;               /* 0.333 first attempt, 0.777 on retries (CS.cpp:352, :379) */
+	uint64_t *keys;
+	float *scores;                   /* two floats per table entry: forward, reverse */
+	float sensitivity, min_hits;
+	int32_t bin_shift;
+};
+hipError_t launch_search_count(const SearchArgs &a, hipStream_t st);
+hipError_t launch_search(const SearchArgs &a, hipStream_t st);
+
 /* reference windows from the 4-bit genome resident in HBM (cvx_genome.hip) */
 hipError_t launch_decode_windows(const uint8_t *bin, const uint64_t *starts, int n_starts,
 		const WindowDesc *win, int n, uint8_t *dst, hipStream_t st);

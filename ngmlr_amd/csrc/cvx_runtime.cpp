@@ -1494,6 +1494,187 @@ int cvx_genome_decode(cvx_handle h, cvx_genome g, int32_t n, const uint64_t *pos
 	ABI_GUARD_END
 }
 
+/* ------------------------------------------------------------------ candidate search (search half) */
+
+struct cvx_index_s {             /* one unit of ngmlr's CompactPrefixTable, resident in HBM (cvx_search.hip) */
+	int device = 0;
+	int32_t k = 0;
+	uint64_t n_index = 0;        /* 4^k + 2 */
+	uint64_t unit_offset = 0;
+	uint32_t n_locs = 0;
+	DevBuf<uint32_t> d_tab;
+	DevBuf<uint8_t> d_used;
+	DevBuf<uint32_t> d_locs;
+};
+
+int cvx_index_upload(cvx_handle h, int32_t k, const void *index, const uint32_t *locs, uint32_t n_locs, uint64_t unit_offset, cvx_index *out) {
+	ABI_GUARD_BEGIN
+	if (!h || !out || !index || (n_locs > 0 && !locs) || k < 4 || k > 15) { set_err("cvx_index_upload: bad argument (kmer_len 4..15)"); return CVX_ERR_ARG; }
+	*out = nullptr;
+	HIP_TRY(hipSetDevice(h->device));
+	const uint64_t n_index = (1ull << (2 * k)) + 2ull;
+	/* unpack the 5-byte Index records (uint m_TabIndex; char m_RevCompIndex, #pragma pack(1): src/PrefixTable.h:15-31) */
+	std::vector<uint32_t> tab((size_t) n_index);
+	std::vector<uint8_t> used((size_t) n_index);
+	const uint8_t *p = static_cast<const uint8_t *>(index);
+	for (uint64_t i = 0; i < n_index; ++i) {
+		uint32_t t;
+		memcpy(&t, p + 5 * i, 4);
+		tab[(size_t) i] = t;
+		used[(size_t) i] = p[5 * i + 4] != 0;                 /* Index::used() */
+	}
+	for (uint64_t i = 0; i + 1 < n_index; ++i)
+		if (used[(size_t) i] && (tab[(size_t) i] == 0 || tab[(size_t) i + 1] < tab[(size_t) i] || (uint64_t) tab[(size_t) i + 1] - 1 > n_locs)) {
+			set_err("cvx_index_upload: index entry %llu points outside the %u locations", (unsigned long long) i, n_locs);
+			return CVX_ERR_ARG;
+		}
+	cvx_index_s *ix = new (std::nothrow) cvx_index_s();
+	if (!ix) return CVX_ERR_OOM;
+	ix->device = h->device; ix->k = k; ix->n_index = n_index; ix->unit_offset = unit_offset; ix->n_locs = n_locs;
+	int rc = ix->d_tab.ensure((size_t) n_index);
+	if (rc == CVX_OK) rc = ix->d_used.ensure((size_t) n_index);
+	if (rc == CVX_OK) rc = ix->d_locs.ensure((size_t) n_locs + 1);
+	hipError_t e = hipSuccess;
+	if (rc == CVX_OK) {
+		e = hipMemcpy(ix->d_tab.p, tab.data(), (size_t) n_index * 4, hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(ix->d_used.p, used.data(), (size_t) n_index, hipMemcpyHostToDevice);
+		if (e == hipSuccess && n_locs) e = hipMemcpy(ix->d_locs.p, locs, (size_t) n_locs * 4, hipMemcpyHostToDevice);
+	}
+	if (rc != CVX_OK || e != hipSuccess) {
+		if (e != hipSuccess) { set_err("cvx_index_upload: %s", hipGetErrorString(e)); rc = CVX_ERR_HIP; }
+		ix->d_tab.release(); ix->d_used.release(); ix->d_locs.release(); delete ix;
+		return rc;
+	}
+	*out = ix;
+	return CVX_OK;
+	ABI_GUARD_END
+}
+
+void cvx_index_free(cvx_handle h, cvx_index ix) {
+	if (!ix) return;
+	if (h) { (void) hipSetDevice(h->device); (void) hipDeviceSynchronize(); }
+	ix->d_tab.release(); ix->d_used.release(); ix->d_locs.release();
+	delete ix;
+}
+
+int cvx_search_batch(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
+		float sensitivity, float min_hits, int32_t bin_shift,
+		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used) {
+	ABI_GUARD_BEGIN
+	static_assert(sizeof(SearchCandidate) == sizeof(cvx_candidate), "SearchCandidate mirrors cvx_candidate");
+	if (!h || !ix || n < 0 || (n > 0 && (!seqs || !lens || !n_candidates || !cand_begin)) || bin_shift < 0 || bin_shift > 30) {
+		set_err("cvx_search_batch: bad argument"); return CVX_ERR_ARG;
+	}
+	if (ix->device != h->device) { set_err("cvx_search_batch: the index lives on device %d, the handle on %d", ix->device, h->device); return CVX_ERR_ARG; }
+	if (cand_used) *cand_used = 0;
+	if (n == 0) return CVX_OK;
+	HIP_TRY(hipSetDevice(h->device));
+	hipStream_t st = h->s_main;
+	/* the reads, a NUL behind each (the N-run scan of PrefixIteration relies on the terminator) */
+	std::vector<uint64_t> off((size_t) n);
+	uint64_t bytes = 0;
+	for (int i = 0; i < n; ++i) {
+		if (!seqs[i] || lens[i] < 0) { set_err("cvx_search_batch: bad read %d", i); return CVX_ERR_ARG; }
+		off[(size_t) i] = bytes;
+		bytes += (uint64_t) lens[i] + 1;
+	}
+	std::vector<uint8_t> hseq((size_t) bytes + 64, 0);
+	for (int i = 0; i < n; ++i) memcpy(hseq.data() + off[(size_t) i], seqs[i], (size_t) lens[i]);
+	DevBuf<uint8_t> d_seq;
+	DevBuf<uint64_t> d_off, d_listoff;
+	DevBuf<int32_t> d_len, d_ncand, d_work;
+	DevBuf<unsigned long long> d_events;
+	DevBuf<float> d_maxhit, d_scores;
+	DevBuf<uint32_t> d_rlist;
+	DevBuf<SearchCandidate> d_cand;
+	DevBuf<uint64_t> d_keys;
+	auto release_all = [&]() {
+		d_seq.release(); d_off.release(); d_listoff.release(); d_len.release(); d_ncand.release(); d_work.release(); d_events.release();
+		d_maxhit.release(); d_scores.release(); d_rlist.release(); d_cand.release(); d_keys.release();
+	};
+	int rc = d_seq.ensure(hseq.size());
+	if (rc == CVX_OK) rc = d_off.ensure((size_t) n);
+	if (rc == CVX_OK) rc = d_listoff.ensure((size_t) n);
+	if (rc == CVX_OK) rc = d_len.ensure((size_t) n);
+	if (rc == CVX_OK) rc = d_ncand.ensure((size_t) n);
+	if (rc == CVX_OK) rc = d_work.ensure((size_t) n);
+	if (rc == CVX_OK) rc = d_events.ensure((size_t) n);
+	if (rc == CVX_OK) rc = d_maxhit.ensure((size_t) n);
+	if (rc != CVX_OK) { release_all(); return rc; }
+	SearchArgs a;
+	memset(&a, 0, sizeof(a));
+	a.tab = ix->d_tab.p; a.used = ix->d_used.p; a.locs = ix->d_locs.p; a.unit_offset = ix->unit_offset; a.k = ix->k;
+	a.seq = d_seq.p; a.seq_off = d_off.p; a.seq_len = d_len.p; a.n = n;
+	a.events = d_events.p; a.list_off = d_listoff.p; a.n_cand = d_ncand.p; a.max_hit = d_maxhit.p;
+	a.sensitivity = sensitivity; a.min_hits = min_hits; a.bin_shift = bin_shift;
+	std::vector<unsigned long long> events((size_t) n);
+	std::vector<uint64_t> list_off((size_t) n);
+	std::vector<int32_t> ncand((size_t) n);
+	hipError_t e = hipMemcpyAsync(d_seq.p, hseq.data(), hseq.size(), hipMemcpyHostToDevice, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_off.p, off.data(), (size_t) n * 8, hipMemcpyHostToDevice, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_len.p, lens, (size_t) n * 4, hipMemcpyHostToDevice, st);
+	if (e == hipSuccess) e = launch_search_count(a, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(events.data(), d_events.p, (size_t) n * 8, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e != hipSuccess) { set_err("cvx_search_batch: %s", hipGetErrorString(e)); release_all(); return CVX_ERR_HIP; }
+	uint64_t total = 0;
+	for (int i = 0; i < n; ++i) { list_off[(size_t) i] = total; total += events[(size_t) i]; }
+	rc = d_rlist.ensure((size_t) total + 64);
+	if (rc == CVX_OK) rc = d_cand.ensure((size_t) (2 * total) + 64);
+	if (rc != CVX_OK) { release_all(); return rc; }
+	a.rlist = d_rlist.p; a.cand = d_cand.p;
+	e = hipMemcpyAsync(d_listoff.p, list_off.data(), (size_t) n * 8, hipMemcpyHostToDevice, st);
+	/* the reference's retry ladder (CS.cpp:345-394): 2^16 entries with a probe budget of a third of the table, then
+	 * 2^18 / 2^19 / 2^20 with 0.777; reads in flight per launch bounded by the memory their vote tables take */
+	static const int kBits[4] = {16, 18, 19, 20};
+	std::vector<int32_t> work((size_t) n);
+	for (int i = 0; i < n; ++i) work[(size_t) i] = i;
+	for (int attempt = 0; attempt < 4 && !work.empty() && e == hipSuccess; ++attempt) {
+		const int bits = kBits[attempt];
+		const size_t per_read = (size_t) 1 << bits;
+		const size_t chunk = std::max<size_t>(64, std::min<size_t>(work.size(), ((size_t) 8 << 30) / (per_read * 16)));     /* <= 8 GB of tables */
+		rc = d_keys.ensure(chunk * per_read);
+		if (rc == CVX_OK) rc = d_scores.ensure(chunk * per_read * 2);
+		if (rc != CVX_OK) { release_all(); return rc; }
+		a.bits = bits;
+		a.hpoc_factor = attempt == 0 ? 0.333f : 0.777f;
+		a.keys = d_keys.p; a.scores = d_scores.p; a.work = d_work.p;
+		for (size_t w0 = 0; w0 < work.size() && e == hipSuccess; w0 += chunk) {
+			const size_t m = std::min(chunk, work.size() - w0);
+			e = hipMemcpyAsync(d_work.p, work.data() + w0, m * 4, hipMemcpyHostToDevice, st);
+			if (e == hipSuccess) e = hipMemsetAsync(d_keys.p, 0xFF, m * per_read * 8, st);          /* every slot empty */
+			a.n_work = (int32_t) m;
+			if (e == hipSuccess) e = launch_search(a, st);
+			if (e == hipSuccess) e = hipStreamSynchronize(st);      /* (the work list is reused by the next chunk) */
+		}
+		if (e == hipSuccess) e = hipMemcpy(ncand.data(), d_ncand.p, (size_t) n * 4, hipMemcpyDeviceToHost);
+		std::vector<int32_t> again;
+		for (int32_t i : work) if (ncand[(size_t) i] < 0) again.push_back(i);
+		work.swap(again);
+	}
+	if (e != hipSuccess) { set_err("cvx_search_batch: %s", hipGetErrorString(e)); release_all(); return CVX_ERR_HIP; }
+	/* dense candidate list in read order */
+	uint64_t need = 0;
+	for (int i = 0; i < n; ++i) { cand_begin[i] = need; n_candidates[i] = ncand[(size_t) i]; if (ncand[(size_t) i] > 0) need += (uint64_t) ncand[(size_t) i]; }
+	if (cand_used) *cand_used = need;
+	if (need > cand_capacity || (need > 0 && !cands)) {
+		set_err("cvx_search_batch: candidate arena too small (%llu needed, %llu given)", (unsigned long long) need, (unsigned long long) cand_capacity);
+		release_all();
+		return CVX_ERR_CAPACITY;
+	}
+	if (need) {
+		std::vector<SearchCandidate> all((size_t) (2 * total));
+		e = hipMemcpy(all.data(), d_cand.p, all.size() * sizeof(SearchCandidate), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) { set_err("cvx_search_batch: %s", hipGetErrorString(e)); release_all(); return CVX_ERR_HIP; }
+		for (int i = 0; i < n; ++i)
+			if (ncand[(size_t) i] > 0)
+				memcpy(cands + cand_begin[i], all.data() + 2 * list_off[(size_t) i], (size_t) ncand[(size_t) i] * sizeof(cvx_candidate));
+	}
+	release_all();
+	return CVX_OK;
+	ABI_GUARD_END
+}
+
 /* ------------------------------------------------------------------ sub-read scoring */
 
 int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char *const *qrys, float *scores) {

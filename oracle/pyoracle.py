@@ -203,3 +203,73 @@ class DecodeOracle:
         st = np.ascontiguousarray(starts, dtype=np.uint64)
         self.lib.decode_oracle_window(b.ctypes.data, st.ctypes.data, len(st), int(pos), int(length), out.ctypes.data)
         return out[:length].tobytes()
+
+
+# --------------------------------------------------------------------------- candidate search (search half)
+
+CS_SO = os.path.join(HERE, "libcs_oracle_port.so")
+
+
+class SearchFixture:
+    """A recorded k-mer table + candidate-search calls (tools/make_golden_cs.sh -> tests/golden/cs_test_3.npz)."""
+
+    def __init__(self, path):
+        z = np.load(path)
+        self.k = int(z["k"])
+        self.unit_offset = int(z["unit_offset"])
+        self.prefix, self.cnt, self.rc, self.locs = z["prefix"], z["cnt"], z["rc"], z["locs"]
+        off = np.concatenate([[0], np.cumsum(z["seq_len"].astype(np.int64))])
+        raw = z["seqs"].tobytes()
+        self.seqs = [raw[int(off[i]):int(off[i + 1])] for i in range(len(z["seq_len"]))]
+        so = np.concatenate([[0], np.cumsum(z["n_scores"].astype(np.int64))])
+        self.want = [(z["loc"][int(so[i]):int(so[i + 1])], z["score"][int(so[i]):int(so[i + 1])], z["rev"][int(so[i]):int(so[i + 1])])
+                     for i in range(len(self.seqs))]
+        self.max_hit, self.thresh, self.rlist_len = z["max_hit"], z["thresh"], z["rlist_len"]
+
+    def index_arrays(self):
+        """The table as ngmlr holds it (src/PrefixTable.h:17-31 Index, packed 5 bytes: uint m_TabIndex, char m_RevCompIndex;
+        src/IRefProvider.h:10-16 Location): (index bytes [(4^k + 2) * 5], locations uint32[])."""
+        n = (1 << (2 * self.k)) + 2
+        cnt_full = np.zeros(n, dtype=np.int64)
+        cnt_full[self.prefix] = self.cnt
+        tab = (1 + np.concatenate([[0], np.cumsum(cnt_full)[:-1]])).astype(np.uint32)
+        rc = np.zeros(n, dtype=np.int8)
+        rc[self.prefix] = self.rc
+        idx = np.zeros(n, dtype=np.dtype([("tab", "<u4"), ("rc", "i1")]))
+        idx["tab"], idx["rc"] = tab, rc
+        assert idx.dtype.itemsize == 5
+        return idx, np.ascontiguousarray(self.locs, dtype=np.uint32)
+
+
+class SearchOracle:
+    """cs_oracle.c: one CS::RunRead (reference src/CS.cpp:324-398) per call."""
+
+    def __init__(self, fx: "SearchFixture"):
+        if not os.path.exists(CS_SO):
+            build("port")
+        self.lib = C.CDLL(CS_SO)
+        self.lib.cs_table_create.restype = C.c_void_p
+        self.lib.cs_table_create.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        self.lib.cs_table_destroy.argtypes = [C.c_void_p]
+        self.lib.cs_search.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        p = np.ascontiguousarray(fx.prefix, dtype=np.uint32)
+        c = np.ascontiguousarray(fx.cnt, dtype=np.uint32)
+        l = np.ascontiguousarray(fx.locs, dtype=np.uint32)
+        self.t = self.lib.cs_table_create(fx.k, fx.unit_offset, len(p), p.ctypes.data, c.ctypes.data, l.ctypes.data, len(l))
+
+    def search(self, seq: bytes, sensitivity=0.8, min_hits=0.0, bin_shift=4, cap=4096):
+        loc = np.zeros(cap, dtype=np.uint64)
+        sc = np.zeros(cap, dtype=np.float32)
+        rev = np.zeros(cap, dtype=np.int32)
+        mh, th, rl, tb = C.c_float(), C.c_float(), C.c_int32(), C.c_int32()
+        n = self.lib.cs_search(self.t, seq, len(seq), sensitivity, min_hits, bin_shift, loc.ctypes.data, sc.ctypes.data, rev.ctypes.data,
+                               cap, C.byref(mh), C.byref(th), C.byref(rl), C.byref(tb))
+        m = max(0, min(n, cap))
+        return {"n": n, "loc": loc[:m].copy(), "score": sc[:m].copy(), "rev": rev[:m].copy(), "max_hit": mh.value, "thresh": th.value,
+                "rlist_len": rl.value, "table_bits": tb.value}
+
+    def close(self):
+        if self.t:
+            self.lib.cs_table_destroy(self.t)
+            self.t = None

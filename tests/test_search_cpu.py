@@ -1,0 +1,58 @@
+"""CPU: the candidate-search oracle (oracle/cs_oracle.c, a restatement of CS::RunRead: src/CS.cpp:57-149, 219-268, 324-398,
+src/CSstatic.cpp:23-73, src/PrefixTable.cpp:476-532) against every candidate-search call recorded from the unmodified
+reference on its own test_3 reads (tools/make_golden_cs.sh): the LocationScore list in the reference's own order, maxHitNumber,
+the threshold applied and the length of rList.  This is what pins the oracle the device kernel is checked against."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.pyoracle import SearchFixture, SearchOracle
+from tests import util
+
+
+def _check(fx, o, idx):
+    bad = []
+    for i in idx:
+        g = o.search(fx.seqs[i])
+        loc, sc, rev = fx.want[i]
+        if not (g["n"] == len(loc) and np.array_equal(g["loc"], loc) and np.array_equal(g["score"], sc) and np.array_equal(g["rev"], rev)
+                and g["max_hit"] == fx.max_hit[i] and g["thresh"] == fx.thresh[i] and g["rlist_len"] == fx.rlist_len[i]):
+            bad.append(i)
+    return bad
+
+
+def test_oracle_reproduces_recorded_candidate_searches(built):
+    fx = SearchFixture(os.path.join(util.GOLDEN, "cs_test_3.npz"))
+    assert len(fx.seqs) > 900 and sum(len(w[0]) for w in fx.want) > 1000
+    o = SearchOracle(fx)
+    assert _check(fx, o, range(len(fx.seqs))) == []
+    o.close()
+
+
+def test_oracle_reproduces_every_recorded_candidate_search(built):
+    path = util.full_golden_path("cs_test_3_full.npz")
+    if path is None:
+        pytest.skip("oracle/_ref/golden_full/cs_test_3_full.npz not generated (tools/make_golden_cs.sh needs /root/reference)")
+    fx = SearchFixture(path)
+    assert len(fx.seqs) == 5663
+    o = SearchOracle(fx)
+    assert _check(fx, o, range(len(fx.seqs))) == []
+    o.close()
+
+
+def test_n_runs_and_the_retry_ladder(built):
+    """Behaviour the recorded reads do not reach: windows holding 'N' are skipped (with the quirk that a run of N at the start of
+    a restarted stretch ends the walk when 13 or fewer characters follow), and a read whose votes overflow the probe budget
+    of the 2^16-entry table is searched again with 2^18 / 2^19 / 2^20 entries (src/CS.cpp:345-394)."""
+    fx, reads = util.synthetic_search_case()
+    o = SearchOracle(fx)
+    res = [o.search(r) for r in reads]
+    o.close()
+    bits = [r["table_bits"] for r in res if r["n"] >= 0]
+    assert 16 in bits and max(bits) > 16                                  # both the first attempt and a retry happened
+    clean, with_n = res[0], res[1]
+    assert clean["n"] > 0 and 0 <= with_n["n"]
+    # 13 characters behind a run of two N: nothing from that tail; behind a single N: one k-mer
+    a, b = res[2], res[3]
+    assert a["max_hit"] < b["max_hit"] or a["n"] <= b["n"]

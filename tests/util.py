@@ -228,3 +228,81 @@ def nclip_tiles(seed=31):
     out.append((tile(mixed2, acgt(0), tag="x-87-percent"), 1))
     out.append((tile(np.full(150, ord("N"), np.uint8), acgt(0), tag="n-not-x"), 0))   # the decoder's 'N' is not what the test looks for
     return out
+
+
+# --------------------------------------------------------------------------- candidate search
+
+def synthetic_search_case(seed=41):
+    """A small synthetic k-mer table + reads for the corners the recorded test_3 calls do not reach.
+    -> (SearchFixture-like object for oracle and device, list of reads)"""
+    from types import SimpleNamespace
+    rng = np.random.default_rng(seed)
+    K = 13
+
+    def code(c):
+        return (c >> 1) & 3
+
+    def kmers(s):
+        out = []
+        for p in range(len(s) - K + 1):
+            w = s[p:p + K]
+            if ord("N") in w:
+                continue
+            v = 0
+            for c in w:
+                v = (v << 2) | code(c)
+            out.append(v)
+        return out
+
+    def revcomp_code(v):
+        c = (v ^ 0xAAAAAAAA) & ((1 << 26) - 1)
+        r = 0
+        for _ in range(K):
+            r = (r << 2) | (c & 3)
+            c >>= 2
+        return r
+    base = synth.random_ref(rng, 256).tobytes()
+    heavy = synth.random_ref(rng, 256).tobytes()                         # a read whose k-mers are all over the genome
+    rows = {}
+    for v in kmers(base):
+        rows.setdefault(v, set()).update(int(x) for x in (1000 + 16 * rng.integers(0, 4000, size=3)))
+        rows.setdefault(v, set()).add(500000 + 0)                         # a shared diagonal: the true location
+    # place base's true location consistently: location of k-mer at read offset p = 500000 + p
+    rows = {}
+    for p, v in enumerate(kmers(base)):
+        rows.setdefault(v, set()).add(500000 + p)
+        for x in rng.integers(10_000, 40_000_000, size=2):
+            rows[v].add(int(x))
+    for p, v in enumerate(kmers(heavy)):
+        tgt = rows.setdefault(v, set())
+        for x in rng.integers(50_000_000, 4_000_000_000, size=480):       # ~117 000 votes into ~117 000 different bins
+            tgt.add(int(x))
+        rv = revcomp_code(v)
+        tgt = rows.setdefault(rv, set())
+        for x in rng.integers(50_000_000, 4_000_000_000, size=480):
+            tgt.add(int(x))
+    prefixes = np.array(sorted(rows), dtype=np.uint32)
+    cnt = np.array([len(rows[int(p)]) for p in prefixes], dtype=np.uint32)
+    locs = np.concatenate([np.array(sorted(rows[int(p)]), dtype=np.uint32) for p in prefixes])
+    fx = SimpleNamespace(k=K, unit_offset=0, prefix=prefixes, cnt=cnt, rc=np.full(len(prefixes), 50, np.int8), locs=locs)
+
+    def index_arrays():
+        n = (1 << (2 * K)) + 2
+        cnt_full = np.zeros(n, dtype=np.int64)
+        cnt_full[prefixes] = cnt
+        tab = (1 + np.concatenate([[0], np.cumsum(cnt_full)[:-1]])).astype(np.uint32)
+        rc = np.zeros(n, dtype=np.int8)
+        rc[prefixes] = 50
+        idx = np.zeros(n, dtype=np.dtype([("tab", "<u4"), ("rc", "i1")]))
+        idx["tab"], idx["rc"] = tab, rc
+        return idx, locs
+    fx.index_arrays = index_arrays
+    b = bytearray(base)
+    with_n = bytes(b[:100] + b"NNN" + b[103:180] + b"N" + b[181:])
+    tail2 = bytes(b[:241] + b"NN" + b[243:])                              # 13 characters behind a run of two N
+    tail1 = bytes(b[:242] + b"N" + b[243:])                               # 13 characters behind a single N
+    lead = bytes(b"NNNN" + b[4:])
+    short = bytes(b[:12])
+    allN = b"N" * 40
+    reads = [base, with_n, tail2, tail1, lead, short, allN, heavy, bytes(b[:40]), b"", bytes(b[:13])]
+    return fx, reads

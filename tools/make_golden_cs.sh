@@ -1,0 +1,96 @@
+#!/bin/bash
+# tools/make_golden_cs.sh -- harvest candidate-search fixtures from the UNMODIFIED reference pipeline.
+#
+# A fresh /tmp copy of /root/reference gets two pass-through recorder hooks, switched on by environment variables:
+#   CS::CollectResultsStd (src/CS.cpp:219-268)   every sub-read it was called for and the LocationScore list it produced
+#                                                 (in list order), plus maxHitNumber / the threshold it applied
+#   CompactPrefixTable::CompactPrefixTable        the k-mer table the search ran on, in compact form: the used prefixes with
+#   (src/PrefixTable.cpp:97-131)                  their slot counts and the RefTable (the 4^13 + 1 entry index is a running
+#                                                 sum over those, GetRefEntry reads nothing else: src/PrefixTable.cpp:476-532)
+# ngmlr then maps the reference's own test_3 reads; tools/pack_golden_cs.py turns the dumps into tests/golden/cs_test_3.npz
+# (a sample) and oracle/_ref/golden_full/cs_test_3_full.npz (every sub-read).  Nothing is written to /root/reference; no
+# reference source enters this repository.  Needs /root/reference, cmake, zlib (this container only).
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REPO="$(dirname "$HERE")"
+WORK="$(mktemp -d /tmp/ngmlr_cs.XXXXXX)"
+cp -r /root/reference "$WORK/src_tree"
+T="$WORK/src_tree"
+python3 - "$T/src" <<'PY'
+import sys
+src = sys.argv[1]
+p = src + '/CS.cpp'
+s = open(p).read()
+anchor = '\tstatic int const maxScores = Config.getMaxCMRs();'
+assert s.count(anchor) == 1
+s = s.replace(anchor, """\tif (getenv("CVX_RECORD_CS")) {   /* recorder hook (tools/make_golden_cs.sh), not part of the reference */
+		static pthread_mutex_t cvx_m = PTHREAD_MUTEX_INITIALIZER;
+		pthread_mutex_lock(&cvx_m);
+		FILE * cf = fopen(getenv("CVX_RECORD_CS"), "ab");
+		int len = read->length, nn = index, rl = rListLength;
+		float mh = maxHitNumber, th = mi_Threshhold;
+		fwrite(&len, 4, 1, cf); fwrite(read->Seq, 1, (size_t) len, cf);
+		fwrite(&mh, 4, 1, cf); fwrite(&th, 4, 1, cf); fwrite(&rl, 4, 1, cf); fwrite(&nn, 4, 1, cf);
+		for (int q = 0; q < nn; ++q) {
+			unsigned long long l = tmp[q].Location.m_Location; float f = tmp[q].Score.f; int r = tmp[q].Location.isReverse() ? 1 : 0;
+			fwrite(&l, 8, 1, cf); fwrite(&f, 4, 1, cf); fwrite(&r, 4, 1, cf);
+		}
+		fclose(cf);
+		pthread_mutex_unlock(&cvx_m);
+	}
+""" + anchor)
+s = s.replace('#include <memory.h>', '#include <memory.h>\n#include <pthread.h>', 1)
+open(p, 'w').write(s)
+p = src + '/PrefixTable.cpp'
+s = open(p).read()
+anchor = '\tdelete[] cacheFile;\n\tcacheFile = 0;'
+assert s.count(anchor) == 1
+s = s.replace(anchor, """\tif (getenv("CVX_RECORD_TABLE")) {   /* recorder hook (tools/make_golden_cs.sh), not part of the reference */
+		FILE * tf = fopen(getenv("CVX_RECORD_TABLE"), "wb");
+		unsigned int k = m_PrefixLength, units = (unsigned int) m_UnitCount, skip = m_RefSkip;
+		unsigned int indexLength = (unsigned int) pow(4.0, (double) m_PrefixLength) + 1;
+		fwrite(&k, 4, 1, tf); fwrite(&units, 4, 1, tf); fwrite(&skip, 4, 1, tf);
+		for (int u = 0; u < m_UnitCount; ++u) {
+			TableUnit & cu = m_Units[u];
+			unsigned long long off = cu.Offset; unsigned int tl = cu.cRefTableLen, nused = 0;
+			for (unsigned int q = 0; q < indexLength - 1; ++q) if (cu.RefTableIndex[q].used()) nused++;
+			fwrite(&off, 8, 1, tf); fwrite(&tl, 4, 1, tf); fwrite(&nused, 4, 1, tf);
+			for (unsigned int q = 0; q < indexLength - 1; ++q) if (cu.RefTableIndex[q].used()) {
+				unsigned int cnt = cu.RefTableIndex[q + 1].m_TabIndex - cu.RefTableIndex[q].m_TabIndex, ti = cu.RefTableIndex[q].m_TabIndex;
+				signed char rc = cu.RefTableIndex[q].m_RevCompIndex;
+				fwrite(&q, 4, 1, tf); fwrite(&ti, 4, 1, tf); fwrite(&cnt, 4, 1, tf); fwrite(&rc, 1, 1, tf);
+			}
+			fwrite(cu.RefTable, 4, (size_t) tl, tf);
+		}
+		fclose(tf);
+	}
+""" + anchor)
+open(p, 'w').write(s)
+PY
+mkdir -p "$T/build" && cd "$T/build"
+cmake .. -DCMAKE_POLICY_VERSION_MINIMUM=3.5 -DCMAKE_BUILD_TYPE=RELWITHDEBINFO > "$WORK/cmake.log" 2>&1
+make -j16 > "$WORK/make.log" 2>&1 || { tail -30 "$WORK/make.log"; exit 1; }
+BIN=$(ls "$T"/bin/ngmlr-*/ngmlr)
+D="$T/test/data"
+python3 - "$D/test_3/read.fa.gz" "$WORK/test_3.fq" <<'PY'
+import sys, gzip
+name = None; seq = []
+out = open(sys.argv[2], 'w')
+def flush():
+    if name is not None:
+        s = ''.join(seq)
+        out.write('@%s\n%s\n+\n%s\n' % (name, s, 'I' * len(s)))
+for line in gzip.open(sys.argv[1], 'rt'):
+    line = line.rstrip()
+    if line.startswith('>'):
+        flush(); name = line[1:]; seq = []
+    else:
+        seq.append(line)
+flush(); out.close()
+PY
+CVX_RECORD_CS="$WORK/test_3.cs" CVX_RECORD_TABLE="$WORK/test_3.table" "$BIN" --skip-write -x pacbio -t 1 -R 0.01 --no-progress \
+	-r "$D/test_3/reference.fasta.gz" -q "$WORK/test_3.fq" > "$WORK/test_3.sam" 2> "$WORK/test_3.log" || true
+echo "test_3: $(stat -c %s "$WORK/test_3.cs") bytes of sub-read records, $(stat -c %s "$WORK/test_3.table") bytes of table"
+mkdir -p "$REPO/oracle/_ref/golden_full"
+python3 "$HERE/pack_golden_cs.py" "$WORK/test_3.cs" "$WORK/test_3.table" "$REPO/tests/golden/cs_test_3.npz" "$REPO/oracle/_ref/golden_full/cs_test_3_full.npz"
+rm -rf "$WORK"

@@ -1,0 +1,54 @@
+"""tools/pack_golden_cs.py CS_DUMP TABLE_DUMP SAMPLE.npz FULL.npz -- the recorder dumps of tools/make_golden_cs.sh as fixtures:
+the k-mer table in compact form (used prefixes, slot counts, RefTable, unit offset) and the recorded candidate-search calls
+(sub-read -> LocationScore list in the reference's order, maxHitNumber, threshold).  SAMPLE keeps every `stride`-th sub-read."""
+import struct
+import sys
+
+import numpy as np
+
+
+def read_table(path):
+    d = open(path, 'rb').read()
+    k, units, skip = struct.unpack_from('<3I', d, 0)
+    pos = 12
+    assert units == 1, "fixtures cover one table unit (genomes below 4 Gbp)"
+    off, tl, nused = struct.unpack_from('<QII', d, pos); pos += 16
+    rec = np.frombuffer(d, dtype=np.dtype([('prefix', '<u4'), ('tab', '<u4'), ('cnt', '<u4'), ('rc', 'i1')]), count=nused, offset=pos)
+    pos += nused * 13
+    locs = np.frombuffer(d, dtype='<u4', count=tl, offset=pos).copy()
+    return dict(k=k, skip=skip, offset=off, prefix=rec['prefix'].copy(), tab=rec['tab'].copy(), cnt=rec['cnt'].copy(), rc=rec['rc'].copy(), locs=locs)
+
+
+def read_cs(path):
+    d = open(path, 'rb').read()
+    pos = 0
+    out = []
+    while pos < len(d):
+        n, = struct.unpack_from('<i', d, pos); pos += 4
+        seq = d[pos:pos + n]; pos += n
+        mh, th, rl, nn = struct.unpack_from('<ffii', d, pos); pos += 16
+        rec = np.frombuffer(d, dtype=np.dtype([('loc', '<u8'), ('score', '<f4'), ('rev', '<i4')]), count=nn, offset=pos).copy()
+        pos += 16 * nn
+        out.append((seq, mh, th, rl, rec))
+    return out
+
+
+def pack(table, calls, out):
+    seqs = b''.join(c[0] for c in calls)
+    lens = np.array([len(c[0]) for c in calls], dtype=np.int32)
+    cnt = np.array([len(c[4]) for c in calls], dtype=np.int32)
+    recs = np.concatenate([c[4] for c in calls]) if calls else np.zeros(0, dtype=[('loc', '<u8'), ('score', '<f4'), ('rev', '<i4')])
+    np.savez_compressed(out, k=np.int32(table['k']), ref_skip=np.int32(table['skip']), unit_offset=np.uint64(table['offset']),
+                        prefix=table['prefix'], tab=table['tab'], cnt=table['cnt'], rc=table['rc'], locs=table['locs'],
+                        seqs=np.frombuffer(seqs, dtype=np.uint8), seq_len=lens, max_hit=np.array([c[1] for c in calls], dtype=np.float32),
+                        thresh=np.array([c[2] for c in calls], dtype=np.float32), rlist_len=np.array([c[3] for c in calls], dtype=np.int32),
+                        n_scores=cnt, loc=recs['loc'], score=recs['score'], rev=recs['rev'])
+
+
+if __name__ == '__main__':
+    table = read_table(sys.argv[2])
+    calls = read_cs(sys.argv[1])
+    print("table: k=%d, %d used prefixes, %d locations; %d recorded sub-reads, %d candidates" % (
+        table['k'], len(table['prefix']), len(table['locs']), len(calls), sum(len(c[4]) for c in calls)))
+    pack(table, calls, sys.argv[4])
+    pack(table, calls[::6], sys.argv[3])
