@@ -146,6 +146,26 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 		}
 		const int n = lo - y + 1;
 		if (n > need) need = n;
+		if (H > 32767) {
+			/* How long can a gap run get in this corridor?  A deletion run stays inside one row (<= its length, tracked
+			 * above); an insertion run stays inside one column, i.e. inside the consecutive rows that contain it: for the
+			 * last column of row y those are the rows up to the first one that starts at or behind hi(y) (row starts do not
+			 * decrease in a regular corridor).  Only when such a stretch exceeds SHRT_MAX can the reference's `short
+			 * indelRun` wrap (src/AlignmentMatrixFast.h:43) and the int16-emulating kernels are needed -- a 100 kb read on
+			 * a 350-column corridor never gets there, and the float-run kernels are three times as fast. */
+			long long lo_y = ol.x > 0 ? ol.x : 0;
+			long long hi_y = (long long) ol.x + (long long) ol.y;
+			if (hi_y > W) hi_y = W;
+			if (hi_y < lo_y) hi_y = lo_y;
+			int a = y + 1, b = H;                    /* rows < a start before hi(y), rows >= b do not */
+			while (a < b) {
+				const int mid = (a + b) >> 1;
+				const int2 om = r[mid];
+				const long long lo_m = om.x > 0 ? om.x : 0;
+				if (lo_m < hi_y) a = mid + 1; else b = mid;
+			}
+			if (a - y > maxlen) maxlen = a - y;      /* folded into the same maximum: either kind of run past 32767 needs the wrap kernels */
+		}
 	}
 	if (H > 0) {
 		atomicAdd(&s_cells[sub], cells);
@@ -170,7 +190,9 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 		/* src/AlignmentMatrixFast.cpp:45: (ulong)(matrixSize / 1000.0f / 1000.0f) < maxMatrixSizeMB */
 		const float mb = (float) s_cells[sub] / 1000.0f / 1000.0f;
 		if (!((unsigned long long) mb < max_matrix_mb)) f |= kPlanTooLarge;
-		if (H > 32767 || s_maxlen[sub] > 32767) f |= kPlanWrap16;
+		/* longest possible deletion (row length) or insertion (column extent, rows above) run; the column bound needs
+		 * row starts that do not decrease, so an irregular corridor that tall keeps the old rule */
+		if (s_maxlen[sub] > 32767 || (H > 32767 && (f & kPlanIrregular))) f |= kPlanWrap16;
 		p.r0 = r0;
 		p.rend = rend;
 		p.flags = f;
@@ -491,6 +513,10 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 #define CVX_FILL_SCHED 0
 #endif
 
+#ifndef CVX_FILL_PRIO
+#define CVX_FILL_PRIO 1
+#endif
+
 enum FillMode { kFillTwoPhase = 0, kFillExact = 1, kFillChain = 2 };
 
 /*
@@ -559,6 +585,13 @@ fill_ring_kernel(const FillArgs a) {
 		y0 = ct.y0;
 	} else {
 		t = a.list[blockIdx.x];
+#if CVX_FILL_PRIO
+		/* The list is longest-first and a tile is a serial chain of steps: in a batch of uneven tiles (ONT mix: median
+		 * 1.3 kb, up to 20 kb) the launch lasts as long as its longest tiles take at a sixth of a SIMD.  The first
+		 * sixteenth of the list runs at raised wave priority: those waves proceed at nearly a whole SIMD's pace, the short
+		 * tiles fill in behind them.  (A batch of equal tiles -- the PacBio bench -- is unaffected.) */
+		if (blockIdx.x < (unsigned) (a.list_n >> 4)) __builtin_amdgcn_s_setprio(2);
+#endif
 		if (MODE == kFillExact) {
 			if (a.tout[t].pad != kPadRedo) return;   /* block-uniform */
 			if (tid == 0) atomicAdd(a.redo_count, 1);
