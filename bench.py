@@ -574,6 +574,53 @@ def main() -> int:
             text_dev = {"Gbp_per_h": float(ts.read_bases) / dtd * 3600.0 / 1e9, "seconds": dtd, "tiles": len(ts), "text_bytes": len(tbuf),
                         "equal_to_host_form": "%d/%d" % (len(host_txt) - nbad, len(host_txt)),
                         "what": "cvx_job_text: text_kernel (lengths + fields), offsets scan, text_kernel (strings), D2H of the dense text"}
+            # SAM record assembly (cvx_sam_batch, host pack threads) fed straight from the device text: one record per tile
+            try:
+                import ctypes as C
+                kk = min(len(ts), 8192)
+                tab_ = ts.table()
+                base_ = C.addressof(tbuf)
+                recs_ = (capi.CvxSamRecord * kk)()
+                for i_ in range(kk):
+                    t_, r_ = trec[i_], recs_[i_]
+                    r_.read_name = b"synthetic_read"; r_.seq = C.cast(int(tab_[i_]["qry"]), C.c_char_p); r_.qual = None
+                    r_.read_length = int(tab_[i_]["qry_len"]); r_.flags = 0; r_.primary = 1; r_.reverse = 0
+                    r_.ref_name = b"chrS"; r_.ref_name_len = 4; r_.location = 1000 + t_.position_offset; r_.mq = 60
+                    r_.cigar = C.cast(base_ + int(toff[i_]), C.c_char_p); r_.md = C.cast(base_ + int(toff[i_]) + t_.cigar_len + 1, C.c_char_p)
+                    r_.cigar_op_count = t_.cigar_op_count; r_.mate_ref_name = b"*"; r_.mate_location = -1; r_.template_length = 0
+                    r_.score = t_.score; r_.nm = t_.nm; r_.identity = t_.identity; r_.qstart = t_.qstart; r_.qend = t_.qend; r_.sv_type = t_.sv_type
+                    r_.n_others = 0; r_.others = None; r_.rg_id = None; r_.hard_clip = 0; r_.bam_cigar_fix = 0; r_.skip = 0
+                offs_ = np.zeros(kk + 1, dtype=np.uint64)
+                w0.al.lib.cvx_sam_batch(kk, recs_, None, 0, offs_.ctypes.data)              # sizes
+                sam_ = C.create_string_buffer(int(offs_[kk]))
+                c0 = time.perf_counter()
+                rc_ = w0.al.lib.cvx_sam_batch(kk, recs_, sam_, int(offs_[kk]), offs_.ctypes.data)
+                dsam = time.perf_counter() - c0
+                valid_ = sum(1 for i_ in range(kk) if trec[i_].ret >= 0)
+                text_dev["sam_records"] = {"records": kk, "valid_alignments": valid_, "bytes": int(offs_[kk]), "seconds": dsam, "rc": rc_,
+                                           "records_per_s": kk / dsam, "GB_per_s": int(offs_[kk]) / dsam * 1e-9,
+                                           "Gbp_per_h": float(ts.H[:kk].sum()) / dsam * 3600.0 / 1e9,
+                                           "what": "cvx_sam_batch: SAMWriter::DoWriteReadGeneric's record (mandatory fields + AS NM XI XS XE XR MD SV QS QE CV) on the pack threads, CIGAR / MD taken from cvx_job_text's buffer"}
+                del sam_, recs_
+            except Exception as e:
+                text_dev["sam_records"] = {"error": str(e)}
+            # nmPerPosition on the device (cvx_job_nm_profile): kernel alone for a range that fits comfortably (12 B per column),
+            # and the same range brought to the host
+            try:
+                kk = min(len(ts), 4096)
+                w0.last.nm_profile(0, kk, to_host=False)
+                off_, _, kms = w0.last.nm_profile(0, kk, to_host=False)
+                c0 = time.perf_counter()
+                off_, tri_, _ = w0.last.nm_profile(0, kk, to_host=True)
+                dnm = time.perf_counter() - c0
+                ent = int(off_[kk])
+                text_dev["nm_profile"] = {"tiles": kk, "entries": ent, "kernel_ms": kms, "kernel_GB_per_s": ent * 12e-6 / max(kms, 1e-9),
+                                          "kernel_Gbp_per_h": float(ts.H[:kk].sum()) / max(kms, 1e-9) * 3.6e-3,
+                                          "to_host_seconds": dnm, "to_host_Gbp_per_h": float(ts.H[:kk].sum()) / dnm * 3600.0 / 1e9,
+                                          "what": "nm_profile_kernel (12 B per EQ/X/D column written to HBM); to_host = the same + D2H into pageable memory incl. this bench's python"}
+                del tri_
+            except Exception as e:
+                text_dev["nm_profile"] = {"error": str(e)}
         except Exception as e:
             text_dev = {"error": str(e)}
         valid = w0.valid

@@ -31,6 +31,9 @@
  *                             src/AlignmentBuffer.cpp:68-197 (a8: the builders stay in ngmlr, their output need not travel)
  * cvx_format_alignment        convertCigar + N-clip flags    src/ConvexAlignFast.cpp:112-333,493-528
  * cvx_job_text                the same for a whole finished job, on the device (next-row f3)
+ * cvx_job_nm_profile          addPosition / nmPerPosition    src/ConvexAlignFast.cpp:76-98,186-269, on the device
+ * cvx_sam_record_text / cvx_sam_batch  SAMWriter::DoWriteReadGeneric  src/SAMWriter.cpp:87-224 (f3: SAM record assembly)
+ * cvx_sam_unmapped_text       SAMWriter::DoWriteUnmappedReadGeneric  src/SAMWriter.cpp:308-357
  * cvx_score_batch             StrippedSW::BatchScore/SingleScore  src/StrippedSW.cpp:118-203 (next-row f2)
  * cvx_genome_* / cvx_submit_windows  SequenceProvider's 4-bit genome + DecodeRefSequenceExact
  *                             src/SequenceProvider.cpp:333-386,475-565 (next-row f4, decode half)
@@ -382,6 +385,93 @@ int cvx_format_batch(int32_t n, const cvx_result *results, const uint32_t *ops_a
  * NUL-terminated string at (*text)[text_off[i]], its MD follows that NUL. */
 int cvx_job_text(cvx_handle h, cvx_job job, const int32_t *ext_qstart, const int32_t *ext_qend,
 		cvx_alignment_text *out, uint64_t *text_off, const char **text, uint64_t *text_bytes);
+
+/* nmPerPosition (reference src/ConvexAlignFast.cpp:76-98,186-269: one (refPosition, readPosition, nm) triple per
+ * EQ / X / D column once both positions passed 16; read by detectMisalignment, src/AlignmentBuffer.cpp:1320) of the
+ * tiles [first, first + count) of a finished job, computed on the device from the resident ops.  After cvx_job_text
+ * (which counts the entries: cvx_alignment_text.nm_count) and before cvx_job_release.  entry_off[count + 1]: tile
+ * first + i owns the triples [entry_off[i], entry_off[i + 1]).  triples: room for cap_entries triples of three
+ * int32 (CVX_ERR_CAPACITY, with entry_off filled in, when that is too little) -- or NULL: the profile stays in HBM
+ * (a consumer on the device; measurement).  A range, not the whole job, because the profile is 12 bytes per column:
+ * several GB for a full batch of long reads.  *kernel_ms (may be NULL): the kernel's own duration. */
+int cvx_job_nm_profile(cvx_handle h, cvx_job job, int32_t first, int32_t count, uint64_t *entry_off,
+		int32_t *triples, uint64_t cap_entries, double *kernel_ms);
+
+/* The same kernel over op lists the caller holds (someone who kept cvx_result + ops and released the job): tile i's
+ * ops are ops_arena[results[i].ops_begin ... + n_ops), ops_total = ints in the arena.  entry_off[n + 1] as above;
+ * triples == NULL: sizes only. */
+int cvx_nm_profile_ops(cvx_handle h, int32_t n, const cvx_result *results, const uint32_t *ops_arena, uint64_t ops_total,
+		uint64_t *entry_off, int32_t *triples, uint64_t cap_entries);
+
+/* ---- SAM record assembly (reference src/SAMWriter.cpp:87-224, :308-357) ----
+ *
+ * The text of one SAM record from the fields ngmlr's writer holds (MappedRead, its LocationScore and Align), byte
+ * for byte what SAMWriter::DoWriteReadGeneric prints: mandatory fields, then RG AS NM XI XS XE XR MD SV SA QS QE CV,
+ * "<read length>S" + CG:B:I when bam_cigar_fix is set and the CIGAR has 65 536 operations or more, hard clipping.
+ * Positions are the reference's 0-based Location.m_Location; the record prints + 1 (report_offset, :19). */
+typedef struct {              /* another alignment of the same read: one SA:Z entry (:183-204) */
+	const char *ref_name;     /* SequenceProvider.GetRefName(Location.getrefId(), len) */
+	int32_t ref_name_len;
+	uint32_t location;        /* Location.m_Location */
+	int32_t reverse;          /* Location.isReverse() */
+	const char *cigar;        /* Align::pBuffer1 */
+	int32_t mq, nm;           /* Align::MQ, Align::NM */
+} cvx_sam_other;
+
+typedef struct {
+	const char *read_name;    /* MappedRead::name */
+	const char *seq;          /* MappedRead::Seq, or RevSeq for a reverse-strand record (:101-108) */
+	char *qual;               /* MappedRead::qlty or NULL ("*").  Reversed IN PLACE over [0, read_length) when the record is
+	                           * on the reverse strand and the string is not empty -- every time such a record is written, as
+	                           * the reference does (:104-106) */
+	int32_t read_length;      /* MappedRead::length */
+	int32_t flags;            /* the caller's flags; 0x800 (not primary) and 0x10 (reverse) are added here (:97-108) */
+	int32_t primary;          /* Align::primary */
+	int32_t reverse;
+	const char *ref_name;
+	int32_t ref_name_len;
+	uint32_t location;
+	int32_t mq;               /* Align::MQ */
+	const char *cigar;        /* Align::pBuffer1 */
+	const char *md;           /* Align::pBuffer2 */
+	int32_t cigar_op_count;   /* Align::cigarOpCount */
+	const char *mate_ref_name;/* pRefName: "*", "=" or a name */
+	int32_t mate_location;    /* pLoc (-1 for none) */
+	int32_t template_length;  /* pDist */
+	float score;              /* Scores[scoreID].Score.f: AS and XE print (int) score */
+	int32_t nm;               /* Align::NM */
+	float identity;           /* Align::Identity: XI prints round(identity * 10000) / 10000 with %g */
+	int32_t qstart, qend;     /* Align::QStart / QEnd */
+	int32_t sv_type;          /* Align::svType: SV:i printed when > -1 */
+	int32_t n_others;         /* the read's other alignments that are not skipped, in order (i != scoreID && !Alignments[i].skip) */
+	const cvx_sam_other *others;
+	const char *rg_id;        /* Config.getRgId() or NULL */
+	int32_t hard_clip;        /* Config.getHardClip() */
+	int32_t bam_cigar_fix;    /* Config.getBamCigarFix() */
+	int32_t skip;             /* Align::skip */
+} cvx_sam_record;
+
+typedef struct {              /* DoWriteUnmappedReadGeneric (:308-357); flags |= 0x4 */
+	const char *read_name, *seq;
+	const char *qual;         /* NULL: "*" */
+	int32_t read_length, flags;
+	const char *ref_name;     /* NULL: "*" (refId -1) */
+	int32_t ref_name_len;
+	int32_t location;         /* loc: printed + 1 */
+	char mate_ref;            /* pRefName, one character */
+	int32_t mate_location, template_length;
+	const char *rg_id;
+} cvx_sam_unmapped;
+
+/* One record (the trailing '\n' included, no NUL).  *len = bytes of the record; CVX_ERR_CAPACITY when cap is smaller
+ * (nothing is reversed then, the call can be repeated). */
+int cvx_sam_record_text(cvx_sam_record *r, char *out, uint64_t cap, uint64_t *len);
+int cvx_sam_unmapped_text(const cvx_sam_unmapped *r, char *out, uint64_t cap, uint64_t *len);
+
+/* n records on the process's pack threads: record i is out[offsets[i] ... offsets[i + 1]).  Same bytes as n calls of
+ * cvx_sam_record_text in order -- including the quality strings' in-place reversal when several records share one
+ * (two records of one read).  CVX_ERR_CAPACITY with offsets[n] = the need when cap is too small (nothing reversed). */
+int cvx_sam_batch(int32_t n, cvx_sam_record *recs, char *out, uint64_t cap, uint64_t *offsets);
 
 #ifdef __cplusplus
 }

@@ -215,6 +215,21 @@ class Job:
             res.append(d)
         return res
 
+    def nm_profile(self, first: int = 0, count: Optional[int] = None, to_host: bool = True):
+        """cvx_job_nm_profile (after text()/text_raw()): nmPerPosition of the tiles [first, first + count) from the device.
+        -> (entry offsets uint64[count + 1], triples int32[entries, 3] or None when to_host is False, kernel ms)"""
+        count = self.n - first if count is None else count
+        off = np.zeros(count + 1, dtype=np.uint64)
+        ms = C.c_double()
+        lib = self.al.lib
+        # sizes first (a NULL buffer leaves the profile in HBM), then the real call when the caller wants it
+        capi.check(lib.cvx_job_nm_profile(self.al.h, self.j, first, count, off.ctypes.data, None, 0, C.byref(ms)))
+        if not to_host:
+            return off, None, ms.value
+        tri = np.zeros((int(off[count]), 3), dtype=np.int32)
+        capi.check(lib.cvx_job_nm_profile(self.al.h, self.j, first, count, off.ctypes.data, tri.ctypes.data, int(off[count]), C.byref(ms)))
+        return off, tri, ms.value
+
     def release(self) -> None:
         if self.j:
             self.al.lib.cvx_job_release(self.al.h, self.j)

@@ -26,7 +26,8 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_genome_encoded_bytes", "cvx_genome_encode", "cvx_genome_upload", "cvx_genome_free",
            "cvx_genome_decode", "cvx_submit_windows", "cvx_job_text",
            "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id", "cvx_job_poll", "cvx_score_kernel_ms",
-           "cvx_index_upload", "cvx_index_free", "cvx_search_batch")
+           "cvx_index_upload", "cvx_index_free", "cvx_search_batch", "cvx_job_nm_profile", "cvx_nm_profile_ops",
+           "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch")
 
 
 class CvxParams(C.Structure):
@@ -73,6 +74,28 @@ class CvxAlignmentText(C.Structure):
                 ("first_ref", C.c_int32), ("first_read", C.c_int32), ("last_ref", C.c_int32),
                 ("last_read", C.c_int32), ("nm_count", C.c_int32), ("cigar_len", C.c_int32),
                 ("md_len", C.c_int32)]
+
+
+class CvxSamOther(C.Structure):
+    _fields_ = [("ref_name", C.c_char_p), ("ref_name_len", C.c_int32), ("location", C.c_uint32), ("reverse", C.c_int32),
+                ("cigar", C.c_char_p), ("mq", C.c_int32), ("nm", C.c_int32)]
+
+
+class CvxSamRecord(C.Structure):
+    _fields_ = [("read_name", C.c_char_p), ("seq", C.c_char_p), ("qual", C.c_void_p), ("read_length", C.c_int32),
+                ("flags", C.c_int32), ("primary", C.c_int32), ("reverse", C.c_int32), ("ref_name", C.c_char_p),
+                ("ref_name_len", C.c_int32), ("location", C.c_uint32), ("mq", C.c_int32), ("cigar", C.c_char_p),
+                ("md", C.c_char_p), ("cigar_op_count", C.c_int32), ("mate_ref_name", C.c_char_p),
+                ("mate_location", C.c_int32), ("template_length", C.c_int32), ("score", C.c_float), ("nm", C.c_int32),
+                ("identity", C.c_float), ("qstart", C.c_int32), ("qend", C.c_int32), ("sv_type", C.c_int32),
+                ("n_others", C.c_int32), ("others", C.POINTER(CvxSamOther)), ("rg_id", C.c_char_p),
+                ("hard_clip", C.c_int32), ("bam_cigar_fix", C.c_int32), ("skip", C.c_int32)]
+
+
+class CvxSamUnmapped(C.Structure):
+    _fields_ = [("read_name", C.c_char_p), ("seq", C.c_char_p), ("qual", C.c_char_p), ("read_length", C.c_int32),
+                ("flags", C.c_int32), ("ref_name", C.c_char_p), ("ref_name_len", C.c_int32), ("location", C.c_int32),
+                ("mate_ref", C.c_char), ("mate_location", C.c_int32), ("template_length", C.c_int32), ("rg_id", C.c_char_p)]
 
 
 class CvxTextBuffers(C.Structure):
@@ -141,6 +164,11 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_submit_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(CvxTile), C.c_void_p, C.POINTER(C.c_void_p)]
     lib.cvx_job_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CvxAlignmentText), C.c_void_p,
                                  C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    lib.cvx_job_nm_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
+    lib.cvx_nm_profile_ops.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.cvx_sam_record_text.argtypes = [C.POINTER(CvxSamRecord), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.cvx_sam_unmapped_text.argtypes = [C.POINTER(CvxSamUnmapped), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.cvx_sam_batch.argtypes = [C.c_int32, C.POINTER(CvxSamRecord), C.c_void_p, C.c_uint64, C.c_void_p]
     lib.cvx_host_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
     lib.cvx_host_free.argtypes = [C.c_void_p]
     lib.cvx_host_free.restype = None

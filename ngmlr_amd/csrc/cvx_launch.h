@@ -70,6 +70,10 @@ hipError_t launch_decode_windows(const uint8_t *bin, const uint64_t *starts, int
 /* device-side text stage (cvx_text.hip): lengths + fields + offsets, then the strings */
 hipError_t launch_text_size(const TextArgs &a, hipStream_t st);
 hipError_t launch_text_write(const TextArgs &a, hipStream_t st);
+/* nmPerPosition of the tiles [first, first + count): entry counts (TextRec::nm_count, after launch_text_size) -> offsets
+ * (count values + the total behind them), then the triples */
+hipError_t launch_nm_offsets(const TextArgs &a, int first, int count, unsigned long long *len, unsigned long long *off, unsigned long long *total, hipStream_t st);
+hipError_t launch_nm_profile(const TextArgs &a, int first, int count, const unsigned long long *off, int32_t *triples, hipStream_t st);
 
 /* catch-all kernel (cvx_generic.hip): any ring size, state in a global scratch */
 size_t generic_scratch_bytes(int ring);

@@ -203,6 +203,11 @@ struct cvx_batch_s {
 	DevBuf<TextRec> d_trec;
 	DevBuf<unsigned long long> d_tlen;   /* lengths, offsets, total */
 	DevBuf<uint8_t> d_text;
+	bool text_done = false;          /* d_trec holds this job's text records (cvx_job_text ran) */
+	DevBuf<unsigned long long> d_nmoff;  /* nmPerPosition: entry counts, offsets, total of the requested tile range */
+	DevBuf<int32_t> d_nm;            /* ... and the triples */
+	PinBuf h_nmoff;
+	hipEvent_t ev_nm0 = nullptr, ev_nm1 = nullptr;
 	PinBuf h_win;                    /* WindowDesc[n]: reference windows decoded on the device (cvx_submit_windows) */
 	DevBuf<WindowDesc> d_win;
 	PinBuf h_chain;                  /* ChainTask[] of all chain classes, ChainBlk[], tile lists */
@@ -246,6 +251,9 @@ struct cvx_batch_s {
 		h_win.release(); d_win.release();
 		h_ext.release(); h_trec.release(); h_toff.release(); h_text.release();
 		d_ext.release(); d_trec.release(); d_tlen.release(); d_text.release();
+		d_nmoff.release(); d_nm.release(); h_nmoff.release();
+		if (ev_nm0) { (void) hipEventDestroy(ev_nm0); ev_nm0 = nullptr; }
+		if (ev_nm1) { (void) hipEventDestroy(ev_nm1); ev_nm1 = nullptr; }
 		h_chain.release(); d_chain.release(); d_progress.release(); d_bnd.release(); d_chain_out.release();
 		if (ev_in) { (void) hipEventDestroy(ev_in); ev_in = nullptr; }
 		if (ev_res) { (void) hipEventDestroy(ev_res); ev_res = nullptr; }
@@ -321,6 +329,7 @@ void recycle_batch(cvx_context *h, cvx_batch_s *b) {
 	b->state = kEmpty;
 	b->in_flight = false;
 	b->have_ops = false;
+	b->text_done = false;
 	b->fail_rc = CVX_OK;
 	b->fail_msg.clear();
 	if (h) {
@@ -379,6 +388,7 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	b->n = n;
 	b->state = kEmpty;
 	b->have_ops = false;
+	b->text_done = false;
 	b->ops_total = 0;
 	b->seq_total = L.seq_total;
 	b->n_rows = L.n_rows;
@@ -930,6 +940,11 @@ int pump(cvx_context *h, bool block, const cvx_batch_s *upto) {
 
 }  // namespace
 
+/* the process's pack threads for the host-only text code (cvx_sam.cpp) */
+namespace cvx {
+void pack_pool_run(int n_tasks, const std::function<void(int)> &fn) { PackPool::get().run(n_tasks, fn); }
+}
+
 extern "C" {
 
 const char *cvx_last_error(void) { return g_err.c_str(); }
@@ -1415,7 +1430,122 @@ int cvx_job_text(cvx_handle h, cvx_job j, const int32_t *ext_qstart, const int32
 	for (int i = 0; i < n; ++i) text_off[i] = hoff[i];
 	*text = j->h_text.as<char>();
 	if (text_bytes) *text_bytes = total;
+	j->text_done = true;
 	return CVX_OK;
+	ABI_GUARD_END
+}
+
+int cvx_job_nm_profile(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint64_t *entry_off,
+		int32_t *triples, uint64_t cap_entries, double *kernel_ms) {
+	ABI_GUARD_BEGIN
+	if (kernel_ms) *kernel_ms = 0.0;
+	if (!h || !j || j->state < kFinished) { set_err("cvx_job_nm_profile: job not finished (call cvx_wait first)"); return CVX_ERR_ARG; }
+	if (!j->text_done) { set_err("cvx_job_nm_profile: call cvx_job_text first (it counts the entries)"); return CVX_ERR_ARG; }
+	if (first < 0 || count < 0 || (int64_t) first + count > j->n || (count > 0 && !entry_off)) { set_err("cvx_job_nm_profile: bad tile range / NULL offsets"); return CVX_ERR_ARG; }
+	if (count == 0) return CVX_OK;
+	HIP_TRY(hipSetDevice(h->device));
+	hipStream_t st = h->s_main;
+	const size_t c1 = (size_t) count;
+	RC_TRY(j->d_nmoff.ensure(2 * c1 + 8));
+	RC_TRY(j->h_nmoff.ensure((c1 + 1) * sizeof(unsigned long long)));
+	if (!j->ev_nm0) HIP_TRY(hipEventCreate(&j->ev_nm0));
+	if (!j->ev_nm1) HIP_TRY(hipEventCreate(&j->ev_nm1));
+	TextArgs a;
+	memset(&a, 0, sizeof(a));
+	a.seq = j->d_seq.p; a.tin = j->d_tin.p; a.trun = j->d_trun.p; a.tout = j->d_tout.p; a.ops = j->d_regions.p;
+	a.recs = j->d_trec.p;
+	a.n_tiles = j->n;
+	unsigned long long *d_len = j->d_nmoff.p, *d_off = j->d_nmoff.p + c1;      /* the total lands right behind the offsets */
+	HIP_TRY(launch_nm_offsets(a, first, count, d_len, d_off, d_off + c1, st));
+	unsigned long long *hoff = j->h_nmoff.as<unsigned long long>();
+	HIP_TRY(hipMemcpyAsync(hoff, d_off, (c1 + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	for (size_t i = 0; i <= c1; ++i) entry_off[i] = hoff[i];
+	const unsigned long long total = hoff[c1];
+	if (triples && total > cap_entries) { set_err("cvx_job_nm_profile: %llu entries, room for %llu", total, (unsigned long long) cap_entries); return CVX_ERR_CAPACITY; }
+	RC_TRY(j->d_nm.ensure(3 * (size_t) total + 16));
+	HIP_TRY(hipEventRecord(j->ev_nm0, st));
+	HIP_TRY(launch_nm_profile(a, first, count, d_off, j->d_nm.p, st));
+	HIP_TRY(hipEventRecord(j->ev_nm1, st));
+	if (triples && total > 0) HIP_TRY(hipMemcpyAsync(triples, j->d_nm.p, 3 * (size_t) total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (kernel_ms) { float ms = 0.0f; HIP_TRY(hipEventElapsedTime(&ms, j->ev_nm0, j->ev_nm1)); *kernel_ms = ms; }
+	return CVX_OK;
+	ABI_GUARD_END
+}
+
+int cvx_nm_profile_ops(cvx_handle h, int32_t n, const cvx_result *results, const uint32_t *ops_arena, uint64_t ops_total,
+		uint64_t *entry_off, int32_t *triples, uint64_t cap_entries) {
+	ABI_GUARD_BEGIN
+	if (!h || n < 0 || (n > 0 && (!results || !entry_off)) || (ops_total > 0 && !ops_arena)) { set_err("cvx_nm_profile_ops: bad argument"); return CVX_ERR_ARG; }
+	if (n == 0) return CVX_OK;
+	HIP_TRY(hipSetDevice(h->device));
+	const size_t n1 = (size_t) n;
+	std::vector<TileOut> tout(n1);
+	std::vector<TileRun> trun(n1);
+	std::vector<unsigned long long> off(n1 + 1, 0ull);
+	for (size_t i = 0; i < n1; ++i) {
+		const cvx_result &r = results[i];
+		memset(&tout[i], 0, sizeof(TileOut));
+		memset(&trun[i], 0, sizeof(TileRun));
+		tout[i].status = r.status;
+		tout[i].qstart = r.qstart;
+		unsigned long long cnt = 0;
+		if (r.status == CVX_TILE_OK) {
+			if (r.n_ops < 0 || r.ops_begin + (uint64_t) r.n_ops > ops_total) { set_err("cvx_nm_profile_ops: ops of tile %zu outside the arena", i); return CVX_ERR_ARG; }
+			tout[i].n_ops = r.n_ops;
+			trun[i].ops_off = r.ops_begin;
+			/* entries per op, as addPosition admits them (src/ConvexAlignFast.cpp:76-98) */
+			long long pr = 0, pq = r.qstart;
+			for (int k = 0; k < r.n_ops; ++k) {
+				const uint32_t w = ops_arena[r.ops_begin + (uint64_t) k];
+				const long long len = (long long) (w >> 4);
+				const int type = (int) (w & 15u);
+				if (type == CVX_OP_EQ || type == CVX_OP_X) {
+					const long long mn = pr < pq ? pr : pq, skip = 17 - mn > 0 ? 17 - mn : 0;
+					cnt += (unsigned long long) (len - skip > 0 ? len - skip : 0);
+					pr += len; pq += len;
+				} else if (type == CVX_OP_D) {
+					if (pq > 16) { const long long skip = 17 - pr > 0 ? 17 - pr : 0; cnt += (unsigned long long) (len - skip > 0 ? len - skip : 0); }
+					pr += len;
+				} else if (type == CVX_OP_I) {
+					pq += len;
+				} else { set_err("cvx_nm_profile_ops: op code %d in tile %zu", type, i); return CVX_ERR_ARG; }
+			}
+		}
+		off[i + 1] = off[i] + cnt;
+	}
+	for (size_t i = 0; i <= n1; ++i) entry_off[i] = off[i];
+	const unsigned long long total = off[n1];
+	if (!triples) return CVX_OK;                      /* sizes only */
+	if (total > cap_entries) { set_err("cvx_nm_profile_ops: %llu entries, room for %llu", total, (unsigned long long) cap_entries); return CVX_ERR_CAPACITY; }
+	DevBuf<int32_t> d_ops, d_tri;
+	DevBuf<TileOut> d_tout;
+	DevBuf<TileRun> d_trun;
+	DevBuf<unsigned long long> d_off;
+	int rc = CVX_OK;
+	auto body = [&]() -> int {
+		RC_TRY(d_ops.ensure((size_t) ops_total + 16));
+		RC_TRY(d_tri.ensure(3 * (size_t) total + 16));
+		RC_TRY(d_tout.ensure(n1));
+		RC_TRY(d_trun.ensure(n1));
+		RC_TRY(d_off.ensure(n1 + 1));
+		hipStream_t st = h->s_main;
+		if (ops_total) HIP_TRY(hipMemcpyAsync(d_ops.p, ops_arena, (size_t) ops_total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(d_tout.p, tout.data(), n1 * sizeof(TileOut), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(d_trun.p, trun.data(), n1 * sizeof(TileRun), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(d_off.p, off.data(), (n1 + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+		TextArgs a;
+		memset(&a, 0, sizeof(a));
+		a.tout = d_tout.p; a.trun = d_trun.p; a.ops = d_ops.p; a.n_tiles = n;
+		HIP_TRY(launch_nm_profile(a, 0, n, d_off.p, d_tri.p, st));
+		if (total) HIP_TRY(hipMemcpyAsync(triples, d_tri.p, 3 * (size_t) total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		return CVX_OK;
+	};
+	rc = body();
+	d_ops.release(); d_tri.release(); d_tout.release(); d_trun.release(); d_off.release();
+	return rc;
 	ABI_GUARD_END
 }
 

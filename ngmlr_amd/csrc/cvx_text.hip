@@ -9,8 +9,9 @@
  * alignmentLength, cigarOpCount, first/last positions) and the N-clip flags of :493-528 -- the same
  * contract as the host form cvx_format_alignment (cvx_format.cpp), against which it is tested field
  * by field and byte by byte.  The per-position mismatch profile (nmPerPosition, 12 bytes per
- * alignment column) stays with the host form: it is several GB per batch and only
- * detectMisalignment reads it.
+ * alignment column, several GB per batch; only detectMisalignment reads it) has its own kernel
+ * (nm_profile_kernel below) and its own entry point: a caller that wants it on the host pays 12 B per
+ * column of PCIe, a consumer on the device does not.
  *
  * One wave per tile, 64 ops per step.  A CIGAR piece is the sum of a maximal EQ/X run -- a
  * segmented sum: inclusive wave scan minus the scan value in front of the run's first lane, found
@@ -248,6 +249,134 @@ text_kernel(const TextArgs a) {
 	}
 }
 
+/* ------------------------------------------------------------------ nmPerPosition
+ *
+ * src/ConvexAlignFast.cpp:76-98,186-269 as the host form restates it (cvx_format.cpp): a 32-bit shift register over
+ * the alignment columns (every op base is a column) with a bit for every mismatched base and for the first base of
+ * every I / D op; an entry (refPosition - 16, readPosition - 16, Yi) per EQ / X / D column once both positions passed
+ * 16.  Yi of an EQ / X column is the register's population count; the first base of a gap op makes it Yi + 1 (not a
+ * recount), its other bases leave it alone.
+ *
+ * One wave per tile, one op per lane.  No register travels along the alignment: the number of set bits among the 32
+ * columns in front of an op comes from walking back over at most 32 ops, and while a lane emits its op's columns a
+ * second cursor follows 32 columns behind and takes the bits out again.  Entry offsets are a wave scan over the
+ * per-op entry counts (the same counts text_kernel adds up into nm_count).
+ */
+struct OpCursor {          /* the op that contains a given column */
+	int k, start, len, type;
+};
+
+/* set bits among the columns [end - 32, end) where op j ends at column `end`; cur = the op holding column end - 32
+ * (op 0 when that column does not exist) */
+TXT_DEV int window_bits(const int32_t *ops, int j, const int end, OpCursor &cur) {
+	const int lo = end - 32;
+	int bits = 0, e = end;
+	cur.k = 0; cur.start = 0; cur.len = 0; cur.type = 0;
+	bool have = false;
+	while (j >= 0 && e > lo) {
+		const unsigned w = (unsigned) ops[j];
+		const int l = (int) (w >> 4), t = (int) (w & 15u), s = e - l;
+		if (t == 8) bits += e - (s > lo ? s : lo);
+		else if (t == 1 || t == 2) bits += (s >= lo) ? 1 : 0;
+		cur.k = j; cur.start = s; cur.len = l; cur.type = t;
+		have = true;
+		e = s;
+		--j;
+	}
+	if (!have) {       /* nothing in front: the cursor starts at op 0 */
+		const unsigned w = (unsigned) ops[0];
+		cur.len = (int) (w >> 4); cur.type = (int) (w & 15u);
+	}
+	return bits;
+}
+
+TXT_DEV void nm_tile(const int lane, const TileOut o, const int32_t *ops, int32_t *out) {
+	const int n = o.n_ops;
+	int ref_base = 0, read_base = 0, col_base = 0, ent_base = 0;
+	for (int c0 = 0; c0 < n; c0 += 64) {
+		const int k = c0 + lane;
+		const bool valid = k < n;
+		const unsigned w = valid ? (unsigned) ops[k] : 0u;
+		const int len = (int) (w >> 4), type = (int) (w & 15u);
+		const bool isEQ = valid && type == 7, isX = valid && type == 8, isI = valid && type == 1, isD = valid && type == 2;
+		const bool refc = isEQ || isX || isD, readc = isEQ || isX || isI;
+		const int RC = wave_scan(refc ? len : 0, lane), RD = wave_scan(readc ? len : 0, lane), CS = wave_scan(valid ? len : 0, lane);
+		const int pr0 = ref_base + RC - (refc ? len : 0);
+		const int pq0 = o.qstart + read_base + RD - (readc ? len : 0);
+		const int cs = col_base + CS - (valid ? len : 0);            /* alignment columns in front of this op */
+		int cnt = 0, skip = 0;
+		if (isEQ || isX) {
+			const int mn = pr0 < pq0 ? pr0 : pq0;
+			skip = 17 - mn > 0 ? 17 - mn : 0;
+			cnt = len - skip > 0 ? len - skip : 0;
+		} else if (isD && pq0 > 16) {
+			skip = 17 - pr0 > 0 ? 17 - pr0 : 0;
+			cnt = len - skip > 0 ? len - skip : 0;
+		}
+		const int EN = wave_scan(cnt, lane);
+		int32_t *dst = out + 3 * (size_t) (ent_base + EN - cnt);
+		if (cnt > 0) {
+			OpCursor cur;
+			if (isD) {
+				/* Yi in front of the gap ops that end with this one, plus one per gap op */
+				int j = k - 1, g = 1, end = cs;
+				while (j >= 0) {
+					const unsigned wj = (unsigned) ops[j];
+					const int tj = (int) (wj & 15u);
+					if (tj != 1 && tj != 2) break;
+					end -= (int) (wj >> 4);
+					++g;
+					--j;
+				}
+				const int yi = (j >= 0 ? window_bits(ops, j, end, cur) : 0) + g;
+				for (int i = skip; i < len; ++i) {
+					dst[0] = pr0 + i - 16; dst[1] = pq0 - 16; dst[2] = yi;
+					dst += 3;
+				}
+			} else {
+				int P = window_bits(ops, k - 1, cs, cur);
+				const int add = isX ? 1 : 0;
+				for (int i = 0; i < len; ++i) {
+					const int lc = cs + i - 32;          /* the column that leaves the register */
+					P += add;
+					if (lc >= 0) {
+						while (lc >= cur.start + cur.len) {
+							cur.start += cur.len;
+							cur.k += 1;
+							const unsigned wc = (unsigned) ops[cur.k];
+							cur.len = (int) (wc >> 4); cur.type = (int) (wc & 15u);
+						}
+						P -= (cur.type == 8 || ((cur.type == 1 || cur.type == 2) && lc == cur.start)) ? 1 : 0;
+					}
+					if (i >= skip) {
+						dst[0] = pr0 + i - 16; dst[1] = pq0 + i - 16; dst[2] = P;
+						dst += 3;
+					}
+				}
+			}
+		}
+		ent_base += __builtin_amdgcn_readlane(EN, 63);
+		ref_base += __builtin_amdgcn_readlane(RC, 63);
+		read_base += __builtin_amdgcn_readlane(RD, 63);
+		col_base += __builtin_amdgcn_readlane(CS, 63);
+	}
+}
+
+/* entry counts of the tiles [first, first + count) as 64-bit lengths for text_scan_kernel */
+__global__ void __launch_bounds__(256)
+nm_count_kernel(const TextRec *recs, unsigned long long *len, int first, int count) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i < count) len[i] = (unsigned long long) (recs[first + i].nm_count > 0 ? recs[first + i].nm_count : 0);
+}
+
+__global__ void __launch_bounds__(64)
+nm_profile_kernel(const TextArgs a, const unsigned long long *ent_off, int32_t *triples, int first) {
+	const int t = first + (int) blockIdx.x;
+	const TileOut o = a.tout[t];
+	if (o.status != 0) return;
+	nm_tile((int) threadIdx.x, o, a.ops + a.trun[t].ops_off + o.ops_first, triples + 3 * (size_t) ent_off[blockIdx.x]);
+}
+
 /* exclusive prefix sum of the per-tile text lengths (one workgroup, a chunk of tiles per thread) */
 __global__ void __launch_bounds__(256)
 text_scan_kernel(const unsigned long long *len, unsigned long long *off, unsigned long long *total, int n) {
@@ -275,6 +404,19 @@ hipError_t launch_text_size(const TextArgs &a, hipStream_t st) {
 	if (a.n_tiles <= 0) return hipSuccess;
 	hipLaunchKernelGGL(text_kernel<false>, dim3(a.n_tiles), dim3(64), 0, st, a);
 	hipLaunchKernelGGL(text_scan_kernel, dim3(1), dim3(256), 0, st, a.text_len, a.text_off, a.text_total, a.n_tiles);
+	return hipGetLastError();
+}
+
+hipError_t launch_nm_offsets(const TextArgs &a, int first, int count, unsigned long long *len, unsigned long long *off, unsigned long long *total, hipStream_t st) {
+	if (count <= 0) return hipSuccess;
+	hipLaunchKernelGGL(nm_count_kernel, dim3((count + 255) / 256), dim3(256), 0, st, a.recs, len, first, count);
+	hipLaunchKernelGGL(text_scan_kernel, dim3(1), dim3(256), 0, st, len, off, total, count);
+	return hipGetLastError();
+}
+
+hipError_t launch_nm_profile(const TextArgs &a, int first, int count, const unsigned long long *off, int32_t *triples, hipStream_t st) {
+	if (count <= 0) return hipSuccess;
+	hipLaunchKernelGGL(nm_profile_kernel, dim3(count), dim3(64), 0, st, a, off, triples, first);
 	return hipGetLastError();
 }
 

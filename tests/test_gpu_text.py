@@ -119,3 +119,106 @@ def test_n_clip_flags_through_the_host_form(hip_aligner, ref_oracle):
         want = ref_oracle.align(t)
         assert same_alignment(want, g) is None, (t.tag, same_alignment(want, g))
         assert g["sv_type"] == flag == want["sv_type"]
+
+
+# ------------------------------------------------------------------ nmPerPosition on the device (cvx_job_nm_profile)
+
+def _device_profiles(al, tiles, ranges=None):
+    """-> per tile the int32[entries, 3] profile computed on the device (None for invalid tiles), the text records"""
+    job = al.submit(tiles)
+    job.wait()
+    eqs = np.array([t.ext_qstart for t in tiles], dtype=np.int32)
+    eqe = np.array([t.ext_qend for t in tiles], dtype=np.int32)
+    dev = job.text(eqs, eqe)
+    out = [None] * len(tiles)
+    for first, count in (ranges or [(0, len(tiles))]):
+        off, tri, ms = job.nm_profile(first, count)
+        assert ms >= 0.0 and off[0] == 0 and int(off[count]) == len(tri)
+        for i in range(count):
+            d = dev[first + i]
+            n = int(off[i + 1] - off[i])
+            assert n == (d["nm_count"] if d["ret"] >= 0 else 0), (tiles[first + i].tag, n, d["nm_count"])
+            out[first + i] = tri[int(off[i]):int(off[i + 1])]
+    job.release()
+    return out, dev
+
+
+def test_nm_profile_equals_recorded_reference_output(hip_aligner):
+    """The per-position profile the unmodified reference wrote for its own SingleAlign calls (test_2/3/4)."""
+    n = 0
+    for name in ("ref_test_2.npz", "ref_test_4.npz", "ref_test_3.npz"):
+        pairs = util.load_golden(name)
+        got, dev = _device_profiles(hip_aligner, [t for t, _ in pairs])
+        for (t, exp), g, d in zip(pairs, got, dev):
+            if exp["ret"] < 0:
+                assert len(g) == 0
+                continue
+            want = exp["nm_per_position"][:d["nm_count"]]
+            assert g.shape == want.shape and np.array_equal(g, want), (t.tag, np.argwhere(g != want)[:3])
+            n += len(g)
+    assert n > 50000
+
+
+def test_nm_profile_equals_reference_aligner_and_host_form(hip_aligner, ref_oracle):
+    """Against the reference's own ConvexAlignFast (oracle/_ref) and the host form, on the zoo, the edge tiles, gap ops
+    next to each other and next to the start, long gaps, and in tile ranges (the profile of a full batch is GBs)."""
+    from tests.test_gpu_parity import _sv_tile
+    rng = np.random.default_rng(77)
+    tiles = util.tile_zoo(seed=67, n=70, max_w=2000) + util.edge_tiles()
+    tiles.append(_sv_tile(rng, 900, [70, 130], [65, 200], "full"))
+    tiles.append(_sv_tile(rng, 700, [1, 2, 3, 33], [1, 2, 64], "endpoints"))
+    tiles.append(_sv_tile(rng, 600, [31, 32, 33], [31, 32, 33], "full"))
+    n = len(tiles)
+    got, dev = _device_profiles(hip_aligner, tiles, ranges=[(0, 7), (7, n - 20), (n - 13, 13)])
+    valid = entries = 0
+    for t, g, d in zip(tiles, got, dev):
+        want = ref_oracle.align(t)
+        if want["ret"] < 0:
+            assert d["ret"] < 0 and len(g) == 0
+            continue
+        w = want["nm_per_position"]          # alignmentLength rows (what the consumer walks): the entries, then zeros
+        assert len(g) <= len(w) and np.array_equal(g, w[:len(g)]) and not w[len(g):].any(), (t.tag, g.shape, w.shape)
+        valid += 1
+        entries += len(g)
+    assert valid > 40 and entries > 20000
+    # the same entry point refuses what it cannot do
+    job = hip_aligner.submit(tiles[:4])
+    job.wait()
+    off = np.zeros(5, dtype=np.uint64)
+    assert hip_aligner.lib.cvx_job_nm_profile(hip_aligner.h, job.j, 0, 4, off.ctypes.data, None, 0, None) == -3   # no text stage yet
+    job.text()
+    small = np.zeros((1, 3), dtype=np.int32)
+    rc = hip_aligner.lib.cvx_job_nm_profile(hip_aligner.h, job.j, 0, 4, off.ctypes.data, small.ctypes.data, 1, None)
+    assert rc == -6 and off[4] > 1
+    assert hip_aligner.lib.cvx_job_nm_profile(hip_aligner.h, job.j, 2, 3, off.ctypes.data, None, 0, None) == -3   # range past the job
+    job.release()
+
+
+def test_nm_profile_beside_replaced_segments(hip_aligner):
+    """Reads in which a stretch of the reference is replaced by novel bases of another length (the convex scoring reports
+    such a stretch as mismatches plus one gap, or as two gap ops behind each other): device profile == host form."""
+    from ngmlr_amd import synth
+    rng = np.random.default_rng(5)
+    tiles = []
+    for k in range(12):
+        ref = synth.random_ref(rng, 1500)
+        a = 600 + 10 * k
+        # read = ref[:a] + 12..30 novel bases + ref[a+d:], d = 12..30: an I run beside a D run
+        ins = synth.random_ref(rng, 12 + k)
+        d = 30 - k
+        qry = np.concatenate([ref[100:a], ins, ref[a + d:1400]])
+        H, W = len(qry), len(ref)
+        off = (np.arange(H) * (W / H)).astype(np.int32) - 260
+        tiles.append(synth.Tile(ref=ref.tobytes(), qry=qry.tobytes(), row_offset=off, row_length=np.full(H, 520, dtype=np.int32),
+                                tag="gapchain%d" % k))
+    got, dev = _device_profiles(hip_aligner, tiles)
+    job = hip_aligner.submit(tiles)
+    res, ops = job.wait()
+    for i, t in enumerate(tiles):
+        r = capi.CvxResult.from_buffer_copy(res[i].tobytes())
+        host = format_alignment(hip_aligner.lib, r, ops, t)
+        assert host["ret"] >= 0
+        w = host["nm_per_position"][:host["nm_count"]]
+        assert got[i].shape == w.shape and np.array_equal(got[i], w), t.tag
+        assert len(w) > 1000
+    job.release()

@@ -19,15 +19,27 @@ mkdir -p "$REPO/oracle/_ref"
 #   ngmlr_hip_batched  Convex::SharedAligner   all -t N workers share one BatchingAligner per device
 #   ngmlr_hip_full     Convex::SharedAligner + StrippedSWHip at NGM::CreateAlignment (src/NGM.cpp:355): alignment AND
 #                      sub-read scoring on the device
+#                      and the SAM records through cvx_sam_record_text (src/SAMWriter.cpp:87)
+#   ngmlr_sam          the reference's own CPU aligners; only SAMWriter::DoWriteReadGeneric goes through cvx_sam_record_text
+#                      (runs without a GPU: tests/test_sam_cpu.py)
 #   ngmlr_ref          (nothing changed)       the unmodified reference, for wall-clock comparison only
 build_variant() {
-local OUT_NAME=$1 CLASS=$2 SCORER=${3:-}
+local OUT_NAME=$1 CLASS=$2 SCORER=${3:-} SAM=${4:-}
 local T="$WORK/$OUT_NAME"
 cp -r /root/reference "$T"
 if [ "$CLASS" != "unmodified" ]; then
-python3 - "$T" "$REPO" "$CLASS" "$SCORER" <<'PY'
+python3 - "$T" "$REPO" "$CLASS" "$SCORER" "$SAM" <<'PY'
 import re, sys
-T, REPO, CLASS, SCORER = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+T, REPO, CLASS, SCORER, SAM = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5]
+if SAM:
+    p = T + '/src/SAMWriter.cpp'
+    s = open(p).read()
+    m = re.search(r'void SAMWriter::DoWriteReadGeneric\([^)]*\)\s*\{', s)
+    assert m and len(re.findall(r'void SAMWriter::DoWriteReadGeneric\(', s)) == 1
+    s = s[:m.end()] + '\n#include "sam_writer_binding.inc"\n' + s[m.end():]
+    s = s.replace('#include "SAMWriter.h"', '#include "SAMWriter.h"\n#include <vector>\n#include <string.h>\n#include "cvx_align.h"', 1)
+    assert 'cvx_align.h' in s
+    open(p, 'w').write(s)
 if SCORER:
     p = T + '/src/NGM.cpp'
     s = open(p).read()
@@ -36,13 +48,14 @@ if SCORER:
     s = s.replace('#include "StrippedSW.h"', '#include "StrippedSW.h"\n#include "stripped_sw_hip.h"', 1)
     assert 'stripped_sw_hip.h' in s
     open(p, 'w').write(s)
-p = T + '/src/AlignmentBuffer.h'
-s = open(p).read()
-s = s.replace('#include "ConvexAlignFast.h"', '#include "ConvexAlignFast.h"\n#include "convex_align_hip.h"\n#include "batching_aligner.h"', 1)
-pat = re.compile(r'aligner = new Convex::ConvexAlignFast\(', re.S)
-assert len(pat.findall(s)) == 1
-s = pat.sub('aligner = new %s(' % CLASS, s)
-open(p, 'w').write(s)
+if CLASS != 'cpu':
+    p = T + '/src/AlignmentBuffer.h'
+    s = open(p).read()
+    s = s.replace('#include "ConvexAlignFast.h"', '#include "ConvexAlignFast.h"\n#include "convex_align_hip.h"\n#include "batching_aligner.h"', 1)
+    pat = re.compile(r'aligner = new Convex::ConvexAlignFast\(', re.S)
+    assert len(pat.findall(s)) == 1
+    s = pat.sub('aligner = new %s(' % CLASS, s)
+    open(p, 'w').write(s)
 p = T + '/src/CMakeLists.txt'
 c = open(p).read()
 c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp\n%s/ngmlr_amd/csrc/batching_aligner.cpp\n%s/ngmlr_amd/csrc/stripped_sw_hip.cpp' % (REPO, REPO, REPO, REPO, REPO), 1)
@@ -59,9 +72,10 @@ echo "built $REPO/oracle/_ref/$OUT_NAME"
 }
 build_variant ngmlr_hip Convex::ConvexAlignHip &
 build_variant ngmlr_hip_batched Convex::SharedAligner &
-build_variant ngmlr_hip_full Convex::SharedAligner StrippedSWHip &
+build_variant ngmlr_hip_full Convex::SharedAligner StrippedSWHip sam &
+build_variant ngmlr_sam cpu "" sam &
 build_variant ngmlr_ref unmodified &     # the reference as it is: wall-clock yardstick of tools/e2e_rates.py
 wait
-test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched" && test -x "$REPO/oracle/_ref/ngmlr_hip_full"
+test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched" && test -x "$REPO/oracle/_ref/ngmlr_hip_full" && test -x "$REPO/oracle/_ref/ngmlr_sam"
 readelf -d "$REPO/oracle/_ref/ngmlr_hip" | grep -E "RPATH|RUNPATH|NEEDED" | head
 rm -rf "$WORK"
