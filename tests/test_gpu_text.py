@@ -222,3 +222,68 @@ def test_nm_profile_beside_replaced_segments(hip_aligner):
         assert got[i].shape == w.shape and np.array_equal(got[i], w), t.tag
         assert len(w) > 1000
     job.release()
+
+
+def test_nm_profile_of_arbitrary_op_lists(hip_aligner):
+    """cvx_nm_profile_ops on op lists no alignment of the default scoring produces -- gap ops directly behind each other
+    (the Yi + 1 chain), gap ops in front of everything, mismatch runs longer than the 32-column register, ops longer than a
+    wave, hundreds of ops (several 64-op steps) -- against the host form walking the same lists."""
+    import ctypes as C
+    lib = hip_aligner.lib
+    rng = np.random.default_rng(99)
+    EQ, X, I, D = 7, 8, 1, 2
+    lists = [
+        [(5, I), (3, D), (40, EQ), (2, X), (1, I), (1, D), (1, I), (30, EQ)],
+        [(20, D), (20, I), (100, EQ)],
+        [(18, EQ), (50, X), (3, D), (2, I), (4, D), (70, EQ), (33, X), (1, EQ)],
+        [(300, EQ), (1, D), (200, X), (7, I), (90, EQ)],
+    ]
+    for _ in range(40):
+        n = int(rng.integers(1, 400))
+        ops = []
+        for _k in range(n):
+            t = int(rng.choice([EQ, EQ, EQ, X, I, D]))
+            ln = int(rng.integers(1, 4)) if rng.random() < 0.8 else int(rng.integers(4, 120))
+            ops.append((ln, t))
+        lists.append(ops)
+    arena, results, qstarts = [], [], []
+    for li, ops in enumerate(lists):
+        r = capi.CvxResult()
+        r.status = 0
+        r.ref_position = 0
+        r.qstart = int(rng.integers(0, 40)) if li % 2 else 0
+        r.n_ops = len(ops)
+        r.ops_begin = len(arena)
+        arena += [(ln << 4) | t for ln, t in ops]
+        results.append(r)
+    # one invalid tile in the middle: no entries
+    bad = capi.CvxResult()
+    bad.status = 1
+    results.insert(3, bad)
+    lists.insert(3, [])
+    arena = np.array(arena, dtype=np.uint32)
+    res = (capi.CvxResult * len(results))(*results)
+    off = np.zeros(len(results) + 1, dtype=np.uint64)
+    assert lib.cvx_nm_profile_ops(hip_aligner.h, len(results), res, arena.ctypes.data, len(arena), off.ctypes.data, None, 0) == 0
+    tri = np.zeros((int(off[-1]), 3), dtype=np.int32)
+    assert lib.cvx_nm_profile_ops(hip_aligner.h, len(results), res, arena.ctypes.data, len(arena), off.ctypes.data, tri.ctypes.data, len(tri)) == 0
+    total = 0
+    for i, ops in enumerate(lists):
+        got = tri[int(off[i]):int(off[i + 1])]
+        if results[i].status != 0:
+            assert len(got) == 0
+            continue
+        ref_len = sum(ln for ln, t in ops if t != I) + 300
+        qry_len = sum(ln for ln, t in ops if t != D) + results[i].qstart
+        ref = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=ref_len).astype(np.uint8))
+        cap = 16 * (ref_len + qry_len) + 64
+        cig, md = C.create_string_buffer(cap), C.create_string_buffer(cap)
+        nm = np.zeros((ref_len + qry_len + 16, 3), dtype=np.int32)
+        txt = capi.CvxAlignmentText()
+        assert lib.cvx_format_alignment(C.byref(results[i]), arena.ctypes.data, ref, ref_len, qry_len, 0, 0, cig, cap, md, cap,
+                                        nm.ctypes.data, len(nm), C.byref(txt)) == 0
+        want = nm[:txt.nm_count]
+        assert got.shape == want.shape and np.array_equal(got, want), (i, ops[:12], np.argwhere(got != want)[:3] if got.shape == want.shape else (got.shape, want.shape))
+        total += len(got)
+    assert total > 5000
+    assert lib.cvx_nm_profile_ops(hip_aligner.h, 1, res, arena.ctypes.data, 3, off.ctypes.data, None, 0) == -3      # ops outside the arena
