@@ -10,7 +10,8 @@ namespace Convex {
 
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
 		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0),
-		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), stop(false), launches(0), requests(0), maxInFlight(0) {
+		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), stop(false), launches(0), requests(0), maxInFlight(0),
+		parkedNs(0), finishNs(0), busyNs(0) {
 	dispatcher = std::thread([this] { dispatchLoop(); });
 }
 
@@ -81,6 +82,7 @@ void BatchingAligner::dispatchLoop() {
 				l->failed = true;
 			}
 			lk.lock();
+			if (inFlight.empty()) busySince = std::chrono::steady_clock::now();
 			inFlight.push_back(l);
 			if ((long) inFlight.size() > maxInFlight) maxInFlight = (long) inFlight.size();
 			continue;                                        /* maybe a second launch right away */
@@ -111,6 +113,7 @@ void BatchingAligner::dispatchLoop() {
 				}
 			}
 			lk.lock();
+			if (inFlight.empty()) busyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - busySince).count();
 			for (size_t i = 0; i < l->reqs.size(); ++i) {
 				Request * r = l->reqs[i];
 				r->failed = l->failed;
@@ -143,7 +146,10 @@ int BatchingAligner::SingleAlign(int const mode, CorridorLine * corridor, int co
 	requests += 1;
 	parked += 1;
 	cvDispatch.notify_one();
+	std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
 	while (!req.done) cvWorkers.wait(lk);
+	std::chrono::steady_clock::time_point const t1 = std::chrono::steady_clock::now();
+	parkedNs += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
 	parked -= 1;
 	Launch * l = req.launch;
 	bool const failed = req.failed;
@@ -161,6 +167,7 @@ int BatchingAligner::SingleAlign(int const mode, CorridorLine * corridor, int co
 		}
 	}
 	lk.lock();
+	finishNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
 	if (--l->unfinished == 0) {
 		retired.push_back(l);
 		cvDispatch.notify_one();
@@ -184,6 +191,8 @@ int g_deviceUsers[kMaxDevices] = {0};
 int g_users = 0;
 long g_joined = 0;
 long g_lastLaunches = 0, g_lastRequests = 0;
+double g_lastParked = 0.0, g_lastFinish = 0.0, g_lastBusy = 0.0;
+std::chrono::steady_clock::time_point g_firstJoin;
 }
 
 SharedAligner::SharedAligner(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
@@ -194,6 +203,7 @@ SharedAligner::SharedAligner(int const stdOutMode, float const match, float cons
 	if (nDev > kMaxDevices) nDev = kMaxDevices;
 	/* deviceId >= 0 pins the worker; the default spreads them */
 	device = (deviceId >= 0 && nDev > 0) ? deviceId % nDev : (nDev > 0 ? (int) (g_joined % nDev) : 0);
+	if (g_joined == 0) g_firstJoin = std::chrono::steady_clock::now();
 	g_joined += 1;
 	if (g_shared[device] == 0) {
 		int maxBatch = 4096, timeoutUs = 2000;
@@ -216,12 +226,20 @@ SharedAligner::~SharedAligner() {
 	if (g_deviceUsers[device] == 0) {
 		g_lastLaunches += g_shared[device]->Launches();
 		g_lastRequests += g_shared[device]->Requests();
+		g_lastParked += g_shared[device]->ParkedSeconds();
+		g_lastFinish += g_shared[device]->FinishSeconds();
+		g_lastBusy += g_shared[device]->BusySeconds();
 		delete g_shared[device]; g_shared[device] = 0;
 		delete g_backend[device]; g_backend[device] = 0;
 	}
 	if (g_users == 0) {
 		fprintf(stderr, "SharedAligner: %ld alignments in %ld device launches (%.1f per launch)\n", g_lastRequests,
 				g_lastLaunches, g_lastLaunches ? (double) g_lastRequests / (double) g_lastLaunches : 0.0);
+		double const wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_firstJoin).count();
+		fprintf(stderr, "SharedAligner: %ld workers over %.2f s: %.1f %% of their time parked in SingleAlign (%.2f ms per alignment), "
+				"%.1f %% in their text stage; a launch was in flight %.1f %% of the time\n", g_joined, wall,
+				100.0 * g_lastParked / (wall * (double) g_joined), g_lastRequests ? 1e3 * g_lastParked / (double) g_lastRequests : 0.0,
+				100.0 * g_lastFinish / (wall * (double) g_joined), 100.0 * g_lastBusy / wall);
 	}
 }
 

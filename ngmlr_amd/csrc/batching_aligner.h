@@ -72,6 +72,12 @@ public:
 	long Launches() const { return launches; }
 	long Requests() const { return requests; }
 	long MaxInFlight() const { return maxInFlight; }
+	/* seconds all workers together spent parked in SingleAlign (queue + launch + wake-up), seconds they spent in their own
+	 * text stage, and seconds the dispatcher had at least one launch in flight: with the wall time and the worker count
+	 * these say whether the pipeline around the aligner or the device path is the limit */
+	double ParkedSeconds() const { return parkedNs * 1e-9; }
+	double FinishSeconds() const { return finishNs * 1e-9; }
+	double BusySeconds() const { return busyNs * 1e-9; }
 
 private:
 	struct Launch;
@@ -104,6 +110,8 @@ private:
 	int timeoutUs;
 	bool stop;
 	long launches, requests, maxInFlight;
+	long long parkedNs, finishNs, busyNs;       /* under mtx */
+	std::chrono::steady_clock::time_point busySince;
 	std::thread dispatcher;
 
 	void dispatchLoop();

@@ -496,6 +496,8 @@ struct PlanTuning {
 	int force_wrap = 0;    /* route every tile to the int16-run kernels */
 	int chain_m = 0;       /* 1, 2 or 4: force the row-block height class of chained tiles */
 	int force_generic = 0; /* every tile to the catch-all kernel (scoring that needs its SSE-variant instantiation) */
+	int long_steps = 0;    /* > 0: replaces kLongTileSteps (a tile of a small batch with at least this many steps is chained) */
+	int small_batch = 0;   /* > 0: replaces kSmallBatchTiles */
 };
 
 /* rows_of(i, tmp) -> the (offset, length) rows of tile i (may fill and return tmp), or an empty function /
@@ -525,7 +527,7 @@ inline void host_plan_rows(int n, const TilePlan *plan, const TileIn *tin, RowsO
 	std::vector<std::vector<std::vector<ChainTask>>> per_tile((size_t) kNumChainClasses * 2);
 	int n_work = 0;
 	for (int i = 0; i < n; ++i) if (!(plan[(size_t) i].flags & (kPlanTooLarge | kPlanEmpty))) n_work++;
-	const bool small_batch = n_work < kSmallBatchTiles;
+	const bool small_batch = n_work < (tune.small_batch > 0 ? tune.small_batch : kSmallBatchTiles);
 	for (int i = 0; i < n; ++i) {
 		const TilePlan &p = plan[(size_t) i];
 		TileRun &r = hp.trun[(size_t) i];
@@ -552,7 +554,7 @@ inline void host_plan_rows(int n, const TilePlan *plan, const TileIn *tin, RowsO
 		r.ops_off = hp.ops_ints;
 		hp.ops_ints += (uint64_t) r.ops_cap;
 		hp.active += p.active;
-		const bool long_tile = small_batch && p.need >= 128 && (p.rend - p.r0) >= kLongTileSteps;
+		const bool long_tile = small_batch && p.need >= 128 && (p.rend - p.r0) >= (tune.long_steps > 0 ? tune.long_steps : kLongTileSteps);
 		if ((k < 0 || long_tile) && regular && have_rows && tune_min_slots == 0 && !tune.force_generic) {
 			/* more live rows than any ring (or one very long tile in a batch too small to fill the
 			 * device with whole tiles): row blocks chained through boundary streams */

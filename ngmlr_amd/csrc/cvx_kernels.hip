@@ -46,20 +46,6 @@ CVX_DEV float rot1_f(float v) {
 	return __int_as_float(rot1_i(__float_as_int(v)));
 }
 
-/* Boundary records of chained row blocks travel between workgroups through L2.  Write-through
- * (sc0 sc1) 16-byte stores, a drained vmcnt before the progress counter is published, and sc0 sc1
- * loads on the consumer side make that visible across CUs and XCDs without agent-scope fences
- * (which write back / invalidate whole caches and cost microseconds per hand-off). */
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-CVX_DEV void store_through16(void *p, const v4u v) {
-	asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
-CVX_DEV v4u load_through16(const void *p) {
-	v4u v;
-	asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-	return v;
-}
-
 /* ------------------------------------------------------------------ plan */
 
 /* gs(y): anti-diagonal of the first cell of row y; ge(y): one past the last.
@@ -517,6 +503,16 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 #define CVX_FILL_PRIO 1
 #endif
 
+/* What a cell that extends a gap offers: src/ConvexAlignFast.cpp:669-675, E = (score == 0) ? 0 : score + pen with
+ * pen = min(gap_ext_min, gap_ext + run * decay).  score >= 0 and pen < 0, so this is max(score + pen, score * -2^100):
+ * -0 for score 0 (compares equal to the reference's +0 and never reaches an output), score + pen otherwise.  One
+ * function for the cell update and for the consumer of a chained block's boundary records, which rebuilds the up
+ * candidate from (score, run) with exactly these operations. */
+CVX_DEV float gap_extend_value(const float sc, const float runf, const float gem, const float gext, const float decay) {
+	const float pen = fminf(gem, gext + runf * decay);
+	return fmaxf(sc + pen, sc * -0x1p100f);
+}
+
 enum FillMode { kFillTwoPhase = 0, kFillExact = 1, kFillChain = 2 };
 
 /*
@@ -543,9 +539,10 @@ enum FillMode { kFillTwoPhase = 0, kFillExact = 1, kFillChain = 2 };
  * (about need / N of them at a time), so a wide tile is spread over many CUs instead of living
  * in one workgroup.  A wave takes the next task from a ticket counter (tasks are listed in
  * dependency order, so the producer of anything a wave waits for is always running or done);
- * the boundary goes through L2 with write-through stores and a progress counter every
- * kChainChunk steps (a block trails the one above it by about 2 N + 2 kChainChunk steps, so a tile
- * takes about nblk * that many single-wave steps: small chunks, small blocks).
+ * the boundary is a stream of self-validating 8-byte records (BoundaryRec: score, run, insertion bit,
+ * launch epoch) written with device-scope atomic stores as the last row advances and read kChainChunk
+ * steps ahead of their use -- no counter, no release fence in the producer, no round trip to memory on
+ * the consumer's critical path while the producer is ahead (it starts 2 N anti-diagonals earlier).
  */
 template <int M, bool WRAP, int MODE>
 __global__ void __launch_bounds__(64) CVX_FILL_OCC(M)
@@ -570,7 +567,7 @@ fill_ring_kernel(const FillArgs a) {
 	 * The row of a slot's best cell (changes only at a hand-over) lives in LDS too, to keep VGPRs for occupancy. */
 	__shared__ int4 s_rec[CHAIN ? 1 : M][64];
 	__shared__ int s_besty[M][64];
-	__shared__ BoundaryRec s_bnd[CHAIN ? kChainChunk : 1];      /* the predecessor's boundary records of the current chunk of steps */
+	__shared__ BoundaryVal s_bnd[CHAIN ? kChainChunk : 1];      /* the predecessor's boundary records of the current chunk of steps */
 
 	int t;                          /* tile */
 	int task_id = 0, y0 = 0;        /* chain: task index, first read row of the block */
@@ -708,45 +705,60 @@ fill_ring_kernel(const FillArgs a) {
 	/* chain: where this block's last row lives (it feeds the next block) and what has been published */
 	const int out_slot = CHAIN ? (ct.rows - 1) : 0;
 	const int out_lane = out_slot / M, out_j = out_slot % M;
-	BoundaryRec *bnd_out = CHAIN ? a.bnd + ct.bnd_out_off : nullptr;
-	const BoundaryRec *bnd_in = CHAIN ? a.bnd + ct.bnd_in_off : nullptr;
+	u64 *bnd_out = CHAIN ? reinterpret_cast<u64 *>(a.bnd + ct.bnd_out_off) : nullptr;
+	u64 *bnd_in = CHAIN ? reinterpret_cast<u64 *>(a.bnd + ct.bnd_in_off) : nullptr;
+	const unsigned epoch = a.bnd_epoch;
 	int chain_failed = 0;
-	BoundaryRec bcur;               /* boundary record of the next step */
+	BoundaryVal bcur;               /* boundary record of the next step */
 	bcur.V = go; bcur.S = 0.0f; bcur.run = 0u; bcur.is_ins = 0u;
+	u64 bpre = 0ull;                /* this lane's record of the NEXT chunk, requested one chunk early (epoch 0: not valid) */
 
 	/* one 4-step group; TRACK: exact best-cell tracking (else only the lane maximum) */
 	auto group = [&](auto track_tag, const int g) {
 		constexpr bool TRACK = decltype(track_tag)::value;
 		if (CHAIN && (g & (kChainChunk / 4 - 1)) == 0) {
-			/* boundary records of the next kChainChunk steps: record i belongs to column lo + i of the row
-			 * above this block; wait until the producer has published them (it runs ahead of us) */
+			/* boundary records of the next kChainChunk steps: record i belongs to column lo + i of the row above this
+			 * block.  Lane l < kChainChunk owns the record of step r + l; it asked for it one chunk ago. */
 			const int x = (r - y0) + lane;                     /* column of the first row's cell at step r + lane */
 			const int idx = x - ct.bnd_lo;
-			BoundaryRec br;
+			const bool mine = ct.prev >= 0 && lane < kChainChunk && idx >= 0 && idx < ct.bnd_len;
+			u64 q = bpre;
+			bool ok = !mine || (unsigned) (q >> 49) == epoch;
+			int spins = 0;
+			while (!chain_failed && ballot(!ok) != 0ull) {     /* (wave-uniform) the producer has not got there yet */
+				if (!ok) {
+					q = __hip_atomic_load(bnd_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					ok = (unsigned) (q >> 49) == epoch;
+				}
+				if (ballot(!ok) == 0ull) break;
+				if (++spins > (1 << 21)) { chain_failed = 1; break; }     /* seconds: never hang the device */
+				/* back off: a task that was dispatched long before its turn must not flood the fabric with polls */
+				if (spins < 8) __builtin_amdgcn_s_sleep(2);
+				else if (spins < 64) __builtin_amdgcn_s_sleep(32);
+				else __builtin_amdgcn_s_sleep(127);
+			}
+			BoundaryVal br;
 			br.V = go; br.S = 0.0f; br.run = 0u; br.is_ins = 0u;     /* outside the row above: the empty element */
-			if (ct.prev >= 0) {
-				int need_n = (r - y0) + (kChainChunk - 1) - ct.bnd_lo + 1;      /* records up to the chunk's last step */
-				if (need_n > ct.bnd_len) need_n = ct.bnd_len;
-				if (need_n > 0 && !chain_failed) {
-					int spins = 0;
-					for (;;) {
-						const int have = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.progress + ct.prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-						if (have >= need_n) break;
-						if (++spins > (1 << 21)) { chain_failed = 1; break; }     /* seconds: never hang the device */
-						/* back off: a task that was dispatched long before its turn must not flood L2 with polls */
-						if (spins < 8) __builtin_amdgcn_s_sleep(4);
-						else if (spins < 64) __builtin_amdgcn_s_sleep(32);
-						else __builtin_amdgcn_s_sleep(127);
-					}
-				}
-				if (lane < kChainChunk && idx >= 0 && idx < ct.bnd_len && !chain_failed) {
-					const v4u q = load_through16(bnd_in + idx);
-					br.V = __uint_as_float(q.x); br.S = __uint_as_float(q.y); br.run = q.z; br.is_ins = q.w;
-				}
+			if (mine && ok) {
+				const unsigned meta = (unsigned) (q >> 32);
+				const float sc = __uint_as_float((unsigned) q);
+				const unsigned run16 = meta & 0xffffu;
+				const bool ins = (meta >> 16) & 1u;
+				/* the run register as the producer's slot held it, and the run its gap penalty was computed from */
+				const float runf = WRAP ? (float) (int) (short) run16 : (float) run16 - 1.0f;
+				br.S = sc;
+				br.run = WRAP ? (unsigned) (int) (short) run16 : __float_as_uint((float) run16);
+				br.is_ins = ins ? 1u : 0u;
+				br.V = ins ? gap_extend_value(sc, runf, gem, gext, decay) : sc + go;
 			}
 			if (lane < kChainChunk) s_bnd[lane] = br;
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      /* one wave: LDS write -> read order */
 			bcur = s_bnd[0];
+			/* ask for the next chunk's records now: they are on their way while this chunk computes */
+			const int idxn = idx + kChainChunk;
+			bpre = 0ull;
+			if (ct.prev >= 0 && lane < kChainChunk && idxn >= 0 && idxn < ct.bnd_len)
+				bpre = __hip_atomic_load(bnd_in + idxn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		/* this group's reference characters were fetched one group ago */
 		unsigned cw[M];
@@ -777,7 +789,7 @@ fill_ring_kernel(const FillArgs a) {
 			if (CHAIN) {
 				/* the block's first row (lane 0, slot 0) has the previous block's last row above it */
 				/* (the record was fetched from LDS one step ago: its latency is off the step's critical path) */
-				const BoundaryRec br = bcur;
+				const BoundaryVal br = bcur;
 				bcur = s_bnd[((r - r0) + 1) & (kChainChunk - 1)];
 				if (lane == 0) {
 					uV0 = br.V;
@@ -852,11 +864,7 @@ fill_ring_kernel(const FillArgs a) {
 					nd = (run_t) (runf + 1.0f);
 					ni = nd;
 				}
-				const float pen = fminf(gem, gext + runf * decay);
-				/* :669-675  E = (score == 0) ? 0 : score + pen.  score >= 0 and pen < 0, so this is
-				 * max(score + pen, score * -2^100): -0 for score 0 (compares equal to the reference's
-				 * +0 and never reaches an output), score + pen otherwise. */
-				const float E = fmaxf(sc + pen, sc * -0x1p100f);
+				const float E = gap_extend_value(sc, runf, gem, gext, decay);
 				const float O = sc + go;
 
 				dg[j] = uS;
@@ -912,23 +920,13 @@ fill_ring_kernel(const FillArgs a) {
 				if (CHAIN && j == out_j && ct.has_next) {
 					/* the last row's new cell goes to the boundary stream (record index = its column in the row) */
 					if (lane == out_lane && (unsigned) (cnt[j] - 1) < (unsigned) len[j]) {
-						v4u q;
-						q.x = __float_as_uint(V[j]); q.y = __float_as_uint(S[j]);
-						q.z = WRAP ? (unsigned) (int) irun[j] : __float_as_uint((float) irun[j]);
-						q.w = (unsigned) ((mI[j] >> out_lane) & 1ull);
-						store_through16(bnd_out + (cnt[j] - 1), q);
+						const unsigned run16 = WRAP ? ((unsigned) (int) irun[j] & 0xffffu) : ((unsigned) (int) (float) irun[j] & 0xffffu);
+						const unsigned meta = run16 | (unsigned) (((mI[j] >> out_lane) & 1ull) << 16) | (epoch << 17);
+						__hip_atomic_store(bnd_out + (cnt[j] - 1), ((u64) meta << 32) | (u64) __float_as_uint(S[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					}
 				}
 			}
 			r += 1;
-		}
-		if (CHAIN && ct.has_next && (g & (kChainChunk / 4 - 1)) == (kChainChunk / 4 - 1)) {
-			/* publish what the last row has produced so far: records, release, counter */
-			int done_n = 0;
-#pragma unroll
-			for (int j = 0; j < M; ++j) if (j == out_j) done_n = __builtin_amdgcn_readlane(cnt[j] < 0 ? 0 : (cnt[j] > len[j] ? len[j] : cnt[j]), out_lane);
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the write-through record stores have landed */
-			if (lane == 0) __hip_atomic_store(a.progress + ct.blk, done_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		/* hand finished slots to their next row (y + N): a row's last cell is consumed
 		 * by the row below one step after it was computed, so wait for cnt > len
@@ -991,11 +989,6 @@ fill_ring_kernel(const FillArgs a) {
 		if (!EXACT) be = fmaxf(be, __shfl_xor(be, off, 64));
 	}
 	if (CHAIN) {
-		if (ct.has_next) {
-			/* everything the next block may still wait for is out */
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (lane == 0) __hip_atomic_store(a.progress + ct.blk, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
 		if (lane == 0) {
 			ChainOut co;
 			co.score = b;

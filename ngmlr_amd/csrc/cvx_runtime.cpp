@@ -214,6 +214,7 @@ struct cvx_batch_s {
 	DevBuf<uint8_t> d_chain;
 	DevBuf<int32_t> d_progress;
 	DevBuf<BoundaryRec> d_bnd;
+	uint32_t bnd_epoch = 0;          /* tag of the records the latest launch wrote (0: buffer freshly zeroed) */
 	DevBuf<ChainOut> d_chain_out;
 
 	hipEvent_t ev_bt0 = nullptr, ev_bt1 = nullptr;   /* fork / join of the long-read backtrack launch */
@@ -280,6 +281,7 @@ struct cvx_context {
 	int tune_min_slots = 0;   /* tuning knob (env CVX_TUNE_MIN_M): smallest M*NW a tile may use */
 	int tune_late_min = kLateMinGroups;  /* test knob (env CVX_TUNE_LATE_MIN): groups of the exactly tracked tail (huge: exact everywhere) */
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
+	int tune_long_steps = 0, tune_small_batch = 0;   /* tuning knobs (env CVX_TUNE_LONG_STEPS / CVX_TUNE_SMALL_BATCH): see PlanTuning */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
 	int test_fail_compute = 0; /* test knob (env CVX_TUNE_FAIL_COMPUTE = k): the k-th compute stage of this handle fails (error-path tests) */
@@ -606,6 +608,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	PlanTuning tune;
 	tune.min_slots = h->tune_min_slots; tune.max_slots = h->tune_max_slots; tune.force_wrap = h->tune_force_wrap; tune.chain_m = h->tune_chain_m;
 	tune.force_generic = h->sse_variant ? 1 : 0;
+	tune.long_steps = h->tune_long_steps; tune.small_batch = h->tune_small_batch;
 	/* (a tile that gets chained needs its rows on the host: rebuilt from the step stream the batch still owns) */
 	const RowSrc *rsrc = b->h_rsrc.as<RowSrc>();
 	host_plan_rows(n, b->plan(), b->tin(), [&](int i, std::vector<RowDesc> &tmp) -> const RowDesc * {
@@ -682,7 +685,17 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		RC_TRY(b->d_chain.ensure(chain_bytes));
 		RC_TRY(b->d_progress.ensure(hp.chain_blk.size()));
 		RC_TRY(b->d_chain_out.ensure(hp.chain_blk.size()));
-		RC_TRY(b->d_bnd.ensure((size_t) hp.bnd_recs + 64));
+		{
+			/* boundary records validate themselves by the launch epoch in their upper bits: a buffer starts out zeroed
+			 * (epoch 0 = never written) and is zeroed again when the epochs wrap */
+			const size_t had = b->d_bnd.cap;
+			RC_TRY(b->d_bnd.ensure((size_t) hp.bnd_recs + 64));
+			if (b->d_bnd.cap != had || b->bnd_epoch >= kBndEpochMax) {
+				HIP_TRY(hipMemsetAsync(b->d_bnd.p, 0, b->d_bnd.cap * sizeof(BoundaryRec), st));
+				b->bnd_epoch = 0;
+			}
+			b->bnd_epoch += 1;
+		}
 		HIP_TRY(hipMemcpyAsync(b->d_chain.p, hc, chain_bytes, hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemsetAsync(b->d_progress.p, 0, hp.chain_blk.size() * sizeof(int32_t), st));
 	}
@@ -709,7 +722,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		a.list_n = list_n;
 		a.redo_count = b->d_counters.p;
 		a.late_min_groups = h->tune_late_min;
-		a.tasks = nullptr; a.chain_ticket = nullptr; a.progress = nullptr; a.bnd = nullptr; a.chain_out = nullptr;
+		a.tasks = nullptr; a.chain_ticket = nullptr; a.progress = nullptr; a.bnd = nullptr; a.chain_out = nullptr; a.bnd_epoch = 0;
 		a.ops = b->d_regions.p;
 		a.sp = h->sp;
 		return a;
@@ -759,6 +772,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		a.chain_ticket = b->d_counters.p + 8 + (int) c;
 		a.progress = b->d_progress.p;
 		a.bnd = b->d_bnd.p;
+		a.bnd_epoch = b->bnd_epoch;
 		a.chain_out = b->d_chain_out.p;
 		/* tasks are dispatched in order, long before their turn; resident tasks beyond the ones that can
 		 * actually run only poll.  Unused dynamic LDS caps the residency at ~1.5x the blocks that are
@@ -1025,6 +1039,8 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_SCORE_NO_DIAG")) c->score_no_diag = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_M")) c->tune_chain_m = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_LONG_STEPS")) c->tune_long_steps = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_SMALL_BATCH")) c->tune_small_batch = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
 	int prio_lo = 0, prio_hi = 0;
 	(void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     /* numerically lower = higher priority */

@@ -147,10 +147,19 @@ struct ChainTask {         /* one row block = one wave's work */
 	uint64_t bnd_out_off;  /* BoundaryRec offset of this block's own stream */
 };
 
-struct BoundaryRec {       /* what a cell of a block's last row offers the row below */
+struct BoundaryRec {       /* what a cell of a block's last row offers the row below: ONE 8-byte word, stored and loaded
+                            * atomically, that says by itself whether it has been written in this launch */
+	uint32_t s_bits;       /* the cell's score (float bits) */
+	uint32_t meta;         /* [15:0] gap-run register (float kernels: run + 1 as an integer; wrap kernels: the int16 run),
+	                        * [16] the cell is an insertion, [31:17] launch epoch (kBndEpochMax values, never 0).
+	                        * The up candidate V is not stored: it is a function of (score, run, insertion) */
+};
+static const uint32_t kBndEpochMax = 32767;
+
+struct BoundaryVal {       /* a decoded BoundaryRec in LDS */
 	float V, S;            /* up candidate, score */
 	uint32_t run;          /* gap-run register (float bits, or the int16 run of the wrap kernels) */
-	uint32_t is_ins;       /* the cell is an insertion */
+	uint32_t is_ins;
 };
 
 struct ChainOut {          /* best cell of one block, tile coordinates */
@@ -233,6 +242,7 @@ struct FillArgs {
 	int32_t *chain_ticket;   /* zeroed before the launch */
 	int32_t *progress;       /* per block: boundary records published (zeroed before the launch) */
 	BoundaryRec *bnd;
+	uint32_t bnd_epoch;      /* tag of the boundary records written by this launch */
 	ChainOut *chain_out;     /* per block */
 	int32_t late_min_groups; /* exactly tracked tail, in 4-step groups (kLateMinGroups; a test knob raises it) */
 	int32_t *ops;          /* per-tile op regions */

@@ -43,7 +43,8 @@ def run(name, t, ref, fq, extra_env=None):
     recs = sorted(l for l in res.stdout.splitlines() if l and not l.startswith("@"))
     m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", res.stderr)
     mp = re.search(r"Overall time for creating RefTable: ([0-9.]+)s", res.stderr)
-    return {"wall": dt, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None,
+    st = re.search(r"SharedAligner: \d+ workers over.*", res.stderr)
+    return {"wall": dt, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None,
             "map_s": dt - float(mp.group(1)) if mp else None, "err": res.stderr[-400:]}
 
 
@@ -52,6 +53,8 @@ def line(name, t, r, same):
     print("%-18s -t %-4d wall %7.2f s%s  rc %d  SAM %s%s" % (
         name, t, r["wall"], ("  map %6.2f s" % r["map_s"]) if r["map_s"] is not None else "", r["rc"], same,
         ("  %d alignments in %d launches (%.1f per launch)" % (l[0], l[1], l[0] / max(l[1], 1))) if l else ""), flush=True)
+    if r.get("stats"):
+        print("    " + r["stats"], flush=True)
 
 
 def synthetic(n_reads, threads):
