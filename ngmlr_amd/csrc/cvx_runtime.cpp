@@ -212,7 +212,6 @@ struct cvx_batch_s {
 	DevBuf<WindowDesc> d_win;
 	PinBuf h_chain;                  /* ChainTask[] of all chain classes, ChainBlk[], tile lists */
 	DevBuf<uint8_t> d_chain;
-	DevBuf<int32_t> d_progress;
 	DevBuf<BoundaryRec> d_bnd;
 	uint32_t bnd_epoch = 0;          /* tag of the records the latest launch wrote (0: buffer freshly zeroed) */
 	DevBuf<ChainOut> d_chain_out;
@@ -255,7 +254,7 @@ struct cvx_batch_s {
 		d_nmoff.release(); d_nm.release(); h_nmoff.release();
 		if (ev_nm0) { (void) hipEventDestroy(ev_nm0); ev_nm0 = nullptr; }
 		if (ev_nm1) { (void) hipEventDestroy(ev_nm1); ev_nm1 = nullptr; }
-		h_chain.release(); d_chain.release(); d_progress.release(); d_bnd.release(); d_chain_out.release();
+		h_chain.release(); d_chain.release(); d_bnd.release(); d_chain_out.release();
 		if (ev_in) { (void) hipEventDestroy(ev_in); ev_in = nullptr; }
 		if (ev_res) { (void) hipEventDestroy(ev_res); ev_res = nullptr; }
 		if (ev_ops) { (void) hipEventDestroy(ev_ops); ev_ops = nullptr; }
@@ -683,7 +682,6 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		for (size_t c = 0; c < hp.chain_tiles.size(); ++c)
 			if (!hp.chain_tiles[c].empty()) memcpy(hc + chain_tile_off[c], hp.chain_tiles[c].data(), hp.chain_tiles[c].size() * sizeof(int32_t));
 		RC_TRY(b->d_chain.ensure(chain_bytes));
-		RC_TRY(b->d_progress.ensure(hp.chain_blk.size()));
 		RC_TRY(b->d_chain_out.ensure(hp.chain_blk.size()));
 		{
 			/* boundary records validate themselves by the launch epoch in their upper bits: a buffer starts out zeroed
@@ -697,7 +695,6 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 			b->bnd_epoch += 1;
 		}
 		HIP_TRY(hipMemcpyAsync(b->d_chain.p, hc, chain_bytes, hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemsetAsync(b->d_progress.p, 0, hp.chain_blk.size() * sizeof(int32_t), st));
 	}
 	HIP_TRY(hipMemcpyAsync(b->d_trun.p, b->h_trun.p, (size_t) n * sizeof(TileRun), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(b->d_tout.p, b->h_tout.p, (size_t) n * sizeof(TileOut), hipMemcpyHostToDevice, st));
@@ -722,7 +719,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		a.list_n = list_n;
 		a.redo_count = b->d_counters.p;
 		a.late_min_groups = h->tune_late_min;
-		a.tasks = nullptr; a.chain_ticket = nullptr; a.progress = nullptr; a.bnd = nullptr; a.chain_out = nullptr; a.bnd_epoch = 0;
+		a.tasks = nullptr; a.chain_ticket = nullptr; a.bnd = nullptr; a.chain_out = nullptr; a.bnd_epoch = 0;
 		a.ops = b->d_regions.p;
 		a.sp = h->sp;
 		return a;
@@ -770,7 +767,6 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		FillArgs a = fill_args(nullptr, (int) hp.chain_tasks[c].size());
 		a.tasks = reinterpret_cast<const ChainTask *>(b->d_chain.p + chain_task_off[c]);
 		a.chain_ticket = b->d_counters.p + 8 + (int) c;
-		a.progress = b->d_progress.p;
 		a.bnd = b->d_bnd.p;
 		a.bnd_epoch = b->bnd_epoch;
 		a.chain_out = b->d_chain_out.p;

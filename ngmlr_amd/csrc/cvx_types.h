@@ -137,7 +137,7 @@ struct ChainTask {         /* one row block = one wave's work */
 	int32_t rows;          /* rows in the block (<= ring) */
 	int32_t r0;            /* first step; (r0 - TileRun::r0) is a multiple of 32 */
 	int32_t nsteps;
-	int32_t blk;           /* index of this block's ChainBlk / ChainOut / progress counter */
+	int32_t blk;           /* index of this block's ChainBlk / ChainOut */
 	int32_t prev;          /* block index of the block above, -1 for the first block */
 	int32_t bnd_lo;        /* the row above this block: first column and number of cells inside [0, W) */
 	int32_t bnd_len;
@@ -240,7 +240,6 @@ struct FillArgs {
 	/* kFillChain only */
 	const ChainTask *tasks;  /* list_n tasks in dependency order */
 	int32_t *chain_ticket;   /* zeroed before the launch */
-	int32_t *progress;       /* per block: boundary records published (zeroed before the launch) */
 	BoundaryRec *bnd;
 	uint32_t bnd_epoch;      /* tag of the boundary records written by this launch */
 	ChainOut *chain_out;     /* per block */

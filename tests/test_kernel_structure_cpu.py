@@ -52,7 +52,9 @@ def test_fill_kernels_have_flat_uniform_step_loops(device_asm):
             seg = lines[labels[m.group(2)]:i]
             if sum(1 for q in seg if "v_addc_co_u32_e64" in q) >= 8:      # holds the plane updates of a group
                 step_loops += 1
-                assert m.group(1) in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1"), \
+                # (vccz / vccnz test the whole VCC for zero -- a ballot -- and are as wave-uniform as scc; EXEC-based
+                # branches are what a divergent loop would be closed by)
+                assert m.group(1) in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccz", "s_cbranch_vccnz"), \
                     "%s: step loop closed by %s (divergent?)" % (name, m.group(1))
         assert step_loops >= 1, name
         seen += 1
