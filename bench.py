@@ -539,6 +539,7 @@ def main() -> int:
         w0 = workers[0]
         ts = w0.ts
         res, ops = w0.last.results, w0.last.ops
+        n_ops_total = int(np.asarray(res["n_ops"], dtype=np.int64).sum())      # (res / ops are views of the job's buffers: gone after release)
         # outside the timed region: CPU baseline on a bounded sample + parity on every sampled tile
         cpu = parity = parity_detail = None
         if not args.no_cpu_baseline and args.gpus == 1:
@@ -558,11 +559,13 @@ def main() -> int:
             text_stage = {"error": str(e)}
         # the same stage on the device (cvx_job_text): CIGAR + MD + fields of ALL tiles of the step, strings back on the host
         text_dev = None
+        path_columns = None
         try:
             w0.last.text_raw()                                # first call allocates the job's text buffers
             c0 = time.perf_counter()
             trec, toff, tbuf = w0.last.text_raw()
             dtd = time.perf_counter() - c0
+            path_columns = int(np.frombuffer(trec, dtype=np.int32).reshape(-1, 17)[:len(ts), 7].sum())      # alignment_length
             nbad = 0
             if text_stage and "error" not in text_stage:
                 raw = tbuf.raw
@@ -701,6 +704,20 @@ def main() -> int:
                 traffic_src = "no profiles/r*_pmc.json was collected on this build of the kernels (%s): null rather than a stale number" % build_id
         except Exception as e:
             traffic_src = "unavailable: %s" % e
+        # the second kernel of the step: SURVEY 8(d)'s bytes for it are P (one direction per path step) + 4 n_ops
+        backtrack_fig = None
+        try:
+            if resident and "backtrack_ms" in resident:
+                path = int(path_columns) if path_columns else None
+                bms = resident["backtrack_ms"]
+                backtrack_fig = {"kernel": "backtrack_kernel (8 lanes per tile) + finalize + ops compaction", "ms": bms, "path_columns": path, "n_ops": n_ops_total,
+                                 "alg_bytes": (path + 4 * n_ops_total) if path else None,
+                                 "achieved_GB_per_s": ((path + 4 * n_ops_total) / (bms * 1e-3) / 1e9) if path else None,
+                                 "path_columns_per_s": (path / (bms * 1e-3)) if path else None,
+                                 "bound": "latency, not bandwidth: per tile a chain of ~P/32 dependent loads of direction words (2 bits per cell, 32 steps per word); "
+                                          "the stage is 9 % of the step and its HBM-roofline fraction (bytes above / 8 TB/s) is of the order 1e-3 by construction"}
+        except Exception as e:
+            backtrack_fig = {"error": str(e)}
         out = {
             "metric": "aligned Gbp/hour (PacBio 10kb synthetic, convex-gap SW hot path, host buffers in -> results out, CIGAR bit-exact)",
             "value": value,
@@ -750,6 +767,7 @@ def main() -> int:
                                    "what": "HIP-event stage times of the device-resident steps (in the pipelined steps the stages of neighbouring batches overlap)"}
                                   if resident and "fill_ms" in resident else None),
             "device_resident": resident,
+            "backtrack": backtrack_fig,
             "host_ms_per_step": {"cvx_submit": float(w0.host_s[0]) / args.steps * 1e3, "cvx_wait": float(w0.host_s[1]) / args.steps * 1e3,
                                  "what": "wall time the device's host thread spends inside the two calls (packing + queueing / blocked on results)",
                                  "pack_threads_shared_by_the_process": int(os.environ.get("CVX_PACK_THREADS", "0")) or min(os.cpu_count() or 1, 16)},
