@@ -16,7 +16,7 @@ One "cell" below is the cell update of one ring slot as hipcc emits it for fill_
 """
 import sys
 
-FULL = ("v_add_f32", "v_mul_f32", "v_add_u32", "v_mov_b32", "v_fma_f32", "v_and_b32")
+FULL = ("v_add_f32", "v_mul_f32", "v_add_u32", "v_mov_b32", "v_fma_f32", "v_and_b32")      # (classification used for the S= / F= counts printed beside each body; the new probes print as S)
 
 
 def cell(k):
@@ -172,6 +172,33 @@ def main():
         "v_min_f32": lambda i: "v_min_f32 v%d, v%d, v9" % (16 + i % 24, 16 + i % 24),
         "v_med3_f32": lambda i: "v_med3_f32 v%d, v%d, v8, v9" % (16 + i % 24, 16 + i % 24),
         "v_readlane": lambda i: "v_readlane_b32 s%d, v%d, 5" % (34 + i % 16, 16 + i % 24),
+        # round 3, second batch: which integer forms are full-rate (candidates for replacing float min / max / compares)
+        "v_max_i32": lambda i: "v_max_i32 v%d, v%d, v9" % (16 + i % 24, 16 + i % 24),
+        "v_max_u32": lambda i: "v_max_u32 v%d, v%d, v9" % (16 + i % 24, 16 + i % 24),
+        "v_min_u32": lambda i: "v_min_u32 v%d, v%d, v9" % (16 + i % 24, 16 + i % 24),
+        "v_max3_i32": lambda i: "v_max3_i32 v%d, v%d, v%d, 0" % (16 + i % 24, 16 + i % 24, 40 + i % 8),
+        "v_sub_co_u32 -> sgpr": lambda i: "v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (16 + i % 24, sg(i), 16 + i % 24, 40 + i % 8),
+        "v_add_co_u32 -> vcc (e32)": lambda i: "v_add_co_u32_e32 v%d, vcc, v%d, v%d" % (16 + i % 24, 16 + i % 24, 40 + i % 8),
+        "v_cmp_lt_u32 -> sgpr": lambda i: "v_cmp_lt_u32_e64 %s, v%d, v%d" % (sg(i), 16 + i % 24, 40 + i % 8),
+        "v_cmp_eq_u32 -> sgpr": lambda i: "v_cmp_eq_u32_e64 %s, v%d, v%d" % (sg(i), 16 + i % 24, 40 + i % 8),
+        "v_pk_add_f32": lambda i: "v_pk_add_f32 v[%d:%d], v[%d:%d], v[8:9]" % (16 + 2 * (i % 12), 17 + 2 * (i % 12), 16 + 2 * (i % 12), 17 + 2 * (i % 12)),
+        "v_pk_mul_f32": lambda i: "v_pk_mul_f32 v[%d:%d], v[%d:%d], v[8:9]" % (16 + 2 * (i % 12), 17 + 2 * (i % 12), 16 + 2 * (i % 12), 17 + 2 * (i % 12)),
+        "v_pk_fma_f32": lambda i: "v_pk_fma_f32 v[%d:%d], v[%d:%d], v[8:9], v[10:11]" % (16 + 2 * (i % 12), 17 + 2 * (i % 12), 16 + 2 * (i % 12), 17 + 2 * (i % 12)),
+        "v_bfe_u32": lambda i: "v_bfe_u32 v%d, v%d, 8, 8" % (16 + i % 24, 40 + i % 8),
+        "v_xor_b32": lambda i: "v_xor_b32 v%d, v%d, v%d" % (16 + i % 24, 16 + i % 24, 40 + i % 8),
+        "v_lshlrev_b32": lambda i: "v_lshlrev_b32 v%d, 1, v%d" % (16 + i % 24, 16 + i % 24),
+        "v_lshl_add_u32": lambda i: "v_lshl_add_u32 v%d, v%d, 1, v%d" % (16 + i % 24, 16 + i % 24, 40 + i % 8),
+        "v_add3_u32": lambda i: "v_add3_u32 v%d, v%d, v%d, 1" % (16 + i % 24, 16 + i % 24, 40 + i % 8),
+        "v_and_or_b32": lambda i: "v_and_or_b32 v%d, v%d, v%d, v9" % (16 + i % 24, 16 + i % 24, 40 + i % 8),
+        "v_bfi_b32": lambda i: "v_bfi_b32 v%d, v8, v%d, v%d" % (16 + i % 24, 16 + i % 24, 40 + i % 8),
+        "v_perm_b32": lambda i: "v_perm_b32 v%d, v%d, v%d, v9" % (16 + i % 24, 16 + i % 24, 40 + i % 8),
+        "v_sub_f32": lambda i: "v_sub_f32 v%d, v%d, v9" % (16 + i % 24, 16 + i % 24),
+        "v_cvt_f32_u32": lambda i: "v_cvt_f32_u32 v%d, v%d" % (16 + i % 24, 40 + i % 8),
+        "v_cvt_f32_i32": lambda i: "v_cvt_f32_i32 v%d, v%d" % (16 + i % 24, 40 + i % 8),
+        "v_max_i16": lambda i: "v_max_i16 v%d, v%d, v9" % (16 + i % 24, 16 + i % 24),
+        "v_pk_max_i16": lambda i: "v_pk_max_i16 v%d, v%d, v9" % (16 + i % 24, 16 + i % 24),
+        "v_pk_add_u16": lambda i: "v_pk_add_u16 v%d, v%d, v9" % (16 + i % 24, 16 + i % 24),
+        "v_cndmask sdwa?skip": None,
         "s_and_b64": lambda i: "s_and_b64 %s, %s, %s" % (sg(i), sg(i), sg(i + 3)),
         "s_lshl_b64": lambda i: "s_lshl_b64 %s, %s, 1" % (sg(i), sg(i)),
         "s_mov_b64": lambda i: "s_mov_b64 %s, %s" % (sg(i), sg(i + 3)),
@@ -180,6 +207,8 @@ def main():
     }
     kinds.append(("F x24 (v_add_f32)", [(F(i), set(), set()) for i in range(24)]))
     for nm, fn in skinds.items():
+        if fn is None:
+            continue
         kinds.append(("%s x24" % nm, simple(fn, 24)))
         alt = []
         for i in range(12):
