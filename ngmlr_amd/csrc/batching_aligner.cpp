@@ -193,6 +193,7 @@ long g_joined = 0;
 long g_lastLaunches = 0, g_lastRequests = 0;
 double g_lastParked = 0.0, g_lastFinish = 0.0, g_lastBusy = 0.0;
 std::chrono::steady_clock::time_point g_firstJoin;
+std::chrono::steady_clock::time_point const g_loaded = std::chrono::steady_clock::now();      /* ~ process start */
 }
 
 SharedAligner::SharedAligner(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
@@ -240,6 +241,8 @@ SharedAligner::~SharedAligner() {
 				"%.1f %% in their text stage; a launch was in flight %.1f %% of the time\n", g_joined, wall,
 				100.0 * g_lastParked / (wall * (double) g_joined), g_lastRequests ? 1e3 * g_lastParked / (double) g_lastRequests : 0.0,
 				100.0 * g_lastFinish / (wall * (double) g_joined), 100.0 * g_lastBusy / wall);
+		fprintf(stderr, "SharedAligner: library loaded at 0, first worker joined at %.2f s, last one left at %.2f s\n",
+				std::chrono::duration<double>(g_firstJoin - g_loaded).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - g_loaded).count());
 	}
 }
 

@@ -301,7 +301,7 @@ struct cvx_context {
 	DevBuf<ScorePair> sc_pairs;
 	DevBuf<int32_t> sc_rows;
 	DevBuf<float> sc_out;
-	hipEvent_t sc_ev0 = nullptr, sc_ev1 = nullptr;
+	hipEvent_t sc_ev0 = nullptr, sc_ev1 = nullptr, sc_done = nullptr;
 	float sc_kernel_ms = 0.0f;
 	bool score_no_diag = false;   /* test knob (env CVX_TUNE_SCORE_NO_DIAG): always the row-by-row kernels */
 };
@@ -1072,6 +1072,7 @@ void cvx_destroy(cvx_handle h) {
 	h->sc_hseq.release(); h->sc_hpairs.release(); h->sc_hout.release();
 	h->sc_seq.release(); h->sc_pairs.release(); h->sc_rows.release(); h->sc_out.release();
 	if (h->sc_ev0) (void) hipEventDestroy(h->sc_ev0);
+	if (h->sc_done) (void) hipEventDestroy(h->sc_done);
 	if (h->sc_ev1) (void) hipEventDestroy(h->sc_ev1);
 	delete h;
 }
@@ -1865,7 +1866,11 @@ int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char
 		HIP_TRY(launch_score(h->sc_seq.p, h->sc_pairs.p, h->sc_rows.p, h->sc_out.p, n, (int) std::min<size_t>(max_rl, 0x7fffffff), st));
 	HIP_TRY(hipEventRecord(h->sc_ev1, st));
 	HIP_TRY(hipMemcpyAsync(h->sc_hout.p, h->sc_out.p, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
+	/* wait on a blocking event, not by spinning on the stream: in ngmlr dozens of worker threads sit in this call at the
+	 * same time on a host that needs its cores for the stages that stayed on the CPU */
+	if (!h->sc_done) HIP_TRY(hipEventCreateWithFlags(&h->sc_done, hipEventBlockingSync | hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(h->sc_done, st));
+	HIP_TRY(hipEventSynchronize(h->sc_done));
 	memcpy(scores, h->sc_hout.p, (size_t) n * sizeof(float));
 	h->sc_kernel_ms = ev_ms(h->sc_ev0, h->sc_ev1);
 	return CVX_OK;

@@ -3,44 +3,74 @@
 
 #include <cstdio>
 
+#include <atomic>
+#include <chrono>
 #include <mutex>
 
 namespace {
 const int kMaxDevices = 64;
-std::mutex g_mtx[kMaxDevices];
+/* handles per device: a scoring call is synchronous (strings in, scores out) and mostly latency -- copy, a short kernel,
+ * copy -- so one handle behind one mutex serialises 64 workers on ~0.3 ms round trips while the device idles.  Workers
+ * are dealt round-robin over kLanes handles (own streams, own staging); calls on different lanes overlap. */
+const int kLanes = 16;
+std::mutex g_mtx[kMaxDevices][kLanes];
 std::mutex g_tableMtx;
-cvx_handle g_handle[kMaxDevices] = {0};
+cvx_handle g_handle[kMaxDevices][kLanes] = {{0}};
 int g_users[kMaxDevices] = {0};
+long g_joined[kMaxDevices] = {0};
+/* statistics, printed when the last scorer of a device goes (like SharedAligner's line) */
+std::atomic<long> g_calls(0), g_pairs(0), g_single(0);
+std::atomic<long long> g_ns(0), g_ctorNs(0);
+std::chrono::steady_clock::time_point const g_loaded = std::chrono::steady_clock::now();      /* ~ process start */
+double g_firstCtorBegin = -1.0, g_firstCtorEnd = -1.0;
+double since_load() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - g_loaded).count(); }
 }
 
-StrippedSWHip::StrippedSWHip(int const deviceId) : device(deviceId >= 0 && deviceId < kMaxDevices ? deviceId : 0) {
+StrippedSWHip::StrippedSWHip(int const deviceId) : device(deviceId >= 0 && deviceId < kMaxDevices ? deviceId : 0), lane(0) {
+	std::chrono::steady_clock::time_point const c0 = std::chrono::steady_clock::now();
 	std::lock_guard<std::mutex> g(g_tableMtx);
-	if (g_handle[device] == 0) {
+	if (g_firstCtorBegin < 0.0) g_firstCtorBegin = since_load();
+	lane = (int) (g_joined[device]++ % kLanes);
+	if (g_handle[device][lane] == 0) {
 		/* the scoring kernel has fixed weights; the handle only needs a valid scoring triple */
 		cvx_params p = { 2.0f, -5.0f, -5.0f, -5.0f, -1.0f, 0.15f };
-		if (cvx_create(device, &p, 0, &g_handle[device]) != CVX_OK) {
+		if (cvx_create(device, &p, 0, &g_handle[device][lane]) != CVX_OK) {
 			fprintf(stderr, "StrippedSWHip: %s\n", cvx_last_error());
-			g_handle[device] = 0;
+			g_handle[device][lane] = 0;
 			throw "StrippedSWHip: no usable MI355X";
 		}
 	}
 	g_users[device] += 1;
+	if (g_firstCtorEnd < 0.0) g_firstCtorEnd = since_load();
+	g_ctorNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c0).count();
 }
 
 StrippedSWHip::~StrippedSWHip() {
 	std::lock_guard<std::mutex> g(g_tableMtx);
 	if (--g_users[device] == 0) {
-		std::lock_guard<std::mutex> d(g_mtx[device]);
-		cvx_destroy(g_handle[device]);
-		g_handle[device] = 0;
+		std::chrono::steady_clock::time_point const d0 = std::chrono::steady_clock::now();
+		for (int l = 0; l < kLanes; ++l) {
+			std::lock_guard<std::mutex> d(g_mtx[device][l]);
+			if (g_handle[device][l]) cvx_destroy(g_handle[device][l]);
+			g_handle[device][l] = 0;
+		}
+		g_joined[device] = 0;
+		fprintf(stderr, "StrippedSWHip: %ld scoring calls (%ld of them single pairs), %ld pairs, %.2f s inside the calls summed over the workers "
+				"(%.3f ms per call), %.2f s constructing, %.2f s destroying the handles\n", g_calls.load(), g_single.load(), g_pairs.load(),
+				g_ns.load() * 1e-9, g_calls.load() ? g_ns.load() * 1e-6 / (double) g_calls.load() : 0.0, g_ctorNs.load() * 1e-9,
+				std::chrono::duration<double>(std::chrono::steady_clock::now() - d0).count());
+		fprintf(stderr, "StrippedSWHip: library loaded at 0, first scorer constructed %.2f - %.2f s, last one gone at %.2f s\n", g_firstCtorBegin, g_firstCtorEnd, since_load());
 	}
 }
 
 int StrippedSWHip::BatchScore(int const mode, int const batchSize, char const * const * const refSeqList,
 		char const * const * const qrySeqList, float * const results, void * extData) {
 	(void) mode; (void) extData;
-	std::lock_guard<std::mutex> d(g_mtx[device]);
-	if (cvx_score_batch(g_handle[device], batchSize, refSeqList, qrySeqList, results) != CVX_OK) {
+	std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
+	std::lock_guard<std::mutex> d(g_mtx[device][lane]);
+	g_calls += 1; g_pairs += batchSize; if (batchSize == 1) g_single += 1;
+	struct Stop { std::chrono::steady_clock::time_point t; ~Stop() { g_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } stop{t0};
+	if (cvx_score_batch(g_handle[device][lane], batchSize, refSeqList, qrySeqList, results) != CVX_OK) {
 		fprintf(stderr, "StrippedSWHip: %s\n", cvx_last_error());
 		throw 1;
 	}

@@ -8,9 +8,9 @@
  * points throw, as this backend is score-only.
  *
  * ngmlr creates one scoring aligner per worker thread (NGM::CreateAlignment, src/NGM.cpp:350-361, called
- * from src/CS.cpp:416); all StrippedSWHip instances of a process share ONE device handle per device (its
- * staging buffers are reused call after call, so calls are serialised by a mutex: a 1024-pair batch is
- * well under a millisecond of device time, the workers spend theirs elsewhere).
+ * from src/CS.cpp:416); the StrippedSWHip instances of a process share a small set of device handles per
+ * device (a handle's staging buffers are reused call after call, so calls on ONE handle are serialised by a
+ * mutex; workers are dealt round-robin over the handles, calls on different handles overlap).
  */
 #ifndef STRIPPED_SW_HIP_H
 #define STRIPPED_SW_HIP_H
@@ -38,6 +38,7 @@ public:
 
 private:
 	int device;
+	int lane;      /* which of the device's scoring handles this worker uses */
 };
 
 #endif

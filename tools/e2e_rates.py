@@ -44,8 +44,9 @@ def run(name, t, ref, fq, extra_env=None):
     m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", res.stderr)
     mp = re.search(r"Overall time for creating RefTable: ([0-9.]+)s", res.stderr)
     st = re.search(r"SharedAligner: \d+ workers over.*", res.stderr)
-    return {"wall": dt, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None,
-            "map_s": dt - float(mp.group(1)) if mp else None, "err": res.stderr[-400:]}
+    sc = re.search(r"StrippedSWHip: \d+ scoring calls.*", res.stderr)
+    return {"wall": dt, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
+            "map_s": dt - float(mp.group(1)) if mp else None, "err": res.stderr[-400:], "full_err": res.stderr}
 
 
 def line(name, t, r, same):
@@ -55,6 +56,12 @@ def line(name, t, r, same):
         ("  %d alignments in %d launches (%.1f per launch)" % (l[0], l[1], l[0] / max(l[1], 1))) if l else ""), flush=True)
     if r.get("stats"):
         print("    " + r["stats"], flush=True)
+    if r.get("score_stats"):
+        print("    " + r["score_stats"], flush=True)
+    if os.environ.get("E2E_VERBOSE"):
+        for l in r["full_err"].splitlines():
+            if "library loaded" in l or "time" in l.lower() or "Done" in l:
+                print("      | " + l[:200], flush=True)
 
 
 def synthetic(n_reads, threads):
@@ -83,7 +90,8 @@ def synthetic(n_reads, threads):
     cores = os.cpu_count() or 8
     base = None
     best = None
-    for t in sorted({min(cores, 32), min(cores, 64)}):
+    only = os.environ.get("E2E_ONLY")          # one drop-in binary alone, no reference run (SAM then unchecked): quick looks
+    for t in ([] if only else sorted({min(cores, 32)} if os.environ.get("E2E_QUICK") else {min(cores, 32), min(cores, 64)})):
         r = run("ngmlr_ref", t, fa, fq)
         if r is None:
             print("ngmlr_ref not built")
@@ -93,16 +101,16 @@ def synthetic(n_reads, threads):
         line("ngmlr_ref", t, r, "reference" if r["recs"] == base else "DIFFERS from the first ngmlr_ref run")
         if best is None or r["wall"] < best[1]["wall"]:
             best = (t, r)
-    for name in ("ngmlr_hip_batched", "ngmlr_hip_full"):
+    for name in ((only,) if only else ("ngmlr_hip_batched", "ngmlr_hip_full")):
         for t in threads:
             r = run(name, t, fa, fq)
             if r is None:
                 print("%-18s not built" % name)
                 break
-            line(name, t, r, "identical" if r["recs"] == base else "DIFFERENT (%d vs %d records)" % (len(r["recs"]), len(base)))
+            line(name, t, r, "unchecked" if base is None else "identical" if r["recs"] == base else "DIFFERENT (%d vs %d records)" % (len(r["recs"]), len(base)))
             if r["rc"] != 0:
                 print(r["err"])
-            else:
+            elif best is not None:
                 print("    wall / best ngmlr_ref (-t %d): %.2f   map / map: %.2f   mapped bases per hour of `map`: %.1f Gbp/h vs %.1f Gbp/h" % (
                     best[0], r["wall"] / best[1]["wall"], (r["map_s"] or r["wall"]) / (best[1]["map_s"] or best[1]["wall"]),
                     bases / (r["map_s"] or r["wall"]) * 3.6e-6, bases / (best[1]["map_s"] or best[1]["wall"]) * 3.6e-6))
