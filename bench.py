@@ -457,8 +457,8 @@ def main() -> int:
         extra_tiles = {}
         if rank == 0 and args.gpus == 1 and not args.no_extras and not args.no_cpu_baseline:
             # the other BASELINE configs (parity cases with a rate, outside the timed region): generated here, before HIP exists
-            extra_tiles["ont"] = synth.parallel_workload("ont", 24000, 11, pool)
-            extra_tiles["ultralong_sv"] = synth.parallel_workload("ultralong_mix", 2048, 19, pool, chunk=16)
+            extra_tiles["ont"] = synth.parallel_workload("ont", 60000, 11, pool)
+            extra_tiles["ultralong_sv"] = synth.parallel_workload("ultralong_mix", 4096, 19, pool, chunk=16)
             extra_tiles["short"] = synth.parallel_workload("short", 60000, 17, pool, chunk=2048)
     t_gen = time.perf_counter() - t_gen
 

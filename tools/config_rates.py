@@ -8,6 +8,7 @@ from ngmlr_amd.aligner import ConvexAlignHip
 al = ConvexAlignHip()
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, make in (("ont C3 (24k tiles)", lambda: synth.workload_ont(24000, seed=11)),
+                   ("ont C3 (60k tiles)", lambda: synth.workload_ont(60000, seed=11)),
                    ("ultralong+SV C5 (96 tiles)", lambda: synth.workload_ultralong_sv(96, seed=13)),
                    ("ultralong mix C5 (2048 tiles)", lambda: synth.workload_ultralong_mix(2048, seed=19)),
                    ("ultralong mix C5 (6144 tiles)", lambda: synth.workload_ultralong_mix(6144, seed=19)),
