@@ -271,6 +271,8 @@ struct cvx_context {
 	hipStream_t s_io = nullptr;      /* uploads, plan, downloads (high priority: its short kernels and copies
 	                                  * must not queue behind the fill's workgroups) */
 	hipStream_t s_main = nullptr;    /* forward fills (and the small input copies in front of them) */
+	hipStream_t s_text = nullptr;    /* the text stage of FINISHED jobs (cvx_job_text, nm profile): its own stream, never queued behind the
+	                                  * fills of the batches that follow */
 	hipStream_t s_post = nullptr;    /* backtrack, finalize, compaction, result download: runs beside the NEXT batch's fill */
 	hipStream_t aux[kAuxStreams] = {nullptr};  /* concurrent fill classes */
 	ScoreParams sp;
@@ -1042,6 +1044,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	(void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     /* numerically lower = higher priority */
 	hipError_t e = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_post, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_text, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->s_io, hipStreamNonBlocking, prio_hi);
 	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
 	if (e != hipSuccess) {
@@ -1060,6 +1063,7 @@ void cvx_destroy(cvx_handle h) {
 	(void) hipDeviceSynchronize();
 	if (h->s_main) (void) hipStreamDestroy(h->s_main);
 	if (h->s_post) (void) hipStreamDestroy(h->s_post);
+	if (h->s_text) (void) hipStreamDestroy(h->s_text);
 	if (h->s_io) (void) hipStreamDestroy(h->s_io);
 	for (auto &a : h->aux) if (a) (void) hipStreamDestroy(a);
 	for (cvx_batch_s *b : h->pool) { b->release(); delete b; }
@@ -1397,7 +1401,7 @@ int cvx_job_text(cvx_handle h, cvx_job j, const int32_t *ext_qstart, const int32
 	if (text_bytes) *text_bytes = 0;
 	if (n == 0) { if (text) *text = ""; return CVX_OK; }
 	HIP_TRY(hipSetDevice(h->device));
-	hipStream_t st = h->s_main;
+	hipStream_t st = h->s_text;
 	const size_t n1 = (size_t) n;
 	TextArgs a;
 	a.ext_qstart = a.ext_qend = nullptr;
@@ -1457,7 +1461,7 @@ int cvx_job_nm_profile(cvx_handle h, cvx_job j, int32_t first, int32_t count, ui
 	if (first < 0 || count < 0 || (int64_t) first + count > j->n || (count > 0 && !entry_off)) { set_err("cvx_job_nm_profile: bad tile range / NULL offsets"); return CVX_ERR_ARG; }
 	if (count == 0) return CVX_OK;
 	HIP_TRY(hipSetDevice(h->device));
-	hipStream_t st = h->s_main;
+	hipStream_t st = h->s_text;
 	const size_t c1 = (size_t) count;
 	RC_TRY(j->d_nmoff.ensure(2 * c1 + 8));
 	RC_TRY(j->h_nmoff.ensure((c1 + 1) * sizeof(unsigned long long)));
@@ -1543,7 +1547,7 @@ int cvx_nm_profile_ops(cvx_handle h, int32_t n, const cvx_result *results, const
 		RC_TRY(d_tout.ensure(n1));
 		RC_TRY(d_trun.ensure(n1));
 		RC_TRY(d_off.ensure(n1 + 1));
-		hipStream_t st = h->s_main;
+		hipStream_t st = h->s_text;
 		if (ops_total) HIP_TRY(hipMemcpyAsync(d_ops.p, ops_arena, (size_t) ops_total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemcpyAsync(d_tout.p, tout.data(), n1 * sizeof(TileOut), hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemcpyAsync(d_trun.p, trun.data(), n1 * sizeof(TileRun), hipMemcpyHostToDevice, st));
