@@ -49,12 +49,12 @@ static const int kLongTileSteps = 32768;
 inline int chain_class_for(int need, bool small_batch) {
 	/* measured (C5 mix, 96 tiles): 64-row blocks 100 ms, 128-row 117 ms, 256-row 174 ms -- a tile's
 	 * time is its block count times the lag between neighbouring blocks, and a step of a 64-row block
-	 * is the shortest: a batch too small to fill the device takes the smallest blocks.  A batch that
-	 * does fill it is throughput-bound and a 128-row block spends fewer instructions per cell (ONT mix,
-	 * 60 000 tiles: 8 225 -> 8 450 Gbp/h; C5 mix, 2 048 tiles: 3 390 -> 3 430); 256 rows lose again
-	 * (a block's ramp grows with its height).  CVX_TUNE_CHAIN_M overrides. */
-	(void) need;
-	return small_batch ? 0 : 1;
+	 * is the shortest.  Batches that fill the device were tried with 128-row blocks (fewer instructions
+	 * per cell): ONT mix, 60 000 tiles, 7 600-7 650 Gbp/h against 7 660-7 770 with 64-row blocks, and
+	 * with the blocks at raised wave priority (FillArgs::chain_prio) 64 rows win clearly (8 320-8 450
+	 * against 7 580-8 040).  The larger classes stay selectable (CVX_TUNE_CHAIN_M). */
+	(void) need; (void) small_batch;
+	return 0;
 }
 
 /* ------------------------------------------------------------------ host threads */

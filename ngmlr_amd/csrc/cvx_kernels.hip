@@ -580,6 +580,12 @@ fill_ring_kernel(const FillArgs a) {
 		ct = a.tasks[task_id];
 		t = ct.tile;
 		y0 = ct.y0;
+		/* A chained tile is a dependency chain through all of its blocks and, beside thousands of whole tiles (ONT
+		 * mix: 10 % retries at twice the width among 54 000 short tiles; C5: the corridors widened to 2 048 / 8 192
+		 * columns), the long pole of the launch: its waves go first on their SIMDs and the whole-tile classes fill in
+		 * (ONT, 60 000 tiles: 7 660-7 770 -> 8 320-8 450 Gbp/h; C5 mix, 2 048 tiles: 2 860-2 930 -> 3 140).  The host
+		 * can switch it off (CVX_TUNE_CHAIN_PRIO=0). */
+		if (a.chain_prio) __builtin_amdgcn_s_setprio(3);
 	} else {
 		t = a.list[blockIdx.x];
 #if CVX_FILL_PRIO

@@ -283,6 +283,7 @@ struct cvx_context {
 	int tune_late_min = kLateMinGroups;  /* test knob (env CVX_TUNE_LATE_MIN): groups of the exactly tracked tail (huge: exact everywhere) */
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
 	int tune_long_steps = 0, tune_small_batch = 0;   /* tuning knobs (env CVX_TUNE_LONG_STEPS / CVX_TUNE_SMALL_BATCH): see PlanTuning */
+	int tune_chain_prio = -1; /* tuning knob (env CVX_TUNE_CHAIN_PRIO = 0 / 1): wave priority of chained blocks; -1 = the default (raised) */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
 	int test_fail_compute = 0; /* test knob (env CVX_TUNE_FAIL_COMPUTE = k): the k-th compute stage of this handle fails (error-path tests) */
@@ -721,7 +722,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		a.list_n = list_n;
 		a.redo_count = b->d_counters.p;
 		a.late_min_groups = h->tune_late_min;
-		a.tasks = nullptr; a.chain_ticket = nullptr; a.bnd = nullptr; a.chain_out = nullptr; a.bnd_epoch = 0;
+		a.tasks = nullptr; a.chain_ticket = nullptr; a.bnd = nullptr; a.chain_out = nullptr; a.bnd_epoch = 0; a.chain_prio = 0;
 		a.ops = b->d_regions.p;
 		a.sp = h->sp;
 		return a;
@@ -771,6 +772,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		a.chain_ticket = b->d_counters.p + 8 + (int) c;
 		a.bnd = b->d_bnd.p;
 		a.bnd_epoch = b->bnd_epoch;
+		a.chain_prio = (h->tune_chain_prio >= 0) ? h->tune_chain_prio : 1;
 		a.chain_out = b->d_chain_out.p;
 		/* tasks are dispatched in order, long before their turn; resident tasks beyond the ones that can
 		 * actually run only poll.  Unused dynamic LDS caps the residency at ~1.5x the blocks that are
@@ -1037,6 +1039,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_SCORE_NO_DIAG")) c->score_no_diag = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_M")) c->tune_chain_m = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_CHAIN_PRIO")) c->tune_chain_prio = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_LONG_STEPS")) c->tune_long_steps = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_SMALL_BATCH")) c->tune_small_batch = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));

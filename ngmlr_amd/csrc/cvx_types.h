@@ -242,6 +242,7 @@ struct FillArgs {
 	int32_t *chain_ticket;   /* zeroed before the launch */
 	BoundaryRec *bnd;
 	uint32_t bnd_epoch;      /* tag of the boundary records written by this launch */
+	int32_t chain_prio;      /* != 0: chained blocks run at raised wave priority */
 	ChainOut *chain_out;     /* per block */
 	int32_t late_min_groups; /* exactly tracked tail, in 4-step groups (kLateMinGroups; a test knob raises it) */
 	int32_t *ops;          /* per-tile op regions */
