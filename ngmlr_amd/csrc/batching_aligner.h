@@ -111,6 +111,7 @@ private:
 	bool stop;
 	long launches, requests, maxInFlight;
 	long long parkedNs, finishNs, busyNs;       /* under mtx */
+	int maxFlight;                              /* launches the dispatcher keeps in flight (CVX_BATCH_INFLIGHT, default 2) */
 	std::chrono::steady_clock::time_point busySince;
 	std::thread dispatcher;
 

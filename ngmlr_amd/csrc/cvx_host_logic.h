@@ -46,6 +46,8 @@ static const int kNumChainClasses = 3;
  * whatever its width), and its very long tiles are chained even if a ring would hold them. */
 static const int kSmallBatchTiles = 2048;
 static const int kLongTileSteps = 32768;
+/* streaming jobs smaller than this alternate between the runtime's two stream sets (cvx_runtime.cpp, stage_compute) */
+static const int kSmallJobTiles = 2048;
 inline int chain_class_for(int need, bool small_batch) {
 	/* measured (C5 mix, 96 tiles): 64-row blocks 100 ms, 128-row 117 ms, 256-row 174 ms -- a tile's
 	 * time is its block count times the lag between neighbouring blocks, and a step of a 64-row block

@@ -159,6 +159,7 @@ struct cvx_batch_s {
 	int n = 0;
 	int state = kEmpty;
 	bool in_flight = false;          /* submitted through the streaming API and not yet released */
+	hipStream_t s_run = nullptr;     /* the `main` stream of the set that carried this batch's kernels */
 	int fail_rc = CVX_OK;            /* state == kFailed: what went wrong with THIS job (cvx_wait returns it) */
 	std::string fail_msg;
 	uint64_t seq_total = 0, n_rows = 0, n_rowsx = 0;
@@ -275,6 +276,11 @@ struct cvx_context {
 	                                  * fills of the batches that follow */
 	hipStream_t s_post = nullptr;    /* backtrack, finalize, compaction, result download: runs beside the NEXT batch's fill */
 	hipStream_t aux[kAuxStreams] = {nullptr};  /* concurrent fill classes */
+	/* a second set (main, post, aux) for small streaming jobs (experiment, off by default: see single_lane): the jobs of a
+	 * batching driver (tens of tiles each) are latency-bound chains of small kernels on an otherwise empty device;
+	 * consecutive ones can alternate between the two sets */
+	hipStream_t s_main2 = nullptr, s_post2 = nullptr, aux2[kAuxStreams] = {nullptr};
+	unsigned small_jobs = 0;         /* small streaming jobs queued so far (their parity picks the set) */
 	ScoreParams sp;
 	uint64_t max_matrix_mb = 10000;
 	int num_cus = 256;
@@ -283,6 +289,9 @@ struct cvx_context {
 	int tune_late_min = kLateMinGroups;  /* test knob (env CVX_TUNE_LATE_MIN): groups of the exactly tracked tail (huge: exact everywhere) */
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
 	int tune_long_steps = 0, tune_small_batch = 0;   /* tuning knobs (env CVX_TUNE_LONG_STEPS / CVX_TUNE_SMALL_BATCH): see PlanTuning */
+	bool single_lane = true;  /* experiment (env CVX_TUNE_TWO_LANES=1 clears it): small streaming jobs alternate between two stream sets.
+	                           * Measured with the batching dispatcher at four launches in flight: no gain -- 20 000 reads 25.1 s against
+	                           * 21.2 s, launches get smaller and each still lasts as long as its slowest tile -- so it stays off. */
 	int tune_chain_prio = -1; /* tuning knob (env CVX_TUNE_CHAIN_PRIO = 0 / 1): wave priority of chained blocks; -1 = the default (raised) */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
@@ -583,20 +592,26 @@ int stage_plan(cvx_context *h, cvx_batch_s *b, hipStream_t st) {
 }
 
 /* ---- stage 3: host planning, then every kernel of the batch on `main` (+ aux); nothing waits */
-int stage_compute(cvx_context *h, cvx_batch_s *b) {
+int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	const int n = b->n;
 	if (h->test_fail_compute > 0 && --h->test_fail_compute == 0) {      /* test knob: this job fails before anything is queued for it */
 		set_err("stage_compute: failure injected by CVX_TUNE_FAIL_COMPUTE");
 		return CVX_ERR_OOM;
 	}
-	hipStream_t st = h->s_main;
+	/* which stream set carries this batch's kernels (see cvx_context::s_main2) */
+	const bool second = streaming && n > 0 && n < kSmallJobTiles && !h->single_lane && ((h->small_jobs++ & 1u) != 0u);
+	hipStream_t const S_main = second ? h->s_main2 : h->s_main;
+	hipStream_t const S_post = second ? h->s_post2 : h->s_post;
+	hipStream_t const *S_aux = second ? h->aux2 : h->aux;
+	b->s_run = S_main;
+	hipStream_t st = S_main;
 	HIP_TRY(hipEventSynchronize(b->ev_in));        /* queued a whole batch ago in the streaming case */
 	b->launches.clear();
 	b->ops_total = 0;
 	b->have_ops = false;
 	if (n == 0) {
 		HIP_TRY(hipEventRecord(b->ev[4], st));
-		hipStream_t ps = h->overlap_post ? h->s_post : h->s_main;
+		hipStream_t ps = h->overlap_post ? S_post : S_main;
 		HIP_TRY(hipStreamWaitEvent(ps, b->ev[4], 0));
 		HIP_TRY(hipEventRecord(b->ev[2], ps));
 		HIP_TRY(hipEventRecord(b->ev[3], ps));
@@ -746,8 +761,8 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	/* (the `post` stream carries a fill class too unless the post-fill overlap experiment owns it) */
 	hipStream_t fill_streams[kAuxStreams + 2];
 	int n_fill_streams = 0;
-	for (int i = 0; i < kAuxStreams; ++i) fill_streams[n_fill_streams++] = h->aux[i];
-	if (!h->overlap_post) fill_streams[n_fill_streams++] = h->s_post;
+	for (int i = 0; i < kAuxStreams; ++i) fill_streams[n_fill_streams++] = S_aux[i];
+	if (!h->overlap_post) fill_streams[n_fill_streams++] = S_post;
 	fill_streams[n_fill_streams++] = st;
 	auto begin_launch = [&](hipStream_t ls) -> int {
 		while (b->lev.size() < (size_t) (launches + 1) * 3) {
@@ -822,7 +837,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 	 * PacBio tiles), and the fill's own launch stretches from 66 to 76 ms.  It therefore stays OFF by
 	 * default (post == main, stages back to back, clean per-kernel timings); CVX_TUNE_OVERLAP_POST=1
 	 * turns it on. */
-	st = h->overlap_post ? h->s_post : h->s_main;
+	st = h->overlap_post ? S_post : S_main;
 	HIP_TRY(hipStreamWaitEvent(st, b->ev[4], 0));  /* also orders `post` behind the input copies when no fill was launched */
 	for (int i = 0; i < launches; ++i) HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) i * 3 + 2], 0));
 	HIP_TRY(hipEventRecord(b->ev[2], st));
@@ -854,7 +869,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b) {
 		int n_long = 0;
 		while (n_long < n_walk && (uint64_t) tin[(size_t) lists[bt_begin + (size_t) n_long]].H > 3 * mean_h) n_long++;
 		if (n_long > 0) {
-			hipStream_t ls = h->aux[0];
+			hipStream_t ls = S_aux[0];
 			HIP_TRY(hipEventRecord(b->ev_bt0, st));
 			HIP_TRY(hipStreamWaitEvent(ls, b->ev_bt0, 0));
 			HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin, n_long, 32, ls));
@@ -908,7 +923,7 @@ int stage_ops(cvx_context *h, cvx_batch_s *b) {
 		const uint64_t cap = b->ops_total;
 		RC_TRY(b->d_dense.ensure((size_t) cap + 64));
 		b->dense_cap = b->d_dense.cap - 64;
-		hipStream_t ps = h->overlap_post ? h->s_post : h->s_main;
+		hipStream_t ps = b->s_run ? b->s_run : h->s_main;      /* the batch's own stream set: behind everything it queued */
 		HIP_TRY(launch_compact(b->d_regions.p, b->d_trun.p, b->d_tout.p, b->d_dstoff.p, b->d_dense.p, b->n, b->dense_cap, ps));
 		HIP_TRY(hipStreamSynchronize(ps));
 	}
@@ -945,7 +960,7 @@ int pump(cvx_context *h, bool block, const cvx_batch_s *upto) {
 		h->pending.erase(h->pending.begin());
 		/* a failure (say, the direction arena of a multi-GB batch does not fit beside the batches in flight) belongs
 		 * to THIS job: it is recorded on it and reported by its own cvx_wait, never against another job's call */
-		const int rc = stage_compute(h, b);
+		const int rc = stage_compute(h, b, true);
 		if (rc != CVX_OK) (void) fail_job(b, rc);
 		if (upto && b == upto) break;
 	}
@@ -1040,6 +1055,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_M")) c->tune_chain_m = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_PRIO")) c->tune_chain_prio = atoi(e) != 0;
+	if (const char *e = getenv("CVX_TUNE_TWO_LANES")) c->single_lane = atoi(e) == 0;
 	if (const char *e = getenv("CVX_TUNE_LONG_STEPS")) c->tune_long_steps = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_SMALL_BATCH")) c->tune_small_batch = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
@@ -1050,6 +1066,9 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_text, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->s_io, hipStreamNonBlocking, prio_hi);
 	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_main2, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_post2, hipStreamNonBlocking);
+	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux2[i], hipStreamNonBlocking);
 	if (e != hipSuccess) {
 		set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
 		cvx_destroy(c);
@@ -1069,6 +1088,9 @@ void cvx_destroy(cvx_handle h) {
 	if (h->s_text) (void) hipStreamDestroy(h->s_text);
 	if (h->s_io) (void) hipStreamDestroy(h->s_io);
 	for (auto &a : h->aux) if (a) (void) hipStreamDestroy(a);
+	if (h->s_main2) (void) hipStreamDestroy(h->s_main2);
+	if (h->s_post2) (void) hipStreamDestroy(h->s_post2);
+	for (auto &a : h->aux2) if (a) (void) hipStreamDestroy(a);
 	for (cvx_batch_s *b : h->pool) { b->release(); delete b; }
 	h->pool.clear();
 	/* jobs the caller never released (submitted, maybe waited for): the device is idle, free them too --
