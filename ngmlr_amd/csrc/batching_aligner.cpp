@@ -11,7 +11,8 @@ namespace Convex {
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
 		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0),
 		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), stop(false), launches(0), requests(0), maxInFlight(0),
-		parkedNs(0), finishNs(0), busyNs(0), maxFlight(2) {
+		parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000) {
+	if (const char * e = getenv("CVX_BATCH_LEAD_US")) leadUs = atoi(e);      /* < 0: the plain timeout rule while a launch runs */
 	/* launches in flight: the upload and corridor analysis of the second run under the kernels of the first.  More (tried
 	 * with 4, and with the runtime's two stream sets) only makes the launches smaller: 20 000 reads 25.1 s against 21.2 s */
 	if (const char * e = getenv("CVX_BATCH_INFLIGHT")) maxFlight = atoi(e) > 0 ? atoi(e) : 1;
@@ -46,7 +47,16 @@ bool BatchingAligner::shouldCut(bool deviceIdle) const {
 	if ((int) queue.size() >= maxBatch) return true;
 	if (parked >= workers) return true;                      /* nobody left who could add to the launch */
 	if (deviceIdle) return true;                             /* nothing to overlap with: latency first */
-	if (timeoutUs > 0 && std::chrono::steady_clock::now() - oldest >= std::chrono::microseconds(timeoutUs)) return true;
+	std::chrono::steady_clock::time_point const now = std::chrono::steady_clock::now();
+	if (emaServiceUs > 0.0 && leadUs >= 0) {
+		/* A launch is running and the next one cannot start its kernels before that one is done: whatever arrives until
+		 * shortly before then travels for free.  Cut `leadUs` (the time an upload and a corridor analysis take) before the
+		 * running launch is expected to end -- a launch lasts about as long as its slowest tile whatever it carries, so
+		 * tiles per launch is the throughput of the whole device path (20 000 reads: 18 -> 30 tiles per launch). */
+		double const waitUs = emaServiceUs - (double) leadUs;
+		return now - frontSince >= std::chrono::microseconds((long long) (waitUs > 0.0 ? waitUs : 0.0));
+	}
+	if (timeoutUs > 0 && now - oldest >= std::chrono::microseconds(timeoutUs)) return true;
 	return false;
 }
 
@@ -85,7 +95,7 @@ void BatchingAligner::dispatchLoop() {
 				l->failed = true;
 			}
 			lk.lock();
-			if (inFlight.empty()) busySince = std::chrono::steady_clock::now();
+			if (inFlight.empty()) { busySince = std::chrono::steady_clock::now(); frontSince = busySince; }
 			inFlight.push_back(l);
 			if ((long) inFlight.size() > maxInFlight) maxInFlight = (long) inFlight.size();
 			continue;                                        /* maybe a second launch right away */
@@ -116,7 +126,14 @@ void BatchingAligner::dispatchLoop() {
 				}
 			}
 			lk.lock();
-			if (inFlight.empty()) busyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - busySince).count();
+			{
+				/* service time of the launch that just ended: from the moment it was the oldest one in flight */
+				std::chrono::steady_clock::time_point const t = std::chrono::steady_clock::now();
+				double const us = (double) std::chrono::duration_cast<std::chrono::microseconds>(t - frontSince).count();
+				if (!l->failed) emaServiceUs = emaServiceUs > 0.0 ? 0.7 * emaServiceUs + 0.3 * us : us;
+				frontSince = t;
+				if (inFlight.empty()) busyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(t - busySince).count();
+			}
 			for (size_t i = 0; i < l->reqs.size(); ++i) {
 				Request * r = l->reqs[i];
 				r->failed = l->failed;

@@ -16,7 +16,9 @@
  *
  * A launch is cut when   the queue holds maxBatch requests,
  *                   or   every registered worker is parked (nobody else can add to it),
- *                   or   the oldest request has waited timeoutUs,
+ *                   or   the oldest request has waited timeoutUs (while no launch has been timed yet), resp. the launch
+ *                        that is running is expected to end within leadUs (the time an upload + corridor analysis
+ *                        take: what arrives before that travels for free),
  *                   or   the device is idle and something is queued (latency before batch size
  *                        when there is nothing to overlap with).
  *
@@ -112,6 +114,9 @@ private:
 	long launches, requests, maxInFlight;
 	long long parkedNs, finishNs, busyNs;       /* under mtx */
 	int maxFlight;                              /* launches the dispatcher keeps in flight (CVX_BATCH_INFLIGHT, default 2) */
+	double emaServiceUs;                        /* how long a launch lasts once it is the oldest in flight (moving average) */
+	int leadUs;                                 /* cut the next launch this long before the running one should end (CVX_BATCH_LEAD_US) */
+	std::chrono::steady_clock::time_point frontSince;   /* when the oldest launch in flight became the oldest */
 	std::chrono::steady_clock::time_point busySince;
 	std::thread dispatcher;
 
