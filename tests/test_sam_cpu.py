@@ -262,3 +262,69 @@ def test_reference_binary_with_the_writer_rebound(tmp_path):
     with gzip.open(os.path.join(GOLDEN, "test_3.sorted.sam.gz"), "rt") as f:
         want = [l.rstrip("\n") for l in f if l.strip() and not l.startswith("@")]
     assert sorted(got) == want and len(want) > 200
+
+
+def _restated_record(d, qual_reversed):
+    """src/SAMWriter.cpp:87-224 restated with Python's printf (%d, %u, %g, %f are libc's): the fields of a record -> its text.
+    Test infrastructure: the checker of the fuzz test below."""
+    flags = d["flags"] | (0 if d["primary"] else 0x800) | (0x10 if d["reverse"] else 0)
+    L = d["read_length"]
+    clipped = L - d["qstart"] - d["qend"]
+    out = ["%s\t%d\t%s\t%u\t%d\t" % (d["read_name"], flags, d["ref_name"][:d["ref_name_len"]], (d["location"] + 1) & 0xffffffff, d["mq"])]
+    long_cigar = bool(d["bam_cigar_fix"]) and not d["skip"] and d["cigar_op_count"] >= 0x10000
+    out.append(("%dS\t" % (clipped if d["hard_clip"] else L)) if long_cigar else d["cigar"] + "\t")
+    out.append("%s\t%u\t%d\t" % (d["mate_ref_name"], (d["mate_location"] + 1) & 0xffffffff, d["template_length"]))
+    seq = d["seq"]
+    out.append((seq[d["qstart"]:d["qstart"] + max(clipped, 0)] if d["hard_clip"] else seq[:L]) + "\t")
+    if d["qual"] is None:
+        out.append("*\t")
+    else:
+        q = d["qual"][:L][::-1] + d["qual"][L:] if qual_reversed else d["qual"]
+        out.append((q[d["qstart"]:d["qstart"] + max(clipped, 0)] if d["hard_clip"] else q[:L]) + "\t")
+    if d["rg_id"] is not None:
+        out.append("RG:Z:%s\t" % d["rg_id"])
+    score = int(np.float32(d["score"]))                                   # (int) float: truncation
+    ident = float(np.float32(np.round(np.float32(d["identity"]) * np.float32(10000.0)) / np.float32(10000.0)))
+    out.append("AS:i:%d\tNM:i:%d\tXI:f:%g\tXS:i:0\tXE:i:%d\tXR:i:%d\tMD:Z:%s\t" % (score, d["nm"], ident, score, clipped, d["md"]))
+    if d["sv_type"] > -1:
+        out.append("SV:i:%d\t" % d["sv_type"])
+    if d["others"]:
+        out.append("SA:Z:" + "".join("%s,%d,%s,%s,%d,%d;" % (n, loc + 1, "-" if rev else "+", cig, mq, nm) for n, loc, rev, cig, mq, nm in d["others"]) + "\t")
+    covered = float(np.float32(np.float32(L - d["qstart"] - d["qend"]) * np.float32(100.0)) / np.float32(L))
+    out.append("QS:i:%d\tQE:i:%d\tCV:f:%f" % (d["qstart"], L - d["qend"], float(np.float32(covered))))
+    if long_cigar:
+        words = [(int(n) << 4) | "MIDNSH=X".index(c) if c in "MIDNSH" else (int(n) << 4) | {"=": 7, "X": 8}[c]
+                 for n, c in re.findall(r"(\d+)([MIDNSH=X])", d["cigar"])][:d["cigar_op_count"]]
+        out.append("\tCG:B:I" + "".join(",%d" % w for w in words))
+    return "".join(out) + "\n"
+
+
+def test_fuzzed_records_against_the_restated_writer(lib):
+    rng = np.random.default_rng(2718)
+    names = ["chr1", "2/83370031_83380361", "x", "scaffold_12 extra words"]
+    n_checked = 0
+    for it in range(600):
+        L = int(rng.integers(1, 400))
+        seq = "".join(rng.choice(list("ACGTN"), size=L))
+        qs = int(rng.integers(0, L))
+        qe = int(rng.integers(0, L - qs))
+        has_q = rng.random() < 0.8
+        qual = "".join(chr(int(c)) for c in rng.integers(33, 74, size=L)) if has_q else None
+        rname = names[int(rng.integers(0, len(names)))]
+        others = [(names[int(rng.integers(0, len(names)))].split(" ")[0], int(rng.integers(0, 2**31 - 2)), int(rng.integers(0, 2)),
+                   "%dM%dS" % (int(rng.integers(1, 300)), int(rng.integers(1, 300))), int(rng.integers(0, 61)), int(rng.integers(0, 5000)))
+                  for _ in range(int(rng.integers(0, 4)))]
+        d = dict(read_name="read/%d" % it, seq=seq, qual=qual, read_length=L, flags=int(rng.choice([0, 1, 0x41, 0x81, 0x100])),
+                 primary=int(rng.integers(0, 2)), reverse=int(rng.integers(0, 2)), ref_name=rname, ref_name_len=int(rng.integers(1, len(rname) + 1)),
+                 location=int(rng.integers(0, 2**32 - 1)), mq=int(rng.integers(0, 61)), cigar="%dS%dM%dS" % (qs, L - qs - qe, qe) if qs and qe else "%dM" % L,
+                 md=str(int(rng.integers(0, 500))), cigar_op_count=int(rng.integers(1, 4)), mate_ref_name=str(rng.choice(["*", "=", "chr9"])),
+                 mate_location=int(rng.integers(-1, 2**31 - 2)), template_length=int(rng.integers(-5000, 5000)),
+                 score=float(np.float32(rng.uniform(-10, 30000))), nm=int(rng.integers(0, 5000)), identity=float(np.float32(rng.uniform(0, 1))),
+                 qstart=qs, qend=qe, sv_type=int(rng.integers(-1, 4)), others=others, rg_id=(None if rng.random() < 0.7 else "rg%d" % it),
+                 hard_clip=int(rng.random() < 0.3), bam_cigar_fix=int(rng.random() < 0.5), skip=0)
+        r = Rec(**d)
+        rc, got, n = r.text(lib)
+        want = _restated_record(d, qual_reversed=bool(d["reverse"]) and has_q)
+        assert rc == 0 and got == want, (it, got[:200], want[:200])
+        n_checked += 1
+    assert n_checked == 600
