@@ -5,7 +5,7 @@ import re, sys
 args = [a for a in sys.argv[1:] if not a.startswith("-")]
 M = int(args[1]) if len(args) > 1 else 3
 txt = open(args[0]).read()
-name = "_ZN3cvx16fill_ring_kernelILi%dELi1ELb0EEEvNS_8FillArgsE" % M
+name = "_ZN3cvx16fill_ring_kernelILi%dELb0ELi0EEEvNS_8FillArgsE" % M      # <M, WRAP = false, MODE = kFillTwoPhase>
 body = txt[txt.index(name + ":"):]
 body = body[:body.index("s_endpgm")].split("\n")
 # the step loop = the longest stretch between a label and a backward branch to it
