@@ -293,6 +293,26 @@ int main() {
 		for (const ChainTask &t : t2) { CHECK(t.prev < 0 || seen[(size_t) t.prev]); seen[(size_t) t.blk] = 1; }
 		CHECK(t2[0].tile == 0 && t2[1].tile == 1 && t2[2].tile == 0 && t2[2].y0 == N);
 	}
+	// ---------------------------------------------------------------- a long narrow tile: chained only in a batch too small to fill the device
+	{
+		const int H = 21000, W = 21500, w = 340;
+		std::vector<RowDesc> rows((size_t) H);
+		for (int y = 0; y < H; ++y) { rows[(size_t) y].off = y - w / 2; rows[(size_t) y].len = w; }
+		TilePlan p; memset(&p, 0, sizeof(p));
+		p.r0 = 0; p.rend = (H - 1) + std::min(W, (H - 1) - w / 2 + w); p.need = 175; p.cells = (uint64_t) H * w; p.active = p.cells;
+		TileIn in; memset(&in, 0, sizeof(in));
+		in.H = H; in.W = W;
+		HostPlan hl;
+		host_plan(1, &p, &in, rows.data(), PlanTuning(), hl);                       // 42 000 steps >= kLongTileSteps, one tile: chained
+		CHECK(p.rend - p.r0 >= kLongTileSteps && hl.n_chained == 1 && hl.n_fast == 0 && hl.trun[0].mnw == 1);
+		{ PlanTuning tn; tn.long_steps = 50000; host_plan(1, &p, &in, rows.data(), tn, hl); }
+		CHECK(hl.n_chained == 0 && hl.n_fast == 1 && hl.trun[0].mnw == 3);          // below the (raised) threshold: an M = 3 ring
+		{ PlanTuning tn; tn.small_batch = 1; host_plan(1, &p, &in, rows.data(), tn, hl); }
+		CHECK(hl.n_chained == 0 && hl.n_fast == 1);                                 // not a small batch any more: whole tiles
+		{ PlanTuning tn; tn.chain_m = 2; host_plan(1, &p, &in, rows.data(), tn, hl); }
+		CHECK(hl.n_chained == 1 && hl.trun[0].mnw == 2 && hl.trun[0].ring == 128);   // forced block height
+		CHECK(chain_class_for(175, true) == 0 && chain_class_for(4000, false) == 0); // 64-row blocks for every batch
+	}
 	printf(fails ? "host_logic_test: %d FAILED\n" : "host_logic_test: ok\n", fails);
 	return fails ? 1 : 0;
 }
