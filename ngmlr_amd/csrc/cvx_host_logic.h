@@ -46,6 +46,10 @@ static const int kNumChainClasses = 3;
  * whatever its width), and its very long tiles are chained even if a ring would hold them. */
 static const int kSmallBatchTiles = 2048;
 static const int kLongTileSteps = 32768;
+/* whole tiles of at least this many steps are filled by the exact-tracking instantiation right away (cvx_runtime.cpp,
+ * stage_compute), as long as their class holds at most kExactDirectMaxTiles of them */
+static const int kExactDirectSteps = 65536;
+static const int kExactDirectMaxTiles = 4096;
 /* streaming jobs smaller than this alternate between the runtime's two stream sets (cvx_runtime.cpp, stage_compute) */
 static const int kSmallJobTiles = 2048;
 inline int chain_class_for(int need, bool small_batch) {

@@ -292,6 +292,7 @@ struct cvx_context {
 	bool single_lane = true;  /* experiment (env CVX_TUNE_TWO_LANES=1 clears it): small streaming jobs alternate between two stream sets.
 	                           * Measured with the batching dispatcher at four launches in flight: no gain -- 20 000 reads 25.1 s against
 	                           * 21.2 s, launches get smaller and each still lasts as long as its slowest tile -- so it stays off. */
+	int tune_exact_steps = kExactDirectSteps;   /* tuning knob (env CVX_TUNE_EXACT_STEPS, 0 = off): tiles of this many steps go straight to the exact fill */
 	int tune_chain_prio = -1; /* tuning knob (env CVX_TUNE_CHAIN_PRIO = 0 / 1): wave priority of chained blocks; -1 = the default (raised) */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
@@ -652,8 +653,25 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	int32_t *lists = b->h_lists.as<int32_t>();
 	size_t n_listed = 0;
 	std::vector<int> seg_begin(cls.size(), 0);
+	/* Very long tiles go straight to the exact-tracking instantiation.  The two-phase pass saves three half-rate ops per
+	 * cell (~12 %) but a tile whose best cell is not in its last anti-diagonals -- a local alignment: an inverted segment,
+	 * a read that does not reach its end -- is redone from step 0, and for a 100 kb tile that second pass is another
+	 * ~100 ms on one wave behind everything else (C5 mix: 77 ms of a 200 ms fill).  Tiles of kExactDirectSteps steps and
+	 * more are flagged kPadRedo up front and listed first; the exact launch over that prefix does them once.  Only while
+	 * the class cannot fill the device several times over (then 12 % of throughput would cost more than the tail). */
+	std::vector<int> n_direct(cls.size(), 0);
 	for (size_t c = 0; c < cls.size(); ++c) {
 		seg_begin[c] = (int) n_listed;      /* already in LPT order */
+		if (h->tune_exact_steps > 0 && !cls[c].empty()) {
+			int nl = 0;
+			for (int32_t ti : cls[c]) if (hp.trun[(size_t) ti].nsteps >= h->tune_exact_steps) nl++;
+			if (nl > 0 && nl <= kExactDirectMaxTiles) {
+				std::stable_partition(cls[c].begin(), cls[c].end(), [&](int32_t ti) { return hp.trun[(size_t) ti].nsteps >= h->tune_exact_steps; });
+				TileOut *ho = b->h_tout.as<TileOut>();
+				for (int q = 0; q < nl; ++q) ho[(size_t) cls[c][(size_t) q]].pad = kPadRedo;
+				n_direct[c] = nl;
+			}
+		}
 		if (!cls[c].empty()) memcpy(lists + n_listed, cls[c].data(), cls[c].size() * sizeof(int32_t));
 		n_listed += cls[c].size();
 	}
@@ -812,11 +830,16 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		launch_stats(cls[c], kc.m, 1, (int) (c & 1));
 		hipStream_t ls = fill_streams[launches % n_fill_streams];
 		RC_TRY(begin_launch(ls));
-		const FillArgs a = fill_args(b->d_lists.p + seg_begin[c], (int) cls[c].size());
-		HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 0, a, 0, ls));
+		if (n_direct[c] > 0) {
+			/* the very long tiles of the class, exact from the first step (flagged above), before everything else */
+			const FillArgs ad = fill_args(b->d_lists.p + seg_begin[c], n_direct[c]);
+			HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 1, ad, 0, ls));
+		}
+		const FillArgs a = fill_args(b->d_lists.p + seg_begin[c] + n_direct[c], (int) cls[c].size() - n_direct[c]);
+		if (a.list_n > 0) HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 0, a, 0, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
 		/* exact-tracking pass over the tiles the two-phase pass flagged (usually none) */
-		HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 1, a, 0, ls));
+		if (a.list_n > 0) HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 1, a, 0, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
 		launches++;
 	}
@@ -1055,6 +1078,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_M")) c->tune_chain_m = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_PRIO")) c->tune_chain_prio = atoi(e) != 0;
+	if (const char *e = getenv("CVX_TUNE_EXACT_STEPS")) c->tune_exact_steps = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_TWO_LANES")) c->single_lane = atoi(e) == 0;
 	if (const char *e = getenv("CVX_TUNE_LONG_STEPS")) c->tune_long_steps = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_SMALL_BATCH")) c->tune_small_batch = atoi(e);
