@@ -1,0 +1,171 @@
+/* align_pool.cpp -- see align_pool.h.  Compiled only inside ngmlr's tree (tools/build_ngmlr_hip.sh). */
+#include "align_pool.h"
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "AlignmentBuffer.h"
+#include "NGM.h"
+#include "batching_aligner.h"
+
+namespace Convex {
+
+namespace {
+
+struct Item {
+	ReadGroup * group;      /* long read: processLongReadLIS */
+	MappedRead * read;      /* short read: processShortRead */
+};
+
+struct Pool {
+	std::mutex mtx;
+	std::condition_variable cvWork;      /* contexts: something is queued, or stop */
+	std::condition_variable cvSpace;     /* producers: the queue has room again */
+	std::condition_variable cvDrained;   /* Detach: queue empty and nobody busy */
+	std::deque<Item> queue;
+	std::vector<std::thread> threads;
+	int maxContexts, queueLimit;
+	int idle, busy;
+	bool stop;
+	/* statistics */
+	long items, maxQueued, maxBusy;
+	long long producerBlockedNs, busyNs;
+	std::chrono::steady_clock::time_point born;
+
+	Pool() : maxContexts(256), queueLimit(0), idle(0), busy(0), stop(false), items(0), maxQueued(0), maxBusy(0),
+			producerBlockedNs(0), busyNs(0), born(std::chrono::steady_clock::now()) {
+		if (const char * e = getenv("CVX_POOL_CONTEXTS")) maxContexts = atoi(e) > 0 ? atoi(e) : 1;
+		queueLimit = 2 * maxContexts;
+		if (const char * e = getenv("CVX_POOL_QUEUE")) queueLimit = atoi(e) > 0 ? atoi(e) : 1;
+	}
+
+	void contextMain() {
+		/* what CS::DoRun does for its own thread (reference src/CS.cpp:414-419): the constructor writes the SAM
+		 * prolog once, under NGM's output lock */
+		NGM.AquireOutputLock();
+		AlignmentBuffer * buffer = new AlignmentBuffer(Config.getOutputFile());
+		NGM.ReleaseOutputLock();
+		std::unique_lock<std::mutex> lk(mtx);
+		for (;;) {
+			while (queue.empty() && !stop) {
+				idle += 1;
+				cvWork.wait(lk);
+				idle -= 1;
+			}
+			if (queue.empty()) break;      /* stop, and nothing left */
+			Item const it = queue.front();
+			queue.pop_front();
+			busy += 1;
+			if (busy > maxBusy) maxBusy = busy;
+			lk.unlock();
+			cvSpace.notify_one();
+			std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
+			/* this thread counts as a worker of its device's dispatcher only while it holds a read: "every worker is
+			 * parked" then means every context that could still add a tile to the launch */
+			SharedAligner::ThreadBegin();
+			try {
+				if (it.group != 0) buffer->processLongReadLIS(it.group);
+				else buffer->processShortRead(it.read);
+			} catch (...) {
+				/* the reference would have lost the CS thread here (NGMTask::Run rethrows); a context only loses the read */
+				fprintf(stderr, "AlignPool: exception while processing a read (dropped)\n");
+			}
+			SharedAligner::ThreadEnd();
+			lk.lock();
+			busyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+			busy -= 1;
+			if (busy == 0 && queue.empty()) cvDrained.notify_all();
+		}
+		lk.unlock();
+		delete buffer;       /* ~SAMWriter flushes this context's records (src/SAMWriter.h:20-22) */
+	}
+
+	void submit(Item const it) {
+		std::unique_lock<std::mutex> lk(mtx);
+		if ((int) queue.size() >= queueLimit) {
+			std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
+			while ((int) queue.size() >= queueLimit) cvSpace.wait(lk);
+			producerBlockedNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+		}
+		queue.push_back(it);
+		items += 1;
+		if ((long) queue.size() > maxQueued) maxQueued = (long) queue.size();
+		if (idle == 0 && (int) threads.size() < maxContexts) {
+			/* contexts are created on demand: a run of a few reads never pays for K of them */
+			threads.emplace_back([this] { contextMain(); });
+		} else {
+			cvWork.notify_one();
+		}
+	}
+
+	void drainAndStop() {
+		{
+			std::unique_lock<std::mutex> lk(mtx);
+			while (!(queue.empty() && busy == 0)) cvDrained.wait(lk);
+			stop = true;
+		}
+		cvWork.notify_all();
+		for (std::thread & t : threads) t.join();
+		double const wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - born).count();
+		fprintf(stderr, "AlignPool: %ld reads on %zu contexts (limit %d) over %.2f s: at most %ld reads in flight, %ld queued; "
+				"contexts held a read %.1f %% of their time, CS threads waited %.2f s for room in the queue\n",
+				items, threads.size(), maxContexts, wall, maxBusy, maxQueued,
+				threads.empty() ? 0.0 : 100.0 * (double) busyNs * 1e-9 / (wall * (double) threads.size()), (double) producerBlockedNs * 1e-9);
+	}
+};
+
+std::mutex g_poolMtx;
+Pool * g_pool = 0;
+int g_producers = 0;
+
+Pool * poolForSubmit() {
+	std::lock_guard<std::mutex> g(g_poolMtx);
+	if (g_pool == 0) g_pool = new Pool();      /* a producer that never attached (not a reference call path) still works */
+	return g_pool;
+}
+
+}  // namespace
+
+void AlignPool::Attach() {
+	std::lock_guard<std::mutex> g(g_poolMtx);
+	/* the aligner fronts built from now on (the CS threads' own, the contexts') register with their dispatcher per
+	 * read (ThreadBegin / ThreadEnd), not for their lifetime */
+	SharedAligner::UsePoolAccounting(true);
+	if (g_pool == 0) g_pool = new Pool();
+	g_producers += 1;
+}
+
+void AlignPool::Detach() {
+	Pool * last = 0;
+	{
+		std::lock_guard<std::mutex> g(g_poolMtx);
+		g_producers -= 1;
+		if (g_producers == 0) {
+			/* nobody can submit any more (a CS thread that starts later simply opens a new pool) */
+			last = g_pool;
+			g_pool = 0;
+		}
+	}
+	if (last != 0) {
+		last->drainAndStop();
+		delete last;
+	}
+}
+
+void AlignPool::Submit(ReadGroup * group) {
+	Item it; it.group = group; it.read = 0;
+	poolForSubmit()->submit(it);
+}
+
+void AlignPool::SubmitShort(MappedRead * read) {
+	Item it; it.group = 0; it.read = read;
+	poolForSubmit()->submit(it);
+}
+
+}  // namespace Convex

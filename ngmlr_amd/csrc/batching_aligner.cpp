@@ -11,7 +11,9 @@ namespace Convex {
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
 		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0),
 		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), stop(false), launches(0), requests(0), maxInFlight(0),
-		parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000) {
+		target(0), holdUs(20000), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000) {
+	if (const char * e = getenv("CVX_BATCH_TARGET")) target = atoi(e) > 0 ? atoi(e) : 0;
+	if (const char * e = getenv("CVX_BATCH_HOLD_US")) holdUs = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_LEAD_US")) leadUs = atoi(e);      /* < 0: the plain timeout rule while a launch runs */
 	/* launches in flight: the upload and corridor analysis of the second run under the kernels of the first.  More (tried
 	 * with 4, and with the runtime's two stream sets) only makes the launches smaller: 20 000 reads 25.1 s against 21.2 s */
@@ -46,8 +48,15 @@ bool BatchingAligner::shouldCut(bool deviceIdle) const {
 	if (queue.empty()) return false;
 	if ((int) queue.size() >= maxBatch) return true;
 	if (parked >= workers) return true;                      /* nobody left who could add to the launch */
-	if (deviceIdle) return true;                             /* nothing to overlap with: latency first */
 	std::chrono::steady_clock::time_point const now = std::chrono::steady_clock::now();
+	if (target > 0 && (int) queue.size() < target) {
+		/* Many more contexts than cores (align_pool.h): the host stages, not the device, bound the throughput, a launch
+		 * lasts about as long as its slowest tile whatever it carries, and every launch costs the dispatcher, the pack
+		 * threads and `its` workers' wake-ups the same -- so a request may wait for company while other contexts keep
+		 * the cores busy.  Bounded by holdUs, and never when nobody is left to add to the launch (rule above). */
+		return now - oldest >= std::chrono::microseconds(holdUs);
+	}
+	if (deviceIdle) return true;                             /* nothing to overlap with: latency first */
 	if (emaServiceUs > 0.0 && leadUs >= 0) {
 		/* A launch is running and the next one cannot start its kernels before that one is done: whatever arrives until
 		 * shortly before then travels for free.  Cut `leadUs` (the time an upload and a corridor analysis take) before the
@@ -139,12 +148,13 @@ void BatchingAligner::dispatchLoop() {
 				r->failed = l->failed;
 				r->result = l->failed ? 0 : &l->results[i];
 				r->done = true;
+				r->cv.notify_one();      /* under the lock: the request lives on its worker's stack until that worker has seen `done` */
 			}
-			cvWorkers.notify_all();
 			continue;
 		}
 		/* idle: nothing in flight, nothing to cut yet */
-		if (!queue.empty() && timeoutUs > 0) cvDispatch.wait_until(lk, oldest + std::chrono::microseconds(timeoutUs));
+		if (!queue.empty() && target > 0 && (int) queue.size() < target) cvDispatch.wait_until(lk, oldest + std::chrono::microseconds(holdUs));
+		else if (!queue.empty() && timeoutUs > 0) cvDispatch.wait_until(lk, oldest + std::chrono::microseconds(timeoutUs));
 		else cvDispatch.wait(lk);
 	}
 }
@@ -167,7 +177,7 @@ int BatchingAligner::SingleAlign(int const mode, CorridorLine * corridor, int co
 	parked += 1;
 	cvDispatch.notify_one();
 	std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
-	while (!req.done) cvWorkers.wait(lk);
+	while (!req.done) req.cv.wait(lk);
 	std::chrono::steady_clock::time_point const t1 = std::chrono::steady_clock::now();
 	parkedNs += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
 	parked -= 1;
@@ -214,11 +224,21 @@ long g_lastLaunches = 0, g_lastRequests = 0;
 double g_lastParked = 0.0, g_lastFinish = 0.0, g_lastBusy = 0.0;
 std::chrono::steady_clock::time_point g_firstJoin;
 std::chrono::steady_clock::time_point const g_loaded = std::chrono::steady_clock::now();      /* ~ process start */
+bool g_poolAccounting = false;                       /* under g_sharedMtx */
+thread_local BatchingAligner * tl_dispatcher = 0;    /* the dispatcher of the SharedAligner this thread constructed (pool accounting) */
 }
 
-SharedAligner::SharedAligner(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
-		float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId) : shared(0), device(0) {
+void SharedAligner::UsePoolAccounting(bool on) {
 	std::lock_guard<std::mutex> g(g_sharedMtx);
+	g_poolAccounting = on;
+}
+void SharedAligner::ThreadBegin() { if (tl_dispatcher) tl_dispatcher->WorkerJoined(); }
+void SharedAligner::ThreadEnd() { if (tl_dispatcher) tl_dispatcher->WorkerDone(); }
+
+SharedAligner::SharedAligner(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
+		float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId) : shared(0), device(0), perRead(false) {
+	std::lock_guard<std::mutex> g(g_sharedMtx);
+	perRead = g_poolAccounting;
 	int nDev = cvx_device_count();
 	if (const char * e = getenv("CVX_DEVICES")) nDev = atoi(e) < nDev ? atoi(e) : nDev;      /* use only the first k devices */
 	if (nDev > kMaxDevices) nDev = kMaxDevices;
@@ -233,14 +253,16 @@ SharedAligner::SharedAligner(int const stdOutMode, float const match, float cons
 		g_backend[device] = new ConvexAlignHip(stdOutMode, match, mismatch, gapOpen, gapExtend, gapExtendMin, gapDecay, device);   /* throws without a usable device */
 		g_shared[device] = new BatchingAligner(g_backend[device], 0, maxBatch, timeoutUs);   /* workers join one by one */
 	}
-	g_shared[device]->WorkerJoined();
+	if (perRead) tl_dispatcher = g_shared[device];
+	else g_shared[device]->WorkerJoined();
 	g_deviceUsers[device] += 1;
 	g_users += 1;
 	shared = g_shared[device];
 }
 
 SharedAligner::~SharedAligner() {
-	shared->WorkerDone();        /* (outside the process-wide lock: it only touches this device's aligner) */
+	if (perRead) { if (tl_dispatcher == shared) tl_dispatcher = 0; }
+	else shared->WorkerDone();   /* (outside the process-wide lock: it only touches this device's aligner) */
 	std::lock_guard<std::mutex> g(g_sharedMtx);
 	g_deviceUsers[device] -= 1;
 	g_users -= 1;

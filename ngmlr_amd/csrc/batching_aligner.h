@@ -16,6 +16,9 @@
  *
  * A launch is cut when   the queue holds maxBatch requests,
  *                   or   every registered worker is parked (nobody else can add to it),
+ *                   or   (only with a batch target, CVX_BATCH_TARGET > 0: many more alignment contexts than cores,
+ *                        align_pool.h) -- while fewer than `target` requests wait, only once the oldest has waited
+ *                        holdUs (CVX_BATCH_HOLD_US); from `target` requests on the rules below apply,
  *                   or   the oldest request has waited timeoutUs (while no launch has been timed yet), resp. the launch
  *                        that is running is expected to end within leadUs (the time an upload + corridor analysis
  *                        take: what arrives before that travels for free),
@@ -89,6 +92,8 @@ private:
 		cvx_result const * result;         /* set when the launch is done */
 		bool done;
 		bool failed;                       /* the whole launch failed */
+		std::condition_variable cv;        /* its own worker sleeps here: a finished launch wakes its own workers only (with
+		                                    * hundreds of contexts parked, one shared condition woke them all per launch) */
 	};
 	struct Launch {
 		cvx_job job;
@@ -100,7 +105,6 @@ private:
 	};
 	ConvexAlignHip * backend;
 	std::mutex mtx;
-	std::condition_variable cvWorkers;     /* results are ready */
 	std::condition_variable cvDispatch;    /* something to do for the dispatcher */
 	std::vector<Request *> queue;
 	std::chrono::steady_clock::time_point oldest;
@@ -110,6 +114,8 @@ private:
 	int parked;
 	int maxBatch;
 	int timeoutUs;
+	int target;                                 /* batch target (CVX_BATCH_TARGET, 0 = none) and how long the oldest request may */
+	int holdUs;                                 /* wait for it (CVX_BATCH_HOLD_US) */
 	bool stop;
 	long launches, requests, maxInFlight;
 	long long parkedNs, finishNs, busyNs;       /* under mtx */
@@ -158,9 +164,18 @@ public:
 	static long Launches();
 	static long Requests();
 
+	/* Pool accounting (align_pool.h): with K >> cores alignment contexts most aligner fronts belong to threads that hold
+	 * no read, and "every registered worker is parked" must count only those that do.  After UsePoolAccounting(true) a
+	 * SharedAligner no longer registers for its lifetime; the thread that constructed it registers between ThreadBegin()
+	 * and ThreadEnd() (no-ops for a thread without such an aligner). */
+	static void UsePoolAccounting(bool on);
+	static void ThreadBegin();
+	static void ThreadEnd();
+
 private:
 	BatchingAligner * shared;
 	int device;
+	bool perRead;      /* registers per read (pool accounting), not for its lifetime */
 };
 
 }  // namespace Convex

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip")
 BIN_BATCHED = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_batched")
 BIN_FULL = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_full")
+BIN_POOL = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_pool")
 E2E = os.path.join(ROOT, "tests", "golden", "e2e")
 
 
@@ -20,11 +21,11 @@ def _records(text):
     return [l for l in text.splitlines() if l and not l.startswith("@")]
 
 
-def _run(args, tmp_path, binary=BIN):
+def _run(args, tmp_path, binary=BIN, env=None):
     if not os.path.exists(binary):
         pytest.skip("%s not built (tools/build_ngmlr_hip.sh needs /root/reference)" % os.path.relpath(binary, ROOT))
     res = subprocess.run([binary, "--skip-write"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                         text=True, timeout=600, cwd=str(tmp_path))
+                         text=True, timeout=600, cwd=str(tmp_path), env=dict(os.environ, **(env or {})))
     assert res.returncode == 0, res.stderr[-3000:]
     maps = open("/proc/self/maps").read()  # noqa: F841  (the child loaded libcvxalign.so via its RUNPATH)
     return _records(res.stdout), res.stderr
@@ -96,6 +97,27 @@ def test_test_3_both_plugins_on_the_device(built, tmp_path):
     assert m and int(m.group(1)) == 985, err[-2000:]
     syms = subprocess.run(["nm", "-C", BIN_FULL], stdout=subprocess.PIPE, text=True).stdout
     assert "StrippedSWHip::BatchScore" in syms
+
+
+@pytest.mark.parametrize("target", [0, 64])
+def test_test_3_alignment_contexts_off_the_cs_threads(built, tmp_path, target):
+    """SURVEY 8 f1, second half (Convex::AlignPool, ngmlr_amd/csrc/align_pool.h): `-t 16` CS threads, 256 alignment
+    contexts -- processLongReadLIS runs on a pool context instead of on the CS thread that scored the read's last
+    sub-read (reference src/ScoreBuffer.cpp:152-159), so reads in flight are no longer bounded by -t.  Alignment,
+    scoring and SAM records on the drop-ins; with and without a batch target for the dispatcher.  SAM records
+    identical to the unmodified reference (sorted)."""
+    import re
+    env = {"CVX_POOL_CONTEXTS": "256"}
+    if target:
+        env.update(CVX_BATCH_TARGET=str(target), CVX_BATCH_HOLD_US="20000")
+    got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_POOL, env=env)
+    assert sorted(got) == _test_3_want()
+    m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", err)
+    assert m and int(m.group(1)) == 985, err[-2000:]
+    p = re.search(r"AlignPool: (\d+) reads on (\d+) contexts \(limit 256\).*at most (\d+) reads in flight", err)
+    assert p and int(p.group(1)) == 142, err[-2000:]
+    assert int(p.group(3)) > 16          # more reads in flight than CS threads: the point of the pool
+    print("test_3 -t 16, pool of 256 (target %d): %s alignments in %s launches, %s reads in flight at most" % (target, m.group(1), m.group(2), p.group(3)))
 
 
 def test_binary_links_the_device_library(built):

@@ -22,15 +22,46 @@ mkdir -p "$REPO/oracle/_ref"
 #                      and the SAM records through cvx_sam_record_text (src/SAMWriter.cpp:87)
 #   ngmlr_sam          the reference's own CPU aligners; only SAMWriter::DoWriteReadGeneric goes through cvx_sam_record_text
 #                      (runs without a GPU: tests/test_sam_cpu.py)
+#   ngmlr_hip_pool     ngmlr_hip_full + Convex::AlignPool: processLongReadLIS / processShortRead run on K >> t alignment
+#                      contexts instead of on the CS thread (align_pool.h; SURVEY 8 f1's second half), the main loop polls
+#                      for the end of the run every 20 ms instead of every 2 s, SAM buffers flush at 1 MB instead of 10 MB
+#   ngmlr_pool_cpu     the reference's CPU aligners + the same pool: the pool's own correctness without a GPU (tests/test_pool_cpu.py)
 #   ngmlr_ref          (nothing changed)       the unmodified reference, for wall-clock comparison only
 build_variant() {
-local OUT_NAME=$1 CLASS=$2 SCORER=${3:-} SAM=${4:-}
+local OUT_NAME=$1 CLASS=$2 SCORER=${3:-} SAM=${4:-} POOL=${5:-}
 local T="$WORK/$OUT_NAME"
 cp -r /root/reference "$T"
 if [ "$CLASS" != "unmodified" ]; then
-python3 - "$T" "$REPO" "$CLASS" "$SCORER" "$SAM" <<'PY'
+python3 - "$T" "$REPO" "$CLASS" "$SCORER" "$SAM" "$POOL" <<'PY'
 import re, sys
-T, REPO, CLASS, SCORER, SAM = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5]
+T, REPO, CLASS, SCORER, SAM, POOL = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6]
+def sub1(s, old, new, what):
+    assert s.count(old) == 1, (what, s.count(old))
+    return s.replace(old, new, 1)
+if POOL:
+    # reads in flight decoupled from the CS threads (ngmlr_amd/csrc/align_pool.h)
+    p = T + '/src/CS.cpp'
+    s = open(p).read()
+    s = sub1(s, '#include "AlignmentBuffer.h"', '#include "AlignmentBuffer.h"\n#include "align_pool.h"', 'CS include')
+    s = sub1(s, 'void CS::DoRun() {', 'void CS::DoRun() {\n\tConvex::AlignPool::Attach();', 'CS::DoRun entry')
+    s = sub1(s, '\tdelete scoreBuffer;\n\tscoreBuffer = 0;', '\tConvex::AlignPool::Detach();\n\tdelete scoreBuffer;\n\tscoreBuffer = 0;', 'CS::DoRun exit')
+    s = sub1(s, 'out->processLongReadLIS(read->group);', 'Convex::AlignPool::Submit(read->group);', 'CS.cpp:296')
+    open(p, 'w').write(s)
+    p = T + '/src/ScoreBuffer.cpp'
+    s = open(p).read()
+    s = sub1(s, '#include "AlignmentBuffer.h"', '#include "AlignmentBuffer.h"\n#include "align_pool.h"', 'ScoreBuffer include')
+    s = sub1(s, 'out->processLongReadLIS(group);', 'Convex::AlignPool::Submit(group);', 'ScoreBuffer.cpp:155')
+    s = sub1(s, 'out->processShortRead(cur_read);', 'Convex::AlignPool::SubmitShort(cur_read);', 'ScoreBuffer.cpp:159')
+    s = sub1(s, 'out->processShortRead(read);', 'Convex::AlignPool::SubmitShort(read);', 'ScoreBuffer.cpp:283')
+    open(p, 'w').write(s)
+    p = T + '/src/NGM.cpp'
+    s = open(p).read()
+    s = sub1(s, 'Sleep(2000);', 'for (int cvxPoll = 0; cvxPoll < 100 && Running(); ++cvxPoll) Sleep(20);', 'NGM::MainLoop')
+    open(p, 'w').write(s)
+    p = T + '/src/GenericReadWriter.h'
+    s = open(p).read()
+    s = sub1(s, 'BUFFER_LIMIT =  10000000;', 'BUFFER_LIMIT =  1000000;', 'BUFFER_LIMIT')
+    open(p, 'w').write(s)
 if SAM:
     p = T + '/src/SAMWriter.cpp'
     s = open(p).read()
@@ -58,7 +89,7 @@ if CLASS != 'cpu':
     open(p, 'w').write(s)
 p = T + '/src/CMakeLists.txt'
 c = open(p).read()
-c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp\n%s/ngmlr_amd/csrc/batching_aligner.cpp\n%s/ngmlr_amd/csrc/stripped_sw_hip.cpp' % (REPO, REPO, REPO, REPO, REPO), 1)
+c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp\n%s/ngmlr_amd/csrc/batching_aligner.cpp\n%s/ngmlr_amd/csrc/stripped_sw_hip.cpp%s' % (REPO, REPO, REPO, REPO, REPO, ('\n%s/ngmlr_amd/csrc/align_pool.cpp' % REPO) if POOL else ''), 1)
 c = c.replace('TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})', 'TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})\nTARGET_LINK_LIBRARIES(ngmlr %s/ngmlr_amd/libcvxalign.so)\nset_target_properties(ngmlr PROPERTIES BUILD_RPATH "\\$ORIGIN/../../ngmlr_amd;/opt/rocm/lib" SKIP_BUILD_RPATH FALSE)' % REPO, 1)
 open(p, 'w').write(c)
 PY
@@ -74,8 +105,10 @@ build_variant ngmlr_hip Convex::ConvexAlignHip &
 build_variant ngmlr_hip_batched Convex::SharedAligner &
 build_variant ngmlr_hip_full Convex::SharedAligner StrippedSWHip sam &
 build_variant ngmlr_sam cpu "" sam &
+build_variant ngmlr_hip_pool Convex::SharedAligner StrippedSWHip sam pool &
+build_variant ngmlr_pool_cpu cpu "" "" pool &
 build_variant ngmlr_ref unmodified &     # the reference as it is: wall-clock yardstick of tools/e2e_rates.py
 wait
-test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched" && test -x "$REPO/oracle/_ref/ngmlr_hip_full" && test -x "$REPO/oracle/_ref/ngmlr_sam"
+test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched" && test -x "$REPO/oracle/_ref/ngmlr_hip_full" && test -x "$REPO/oracle/_ref/ngmlr_sam" && test -x "$REPO/oracle/_ref/ngmlr_hip_pool" && test -x "$REPO/oracle/_ref/ngmlr_pool_cpu"
 readelf -d "$REPO/oracle/_ref/ngmlr_hip" | grep -E "RPATH|RUNPATH|NEEDED" | head
 rm -rf "$WORK"

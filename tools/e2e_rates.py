@@ -45,7 +45,8 @@ def run(name, t, ref, fq, extra_env=None):
     mp = re.search(r"Overall time for creating RefTable: ([0-9.]+)s", res.stderr)
     st = re.search(r"SharedAligner: \d+ workers over.*", res.stderr)
     sc = re.search(r"StrippedSWHip: \d+ scoring calls.*", res.stderr)
-    return {"wall": dt, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
+    po = re.search(r"AlignPool: \d+ reads on.*", res.stderr)
+    return {"wall": dt, "pool_stats": po.group(0) if po else None, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
             "map_s": dt - float(mp.group(1)) if mp else None, "err": res.stderr[-400:], "full_err": res.stderr}
 
 
@@ -58,10 +59,29 @@ def line(name, t, r, same):
         print("    " + r["stats"], flush=True)
     if r.get("score_stats"):
         print("    " + r["score_stats"], flush=True)
+    if r.get("pool_stats"):
+        print("    " + r["pool_stats"], flush=True)
     if os.environ.get("E2E_VERBOSE"):
         for l in r["full_err"].splitlines():
             if "library loaded" in l or "time" in l.lower() or "Done" in l:
                 print("      | " + l[:200], flush=True)
+
+
+def effective_cores():
+    """what this process may actually use: affinity mask and the cgroup's CPU quota (cpu.max = quota period)"""
+    out = ["affinity %d" % len(os.sched_getaffinity(0))]
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                out.append("cgroup cpu.max %s" % ("unlimited" if txt[0] == "max" else "%.1f cores" % (float(txt[0]) / float(txt[1]))))
+            else:
+                q = float(txt[0])
+                out.append("cgroup quota %s" % ("unlimited" if q < 0 else "%.1f cores" % (q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))))
+            break
+        except Exception:
+            continue
+    return ", ".join(out)
 
 
 def synthetic(n_reads, threads):
@@ -86,7 +106,7 @@ def synthetic(n_reads, threads):
                 q = synth.revcomp(q)
             bases += len(q)
             f.write("@r%d_%d\n%s\n+\n%s\n" % (i, a, q.tobytes().decode(), "I" * len(q)))
-    print("synthetic: %d reads, %.1f Mbp, reference %d bp; host has %d hardware threads" % (n_reads, bases / 1e6, L, os.cpu_count()))
+    print("synthetic: %d reads, %.1f Mbp, reference %d bp; host has %d hardware threads, %s" % (n_reads, bases / 1e6, L, os.cpu_count(), effective_cores()))
     cores = os.cpu_count() or 8
     base = None
     best = None
@@ -101,12 +121,28 @@ def synthetic(n_reads, threads):
         line("ngmlr_ref", t, r, "reference" if r["recs"] == base else "DIFFERS from the first ngmlr_ref run")
         if best is None or r["wall"] < best[1]["wall"]:
             best = (t, r)
-    for name in ((only,) if only else ("ngmlr_hip_batched", "ngmlr_hip_full")):
-        for t in threads:
-            r = run(name, t, fa, fq)
+    # E2E_POOL="t:K:target:hold_us,..." : ngmlr_hip_pool (alignment contexts off the CS threads, align_pool.h) with t CS
+    # threads, K contexts, the dispatcher's batch target and hold time
+    runs = [(name, t, None, "") for name in ((only,) if only else () if os.environ.get("E2E_SKIP_OLD") else ("ngmlr_hip_batched", "ngmlr_hip_full")) for t in threads]
+    for spec in [x for x in os.environ.get("E2E_POOL", "").split(",") if x]:
+        f = spec.split(":")
+        env = {"CVX_POOL_CONTEXTS": f[1]}
+        if len(f) > 2 and int(f[2]) > 0:
+            env["CVX_BATCH_TARGET"] = f[2]
+        if len(f) > 3:
+            env["CVX_BATCH_HOLD_US"] = f[3]
+        for extra in f[4:]:
+            k, v = extra.split("=")
+            env[k] = v
+        runs.append(("ngmlr_hip_pool", int(f[0]), env, "  [" + " ".join("%s=%s" % kv for kv in sorted(env.items())) + "]"))
+    for name, t, env, note in runs:
+        if True:
+            r = run(name, t, fa, fq, env)
+            if note and r is not None:
+                print(note.strip(), flush=True)
             if r is None:
                 print("%-18s not built" % name)
-                break
+                continue
             line(name, t, r, "unchecked" if base is None else "identical" if r["recs"] == base else "DIFFERENT (%d vs %d records)" % (len(r["recs"]), len(base)))
             if r["rc"] != 0:
                 print(r["err"])
