@@ -406,6 +406,10 @@ def main() -> int:
     ap.add_argument("--no-pin", action="store_true", help="keep the sequences in ordinary (pageable) memory: cvx_submit packs them into its own staging")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs (ONT mix, ultra-long + SV, short reads) reported beside the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--alias-device", type=int, default=-1, metavar="D",
+                    help="run the --gpus N code path (N handles, N host threads, one shared pack pool; --strong too) with every handle on physical "
+                         "device D: exercises the N-device path on a one-GPU box -- NOT a scaling measurement (N batches' arenas share one HBM: "
+                         "use --tiles <= 16384 for N = 2)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -429,6 +433,11 @@ def main() -> int:
             os._exit(255)
     n_dev = os.WEXITSTATUS(os.waitpid(pid, 0)[1])
     need = (local_rank + 1) if under_launcher else args.gpus
+    if args.alias_device >= 0:
+        if under_launcher:
+            print("bench.py: --alias-device is for the single-process form", file=sys.stderr)
+            return 2
+        need = args.alias_device + 1
     if n_dev == 255:
         print("bench.py: libcvxalign.so could not be loaded (run __graft_entry__.build())", file=sys.stderr)
         return 2
@@ -477,6 +486,8 @@ def main() -> int:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     devs = [local_rank] if under_launcher else list(range(n_local))
+    if args.alias_device >= 0:
+        devs = [args.alias_device] * n_local       # N handles + N host threads on ONE physical device
     workers = [Worker(d, ts, args.depth) for d, ts in zip(devs, tilesets)]
     # corridors travel as the closed forms of the reference's builders (the device generates the rows), sequences sit
     # in page-locked arenas the device pulls from directly: cvx_submit touches no base and no row
@@ -745,6 +756,7 @@ def main() -> int:
                 "strong_scaling_partition": ({"tiles_total": args.tiles, "tiles_per_device": [len(p_) for p_ in strong_parts], "by": "sum of corridor cells (LPT)",
                                               "order_restored": sorted(i_ for p_ in strong_parts for i_ in p_) == list(range(args.tiles))} if strong_parts is not None else None),
                 "launch": "torch.distributed.run, one rank per device" if under_launcher else "one process, one host thread + handle per device",
+                "alias_device": (None if args.alias_device < 0 else "all %d handles on physical device %d: the N-device code path on one GPU, not a scaling measurement" % (args.gpus, args.alias_device)),
                 "sharding": "reads sharded across devices, no collective on the data path",
             },
             "roofline": {

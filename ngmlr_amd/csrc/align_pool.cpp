@@ -10,6 +10,8 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+
 #include "AlignmentBuffer.h"
 #include "NGM.h"
 #include "batching_aligner.h"
@@ -46,6 +48,7 @@ struct Pool {
 	}
 
 	void contextMain() {
+		pthread_setname_np(pthread_self(), "cvx-context");
 		/* what CS::DoRun does for its own thread (reference src/CS.cpp:414-419): the constructor writes the SAM
 		 * prolog once, under NGM's output lock */
 		NGM.AquireOutputLock();
@@ -133,6 +136,7 @@ Pool * poolForSubmit() {
 }  // namespace
 
 void AlignPool::Attach() {
+	pthread_setname_np(pthread_self(), "ngm-cs");      /* the calling CS thread */
 	std::lock_guard<std::mutex> g(g_poolMtx);
 	/* the aligner fronts built from now on (the CS threads' own, the contexts') register with their dispatcher per
 	 * read (ThreadBegin / ThreadEnd), not for their lifetime */

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <pthread.h>
+
 namespace Convex {
 
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
@@ -47,8 +49,12 @@ void BatchingAligner::WorkerJoined() {
 bool BatchingAligner::shouldCut(bool deviceIdle) const {
 	if (queue.empty()) return false;
 	if ((int) queue.size() >= maxBatch) return true;
-	if (parked >= workers) return true;                      /* nobody left who could add to the launch */
 	std::chrono::steady_clock::time_point const now = std::chrono::steady_clock::now();
+	/* nobody left who could add to the launch -- decisive only without a batch target: with many more contexts than cores
+	 * (align_pool.h) the contexts that hold a read are parked nearly all the time (their host stages are short), while idle
+	 * contexts and the CS threads are about to bring more; measured with this rule in front: 27-31 tiles per launch
+	 * whatever the target (gpurun_out r04a) */
+	if (target <= 0 && parked >= workers) return true;
 	if (target > 0 && (int) queue.size() < target) {
 		/* Many more contexts than cores (align_pool.h): the host stages, not the device, bound the throughput, a launch
 		 * lasts about as long as its slowest tile whatever it carries, and every launch costs the dispatcher, the pack
@@ -72,6 +78,7 @@ bool BatchingAligner::shouldCut(bool deviceIdle) const {
 /* The one thread that owns the device handle.  Up to maxFlight (two) launches in flight: the upload and corridor analysis
  * of the younger run under the kernels of the older; requests that arrive meanwhile form the launch after that. */
 void BatchingAligner::dispatchLoop() {
+	pthread_setname_np(pthread_self(), "cvx-dispatch");      /* (thread names: tools/e2e_rates.py splits the process's CPU time by them) */
 	std::unique_lock<std::mutex> lk(mtx);
 	for (;;) {
 		/* buffers of launches whose workers have all finished writing */
@@ -242,6 +249,10 @@ SharedAligner::SharedAligner(int const stdOutMode, float const match, float cons
 	int nDev = cvx_device_count();
 	if (const char * e = getenv("CVX_DEVICES")) nDev = atoi(e) < nDev ? atoi(e) : nDev;      /* use only the first k devices */
 	if (nDev > kMaxDevices) nDev = kMaxDevices;
+	/* CVX_ALIAS_DEVICES=k: deal the workers over k LOGICAL devices (own backend, own dispatcher each) that all live on the
+	 * physical devices present -- the multi-device path of this class on a one-GPU box (tests; not a scaling measurement) */
+	int const nPhysical = nDev;
+	if (const char * e = getenv("CVX_ALIAS_DEVICES")) { if (atoi(e) > 0 && nPhysical > 0) nDev = atoi(e) < kMaxDevices ? atoi(e) : kMaxDevices; }
 	/* deviceId >= 0 pins the worker; the default spreads them */
 	device = (deviceId >= 0 && nDev > 0) ? deviceId % nDev : (nDev > 0 ? (int) (g_joined % nDev) : 0);
 	if (g_joined == 0) g_firstJoin = std::chrono::steady_clock::now();
@@ -250,7 +261,7 @@ SharedAligner::SharedAligner(int const stdOutMode, float const match, float cons
 		int maxBatch = 4096, timeoutUs = 2000;
 		if (const char * e = getenv("CVX_BATCH_MAX")) maxBatch = atoi(e);
 		if (const char * e = getenv("CVX_BATCH_TIMEOUT_US")) timeoutUs = atoi(e);
-		g_backend[device] = new ConvexAlignHip(stdOutMode, match, mismatch, gapOpen, gapExtend, gapExtendMin, gapDecay, device);   /* throws without a usable device */
+		g_backend[device] = new ConvexAlignHip(stdOutMode, match, mismatch, gapOpen, gapExtend, gapExtendMin, gapDecay, nPhysical > 0 ? device % nPhysical : device);   /* throws without a usable device */
 		g_shared[device] = new BatchingAligner(g_backend[device], 0, maxBatch, timeoutUs);   /* workers join one by one */
 	}
 	if (perRead) tl_dispatcher = g_shared[device];
@@ -298,6 +309,12 @@ long SharedAligner::Launches() {
 	std::lock_guard<std::mutex> g(g_sharedMtx);
 	long n = g_lastLaunches;
 	for (int d = 0; d < kMaxDevices; ++d) if (g_shared[d]) n += g_shared[d]->Launches();
+	return n;
+}
+int SharedAligner::ActiveDevices() {
+	std::lock_guard<std::mutex> g(g_sharedMtx);
+	int n = 0;
+	for (int d = 0; d < kMaxDevices; ++d) if (g_shared[d]) n += 1;
 	return n;
 }
 long SharedAligner::Requests() {

@@ -163,6 +163,8 @@ public:
 	/* statistics of the process-wide aligner (0 when none exists) */
 	static long Launches();
 	static long Requests();
+	/* logical devices that have a dispatcher right now (CVX_ALIAS_DEVICES puts several on one physical device) */
+	static int ActiveDevices();
 
 	/* Pool accounting (align_pool.h): with K >> cores alignment contexts most aligner fronts belong to threads that hold
 	 * no read, and "every registered worker is parked" must count only those that do.  After UsePoolAccounting(true) a

@@ -67,7 +67,7 @@ fill_generic_kernel(const FillArgs a, uint8_t *scratch, const uint64_t *scratch_
 	const int t = a.list[qi];
 	const TileIn ti = a.tin[t];
 	const TileRun tr = a.trun[t];
-	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off;
+	const RowView rows = row_view(a.rsrc[t], a.rows, ti.row_off);      /* closed-form corridors are evaluated in registers */
 	const uint8_t *ref = a.seq + ti.ref_off;
 	const uint8_t *qry = a.seq + ti.qry_off;
 	const int H = ti.H, W = ti.W;
@@ -85,7 +85,7 @@ fill_generic_kernel(const FillArgs a, uint8_t *scratch, const uint64_t *scratch_
 	auto bind = [&](Slot &s, int yy, int rnext) {
 		s.y = yy;
 		if (yy < H) {
-			const int2 ol = rows[yy];
+			const RowDesc2 ol = row_at(rows, yy);
 			long long lo = ol.x > 0 ? ol.x : 0;
 			long long hi = (long long) ol.x + (long long) ol.y;
 			if (hi > W) hi = W;

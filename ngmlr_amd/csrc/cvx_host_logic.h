@@ -8,6 +8,7 @@
 #define CVX_HOST_LOGIC_H
 
 #include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,8 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+
+#include <pthread.h>
 
 #include "cvx_align.h"
 #include "cvx_types.h"
@@ -121,6 +124,7 @@ private:
 		if (last) done_.notify_all();
 	}
 	void loop() {
+		pthread_setname_np(pthread_self(), "cvx-pack");
 		for (;;) {
 			Task t;
 			{
@@ -171,7 +175,8 @@ struct UploadLayout {
 	uint64_t seq_total = 0;         /* bytes of the seq arena: [pad][every read][pad][every reference][pad] */
 	uint64_t qry_base = 0, qry_bytes = 0;   /* arena offset / size of the block of reads */
 	uint64_t ref_base = 0, ref_bytes = 0;   /* ... of the block of references (ref_base is a multiple of 256) */
-	uint64_t n_rows = 0;            /* entries of the rows arena */
+	uint64_t n_rows = 0;            /* read rows of all tiles */
+	uint64_t arena_rows = 0;        /* entries of the rows arena: the rows of the tiles whose corridors came as arrays (closed forms own none) */
 	uint64_t delta_total = 0;       /* bytes of the row-step stream (H bytes, 4-byte aligned, per tile whose rows come as arrays) */
 	std::vector<RowSrc> rsrc;       /* per tile: where its rows come from (src_off = offset into the step stream until packed) */
 	bool windows = false;           /* references decoded on the device from the resident genome: their block is not uploaded */
@@ -182,6 +187,17 @@ struct UploadLayout {
 };
 
 enum { kLayoutOk = 0, kLayoutMalformed = 1, kLayoutTooLarge = 2 };
+
+/* A closed form the device and the host evaluate alike: finite parameters, a positive finite slope, and every row's
+ * offset ((float) y - d) / k - right inside the int32 range with room to spare -- the float -> int conversion of
+ * affine_row_offset is undefined behaviour on the host and saturating on the device beyond it.  The
+ * expression is monotone in y for k > 0, so rows 0 and H bound all of them. */
+inline bool affine_form_ok(float k, float d, float right, int32_t H) {
+	if (!(k > 0.0f && k < 3.0e38f) || !std::isfinite(d) || !std::isfinite(right)) return false;
+	const double lo = (0.0 - (double) d) / (double) k - (double) right;
+	const double hi = ((double) (H > 0 ? H : 0) - (double) d) / (double) k - (double) right;
+	return std::fabs(lo) < 2.0e9 && std::fabs(hi) < 2.0e9;
+}
 
 /* Validates the tiles and assigns arena offsets (TileIn).  On kLayoutMalformed *bad is the
  * offending tile; kLayoutTooLarge: more than 4 GiB of bases (32-bit sequence offsets). */
@@ -196,8 +212,7 @@ inline int upload_layout(int n, const cvx_tile *tiles, std::vector<TileIn> &tin,
 				(rows_given && t.qry_len > 0 && (!t.row_offset || !t.row_length)) ||
 				(rows_given && ((t.row_stride_bytes & 3) || t.row_stride_bytes < 4)) ||
 				t.corridor_kind < CVX_CORRIDOR_ROWS || t.corridor_kind > CVX_CORRIDOR_CONST ||
-				(t.corridor_kind == CVX_CORRIDOR_AFFINE && !(t.corridor_k > 0.0f && t.corridor_k < 3.0e38f &&
-					t.corridor_d == t.corridor_d && t.corridor_right == t.corridor_right)) ||
+				(t.corridor_kind == CVX_CORRIDOR_AFFINE && !affine_form_ok(t.corridor_k, t.corridor_d, t.corridor_right, t.qry_len)) ||
 				(!rows_given && t.corridor_width < 0)) {
 			if (bad) *bad = i;
 			return kLayoutMalformed;
@@ -235,9 +250,8 @@ inline int upload_layout(int n, const cvx_tile *tiles, std::vector<TileIn> &tin,
 		qo += (uint64_t) t.qry_len;
 		ti.W = t.ref_len;
 		ti.H = t.qry_len;
-		ti.row_off = ro;
+		ti.row_off = 0;
 		ti.reserved = 0;
-		ro += (uint64_t) t.qry_len;
 		RowSrc &rs = L.rsrc[(size_t) i];
 		memset(&rs, 0, sizeof(rs));
 		uint64_t row_work = 0;
@@ -247,12 +261,15 @@ inline int upload_layout(int n, const cvx_tile *tiles, std::vector<TileIn> &tin,
 			rs.fmt = kRowsConst; rs.width = t.corridor_width; rs.off0 = t.corridor_offset;
 		} else {
 			rs.src_off = dof; rs.fmt = kRowsDelta8;
+			ti.row_off = ro;                       /* only corridors that came as arrays own a slice of the rows arena */
+			ro += (uint64_t) t.qry_len;
 			dof += ((uint64_t) t.qry_len + 3) / 4 * 4;
 			row_work = 9ull * (uint64_t) t.qry_len;
 		}
 		L.wprefix[(size_t) i + 1] = L.wprefix[(size_t) i] + (windows ? 0 : (uint64_t) t.ref_len) + (uint64_t) t.qry_len + row_work + 64;
 	}
 	L.delta_total = dof;
+	L.arena_rows = ro;
 	return kLayoutOk;
 }
 

@@ -64,14 +64,18 @@ CVX_DEV void row_span(const int2 ol, int W, int y, int &gs, int &ge) {
  * threads and workgroup launches (short-read config: 1.7 of 8.9 ms per 100 000 tiles) */
 template <int TPT>
 __global__ void __launch_bounds__(256)
-plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, unsigned long long max_matrix_mb) {
+plan_kernel(const int2 *rows, const RowSrc *rsrc, const TileIn *tin, TilePlan *plan, int n_tiles, unsigned long long max_matrix_mb) {
 	constexpr int TPB = 256 / TPT;                 /* tiles per block */
 	const int sub = threadIdx.x / TPT;             /* tile slot inside the block */
 	const int ltid = threadIdx.x % TPT;
 	const int t = blockIdx.x * TPB + sub;
 	const bool live = t < n_tiles;
 	const TileIn ti = tin[live ? t : 0];
-	const int2 *r = rows + ti.row_off;
+	/* rows of a closed-form corridor are evaluated in registers (RowView): the analysis of such a tile reads nothing
+	 * but its 32-byte description -- it used to read 8 H bytes a handful of times (3.5 ms per 49 152 PacBio tiles, and
+	 * most of a fill's duration when it ran beside one) */
+	const RowView rv = row_view(rsrc[live ? t : 0], reinterpret_cast<const RowDesc2 *>(rows), ti.row_off);
+	auto row = [&](const int y) { const RowDesc2 q = row_at(rv, y); return make_int2(q.x, q.y); };
 	const int H = live ? ti.H : 0, W = ti.W;
 
 	__shared__ unsigned long long s_cells[TPB], s_active[TPB];
@@ -82,7 +86,7 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 	unsigned long long cells = 0, active = 0;
 	int need = 1, flags = 0, maxlen = 0, rendmax = -0x7fffffff, r0min = 0x7fffffff;
 	for (int y = ltid; y < H; y += TPT) {
-		const int2 ol = r[y];
+		const int2 ol = row(y);
 		int gs, ge;
 		row_span(ol, W, y, gs, ge);
 		cells += (unsigned long long) (long long) ol.y;
@@ -92,7 +96,7 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 		if (gs < r0min) r0min = gs;
 		if (y > 0) {
 			int pgs, pge;
-			row_span(r[y - 1], W, y - 1, pgs, pge);
+			row_span(row(y - 1), W, y - 1, pgs, pge);
 			if (gs <= pgs) flags |= kPlanIrregular;  /* ring schedule needs increasing row starts */
 			/* ... and rows that end in order: the fill hands slots over in row order (its staged row
 			 * records are overwritten on that assumption).  True for every corridor the reference builds
@@ -105,7 +109,7 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 		const int lim = ge + kSwitchMargin;
 		auto starts_before = [&](int yy) {       /* gs(yy) < lim */
 			int mgs, mge;
-			row_span(r[yy], W, yy, mgs, mge);
+			row_span(row(yy), W, yy, mgs, mge);
 			return mgs < lim;
 		};
 		int lo = y + 1, hi = H;                  /* rows < lo start before lim, rows >= hi do not */
@@ -146,7 +150,7 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
 			int a = y + 1, b = H;                    /* rows < a start before hi(y), rows >= b do not */
 			while (a < b) {
 				const int mid = (a + b) >> 1;
-				const int2 om = r[mid];
+				const int2 om = row(mid);
 				const long long lo_m = om.x > 0 ? om.x : 0;
 				if (lo_m < hi_y) a = mid + 1; else b = mid;
 			}
@@ -193,7 +197,7 @@ plan_kernel(const int2 *rows, const TileIn *tin, TilePlan *plan, int n_tiles, un
  * the rows verbatim for the tiles that do not fit that form.  The result is exactly the caller's
  * CorridorLine[] minus offsetInMatrix; everything downstream reads this arena as before. */
 __global__ void __launch_bounds__(64)
-expand_rows_kernel(const RowSrc *rsrc, const TileIn *tin, const uint8_t *delta, const int2 *rowsx, int2 *rows, int n_tiles) {
+expand_rows_kernel(const RowSrc *rsrc, const TileIn *tin, const uint8_t *delta, const int2 *rowsx, int2 *rows, int n_tiles, int closed_forms) {
 	/* one wave per tile, 64 rows per pass, the running offset in a register: no LDS, no barrier -- the
 	 * kernel runs on the upload stream beside the previous batch's fill, where a workgroup barrier per
 	 * 256 rows cost it tens of ms (measured: 46 ms average in the pipelined bench, 1.6 ms alone) */
@@ -209,6 +213,7 @@ expand_rows_kernel(const RowSrc *rsrc, const TileIn *tin, const uint8_t *delta, 
 		for (int y = lane; y < H; y += 64) out[y] = src[y];
 		return;
 	}
+	if ((rs.fmt == kRowsAffine || rs.fmt == kRowsConst) && !closed_forms) return;      /* evaluated in registers wherever a row is needed (RowView) */
 	if (rs.fmt == kRowsAffine) {
 		/* the reference's corridor builders in closed form (cvx_types.h affine_row_offset; src/AlignmentBuffer.cpp:107-127,
 		 * 178-191, 68-82): binary32 subtract, correctly rounded divide, subtract, truncation -- row by row, no carried state */
@@ -291,7 +296,7 @@ CVX_DEV unsigned plane_code(const unsigned wx, const unsigned wy, const int bit)
  */
 template <bool CHAINED>
 CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int r0, const int ops_cap,
-		const int2 *rows, const uint2 *dirs, const ChainBlk *blk, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
+		const RowView &rows, const uint2 *dirs, const ChainBlk *blk, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
 	/* make the walk's state provably wave-uniform so that it runs on scalar branches */
 	const int best_x = __builtin_amdgcn_readfirstlane(o.best_x);
 	const int best_y = __builtin_amdgcn_readfirstlane(o.best_y);
@@ -333,7 +338,7 @@ CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int 
 		if (sl < 0) sl += N;
 		const int tt = cx + cy - r0;
 		const int ttc = tt > 0 ? tt : 0;
-		const int2 ol = rows[ly];
+		const RowDesc2 ol = row_at(rows, ly);
 		uint2 w;
 		if (CHAINED) {
 			/* row block of the probed cell -> its own region of direction words (N is a power of two here) */
@@ -450,7 +455,7 @@ CVX_DEV void backtrack_walk(const int lane, const int H, const int N, const int 
 
 /* first cell of the tile in (y, x) order: *fy = -1 when no row has a cell inside [0, W).
  * Rare path (a tile without any positive score), run by backtrack_kernel. */
-CVX_DEV void first_cell(const int2 *rows, int H, int W, int lane, int *fy, int *fx) {
+CVX_DEV void first_cell(const RowView &rows, int H, int W, int lane, int *fy, int *fx) {
 	*fy = -1;
 	*fx = 0;
 	for (int y0 = 0; y0 < H; y0 += 64) {
@@ -458,7 +463,7 @@ CVX_DEV void first_cell(const int2 *rows, int H, int W, int lane, int *fy, int *
 		bool has = false;
 		int lo_i = 0;
 		if (yy < H) {
-			const int2 ol = rows[yy];
+			const RowDesc2 ol = row_at(rows, yy);
 			long long lo = ol.x > 0 ? ol.x : 0;
 			long long hi = (long long) ol.x + (long long) ol.y;
 			if (hi > W) hi = W;
@@ -602,7 +607,7 @@ fill_ring_kernel(const FillArgs a) {
 	}
 	const TileIn ti = a.tin[t];
 	const TileRun tr = a.trun[t];
-	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off + y0;
+	const RowView rv = row_view(a.rsrc[t], a.rows, ti.row_off, y0);      /* wave-uniform: closed forms are evaluated in make_rec */
 	const uint8_t *seq = a.seq;
 	const int H = CHAIN ? ct.rows : ti.H, W = ti.W;     /* rows of this task */
 	const unsigned qry_off = ti.qry_off + (unsigned) y0;
@@ -643,7 +648,7 @@ fill_ring_kernel(const FillArgs a) {
 		int4 rec;
 		rec.w = (int) (ref_base - (unsigned) yy);
 		if (yy < H) {
-			const int2 ol = rows[yy];
+			const RowDesc2 ol = row_at(rv, yy);
 			long long lo = ol.x > 0 ? ol.x : 0;
 			long long hi = (long long) ol.x + (long long) ol.y;
 			if (hi > W) hi = W;
@@ -1049,7 +1054,7 @@ CVX_DEV void walk_tile(const BacktrackArgs &a, const int t, const int lane) {
 	if (o.status != 0 || o.pad != 0) return;
 	const int wi = rec_load(a.tin + t, 8, lane);     /* ref_off 0, qry_off 1, W 2, H 3, row_off 4-5 */
 	const int H = fld(wi, 3), W = fld(wi, 2);
-	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + fld64(wi, 4);
+	const RowView rows = row_view(a.rsrc[t], a.rows, fld64(wi, 4));
 	if (!(o.score > 0.0f)) {
 		/* no positive score: the reference's best cell is the first cell in (y, x) order with
 		 * score 0 (curr_max starts at -1, src/ConvexAlignFast.cpp:758-763) */
@@ -1103,7 +1108,7 @@ struct Group {
 
 template <int G>
 CVX_DEV void backtrack_walk_grp(const Group<G> g, const bool has_tile, const bool chained, const int H, const int N, const int r0, const int ops_cap,
-		const int2 *rows, const uint2 *dirs, const ChainBlk *blk, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
+		const RowView &rows, const uint2 *dirs, const ChainBlk *blk, const uint8_t *ref, const uint8_t *qry, int *ops, TileOut &o) {
 	/* `chained` is a property of the group's tile (a wave may carry both kinds): dirs is the tile's own
 	 * region for whole tiles and the arena for chained ones, whose blocks carry their offsets */
 	const int gl = g.gl;
@@ -1150,7 +1155,7 @@ CVX_DEV void backtrack_walk_grp(const Group<G> g, const bool has_tile, const boo
 				if (sl < 0) sl += N;
 				const int tt = cx + cy - r0;
 				const int ttc = tt > 0 ? tt : 0;
-				const int2 ol = rows[ly];
+				const RowDesc2 ol = row_at(rows, ly);
 				size_t widx = (size_t) (ttc >> 5) * N + sl;
 				if (chained) {
 					/* the block record of this lane's row: kept from the previous probe while the row stays in
@@ -1318,7 +1323,8 @@ backtrack_grp_kernel(const BacktrackArgs a, const int32_t *order, const int n_or
 		if (tr.skip != 0 || o.status != 0 || o.pad != 0) has = false;
 	}
 	const int H = ti.H, W = ti.W;
-	const int2 *rows = reinterpret_cast<const int2 *>(a.rows) + ti.row_off;
+	/* (a group's tile may be of either kind: per-lane fmt; a batch is all of one kind in practice and the branch in row_at uniform) */
+	const RowView rows = row_view(a.rsrc[t], a.rows, ti.row_off);
 	bool dead = false;       /* no cell at all: status 5 */
 	if (__builtin_amdgcn_ballot_w64(has && !(o.score > 0.0f)) != 0ull) {
 		/* no positive score: the reference's best cell is the first cell in (y, x) order with score 0
@@ -1332,7 +1338,7 @@ backtrack_grp_kernel(const BacktrackArgs a, const int32_t *order, const int n_or
 					bool hc = false;
 					int lo_i = 0;
 					if (yy < H) {
-						const int2 ol = rows[yy];
+						const RowDesc2 ol = row_at(rows, yy);
 						long long lo = ol.x > 0 ? ol.x : 0;
 						long long hi = (long long) ol.x + (long long) ol.y;
 						if (hi > W) hi = W;
@@ -1524,22 +1530,22 @@ hipError_t launch_chain_reduce(const int32_t *tiles, int n_tiles, const TileRun 
 }
 
 hipError_t launch_expand_rows(const RowSrc *rsrc, const TileIn *tin, const uint8_t *delta, const RowDesc *rowsx, RowDesc *rows,
-		int n_tiles, hipStream_t st) {
+		int n_tiles, bool closed_forms, hipStream_t st) {
 	if (n_tiles <= 0) return hipSuccess;
 	hipLaunchKernelGGL(expand_rows_kernel, dim3(n_tiles), dim3(64), 0, st, rsrc, tin, delta,
-			reinterpret_cast<const int2 *>(rowsx), reinterpret_cast<int2 *>(rows), n_tiles);
+			reinterpret_cast<const int2 *>(rowsx), reinterpret_cast<int2 *>(rows), n_tiles, closed_forms ? 1 : 0);
 	return hipGetLastError();
 }
 
-hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles, uint64_t rows_per_tile,
+hipError_t launch_plan(const RowDesc *rows, const RowSrc *rsrc, const TileIn *tin, TilePlan *plan, int n_tiles, uint64_t rows_per_tile,
 		unsigned long long max_matrix_mb, hipStream_t st) {
 	if (n_tiles <= 0) return hipSuccess;
 	if (rows_per_tile >= 1024)
 		hipLaunchKernelGGL(plan_kernel<256>, dim3(n_tiles), dim3(256), 0, st,
-				reinterpret_cast<const int2 *>(rows), tin, plan, n_tiles, max_matrix_mb);
+				reinterpret_cast<const int2 *>(rows), rsrc, tin, plan, n_tiles, max_matrix_mb);
 	else
 		hipLaunchKernelGGL(plan_kernel<64>, dim3((n_tiles + 3) / 4), dim3(256), 0, st,
-				reinterpret_cast<const int2 *>(rows), tin, plan, n_tiles, max_matrix_mb);
+				reinterpret_cast<const int2 *>(rows), rsrc, tin, plan, n_tiles, max_matrix_mb);
 	return hipGetLastError();
 }
 

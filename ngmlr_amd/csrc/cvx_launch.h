@@ -80,10 +80,11 @@ size_t generic_scratch_bytes(int ring);
 /* sse_variant: the reference's SSE-path semantics for scoring outside the scalar-equivalent regime */
 hipError_t launch_fill_generic(const FillArgs &a, bool sse_variant, uint8_t *scratch, const uint64_t *scratch_off, hipStream_t st);
 /* the rows arena from the one-byte-per-row step stream (+ verbatim rows of the tiles that do not fit it) */
+/* closed_forms: also write out the rows of closed-form corridors (cvx_corridor_rows; the product evaluates those in registers) */
 hipError_t launch_expand_rows(const RowSrc *rsrc, const TileIn *tin, const uint8_t *delta, const RowDesc *rowsx, RowDesc *rows,
-		int n_tiles, hipStream_t st);
+		int n_tiles, bool closed_forms, hipStream_t st);
 /* rows_per_tile: mean read rows per tile of the batch (picks 256 threads or one wave per tile) */
-hipError_t launch_plan(const RowDesc *rows, const TileIn *tin, TilePlan *plan, int n_tiles, uint64_t rows_per_tile,
+hipError_t launch_plan(const RowDesc *rows, const RowSrc *rsrc, const TileIn *tin, TilePlan *plan, int n_tiles, uint64_t rows_per_tile,
 		unsigned long long max_matrix_mb, hipStream_t st);
 /* group: 16 = sixteen lanes per tile, four tiles per wave, tiles taken from order[0, n_order) (largest first);
  * anything else = one wave per tile over all a.n_tiles */

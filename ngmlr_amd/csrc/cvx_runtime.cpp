@@ -409,7 +409,7 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	memset(&b->timing, 0, sizeof(b->timing));
 	RC_TRY(b->make_events());
 	const size_t n1 = (size_t) std::max(n, 1);
-	const size_t rows1 = (size_t) std::max<uint64_t>(L.n_rows, 1);
+	const size_t rows1 = (size_t) std::max<uint64_t>(L.arena_rows, 1);      /* closed-form corridors own no rows (RowView, cvx_types.h) */
 	RC_TRY(b->h_delta.ensure((size_t) L.delta_total + 256));
 	RC_TRY(b->h_rsrc.ensure(n1 * sizeof(RowSrc)));
 	RC_TRY(b->d_delta.ensure((size_t) L.delta_total + 256));
@@ -558,7 +558,8 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 		}
 		memcpy(b->h_rsrc.p, L.rsrc.data(), (size_t) n * sizeof(RowSrc));
 		HIP_TRY(hipMemcpyAsync(b->d_rsrc.p, b->h_rsrc.p, (size_t) n * sizeof(RowSrc), hipMemcpyHostToDevice, st));
-		HIP_TRY(launch_expand_rows(b->d_rsrc.p, b->d_tin.p, b->d_delta.p, b->d_rowsx.p, b->d_rows.p, n, st));
+		/* rows arena: only for the tiles whose corridors came as arrays; closed forms are evaluated where they are needed */
+		if (L.arena_rows) HIP_TRY(launch_expand_rows(b->d_rsrc.p, b->d_tin.p, b->d_delta.p, b->d_rowsx.p, b->d_rows.p, n, false, st));
 	}
 	if (windows && n) {
 		/* the references: decoded from the resident genome straight into the arena (and its last pad cleared) */
@@ -583,7 +584,7 @@ int stage_plan(cvx_context *h, cvx_batch_s *b, hipStream_t st) {
 	const int n = b->n;
 	HIP_TRY(hipEventRecord(b->ev[0], st));
 	if (n) {
-		HIP_TRY(launch_plan(b->d_rows.p, b->d_tin.p, b->d_plan.p, n, b->n_rows / (uint64_t) n, h->max_matrix_mb, st));
+		HIP_TRY(launch_plan(b->d_rows.p, b->d_rsrc.p, b->d_tin.p, b->d_plan.p, n, b->n_rows / (uint64_t) n, h->max_matrix_mb, st));
 		HIP_TRY(hipMemcpyAsync(b->h_plan.p, b->d_plan.p, (size_t) n * sizeof(TilePlan), hipMemcpyDeviceToHost, st));
 	}
 	HIP_TRY(hipEventRecord(b->ev[1], st));
@@ -747,6 +748,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		FillArgs a;
 		a.seq = b->d_seq.p;
 		a.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
+		a.rsrc = b->d_rsrc.p;
 		a.tin = b->d_tin.p;
 		a.trun = b->d_trun.p;
 		a.tout = b->d_tout.p;
@@ -870,6 +872,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	ba.chain_blk = hp.n_chained ? reinterpret_cast<const ChainBlk *>(b->d_chain.p + chain_blk_off) : nullptr;
 	ba.seq = b->d_seq.p;
 	ba.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
+	ba.rsrc = b->d_rsrc.p;
 	ba.tin = b->d_tin.p;
 	ba.trun = b->d_trun.p;
 	ba.tout = b->d_tout.p;
@@ -1362,7 +1365,8 @@ int cvx_corridor_rows(cvx_handle h, const cvx_tile *tile, int32_t *offset, int32
 		}
 		return CVX_OK;
 	}
-	/* the closed forms are evaluated where the product evaluates them: by expand_rows_kernel */
+	/* the closed forms are evaluated as the product evaluates them: on the device, by the function every kernel uses for
+	 * the rows of such a tile (affine_row_offset; here through expand_rows_kernel, which writes them out) */
 	cvx_tile t = *tile;
 	static const char dummy[1] = {0};
 	t.ref = t.qry = dummy;      /* only the corridor matters here */
@@ -1371,8 +1375,7 @@ int cvx_corridor_rows(cvx_handle h, const cvx_tile *tile, int32_t *offset, int32
 	UploadLayout L;
 	int bad = -1;
 	{
-		cvx_tile probe = t;
-		probe.qry_len = 0;       /* validate the descriptor without sequences */
+		cvx_tile probe = t;      /* validate the descriptor (its bounds depend on the number of rows); no sequence is read */
 		if (upload_layout(1, &probe, tin, L, &bad, false) != kLayoutOk) { set_err("cvx_corridor_rows: malformed corridor descriptor"); return CVX_ERR_ARG; }
 	}
 	HIP_TRY(hipSetDevice(h->device));
@@ -1391,7 +1394,7 @@ int cvx_corridor_rows(cvx_handle h, const cvx_tile *tile, int32_t *offset, int32
 	if (rc == CVX_OK) {
 		e = hipMemcpy(d_rs.p, &rs, sizeof(rs), hipMemcpyHostToDevice);
 		if (e == hipSuccess) e = hipMemcpy(d_ti.p, &ti, sizeof(ti), hipMemcpyHostToDevice);
-		if (e == hipSuccess) e = launch_expand_rows(d_rs.p, d_ti.p, nullptr, nullptr, d_rows.p, 1, h->s_main);
+		if (e == hipSuccess) e = launch_expand_rows(d_rs.p, d_ti.p, nullptr, nullptr, d_rows.p, 1, true, h->s_main);
 		if (e == hipSuccess) e = hipStreamSynchronize(h->s_main);
 		if (e == hipSuccess) e = hipMemcpy(rows.data(), d_rows.p, (size_t) H * sizeof(RowDesc), hipMemcpyDeviceToHost);
 	}

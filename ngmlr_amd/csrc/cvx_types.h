@@ -77,7 +77,7 @@ struct RowSrc {
 /* The closed form, shared by the device kernel and the host's chain planning: binary32 throughout, every
  * operation rounded on its own (the files that include this are compiled with -ffp-contract=off), the
  * divide correctly rounded on both sides, C truncation. */
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline int32_t affine_row_offset(int y, float d, float k, float right) {
@@ -87,11 +87,43 @@ inline int32_t affine_row_offset(int y, float d, float k, float right) {
 	return (int32_t) r;
 }
 
+#if defined(__HIPCC__)
+/* The rows of one tile wherever they live (round 4): a closed-form corridor is evaluated in registers by every kernel
+ * that needs a row -- plan, fill (row records), backtrack, catch-all -- so such a tile has no slice of the rows arena
+ * at all (no expand_rows_kernel pass, no 8 bytes per read row in HBM); tiles whose rows travelled as arrays read their
+ * slice as before.  fmt is a property of the tile, hence uniform wherever one wave works on one tile. */
+struct RowView {
+	const RowDesc2 *rows;  /* slice of the rows arena (kRowsDelta8 / kRowsExplicit tiles), first row of the view */
+	int32_t fmt;           /* kRowsAffine / kRowsConst: closed form; anything else: rows[y] */
+	int32_t width;
+	int32_t y0;            /* row index of the view's row 0 inside the tile (chained row blocks) */
+	float k, d, right;     /* kRowsConst: the bits of `right` are the constant offset */
+};
+__device__ __forceinline__ RowView row_view(const RowSrc &rs, const RowDesc2 *arena, const uint64_t row_off, const int y0 = 0) {
+	RowView v;
+	v.rows = arena + row_off + y0;
+	v.fmt = rs.fmt; v.width = rs.width; v.y0 = y0;
+	v.k = rs.k; v.d = rs.d;
+	v.right = rs.fmt == kRowsConst ? __int_as_float(rs.off0) : rs.right;
+	return v;
+}
+__device__ __forceinline__ RowDesc2 row_at(const RowView &v, const int y) {
+	RowDesc2 r;
+	if (v.fmt == kRowsAffine || v.fmt == kRowsConst) {
+		r.x = v.fmt == kRowsConst ? __float_as_int(v.right) : affine_row_offset(y + v.y0, v.d, v.k, v.right);
+		r.y = v.width;
+	} else {
+		r = v.rows[y];
+	}
+	return r;
+}
+#endif
+
 struct TileIn {            /* written by the host at upload */
 	uint32_t ref_off;      /* byte offset of ref[0] in the seq arena */
 	uint32_t qry_off;      /* byte offset of qry[0] */
 	int32_t W, H;
-	uint64_t row_off;      /* index of row 0 in the rows arena (int2 units) */
+	uint64_t row_off;      /* index of row 0 in the rows arena (int2 units); closed-form corridors own no rows there */
 	uint64_t reserved;
 };
 
@@ -230,6 +262,7 @@ struct TextArgs {          /* device-side text stage (cvx_text.hip) */
 struct FillArgs {
 	const uint8_t *seq;
 	const RowDesc2 *rows;
+	const RowSrc *rsrc;    /* per tile: which form its rows have (RowView) */
 	const TileIn *tin;
 	const TileRun *trun;
 	TileOut *tout;
@@ -253,6 +286,7 @@ struct BacktrackArgs {
 	const ChainBlk *chain_blk;
 	const uint8_t *seq;
 	const RowDesc2 *rows;
+	const RowSrc *rsrc;
 	const TileIn *tin;
 	const TileRun *trun;
 	TileOut *tout;

@@ -28,8 +28,14 @@ struct Rec {
 };
 
 int main(int argc, char ** argv) {
-	if (argc < 3) { fprintf(stderr, "usage: batching_test records.bin threads\n"); return 2; }
+	if (argc < 3) { fprintf(stderr, "usage: batching_test records.bin threads [shared | handles]\n"); return 2; }
 	int const T = atoi(argv[2]);
+	/* "shared":  every thread constructs its own Convex::SharedAligner, as ngmlr's workers do (src/AlignmentBuffer.h:355); with
+	 *            CVX_ALIAS_DEVICES=2 in the environment they are dealt over two logical devices -- two backends, two dispatchers
+	 *            -- on the one physical device: the multi-device path of the class on a one-GPU box
+	 * "handles": T threads, each with its OWN ConvexAlignHip handle, aligning their shares concurrently through AlignTiles
+	 *            (what bench.py --gpus N does with one handle and one host thread per device) */
+	std::string const mode = argc > 3 ? argv[3] : "";
 	FILE * f = fopen(argv[1], "rb");
 	if (!f) { perror(argv[1]); return 2; }
 	std::vector<Rec *> recs;
@@ -69,10 +75,63 @@ int main(int argc, char ** argv) {
 	for (size_t i = 0; i < recs.size(); ++i) if (recs[i]->ret >= 0 && recs[i]->cigar.size() > 16) { poisoned = i; break; }
 	if (poisoned < recs.size()) recs[poisoned]->align->maxBufferLength = 8;
 
+	std::vector<std::thread> th;
+	if (mode == "shared" || mode == "handles") {
+		if (poisoned < recs.size()) recs[poisoned]->align->maxBufferLength = (int) recs[poisoned]->qry.size() * 4;   /* (no poisoned request here) */
+		std::atomic<int> devicesSeen(0);
+		for (int w = 0; w < T; ++w) {
+			th.emplace_back([&, w]() {
+				if (mode == "shared") {
+					Convex::SharedAligner mine(0, 2.0f, -5.0f, -5.0f, -5.0f, -1.0f, 0.15f);
+					int const d = Convex::SharedAligner::ActiveDevices();
+					int seen = devicesSeen.load();
+					while (d > seen && !devicesSeen.compare_exchange_weak(seen, d)) { }
+					for (size_t i = (size_t) w; i < recs.size(); i += (size_t) T) {
+						Rec & r = *recs[i];
+						try {
+							r.got_ret = mine.SingleAlign(0, r.lines.data(), (int) r.lines.size(), r.ref.c_str(), r.qry.c_str(), *r.align, r.eqs, r.eqe, 0);
+						} catch (...) { r.threw = true; }
+					}
+				} else {
+					Convex::ConvexAlignHip mine(0, 2.0f, -5.0f, -5.0f, -5.0f, -1.0f, 0.15f);
+					std::vector<Convex::ConvexAlignHip::Tile> tiles;
+					std::vector<size_t> which;
+					for (size_t i = (size_t) w; i < recs.size(); i += (size_t) T) {
+						Rec & r = *recs[i];
+						Convex::ConvexAlignHip::Tile t;
+						t.corridor = r.lines.data(); t.corridorHeight = (int) r.lines.size(); t.refSeq = r.ref.c_str(); t.qrySeq = r.qry.c_str();
+						t.result = r.align; t.externalQStart = r.eqs; t.externalQEnd = r.eqe; t.ret = -1; t.failed = false; t.refLen = t.qryLen = 0;
+						tiles.push_back(t); which.push_back(i);
+					}
+					/* three launches per handle so that the handles' uploads, kernels and downloads interleave */
+					size_t const third = (tiles.size() + 2) / 3;
+					for (size_t b = 0; b < tiles.size(); b += third) {
+						size_t const e = b + third < tiles.size() ? b + third : tiles.size();
+						try {
+							mine.AlignTiles(tiles.data() + b, (int) (e - b));
+						} catch (...) { for (size_t i = b; i < e; ++i) recs[which[i]]->threw = true; }
+					}
+					for (size_t i = 0; i < tiles.size(); ++i) { recs[which[i]]->got_ret = tiles[i].ret; if (tiles[i].failed) recs[which[i]]->threw = true; }
+				}
+			});
+		}
+		for (auto & t : th) t.join();
+		int bad = 0;
+		for (size_t i = 0; i < recs.size(); ++i) {
+			Rec & r = *recs[i];
+			uint32_t sb; memcpy(&sb, &r.align->Score, 4);
+			bool ok = (r.ret < 0) ? (r.got_ret == -1) : (r.got_ret == r.ret && sb == r.score_bits && r.cigar == r.align->pBuffer1 && r.md == r.align->pBuffer2);
+			if (r.threw) ok = false;
+			if (!ok) { bad++; fprintf(stderr, "tile %zu differs (ret %d vs %d)\n", i, r.got_ret, r.ret); }
+		}
+		printf("batching_test %s: %zu requests from %d threads, %d logical devices in use, %d mismatches\n", mode.c_str(), recs.size(), T,
+				mode == "shared" ? devicesSeen.load() : T, bad);
+		return bad ? 1 : 0;
+	}
+
 	Convex::ConvexAlignHip backend(0, 2.0f, -5.0f, -5.0f, -5.0f, -1.0f, 0.15f);
 	Convex::BatchingAligner shared(&backend, T, 256, 5000);
 	IAlignment * aligner = &shared;
-	std::vector<std::thread> th;
 	for (int w = 0; w < T; ++w) {
 		th.emplace_back([&, w]() {
 			for (size_t i = (size_t) w; i < recs.size(); i += (size_t) T) {

@@ -84,10 +84,13 @@ int main() {
 	for (int i = 0; i < n; ++i) {
 		CHECK(tin[i].ref_off == so); so += tiles[i].ref_len;
 		CHECK(tin[i].qry_off == qo); qo += tiles[i].qry_len;
-		CHECK(tin[i].row_off == ro); ro += tiles[i].qry_len;
+		// only corridors that came as row arrays own a slice of the rows arena (closed forms are evaluated in registers)
+		if (tiles[i].corridor_kind == CVX_CORRIDOR_ROWS) { CHECK(tin[i].row_off == ro); ro += tiles[i].qry_len; }
+		else CHECK(tin[i].row_off == 0);
 		CHECK(tin[i].H == tiles[i].qry_len && tin[i].W == tiles[i].ref_len);
 	}
-	CHECK(qo == L.qry_base + L.qry_bytes && so == L.ref_base + L.ref_bytes && so + L.pad + 64 == L.seq_total && ro == L.n_rows);
+	CHECK(qo == L.qry_base + L.qry_bytes && so == L.ref_base + L.ref_bytes && so + L.pad + 64 == L.seq_total && ro == L.arena_rows);
+	CHECK(L.arena_rows == L.n_rows - n_closed_rows);
 	CHECK(!L.qry_contig && !L.ref_contig);                                           // every tile has its own std::string
 	CHECK(L.wprefix.size() == (size_t) n + 1 && L.wprefix[0] == 0);
 
@@ -155,6 +158,16 @@ int main() {
 		std::vector<cvx_tile> t3(tiles.begin(), tiles.begin() + 3);
 		t3[1].corridor_kind = CVX_CORRIDOR_AFFINE; t3[1].corridor_k = 0.0f; t3[1].corridor_width = 300;
 		CHECK(upload_layout(3, t3.data(), tin, L, &bad) == kLayoutMalformed && bad == 1);
+		// ... and forms whose (float -> int) row offset would leave the int32 range or is not finite: refused, never
+		// evaluated (undefined on the host, saturating on the device)
+		t3[1].corridor_k = 1.0f; t3[1].corridor_d = 0.0f; t3[1].corridor_right = 1.0f;
+		CHECK(upload_layout(3, t3.data(), tin, L, &bad) == kLayoutOk);
+		t3[1].corridor_right = 3.0e9f;
+		CHECK(upload_layout(3, t3.data(), tin, L, &bad) == kLayoutMalformed && bad == 1);
+		t3[1].corridor_right = 0.0f; t3[1].corridor_d = std::numeric_limits<float>::infinity();
+		CHECK(upload_layout(3, t3.data(), tin, L, &bad) == kLayoutMalformed && bad == 1);
+		t3[1].corridor_d = 0.0f; t3[1].corridor_k = 1.0e-9f;       // (H - d) / k beyond 2^31 for any real tile height
+		CHECK(upload_layout(3, t3.data(), tin, L, &bad) == (t3[1].qry_len >= 3 ? kLayoutMalformed : kLayoutOk));
 		std::string arena_q, arena_r;
 		for (int i = 0; i < 3; ++i) { arena_q += qrys[i]; arena_r += refs[i]; }
 		size_t aq = 0, ar = 0;

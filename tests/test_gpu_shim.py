@@ -65,3 +65,24 @@ def test_batching_aligner_many_threads(built, port_oracle, tmp_path):
     res = subprocess.run([exe, rec, "24"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr[-2000:]
     assert "0 mismatches" in res.stdout
+
+
+@pytest.mark.parametrize("mode,threads,env", [("shared", 24, {"CVX_ALIAS_DEVICES": "2"}), ("handles", 2, {}), ("handles", 4, {})])
+def test_two_devices_worth_of_handles_on_one_gpu(built, port_oracle, tmp_path, mode, threads, env):
+    """The N-device code paths on the one device a test box has: `shared` = ngmlr's form, every
+    worker thread constructs its own Convex::SharedAligner and CVX_ALIAS_DEVICES=2 deals them over two logical devices
+    (two backends + two dispatcher threads, both on device 0); `handles` = bench.py --gpus N's form, one
+    ConvexAlignHip handle per host thread, all launching concurrently.  Results identical to the serial oracle."""
+    import re
+    exe = os.path.join(ROOT, "ngmlr_amd", "batching_test")
+    assert os.path.exists(exe), "batching_test not built"
+    tiles = util.tile_zoo(seed=123, n=180, max_w=1800)
+    pairs = [(t, port_oracle.align(t)) for t in tiles]
+    rec = str(tmp_path / "tiles.bin")
+    write_records(rec, pairs)
+    res = subprocess.run([exe, rec, str(threads), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                         env=dict(os.environ, **env))
+    assert res.returncode == 0, res.stdout + res.stderr[-2000:]
+    assert "0 mismatches" in res.stdout
+    m = re.search(r"(\d+) logical devices in use", res.stdout)
+    assert m and int(m.group(1)) == (2 if mode == "shared" else threads), res.stdout

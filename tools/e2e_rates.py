@@ -36,17 +36,55 @@ def run(name, t, ref, fq, extra_env=None):
     open(ref_copy, "wb").write(open(ref, "rb").read())
     env = dict(os.environ)
     env.update(extra_env or {})
+    # stdout / stderr to files (a 500 MB SAM through a pipe would bill this script's reading to the run), and a sampler over
+    # /proc/<pid>/task: CPU seconds by thread name (cvx-dispatch, cvx-context, cvx-pack, ngm-cs; unnamed = ngmlr's own and the
+    # HIP runtime's), plus the cgroup's throttling counters -- a CPU quota stalls every thread of the process at once
+    out_path, err_path = os.path.join(tmp, "run.out"), os.path.join(tmp, "run.err")
+    cg0 = cgroup_cpu_stat()
     t0 = time.perf_counter()
-    res = subprocess.run([binary, "--skip-write", "-x", "pacbio", "-t", str(t), "-R", "0.01", "--no-progress", "-r", ref_copy, "-q", fq],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=3000, env=env)
+    with open(out_path, "wb") as fo, open(err_path, "wb") as fe:
+        proc = subprocess.Popen([binary, "--skip-write", "-x", "pacbio", "-t", str(t), "-R", "0.01", "--no-progress", "-r", ref_copy, "-q", fq],
+                                stdout=fo, stderr=fe, cwd=tmp, env=env)
+        ticks = {}
+        hz = os.sysconf("SC_CLK_TCK")
+        while proc.poll() is None:
+            try:
+                for tid in os.listdir("/proc/%d/task" % proc.pid):
+                    try:
+                        st = open("/proc/%d/task/%s/stat" % (proc.pid, tid)).read()
+                    except OSError:
+                        continue
+                    comm = st[st.index("(") + 1:st.rindex(")")]
+                    f = st[st.rindex(")") + 2:].split()
+                    ticks[tid] = (comm, int(f[11]) + int(f[12]))
+            except OSError:
+                pass
+            time.sleep(0.1)
     dt = time.perf_counter() - t0
+    cg1 = cgroup_cpu_stat()
+
+    class Res:
+        pass
+    res = Res()
+    res.returncode = proc.returncode
+    res.stdout = open(out_path, "r", errors="replace").read()
+    res.stderr = open(err_path, "r", errors="replace").read()
+    by = {}
+    for comm, tk in ticks.values():
+        c, n = by.get(comm, (0.0, 0))
+        by[comm] = (c + tk / hz, n + 1)
+    cpu_note = "cpu %.1f s sampled (" % sum(c for c, _ in by.values()) + ", ".join("%s x%d: %.1f" % (k, n, c) for k, (c, n) in sorted(by.items(), key=lambda kv: -kv[1][0])) + ")"
+    if cg0 and cg1:
+        cpu_note += "; cgroup: %.1f cpu-s, throttled %d times for %.1f s" % ((cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) * 1e-6,
+                                                                           cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                                                                           (cg1.get("throttled_usec", cg1.get("throttled_time", 0) * 1e-3) - cg0.get("throttled_usec", cg0.get("throttled_time", 0) * 1e-3)) * 1e-6)
     recs = sorted(l for l in res.stdout.splitlines() if l and not l.startswith("@"))
     m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", res.stderr)
     mp = re.search(r"Overall time for creating RefTable: ([0-9.]+)s", res.stderr)
     st = re.search(r"SharedAligner: \d+ workers over.*", res.stderr)
     sc = re.search(r"StrippedSWHip: \d+ scoring calls.*", res.stderr)
     po = re.search(r"AlignPool: \d+ reads on.*", res.stderr)
-    return {"wall": dt, "pool_stats": po.group(0) if po else None, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
+    return {"wall": dt, "cpu_note": cpu_note, "pool_stats": po.group(0) if po else None, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
             "map_s": dt - float(mp.group(1)) if mp else None, "err": res.stderr[-400:], "full_err": res.stderr}
 
 
@@ -55,6 +93,8 @@ def line(name, t, r, same):
     print("%-18s -t %-4d wall %7.2f s%s  rc %d  SAM %s%s" % (
         name, t, r["wall"], ("  map %6.2f s" % r["map_s"]) if r["map_s"] is not None else "", r["rc"], same,
         ("  %d alignments in %d launches (%.1f per launch)" % (l[0], l[1], l[0] / max(l[1], 1))) if l else ""), flush=True)
+    if r.get("cpu_note"):
+        print("    " + r["cpu_note"], flush=True)
     if r.get("stats"):
         print("    " + r["stats"], flush=True)
     if r.get("score_stats"):
@@ -65,6 +105,15 @@ def line(name, t, r, same):
         for l in r["full_err"].splitlines():
             if "library loaded" in l or "time" in l.lower() or "Done" in l:
                 print("      | " + l[:200], flush=True)
+
+
+def cgroup_cpu_stat():
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            return {k: int(v) for k, v in (l.split() for l in open(path))}
+        except Exception:
+            continue
+    return None
 
 
 def effective_cores():
