@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define CVX_ABI_VERSION 4
+#define CVX_ABI_VERSION 5
 
 /* return codes */
 enum {
@@ -313,7 +313,17 @@ int cvx_submit_windows(cvx_handle h, cvx_genome g, int32_t n_tiles, const cvx_ti
  *                      kept) -- in cands[cand_begin[i] .. + n_candidates[i]); n_candidates[i] = -1 where the reference gives up
  *                      ("too many candidates": every table size of the retry ladder 2^16 / 2^18 / 2^19 / 2^20 overflowed its
  *                      probe budget).  sensitivity = Config.getSensitivity() (0.8), min_kmer_hits = getMinKmerHits() (0),
- *                      bin_shift = getBinSize() (4).  CVX_ERR_CAPACITY with *cand_used = the need when cands is too small. */
+ *                      bin_shift = getBinSize() (4; 1..30).  CVX_ERR_CAPACITY with *cand_used = the need when cands is too small.
+ *   cvx_search_batch_ex  the same with what CS::RunRead leaves behind beside the list (ABI 5): first_bits = the vote-table size
+ *                      of the first attempt, CS::c_SrchTableBitLen (0 = 16, the value a CS thread starts with; the ladder is then
+ *                      first_bits + 2, + 3, ... up to 20 as at src/CS.cpp:363-394 -- the size only decides when an attempt
+ *                      runs out of its probe budget, a successful attempt returns the same list at every size);
+ *                      max_hit[i] = maxHitNumber of the successful attempt (MappedRead::s, src/CS.cpp:226; 0 when the read
+ *                      got no list); kmer_misses[i] = kCount, the k-mers of the read found in the table in neither
+ *                      orientation, summed over the attempts as the reference sums them (src/CS.cpp:67-69, :221-224: more
+ *                      than 0.9 (length - k + 1) of them zero the read's mapping quality).  Either may be NULL.  The handle
+ *                      keeps its staging and device buffers between calls (no allocation in the steady state) and the
+ *                      calling thread sleeps while the device works: one handle per searching thread. */
 typedef struct cvx_index_s *cvx_index;
 typedef struct {
 	uint64_t location;       /* LocationScore::Location.m_Location = ResolveBin(bin) */
@@ -326,6 +336,10 @@ void cvx_index_free(cvx_handle h, cvx_index ix);
 int cvx_search_batch(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
 		float sensitivity, float min_kmer_hits, int32_t bin_shift,
 		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used);
+int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
+		float sensitivity, float min_kmer_hits, int32_t bin_shift, int32_t first_bits,
+		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used,
+		float *max_hit, int32_t *kmer_misses);
 
 /* Sub-read scoring: what StrippedSW::BatchScore / SingleScore return
  * (reference src/StrippedSW.cpp:118-203 over ssw.c): refs/qrys are NUL-terminated strings,

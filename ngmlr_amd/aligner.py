@@ -335,9 +335,13 @@ class KmerIndex:
         loc = np.ascontiguousarray(locations, dtype=np.uint32)
         capi.check(aligner.lib.cvx_index_upload(aligner.h, kmer_len, idx.ctypes.data, loc.ctypes.data, len(loc), unit_offset, C.byref(self.ix)))
 
-    def search(self, reads: Sequence[bytes], sensitivity: float = 0.8, min_kmer_hits: float = 0.0, bin_shift: int = 4):
-        """-> list (one per read) of CANDIDATE_DTYPE arrays in the reference's list order; None where the reference gives up."""
+    def search(self, reads: Sequence[bytes], sensitivity: float = 0.8, min_kmer_hits: float = 0.0, bin_shift: int = 4,
+               first_bits: int = 0, extras: bool = False):
+        """-> list (one per read) of CANDIDATE_DTYPE arrays in the reference's list order; None where the reference gives up.
+        extras: also (max_hit float32[n], kmer_misses int32[n]) -- MappedRead::s and kCount of CS::RunRead."""
         n = len(reads)
+        max_hit = np.zeros(max(n, 1), dtype=np.float32)
+        misses = np.zeros(max(n, 1), dtype=np.int32)
         arr = (C.c_char_p * max(n, 1))(*reads)
         lens = np.array([len(r) for r in reads], dtype=np.int32)
         ncand = np.zeros(max(n, 1), dtype=np.int32)
@@ -346,14 +350,16 @@ class KmerIndex:
         cap = 1 << 16
         while True:
             cands = np.zeros(cap, dtype=CANDIDATE_DTYPE)
-            rc = self.al.lib.cvx_search_batch(self.al.h, self.ix, n, arr, lens.ctypes.data, sensitivity, min_kmer_hits, bin_shift,
-                                             ncand.ctypes.data, begin.ctypes.data, cands.ctypes.data, cap, C.byref(used))
+            rc = self.al.lib.cvx_search_batch_ex(self.al.h, self.ix, n, arr, lens.ctypes.data, sensitivity, min_kmer_hits, bin_shift, first_bits,
+                                                ncand.ctypes.data, begin.ctypes.data, cands.ctypes.data, cap, C.byref(used),
+                                                max_hit.ctypes.data, misses.ctypes.data)
             if rc == -6 and used.value > cap:
                 cap = int(used.value) + 64
                 continue
             capi.check(rc)
             break
-        return [None if ncand[i] < 0 else cands[int(begin[i]):int(begin[i]) + int(ncand[i])].copy() for i in range(n)]
+        lists = [None if ncand[i] < 0 else cands[int(begin[i]):int(begin[i]) + int(ncand[i])].copy() for i in range(n)]
+        return (lists, max_hit[:n], misses[:n]) if extras else lists
 
     def free(self) -> None:
         if self.ix:

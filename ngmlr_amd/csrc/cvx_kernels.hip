@@ -708,7 +708,7 @@ fill_ring_kernel(const FillArgs a) {
 	}
 
 	const int ngroups = (nsteps + 3) >> 2;
-	int late = ngroups >> 3;
+	int late = ngroups >> a.late_shift;
 	if (late < a.late_min_groups) late = a.late_min_groups;
 	const int gswitch = (EXACT || late >= ngroups) ? 0 : ngroups - late;   /* first exactly tracked group */
 	int r = r0;
@@ -1370,9 +1370,10 @@ backtrack_grp_kernel(const BacktrackArgs a, const int32_t *order, const int n_or
  * down by as much as the backtrack took -- both phases are bound by instruction issue,
  * DESIGN.md 5.) */
 __global__ void __launch_bounds__(64)
-backtrack_kernel(const BacktrackArgs a) {
-	const int t = blockIdx.x;
-	if (t >= a.n_tiles) return;
+backtrack_kernel(const BacktrackArgs a, const int32_t *order, const int n_order) {
+	/* block b walks tile order[b] (longest read first; a class's own tiles when a batch walks class by class), or tile b */
+	if ((int) blockIdx.x >= n_order) return;
+	const int t = order ? order[blockIdx.x] : (int) blockIdx.x;
 	walk_tile(a, t, threadIdx.x);
 }
 
@@ -1561,7 +1562,9 @@ hipError_t launch_backtrack(const BacktrackArgs &a, const int32_t *order, int n_
 		if (n_order <= 0) return hipSuccess;
 		hipLaunchKernelGGL(backtrack_grp_kernel<32>, dim3((n_order + 1) / 2), dim3(64), 0, st, a, order, n_order);   /* two tiles per wave */
 	} else {
-		hipLaunchKernelGGL(backtrack_kernel, dim3(a.n_tiles), dim3(64), 0, st, a);   /* one wave per tile */
+		const int nb = order != nullptr ? n_order : a.n_tiles;
+		if (nb <= 0) return hipSuccess;
+		hipLaunchKernelGGL(backtrack_kernel, dim3(nb), dim3(64), 0, st, a, order, nb);   /* one wave per tile */
 	}
 	return hipGetLastError();
 }

@@ -50,6 +50,7 @@ struct SearchArgs {
 	SearchCandidate *cand;
 	int32_t *n_cand;                 /* -1: the probe budget ran out at this table size */
 	float *max_hit;
+	int32_t *kmer_misses;            /* += k-mers found in neither orientation (kCount, CS.cpp:67-69); NULL: not wanted */
 	/* this attempt */
 	const int32_t *work;             /* read indices (NULL: all n) */
 	int32_t n_work;
@@ -62,6 +63,8 @@ struct SearchArgs {
 };
 hipError_t launch_search_count(const SearchArgs &a, hipStream_t st);
 hipError_t launch_search(const SearchArgs &a, hipStream_t st);
+hipError_t launch_search_compact(const SearchCandidate *sparse, const uint64_t *list_off, const int32_t *n_cand, const uint64_t *dst_begin,
+		SearchCandidate *dense, int n, hipStream_t st);
 
 /* reference windows from the 4-bit genome resident in HBM (cvx_genome.hip) */
 hipError_t launch_decode_windows(const uint8_t *bin, const uint64_t *starts, int n_starts,
@@ -86,8 +89,9 @@ hipError_t launch_expand_rows(const RowSrc *rsrc, const TileIn *tin, const uint8
 /* rows_per_tile: mean read rows per tile of the batch (picks 256 threads or one wave per tile) */
 hipError_t launch_plan(const RowDesc *rows, const RowSrc *rsrc, const TileIn *tin, TilePlan *plan, int n_tiles, uint64_t rows_per_tile,
 		unsigned long long max_matrix_mb, hipStream_t st);
-/* group: 16 = sixteen lanes per tile, four tiles per wave, tiles taken from order[0, n_order) (largest first);
- * anything else = one wave per tile over all a.n_tiles */
+/* group 8 / 16 / 32: that many lanes per tile, 64 / group tiles per wave (16 is reached through CVX_TUNE_BT_GROUP only);
+ * anything else: one wave per tile.  Tiles are taken from order[0, n_order) (longest read first); order == NULL (one wave
+ * per tile only): tile b for block b over all a.n_tiles */
 hipError_t launch_backtrack(const BacktrackArgs &a, const int32_t *order, int n_order, int group, hipStream_t st);
 hipError_t launch_finalize(const TileOut *tout, const TilePlan *plan, uint64_t *dst_off, ResultRec *res,
 		BatchSummary *sum, int32_t *counters, int n_tiles, uint64_t dense_cap, hipStream_t st);

@@ -222,7 +222,7 @@ struct cvx_batch_s {
 	hipEvent_t ev_res = nullptr;     /* result records on the host */
 	hipEvent_t ev_ops = nullptr;     /* dense ops on the host */
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   /* timing: plan begin/end, fills done, all done, fills may start */
-	std::vector<hipEvent_t> lev;     /* 3 events per fill class: start, two-phase pass done, exact pass done */
+	std::vector<hipEvent_t> lev;     /* 4 events per fill class: start, two-phase pass done, exact pass done, the class's own backtrack done */
 	std::vector<cvx_launch_info> launches;
 	cvx_timing timing;
 
@@ -267,6 +267,44 @@ struct cvx_batch_s {
 	}
 };
 
+/* Per-handle state of the candidate search: staging and device buffers live as long as the handle, so that the steady
+ * state of a caller that searches batch after batch (ngmlr's CS threads: a few hundred sub-reads per call) allocates
+ * nothing, copies through page-locked memory and sleeps on a blocking event while the device works. */
+struct cvx_search_state {
+	PinBuf h_seq, h_meta, h_out;       /* reads; offsets + lengths + list offsets + work list + dense begins; results coming back */
+	DevBuf<uint8_t> d_seq;
+	DevBuf<uint64_t> d_off, d_listoff, d_begin;
+	DevBuf<int32_t> d_len, d_ncand, d_work, d_miss;
+	DevBuf<unsigned long long> d_events;
+	DevBuf<float> d_maxhit, d_scores;
+	DevBuf<uint32_t> d_rlist;
+	DevBuf<SearchCandidate> d_cand, d_dense;
+	DevBuf<uint64_t> d_keys;
+	hipEvent_t done = nullptr;
+	void release() {
+		h_seq.release(); h_meta.release(); h_out.release();
+		d_seq.release(); d_off.release(); d_listoff.release(); d_begin.release(); d_len.release(); d_ncand.release(); d_work.release(); d_miss.release();
+		d_events.release(); d_maxhit.release(); d_scores.release(); d_rlist.release(); d_cand.release(); d_dense.release(); d_keys.release();
+		if (done) { (void) hipEventDestroy(done); done = nullptr; }
+	}
+};
+
+namespace {
+/* everything queued on `st` so far is done; the calling thread sleeps meanwhile (hipStreamSynchronize spins) */
+int search_wait(cvx_search_state *ss, hipStream_t st) {
+	if (!ss->done) HIP_TRY(hipEventCreateWithFlags(&ss->done, hipEventBlockingSync | hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(ss->done, st));
+	HIP_TRY(hipEventSynchronize(ss->done));
+	return CVX_OK;
+}
+}  // namespace
+
+void cvx_search_state_free(cvx_search_state *ss) {
+	if (!ss) return;
+	ss->release();
+	delete ss;
+}
+
 struct cvx_context {
 	int device = 0;
 	hipStream_t s_io = nullptr;      /* uploads, plan, downloads (high priority: its short kernels and copies
@@ -287,6 +325,7 @@ struct cvx_context {
 	int pack_threads = 16;
 	int tune_min_slots = 0;   /* tuning knob (env CVX_TUNE_MIN_M): smallest M*NW a tile may use */
 	int tune_late_min = kLateMinGroups;  /* test knob (env CVX_TUNE_LATE_MIN): groups of the exactly tracked tail (huge: exact everywhere) */
+	int tune_late_shift = kLateShift;    /* tuning knob (env CVX_TUNE_LATE_SHIFT): the exactly tracked tail is groups >> this (at least tune_late_min) */
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
 	int tune_long_steps = 0, tune_small_batch = 0;   /* tuning knobs (env CVX_TUNE_LONG_STEPS / CVX_TUNE_SMALL_BATCH): see PlanTuning */
 	bool single_lane = true;  /* experiment (env CVX_TUNE_TWO_LANES=1 clears it): small streaming jobs alternate between two stream sets.
@@ -317,6 +356,7 @@ struct cvx_context {
 	hipEvent_t sc_ev0 = nullptr, sc_ev1 = nullptr, sc_done = nullptr;
 	float sc_kernel_ms = 0.0f;
 	bool score_no_diag = false;   /* test knob (env CVX_TUNE_SCORE_NO_DIAG): always the row-by-row kernels */
+	struct cvx_search_state *search = nullptr;   /* candidate search (cvx_search_batch): persistent staging and device buffers */
 };
 
 struct cvx_genome_s {            /* an encoded reference genome resident in HBM (cvx_genome.hip) */
@@ -681,17 +721,33 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	n_listed += generic.size();
 	/* behind the fill lists: every computed tile once, longest read first (counting sort on H / 32) --
 	 * the order in which the backtrack takes them, four to a wave: the walk of a tile is a serial
-	 * chain of ~H / 7 probes, so the long ones must start first and share their wave with their like */
+	 * chain of ~H / 7 probes, so the long ones must start first and share their wave with their like.
+	 * One segment per fill launch, in launch order (chained classes, whole-tile classes from the widest ring down, the
+	 * catch-all kernel): a batch of several classes walks each class right behind its own fill, on that fill's stream,
+	 * while the other classes still fill; a batch of one class has one segment = the whole list. */
 	const size_t bt_begin = n_listed;
+	std::vector<const std::vector<int32_t> *> launch_tiles;
+	for (size_t c = 0; c < hp.chain_tasks.size(); ++c) if (!hp.chain_tasks[c].empty()) launch_tiles.push_back(&hp.chain_tiles[c]);
+	for (int cc = (int) cls.size() - 1; cc >= 0; --cc) if (!cls[(size_t) cc].empty()) launch_tiles.push_back(&cls[(size_t) cc]);
+	if (!generic.empty()) launch_tiles.push_back(&generic);
+	std::vector<std::pair<size_t, int>> bt_seg;      /* (offset in lists, tiles) per launch */
 	{
 		const TileIn *tin = b->tin();
 		constexpr int kBuckets = 4096;
-		std::vector<int32_t> count((size_t) kBuckets + 1, 0);
 		auto bucket = [&](int32_t ti) { const int k = tin[(size_t) ti].H >> 5; return kBuckets - 1 - (k < kBuckets ? k : kBuckets - 1); };
-		for (int i = 0; i < n; ++i) if (!hp.trun[(size_t) i].skip) count[(size_t) bucket(i) + 1]++;
-		for (int k = 0; k < kBuckets; ++k) count[(size_t) k + 1] += count[(size_t) k];
-		n_listed += (size_t) count[(size_t) kBuckets];
-		for (int i = 0; i < n; ++i) if (!hp.trun[(size_t) i].skip) lists[bt_begin + (size_t) count[(size_t) bucket(i)]++] = i;
+		std::vector<int32_t> count((size_t) kBuckets + 1);
+		for (const std::vector<int32_t> *v : launch_tiles) {
+			std::fill(count.begin(), count.end(), 0);
+			for (int32_t ti : *v) if (!hp.trun[(size_t) ti].skip) count[(size_t) bucket(ti) + 1]++;
+			for (int k = 0; k < kBuckets; ++k) count[(size_t) k + 1] += count[(size_t) k];
+			const size_t at = n_listed;
+			const int m = count[(size_t) kBuckets];
+			std::vector<int32_t> sorted_v(v->begin(), v->end());
+			std::sort(sorted_v.begin(), sorted_v.end());          /* tile order inside a bucket, as the single global pass had it */
+			for (int32_t ti : sorted_v) if (!hp.trun[(size_t) ti].skip) lists[at + (size_t) count[(size_t) bucket(ti)]++] = ti;
+			n_listed += (size_t) m;
+			bt_seg.emplace_back(at, m);
+		}
 	}
 	const int n_walk = (int) (n_listed - bt_begin);
 	if (!generic.empty()) {
@@ -757,6 +813,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		a.list_n = list_n;
 		a.redo_count = b->d_counters.p;
 		a.late_min_groups = h->tune_late_min;
+		a.late_shift = h->tune_late_shift;
 		a.tasks = nullptr; a.chain_ticket = nullptr; a.bnd = nullptr; a.chain_out = nullptr; a.bnd_epoch = 0; a.chain_prio = 0;
 		a.ops = b->d_regions.p;
 		a.sp = h->sp;
@@ -775,6 +832,53 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		}
 		b->launches.push_back(li);
 	};
+	/* backtrack, device-side result records + prefix sums, ops compaction */
+	BacktrackArgs ba;
+	ba.chain_blk = hp.n_chained ? reinterpret_cast<const ChainBlk *>(b->d_chain.p + chain_blk_off) : nullptr;
+	ba.seq = b->d_seq.p;
+	ba.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
+	ba.rsrc = b->d_rsrc.p;
+	ba.tin = b->d_tin.p;
+	ba.trun = b->d_trun.p;
+	ba.tout = b->d_tout.p;
+	ba.dirs = b->d_dirs.p;
+	ba.ops = b->d_regions.p;
+	ba.n_tiles = n;
+	/* the walk of lists[at, at + count) (longest read first) on `ws`.  Few tiles in the batch: the walk is latency-bound and
+	 * 64 probing lanes per tile take the long diagonal runs in a quarter of the probes; many tiles: it is issue-bound and
+	 * several tiles share a wave -- eight for the bulk; the few reads much longer than the rest (a latency-bound tail, a
+	 * serial chain of H / 7 probes each) get 32 lanes per tile, beside the bulk on `side` when `fork` (one walk for the whole
+	 * batch), in front of it on the same stream otherwise (measured: PacBio 5.4 -> 4.9 ms with 8 lanes, ONT mix 8.2 -> 6.6 with 32) */
+	auto walk_list = [&](size_t at, int count, hipStream_t ws, hipStream_t side, bool fork) -> int {
+		if (count <= 0) return CVX_OK;
+		if (n_walk < 4096) {
+			HIP_TRY(launch_backtrack(ba, b->d_lists.p + at, count, 64, ws));
+		} else if (h->bt_group != 0) {
+			HIP_TRY(launch_backtrack(ba, b->d_lists.p + at, count, h->bt_group, ws));
+		} else {
+			const TileIn *tin = b->tin();
+			const uint64_t mean_h = b->n_rows / (uint64_t) std::max(n, 1);
+			int n_long = 0;
+			while (n_long < count && (uint64_t) tin[(size_t) lists[at + (size_t) n_long]].H > 3 * mean_h) n_long++;
+			if (n_long > 0 && fork) {
+				HIP_TRY(hipEventRecord(b->ev_bt0, ws));
+				HIP_TRY(hipStreamWaitEvent(side, b->ev_bt0, 0));
+				HIP_TRY(launch_backtrack(ba, b->d_lists.p + at, n_long, 32, side));
+				HIP_TRY(hipEventRecord(b->ev_bt1, side));
+			} else if (n_long > 0) {
+				HIP_TRY(launch_backtrack(ba, b->d_lists.p + at, n_long, 32, ws));
+			}
+			HIP_TRY(launch_backtrack(ba, b->d_lists.p + at + n_long, count - n_long, 8, ws));
+			if (n_long > 0 && fork) HIP_TRY(hipStreamWaitEvent(ws, b->ev_bt1, 0));
+		}
+		return CVX_OK;
+	};
+	/* Several fill classes (ONT mix: chained retries, M = 4, M = 3; C5): each class is walked right behind its own fill on
+	 * that fill's stream.  The launch of such a batch lasts as long as its longest dependency chain, and while the last
+	 * chains finish on a few waves the device has issue slots to spare: the other classes' walks run there instead of
+	 * behind everything (CVX_TUNE_BT_PER_CLASS=0: one walk behind all fills, as a batch of one class has it anyway). */
+	static const bool bt_per_class_env = !(getenv("CVX_TUNE_BT_PER_CLASS") && atoi(getenv("CVX_TUNE_BT_PER_CLASS")) == 0);
+	const bool per_class = bt_per_class_env && launch_tiles.size() > 1 && !h->overlap_post;
 	int launches = 0;
 	/* fill launches go round-robin over the two aux streams and the main stream itself (which has
 	 * nothing else to do until they are all done): three classes side by side */
@@ -785,13 +889,20 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	if (!h->overlap_post) fill_streams[n_fill_streams++] = S_post;
 	fill_streams[n_fill_streams++] = st;
 	auto begin_launch = [&](hipStream_t ls) -> int {
-		while (b->lev.size() < (size_t) (launches + 1) * 3) {
+		while (b->lev.size() < (size_t) (launches + 1) * 4) {
 			hipEvent_t e;
 			HIP_TRY(hipEventCreate(&e));
 			b->lev.push_back(e);
 		}
 		HIP_TRY(hipStreamWaitEvent(ls, b->ev[4], 0));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3], ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4], ls));
+		return CVX_OK;
+	};
+	/* closes launch number `launches` on its stream: the class's own walk (per_class), then the event everything after waits for */
+	auto end_launch = [&](hipStream_t ls) -> int {
+		if (per_class) RC_TRY(walk_list(bt_seg[(size_t) launches].first, bt_seg[(size_t) launches].second, ls, ls, false));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 3], ls));
+		launches++;
 		return CVX_OK;
 	};
 	/* chained tiles first (their dependency chains are the longest thing in a batch): the row-block
@@ -821,9 +932,9 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		HIP_TRY(launch_fill(m, (c & 1) != 0, 2, a, pad_lds, ls));
 		HIP_TRY(launch_chain_reduce(reinterpret_cast<const int32_t *>(b->d_chain.p + chain_tile_off[c]), (int) hp.chain_tiles[c].size(),
 				b->d_trun.p, b->d_chain_out.p, b->d_tout.p, ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
-		launches++;
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 1], ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 2], ls));
+		RC_TRY(end_launch(ls));
 	}
 	for (int cc = (int) cls.size() - 1; cc >= 0; --cc) {
 		const size_t c = (size_t) cc;
@@ -839,11 +950,11 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		}
 		const FillArgs a = fill_args(b->d_lists.p + seg_begin[c] + n_direct[c], (int) cls[c].size() - n_direct[c]);
 		if (a.list_n > 0) HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 0, a, 0, ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 1], ls));
 		/* exact-tracking pass over the tiles the two-phase pass flagged (usually none) */
 		if (a.list_n > 0) HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 1, a, 0, ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
-		launches++;
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 2], ls));
+		RC_TRY(end_launch(ls));
 	}
 	if (!generic.empty()) {
 		launch_stats(generic, 0, 16, 1);
@@ -851,9 +962,9 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		RC_TRY(begin_launch(ls));
 		const FillArgs a = fill_args(b->d_lists.p + generic_begin, (int) generic.size());
 		HIP_TRY(launch_fill_generic(a, h->sse_variant, b->d_gscratch.p, b->d_gscratch_off.p, ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 1], ls));
-		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 3 + 2], ls));
-		launches++;
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 1], ls));
+		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 2], ls));
+		RC_TRY(end_launch(ls));
 	}
 	/* Everything after the fills CAN run on its own stream, so that `main` goes straight on to the next
 	 * batch's fills while this batch's backtrack (one wave per tile) and small kernels run beside them. */
@@ -864,45 +975,11 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	 * turns it on. */
 	st = h->overlap_post ? S_post : S_main;
 	HIP_TRY(hipStreamWaitEvent(st, b->ev[4], 0));  /* also orders `post` behind the input copies when no fill was launched */
-	for (int i = 0; i < launches; ++i) HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) i * 3 + 2], 0));
+	for (int i = 0; i < launches; ++i) HIP_TRY(hipStreamWaitEvent(st, b->lev[(size_t) i * 4 + 3], 0));
 	HIP_TRY(hipEventRecord(b->ev[2], st));
 
-	/* backtrack, device-side result records + prefix sums, ops compaction */
-	BacktrackArgs ba;
-	ba.chain_blk = hp.n_chained ? reinterpret_cast<const ChainBlk *>(b->d_chain.p + chain_blk_off) : nullptr;
-	ba.seq = b->d_seq.p;
-	ba.rows = reinterpret_cast<const RowDesc2 *>(b->d_rows.p);
-	ba.rsrc = b->d_rsrc.p;
-	ba.tin = b->d_tin.p;
-	ba.trun = b->d_trun.p;
-	ba.tout = b->d_tout.p;
-	ba.dirs = b->d_dirs.p;
-	ba.ops = b->d_regions.p;
-	ba.n_tiles = n;
-	/* few tiles: the walk is latency-bound and 64 probing lanes per tile take the long diagonal runs in
-	 * a quarter of the probes; many tiles: it is issue-bound and four tiles share a wave */
-	if (n_walk < 4096) {
-		HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin, n_walk, 64, st));
-	} else if (h->bt_group != 0) {
-		HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin, n_walk, h->bt_group, st));
-	} else {
-		/* auto: the bulk of a batch is issue-bound and walks fastest eight tiles to a wave; the few
-		 * reads much longer than the rest (the list is sorted by length) are a latency-bound tail
-		 * -- a serial chain of H / 7 probes each -- and get 32 lanes per tile, on a second stream
-		 * beside the bulk (measured: PacBio 5.4 -> 4.9 ms with 8 lanes, ONT mix 8.2 -> 6.6 with 32) */
-		const TileIn *tin = b->tin();
-		const uint64_t mean_h = b->n_rows / (uint64_t) std::max(n, 1);
-		int n_long = 0;
-		while (n_long < n_walk && (uint64_t) tin[(size_t) lists[bt_begin + (size_t) n_long]].H > 3 * mean_h) n_long++;
-		if (n_long > 0) {
-			hipStream_t ls = S_aux[0];
-			HIP_TRY(hipEventRecord(b->ev_bt0, st));
-			HIP_TRY(hipStreamWaitEvent(ls, b->ev_bt0, 0));
-			HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin, n_long, 32, ls));
-			HIP_TRY(hipEventRecord(b->ev_bt1, ls));
-		}
-		HIP_TRY(launch_backtrack(ba, b->d_lists.p + bt_begin + n_long, n_walk - n_long, 8, st));
-		if (n_long > 0) HIP_TRY(hipStreamWaitEvent(st, b->ev_bt1, 0));
+	if (!per_class) {
+		RC_TRY(walk_list(bt_begin, n_walk, st, S_aux[0], true));
 	}
 	ResultRec *d_rec = reinterpret_cast<ResultRec *>(b->d_res.p);
 	BatchSummary *d_sum = reinterpret_cast<BatchSummary *>(b->d_res.p + (size_t) n * sizeof(ResultRec));
@@ -931,7 +1008,7 @@ int stage_results(cvx_context *h, cvx_batch_s *b) {
 	const BatchSummary *s = b->summary();
 	b->ops_total = s->ops_total;
 	const int launches = b->timing.n_fill_launches;
-	for (int i = 0; i < launches; ++i) b->launches[(size_t) i].ms = ev_ms(b->lev[(size_t) i * 3], b->lev[(size_t) i * 3 + 1]);
+	for (int i = 0; i < launches; ++i) b->launches[(size_t) i].ms = ev_ms(b->lev[(size_t) i * 4], b->lev[(size_t) i * 4 + 1]);
 	b->timing.plan_ms = ev_ms(b->ev[0], b->ev[1]);
 	b->timing.fill_ms = ev_ms(b->ev[4], b->ev[2]);
 	b->timing.backtrack_ms = ev_ms(b->ev[2], b->ev[3]);
@@ -1086,6 +1163,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_LONG_STEPS")) c->tune_long_steps = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_SMALL_BATCH")) c->tune_small_batch = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
+	if (const char *e = getenv("CVX_TUNE_LATE_SHIFT")) c->tune_late_shift = std::min(16, std::max(0, atoi(e)));
 	int prio_lo = 0, prio_hi = 0;
 	(void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     /* numerically lower = higher priority */
 	hipError_t e = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
@@ -1130,6 +1208,7 @@ void cvx_destroy(cvx_handle h) {
 	if (h->sc_ev0) (void) hipEventDestroy(h->sc_ev0);
 	if (h->sc_done) (void) hipEventDestroy(h->sc_done);
 	if (h->sc_ev1) (void) hipEventDestroy(h->sc_ev1);
+	cvx_search_state_free(h->search);
 	delete h;
 }
 
@@ -1756,122 +1835,142 @@ void cvx_index_free(cvx_handle h, cvx_index ix) {
 	delete ix;
 }
 
-int cvx_search_batch(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
-		float sensitivity, float min_hits, int32_t bin_shift,
-		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used) {
+int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
+		float sensitivity, float min_hits, int32_t bin_shift, int32_t first_bits,
+		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used,
+		float *max_hit, int32_t *kmer_misses) {
 	ABI_GUARD_BEGIN
 	static_assert(sizeof(SearchCandidate) == sizeof(cvx_candidate), "SearchCandidate mirrors cvx_candidate");
-	if (!h || !ix || n < 0 || (n > 0 && (!seqs || !lens || !n_candidates || !cand_begin)) || bin_shift < 0 || bin_shift > 30) {
-		set_err("cvx_search_batch: bad argument"); return CVX_ERR_ARG;
+	/* bin_shift >= 1: the "bin is listed" flag lives in bit 63 of the vote table's key, and with a shift of 0 a vote near the
+	 * start of the genome (location - offset in the read < 0) would set that bit itself; ngmlr's bin size is 4 */
+	if (!h || !ix || n < 0 || (n > 0 && (!seqs || !lens || !n_candidates || !cand_begin)) || bin_shift < 1 || bin_shift > 30 ||
+			(first_bits != 0 && (first_bits < 8 || first_bits > 20))) {
+		set_err("cvx_search_batch: bad argument (bin_shift 1..30, first_bits 0 or 8..20)"); return CVX_ERR_ARG;
 	}
 	if (ix->device != h->device) { set_err("cvx_search_batch: the index lives on device %d, the handle on %d", ix->device, h->device); return CVX_ERR_ARG; }
 	if (cand_used) *cand_used = 0;
 	if (n == 0) return CVX_OK;
 	HIP_TRY(hipSetDevice(h->device));
+	if (!h->search) { h->search = new (std::nothrow) cvx_search_state(); if (!h->search) return CVX_ERR_OOM; }
+	cvx_search_state *ss = h->search;
 	hipStream_t st = h->s_main;
-	/* the reads, a NUL behind each (the N-run scan of PrefixIteration relies on the terminator) */
-	std::vector<uint64_t> off((size_t) n);
+	/* the reads, a NUL behind each (the N-run scan of PrefixIteration relies on the terminator), in page-locked staging */
 	uint64_t bytes = 0;
 	for (int i = 0; i < n; ++i) {
 		if (!seqs[i] || lens[i] < 0) { set_err("cvx_search_batch: bad read %d", i); return CVX_ERR_ARG; }
-		off[(size_t) i] = bytes;
 		bytes += (uint64_t) lens[i] + 1;
 	}
-	std::vector<uint8_t> hseq((size_t) bytes + 64, 0);
-	for (int i = 0; i < n; ++i) memcpy(hseq.data() + off[(size_t) i], seqs[i], (size_t) lens[i]);
-	DevBuf<uint8_t> d_seq;
-	DevBuf<uint64_t> d_off, d_listoff;
-	DevBuf<int32_t> d_len, d_ncand, d_work;
-	DevBuf<unsigned long long> d_events;
-	DevBuf<float> d_maxhit, d_scores;
-	DevBuf<uint32_t> d_rlist;
-	DevBuf<SearchCandidate> d_cand;
-	DevBuf<uint64_t> d_keys;
-	auto release_all = [&]() {
-		d_seq.release(); d_off.release(); d_listoff.release(); d_len.release(); d_ncand.release(); d_work.release(); d_events.release();
-		d_maxhit.release(); d_scores.release(); d_rlist.release(); d_cand.release(); d_keys.release();
-	};
-	int rc = d_seq.ensure(hseq.size());
-	if (rc == CVX_OK) rc = d_off.ensure((size_t) n);
-	if (rc == CVX_OK) rc = d_listoff.ensure((size_t) n);
-	if (rc == CVX_OK) rc = d_len.ensure((size_t) n);
-	if (rc == CVX_OK) rc = d_ncand.ensure((size_t) n);
-	if (rc == CVX_OK) rc = d_work.ensure((size_t) n);
-	if (rc == CVX_OK) rc = d_events.ensure((size_t) n);
-	if (rc == CVX_OK) rc = d_maxhit.ensure((size_t) n);
-	if (rc != CVX_OK) { release_all(); return rc; }
+	const size_t n1 = (size_t) n;
+	RC_TRY(ss->h_seq.ensure((size_t) bytes + 64));
+	/* meta: [off u64 n][list_off u64 n][begin u64 n][len i32 n][work i32 n] */
+	RC_TRY(ss->h_meta.ensure(n1 * (8 + 8 + 8 + 4 + 4) + 64));
+	/* out: [events u64 n][ncand i32 n][miss i32 n][maxhit f32 n] (the dense candidates get their own buffer below) */
+	RC_TRY(ss->h_out.ensure(n1 * (8 + 4 + 4 + 4) + 64));
+	uint8_t *hseq = ss->h_seq.as<uint8_t>();
+	uint64_t *h_off = ss->h_meta.as<uint64_t>(), *h_listoff = h_off + n1, *h_begin = h_listoff + n1;
+	int32_t *h_len = reinterpret_cast<int32_t *>(h_begin + n1), *h_work = h_len + n1;
+	unsigned long long *h_events = ss->h_out.as<unsigned long long>();
+	int32_t *h_ncand = reinterpret_cast<int32_t *>(h_events + n1), *h_miss = h_ncand + n1;
+	float *h_maxhit = reinterpret_cast<float *>(h_miss + n1);
+	{
+		uint64_t at = 0;
+		for (int i = 0; i < n; ++i) {
+			h_off[i] = at;
+			memcpy(hseq + at, seqs[i], (size_t) lens[i]);
+			hseq[at + (uint64_t) lens[i]] = 0;
+			at += (uint64_t) lens[i] + 1;
+			h_len[i] = lens[i];
+		}
+		memset(hseq + at, 0, 64);
+	}
+	RC_TRY(ss->d_seq.ensure((size_t) bytes + 64));
+	RC_TRY(ss->d_off.ensure(n1)); RC_TRY(ss->d_listoff.ensure(n1)); RC_TRY(ss->d_begin.ensure(n1));
+	RC_TRY(ss->d_len.ensure(n1)); RC_TRY(ss->d_ncand.ensure(n1)); RC_TRY(ss->d_work.ensure(n1)); RC_TRY(ss->d_miss.ensure(n1));
+	RC_TRY(ss->d_events.ensure(n1)); RC_TRY(ss->d_maxhit.ensure(n1));
 	SearchArgs a;
 	memset(&a, 0, sizeof(a));
 	a.tab = ix->d_tab.p; a.used = ix->d_used.p; a.locs = ix->d_locs.p; a.unit_offset = ix->unit_offset; a.k = ix->k;
-	a.seq = d_seq.p; a.seq_off = d_off.p; a.seq_len = d_len.p; a.n = n;
-	a.events = d_events.p; a.list_off = d_listoff.p; a.n_cand = d_ncand.p; a.max_hit = d_maxhit.p;
+	a.seq = ss->d_seq.p; a.seq_off = ss->d_off.p; a.seq_len = ss->d_len.p; a.n = n;
+	a.events = ss->d_events.p; a.list_off = ss->d_listoff.p; a.n_cand = ss->d_ncand.p; a.max_hit = ss->d_maxhit.p; a.kmer_misses = ss->d_miss.p;
 	a.sensitivity = sensitivity; a.min_hits = min_hits; a.bin_shift = bin_shift;
-	std::vector<unsigned long long> events((size_t) n);
-	std::vector<uint64_t> list_off((size_t) n);
-	std::vector<int32_t> ncand((size_t) n);
-	hipError_t e = hipMemcpyAsync(d_seq.p, hseq.data(), hseq.size(), hipMemcpyHostToDevice, st);
-	if (e == hipSuccess) e = hipMemcpyAsync(d_off.p, off.data(), (size_t) n * 8, hipMemcpyHostToDevice, st);
-	if (e == hipSuccess) e = hipMemcpyAsync(d_len.p, lens, (size_t) n * 4, hipMemcpyHostToDevice, st);
-	if (e == hipSuccess) e = launch_search_count(a, st);
-	if (e == hipSuccess) e = hipMemcpyAsync(events.data(), d_events.p, (size_t) n * 8, hipMemcpyDeviceToHost, st);
-	if (e == hipSuccess) e = hipStreamSynchronize(st);
-	if (e != hipSuccess) { set_err("cvx_search_batch: %s", hipGetErrorString(e)); release_all(); return CVX_ERR_HIP; }
+	HIP_TRY(hipMemcpyAsync(ss->d_seq.p, hseq, (size_t) ((bytes + 63) / 4 * 4), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(ss->d_off.p, h_off, n1 * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(ss->d_len.p, h_len, n1 * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync(ss->d_miss.p, 0, n1 * 4, st));
+	HIP_TRY(hipMemsetAsync(ss->d_maxhit.p, 0, n1 * 4, st));
+	HIP_TRY(launch_search_count(a, st));
+	HIP_TRY(hipMemcpyAsync(h_events, ss->d_events.p, n1 * 8, hipMemcpyDeviceToHost, st));
+	RC_TRY(search_wait(ss, st));
 	uint64_t total = 0;
-	for (int i = 0; i < n; ++i) { list_off[(size_t) i] = total; total += events[(size_t) i]; }
-	rc = d_rlist.ensure((size_t) total + 64);
-	if (rc == CVX_OK) rc = d_cand.ensure((size_t) (2 * total) + 64);
-	if (rc != CVX_OK) { release_all(); return rc; }
-	a.rlist = d_rlist.p; a.cand = d_cand.p;
-	e = hipMemcpyAsync(d_listoff.p, list_off.data(), (size_t) n * 8, hipMemcpyHostToDevice, st);
-	/* the reference's retry ladder (CS.cpp:345-394): 2^16 entries with a probe budget of a third of the table, then
-	 * 2^18 / 2^19 / 2^20 with 0.777; reads in flight per launch bounded by the memory their vote tables take */
-	static const int kBits[4] = {16, 18, 19, 20};
+	for (int i = 0; i < n; ++i) { h_listoff[i] = total; total += h_events[i]; }
+	RC_TRY(ss->d_rlist.ensure((size_t) total + 64));
+	RC_TRY(ss->d_cand.ensure((size_t) (2 * total) + 64));
+	a.rlist = ss->d_rlist.p; a.cand = ss->d_cand.p;
+	HIP_TRY(hipMemcpyAsync(ss->d_listoff.p, h_listoff, n1 * 8, hipMemcpyHostToDevice, st));
+	/* the reference's retry ladder (CS.cpp:345-394): the current table size with a probe budget of a third of the table, then
+	 * that + 2, + 3, ... up to 2^20 entries with 0.777; first_bits = CS::c_SrchTableBitLen (16 when the thread starts; the
+	 * reference adapts it per batch, CS.cpp:482-489 -- the size only decides WHEN an attempt runs out of budget, a successful
+	 * attempt returns the same list at every size).  Reads in flight per launch bounded by the memory their vote tables take. */
+	const int bits0 = first_bits ? first_bits : 16;
 	std::vector<int32_t> work((size_t) n);
 	for (int i = 0; i < n; ++i) work[(size_t) i] = i;
-	for (int attempt = 0; attempt < 4 && !work.empty() && e == hipSuccess; ++attempt) {
-		const int bits = kBits[attempt];
+	for (int attempt = 0; !work.empty(); ++attempt) {
+		const int bits = attempt == 0 ? bits0 : bits0 + 1 + attempt;
+		if (bits > 20) break;
 		const size_t per_read = (size_t) 1 << bits;
 		const size_t chunk = std::max<size_t>(64, std::min<size_t>(work.size(), ((size_t) 8 << 30) / (per_read * 16)));     /* <= 8 GB of tables */
-		rc = d_keys.ensure(chunk * per_read);
-		if (rc == CVX_OK) rc = d_scores.ensure(chunk * per_read * 2);
-		if (rc != CVX_OK) { release_all(); return rc; }
+		RC_TRY(ss->d_keys.ensure(chunk * per_read));
+		RC_TRY(ss->d_scores.ensure(chunk * per_read * 2));
 		a.bits = bits;
 		a.hpoc_factor = attempt == 0 ? 0.333f : 0.777f;
-		a.keys = d_keys.p; a.scores = d_scores.p; a.work = d_work.p;
-		for (size_t w0 = 0; w0 < work.size() && e == hipSuccess; w0 += chunk) {
+		a.keys = ss->d_keys.p; a.scores = ss->d_scores.p; a.work = ss->d_work.p;
+		for (size_t w0 = 0; w0 < work.size(); w0 += chunk) {
 			const size_t m = std::min(chunk, work.size() - w0);
-			e = hipMemcpyAsync(d_work.p, work.data() + w0, m * 4, hipMemcpyHostToDevice, st);
-			if (e == hipSuccess) e = hipMemsetAsync(d_keys.p, 0xFF, m * per_read * 8, st);          /* every slot empty */
+			memcpy(h_work, work.data() + w0, m * 4);
+			HIP_TRY(hipMemcpyAsync(ss->d_work.p, h_work, m * 4, hipMemcpyHostToDevice, st));
+			HIP_TRY(hipMemsetAsync(ss->d_keys.p, 0xFF, m * per_read * 8, st));          /* every slot empty */
 			a.n_work = (int32_t) m;
-			if (e == hipSuccess) e = launch_search(a, st);
-			if (e == hipSuccess) e = hipStreamSynchronize(st);      /* (the work list is reused by the next chunk) */
+			HIP_TRY(launch_search(a, st));
+			if (w0 + chunk < work.size()) RC_TRY(search_wait(ss, st));      /* (the work list is reused by the next chunk) */
 		}
-		if (e == hipSuccess) e = hipMemcpy(ncand.data(), d_ncand.p, (size_t) n * 4, hipMemcpyDeviceToHost);
+		HIP_TRY(hipMemcpyAsync(h_ncand, ss->d_ncand.p, n1 * 4, hipMemcpyDeviceToHost, st));
+		RC_TRY(search_wait(ss, st));
 		std::vector<int32_t> again;
-		for (int32_t i : work) if (ncand[(size_t) i] < 0) again.push_back(i);
+		for (int32_t i : work) if (h_ncand[i] < 0) again.push_back(i);
 		work.swap(again);
 	}
-	if (e != hipSuccess) { set_err("cvx_search_batch: %s", hipGetErrorString(e)); release_all(); return CVX_ERR_HIP; }
-	/* dense candidate list in read order */
+	/* dense candidate list in read order, compacted on the device: only the entries come back (the sparse arena is
+	 * two slots per vote) */
 	uint64_t need = 0;
-	for (int i = 0; i < n; ++i) { cand_begin[i] = need; n_candidates[i] = ncand[(size_t) i]; if (ncand[(size_t) i] > 0) need += (uint64_t) ncand[(size_t) i]; }
+	for (int i = 0; i < n; ++i) { h_begin[i] = need; cand_begin[i] = need; n_candidates[i] = h_ncand[i]; if (h_ncand[i] > 0) need += (uint64_t) h_ncand[i]; }
 	if (cand_used) *cand_used = need;
+	if (max_hit || kmer_misses) {
+		HIP_TRY(hipMemcpyAsync(h_maxhit, ss->d_maxhit.p, n1 * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(h_miss, ss->d_miss.p, n1 * 4, hipMemcpyDeviceToHost, st));
+	}
 	if (need > cand_capacity || (need > 0 && !cands)) {
+		if (max_hit || kmer_misses) RC_TRY(search_wait(ss, st));
 		set_err("cvx_search_batch: candidate arena too small (%llu needed, %llu given)", (unsigned long long) need, (unsigned long long) cand_capacity);
-		release_all();
 		return CVX_ERR_CAPACITY;
 	}
 	if (need) {
-		std::vector<SearchCandidate> all((size_t) (2 * total));
-		e = hipMemcpy(all.data(), d_cand.p, all.size() * sizeof(SearchCandidate), hipMemcpyDeviceToHost);
-		if (e != hipSuccess) { set_err("cvx_search_batch: %s", hipGetErrorString(e)); release_all(); return CVX_ERR_HIP; }
-		for (int i = 0; i < n; ++i)
-			if (ncand[(size_t) i] > 0)
-				memcpy(cands + cand_begin[i], all.data() + 2 * list_off[(size_t) i], (size_t) ncand[(size_t) i] * sizeof(cvx_candidate));
+		RC_TRY(ss->d_dense.ensure((size_t) need + 64));
+		HIP_TRY(hipMemcpyAsync(ss->d_begin.p, h_begin, n1 * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(launch_search_compact(ss->d_cand.p, ss->d_listoff.p, ss->d_ncand.p, ss->d_begin.p, ss->d_dense.p, n, st));
+		/* (straight into the caller's memory: pageable unless it came from cvx_host_alloc, then the copy is staged by the runtime) */
+		HIP_TRY(hipMemcpyAsync(cands, ss->d_dense.p, (size_t) need * sizeof(SearchCandidate), hipMemcpyDeviceToHost, st));
 	}
-	release_all();
+	RC_TRY(search_wait(ss, st));
+	if (max_hit) memcpy(max_hit, h_maxhit, n1 * 4);
+	if (kmer_misses) memcpy(kmer_misses, h_miss, n1 * 4);
 	return CVX_OK;
 	ABI_GUARD_END
+}
+
+int cvx_search_batch(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
+		float sensitivity, float min_hits, int32_t bin_shift,
+		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used) {
+	return cvx_search_batch_ex(h, ix, n, seqs, lens, sensitivity, min_hits, bin_shift, 0, n_candidates, cand_begin, cands, cand_capacity, cand_used, nullptr, nullptr);
 }
 
 /* ------------------------------------------------------------------ sub-read scoring */

@@ -99,6 +99,7 @@ search_kernel(const SearchArgs a) {
 	int rlen = 0;
 	bool overflow = false;
 	unsigned long long offset = 0;
+	int misses = 0;        /* k-mers neither whose row nor whose reverse complement's row is in the table: kCount, CS.cpp:67-69 */
 
 	auto add = [&](const uint64_t bin, const bool reverse) {           /* CS.cpp:101-149 */
 		uint32_t e = (uint32_t) ((bin * 11400714819323199488ull) >> (64 - bits));
@@ -149,9 +150,12 @@ search_kernel(const SearchArgs a) {
 			prefix = ((prefix << 2) | (uint64_t) ((ch >> 1) & 3)) & mask;
 			const unsigned long long pos = offset + (unsigned long long) p + 1ull - (unsigned long long) K;
 			/* CS.cpp:57-99 over GetRefEntry (PrefixTable.cpp:476-532): forward row, then the reverse complement's row */
+			const uint64_t rcp = rev_comp13(prefix, K);
+			const bool use_f = a.used[prefix] != 0, use_r = a.used[rcp] != 0;
+			if (!use_f && !use_r) misses += 1;       /* entries[0].refTotal == 0 (PrefixTable.cpp:489-525), counted before the votes */
 			for (int rev = 0; rev < 2 && !overflow; ++rev) {
-				const uint64_t pr = rev ? rev_comp13(prefix, K) : prefix;
-				if (!a.used[pr]) continue;
+				const uint64_t pr = rev ? rcp : prefix;
+				if (!(rev ? use_r : use_f)) continue;
 				const uint32_t start = a.tab[pr] - 1u, nloc = a.tab[pr + 1] - 1u - start;
 				const unsigned long long corr = rev ? (unsigned long long) read_len - (pos + (unsigned long long) K) : pos;
 				for (uint32_t j = 0; j < nloc && !overflow; ++j) {
@@ -163,6 +167,8 @@ search_kernel(const SearchArgs a) {
 		if (!restart) break;
 	}
 
+	/* kCount is reset per read, not per attempt (CS.cpp:338): the k-mers an overflowed attempt visited stay counted */
+	if (a.kmer_misses) a.kmer_misses[i] += misses;
 	if (overflow) { a.n_cand[i] = -1; return; }
 	/* CollectResultsStd, CS.cpp:219-268 */
 	const float thr = a.min_hits > thresh ? a.min_hits : thresh;
@@ -178,6 +184,25 @@ search_kernel(const SearchArgs a) {
 	}
 	a.n_cand[i] = n;
 	a.max_hit[i] = max_hit;
+}
+
+/* dense[dst_begin[i] ...) = the n_cand[i] candidates of read i (its region of the sparse arena starts at 2 * list_off[i]) */
+__global__ void __launch_bounds__(64)
+search_compact_kernel(const SearchCandidate *sparse, const uint64_t *list_off, const int32_t *n_cand, const uint64_t *dst_begin,
+		SearchCandidate *dense, int n) {
+	const int i = blockIdx.x;
+	if (i >= n) return;
+	const int m = n_cand[i];
+	const SearchCandidate *src = sparse + 2ull * list_off[i];
+	SearchCandidate *dst = dense + dst_begin[i];
+	for (int q = threadIdx.x; q < m; q += 64) dst[q] = src[q];
+}
+
+hipError_t launch_search_compact(const SearchCandidate *sparse, const uint64_t *list_off, const int32_t *n_cand, const uint64_t *dst_begin,
+		SearchCandidate *dense, int n, hipStream_t st) {
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(search_compact_kernel, dim3(n), dim3(64), 0, st, sparse, list_off, n_cand, dst_begin, dense, n);
+	return hipGetLastError();
 }
 
 hipError_t launch_search_count(const SearchArgs &a, hipStream_t st) {

@@ -50,6 +50,7 @@ static const int kRingMax = 4096;      /* largest ring any fill kernel provides 
  * max(kLateMinGroups, groups / 8) four-step groups are tracked exactly; TileOut::pad == kPadRedo
  * marks a tile whose best cell may lie before them (redone by the exact instantiation) */
 static const int kLateMinGroups = 128;
+static const int kLateShift = 3;
 static const int kPadRedo = 2;
 static const int kChainChunk = 16;     /* chained row blocks: steps per boundary hand-off (multiple of 4, power of two, <= 64) */
 
@@ -278,6 +279,7 @@ struct FillArgs {
 	int32_t chain_prio;      /* != 0: chained blocks run at raised wave priority */
 	ChainOut *chain_out;     /* per block */
 	int32_t late_min_groups; /* exactly tracked tail, in 4-step groups (kLateMinGroups; a test knob raises it) */
+	int32_t late_shift;      /* ... or groups >> late_shift of them if that is more (kLateShift) */
 	int32_t *ops;          /* per-tile op regions */
 	ScoreParams sp;
 };

@@ -98,6 +98,7 @@ typedef struct {
 	float max_hit, thresh, sens;
 	int bin_shift, read_len;
 	int overflow;
+	int misses;              /* kCount: k-mers found in neither orientation (CS.cpp:67-69) */
 } cs_run;
 
 /* CS.cpp:101-149 */
@@ -128,6 +129,9 @@ static void add_location(cs_run *c, uint64_t bin, int reverse) {
 static void prefix_search(cs_run *c, uint64_t prefix, uint64_t pos) {
 	const cs_table *t = c->t;
 	const uint64_t pr[2] = { prefix, rev_comp(prefix, t->k) };
+	/* CS.cpp:67-69: `cur->refTotal == 0` of the forward entry = neither the k-mer's row nor its reverse complement's is in
+	 * the table (PrefixTable.cpp:489-525: the forward entry's refTotal is the sum of both rows) */
+	if (!t->used[pr[0]] && !t->used[pr[1]]) c->misses += 1;
 	for (int rev = 0; rev < 2 && !c->overflow; ++rev) {
 		const uint64_t p = pr[rev];
 		if (!t->used[p]) continue;
@@ -177,15 +181,31 @@ static void prefix_iteration(cs_run *c, const char *seq, uint64_t length) {
 /* One CS::RunRead (CS.cpp:324-398): returns the number of LocationScore entries (CollectResultsStd, :219-268) written to
  * out_* in list order, -1 when every table size overflowed ("too many candidates": the read gets none).  seq must be
  * NUL-terminated (the N-run scan relies on it, like the reference). */
+int cs_search_ex(void *h, const char *seq, int len, float sensitivity, float min_hits, int bin_shift, int first_bits,
+		uint64_t *out_loc, float *out_score, int32_t *out_rev, int cap, float *max_hit, float *thresh, int32_t *rlist_len, int32_t *table_bits,
+		int32_t *kmer_misses);
+
 int cs_search(void *h, const char *seq, int len, float sensitivity, float min_hits, int bin_shift,
 		uint64_t *out_loc, float *out_score, int32_t *out_rev, int cap, float *max_hit, float *thresh, int32_t *rlist_len, int32_t *table_bits) {
+	return cs_search_ex(h, seq, len, sensitivity, min_hits, bin_shift, 16, out_loc, out_score, out_rev, cap, max_hit, thresh, rlist_len, table_bits, 0);
+}
+
+/* The same with the table size of the first attempt as a parameter (CS::c_SrchTableBitLen, 16 when a CS thread starts and
+ * adapted per batch, CS.cpp:482-489; the retries then take first_bits + 2, + 3, ... up to 20, CS.cpp:363-394) and kCount:
+ * the k-mers found in neither orientation, reset per read and NOT per attempt (CS.cpp:338), so the k-mers an overflowed
+ * attempt visited before it gave up stay counted. */
+int cs_search_ex(void *h, const char *seq, int len, float sensitivity, float min_hits, int bin_shift, int first_bits,
+		uint64_t *out_loc, float *out_score, int32_t *out_rev, int cap, float *max_hit, float *thresh, int32_t *rlist_len, int32_t *table_bits,
+		int32_t *kmer_misses) {
 	const cs_table *t = (const cs_table *) h;
-	static const int kBits[4] = { 16, 18, 19, 20 };
-	for (int attempt = 0; attempt < 4; ++attempt) {
+	int misses = 0;
+	if (kmer_misses) *kmer_misses = 0;
+	for (int attempt = 0; ; ++attempt) {
 		cs_run c;
 		memset(&c, 0, sizeof(c));
 		c.t = t;
-		c.bits = kBits[attempt];
+		c.bits = attempt == 0 ? first_bits : first_bits + 1 + attempt;
+		if (c.bits > 20) break;
 		const uint32_t size = 1u << c.bits;
 		c.table = (cs_entry *) malloc((size_t) size * sizeof(cs_entry));
 		c.rlist = (uint32_t *) malloc((size_t) size * 4);
@@ -196,6 +216,8 @@ int cs_search(void *h, const char *seq, int len, float sensitivity, float min_hi
 		c.bin_shift = bin_shift;
 		c.read_len = len;
 		prefix_iteration(&c, seq, (uint64_t) len);
+		misses += c.misses;
+		if (kmer_misses) *kmer_misses = misses;
 		int n = -1;
 		if (!c.overflow) {
 			const float thr = min_hits > c.thresh ? min_hits : c.thresh;

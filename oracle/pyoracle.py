@@ -253,21 +253,23 @@ class SearchOracle:
         self.lib.cs_table_destroy.argtypes = [C.c_void_p]
         self.lib.cs_search.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        self.lib.cs_search_ex.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         p = np.ascontiguousarray(fx.prefix, dtype=np.uint32)
         c = np.ascontiguousarray(fx.cnt, dtype=np.uint32)
         l = np.ascontiguousarray(fx.locs, dtype=np.uint32)
         self.t = self.lib.cs_table_create(fx.k, fx.unit_offset, len(p), p.ctypes.data, c.ctypes.data, l.ctypes.data, len(l))
 
-    def search(self, seq: bytes, sensitivity=0.8, min_hits=0.0, bin_shift=4, cap=4096):
+    def search(self, seq: bytes, sensitivity=0.8, min_hits=0.0, bin_shift=4, cap=4096, first_bits=16):
         loc = np.zeros(cap, dtype=np.uint64)
         sc = np.zeros(cap, dtype=np.float32)
         rev = np.zeros(cap, dtype=np.int32)
-        mh, th, rl, tb = C.c_float(), C.c_float(), C.c_int32(), C.c_int32()
-        n = self.lib.cs_search(self.t, seq, len(seq), sensitivity, min_hits, bin_shift, loc.ctypes.data, sc.ctypes.data, rev.ctypes.data,
-                               cap, C.byref(mh), C.byref(th), C.byref(rl), C.byref(tb))
+        mh, th, rl, tb, km = C.c_float(), C.c_float(), C.c_int32(), C.c_int32(), C.c_int32()
+        n = self.lib.cs_search_ex(self.t, seq, len(seq), sensitivity, min_hits, bin_shift, first_bits, loc.ctypes.data, sc.ctypes.data, rev.ctypes.data,
+                                  cap, C.byref(mh), C.byref(th), C.byref(rl), C.byref(tb), C.byref(km))
         m = max(0, min(n, cap))
-        return {"n": n, "loc": loc[:m].copy(), "score": sc[:m].copy(), "rev": rev[:m].copy(), "max_hit": mh.value, "thresh": th.value,
-                "rlist_len": rl.value, "table_bits": tb.value}
+        return {"n": n, "loc": loc[:m].copy(), "score": sc[:m].copy(), "rev": rev[:m].copy(), "max_hit": mh.value if n >= 0 else 0.0, "thresh": th.value,
+                "rlist_len": rl.value, "table_bits": tb.value, "kmer_misses": km.value}
 
     def close(self):
         if self.t:

@@ -14,6 +14,7 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip")
 BIN_BATCHED = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_batched")
 BIN_FULL = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_full")
 BIN_POOL = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_pool")
+BIN_ALL = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_all")
 E2E = os.path.join(ROOT, "tests", "golden", "e2e")
 
 
@@ -118,6 +119,26 @@ def test_test_3_alignment_contexts_off_the_cs_threads(built, tmp_path, target):
     assert p and int(p.group(1)) == 142, err[-2000:]
     assert int(p.group(3)) > 16          # more reads in flight than CS threads: the point of the pool
     print("test_3 -t 16, pool of 256 (target %d): %s alignments in %s launches, %s reads in flight at most" % (target, m.group(1), m.group(2), p.group(3)))
+
+
+def test_candidate_search_bound_in_the_pipeline(built, tmp_path):
+    """SURVEY 8 f4 (search half) where it belongs: CS::RunBatch hands every CS thread's batch of sub-reads to
+    Convex::CandidateSearchHip (cvx_search_batch_ex over ngmlr's own k-mer table resident in HBM) instead of voting read
+    by read in CS::RunRead (reference src/CS.cpp:324-398); alignment contexts, scoring and SAM records on the drop-ins as
+    well (oracle/_ref/ngmlr_hip_all).  test_2 (short and long reads), test_4 and test_3 (-t 16, 256 contexts): every SAM
+    record identical to the unmodified reference's."""
+    import re
+    got, err = _run(["-t", "1", "-r", os.path.join(E2E, "ref_chr21_20kb.fa"), "-q", os.path.join(E2E, "reads_100_2200bp.fa")], tmp_path, binary=BIN_ALL)
+    assert sorted(got) == sorted(_records(open(os.path.join(ROOT, "tests", "golden", "test_2.sam")).read())) and len(got) == 12
+    assert re.search(r"CandidateSearchHip: [1-9]\d* search calls", err), err[-1500:]
+    got, err = _run(["-x", "pacbio", "-t", "1", "-r", os.path.join(E2E, "test_4_reference.fasta.gz"),
+                     "-q", os.path.join(E2E, "test_4_read.fa.gz")], tmp_path, binary=BIN_ALL)
+    assert got == _records(open(os.path.join(ROOT, "tests", "golden", "test_4.sam")).read()) and len(got) == 1
+    got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_ALL, env={"CVX_POOL_CONTEXTS": "256"})
+    assert sorted(got) == _test_3_want()
+    m = re.search(r"CandidateSearchHip: (\d+) search calls, (\d+) reads", err)
+    assert m and int(m.group(2)) >= 5663, err[-1500:]          # every sub-read of test_3's 142 reads went through the device search (5 663 lists were recorded from the reference)
+    assert re.search(r"SharedAligner: 985 alignments", err), err[-1500:]
 
 
 def test_binary_links_the_device_library(built):

@@ -28,12 +28,21 @@ def test_device_search_equals_recorded_reference_calls(hip_aligner, which):
     idx, locs = fx.index_arrays()
     ix = KmerIndex(hip_aligner, fx.k, idx, locs, fx.unit_offset)
     try:
-        got = ix.search(fx.seqs)
+        got, max_hit, misses = ix.search(fx.seqs, extras=True)
+        got12 = ix.search(fx.seqs[:600], first_bits=12)        # CS::c_SrchTableBitLen adapted down (src/CS.cpp:482-489): same lists
     finally:
         ix.free()
     bad = [i for i in range(len(fx.seqs)) if not _same(got[i], *fx.want[i])]
     assert not bad, (len(bad), bad[:5])
     assert sum(len(g) for g in got) == sum(len(w[0]) for w in fx.want) > 1000
+    assert all(_same(got12[i], *fx.want[i]) for i in range(len(got12)))
+    # maxHitNumber as the reference recorded it (MappedRead::s), kCount against the checker's restatement of src/CS.cpp:67-69
+    assert np.array_equal(max_hit, fx.max_hit.astype(np.float32))
+    o = SearchOracle(fx)
+    sample = list(range(0, len(fx.seqs), max(1, len(fx.seqs) // 400)))
+    want_miss = [o.search(fx.seqs[i], cap=1 << 16)["kmer_misses"] for i in sample]
+    o.close()
+    assert [int(misses[i]) for i in sample] == want_miss and max(want_miss) > 0
 
 
 def test_device_search_corners_against_the_checker(hip_aligner):
@@ -44,10 +53,21 @@ def test_device_search_corners_against_the_checker(hip_aligner):
     idx, locs = fx.index_arrays()
     ix = KmerIndex(hip_aligner, fx.k, idx, locs, 0)
     try:
-        got = ix.search(reads)
+        got, max_hit, misses = ix.search(reads, extras=True)
         got2 = ix.search(reads, sensitivity=0.5, min_kmer_hits=2.0, bin_shift=2)
+        got10, max_hit10, misses10 = ix.search(reads, first_bits=10, extras=True)
     finally:
         ix.free()
+    # what CS::RunRead leaves behind beside the list: maxHitNumber, and kCount summed over the attempts of the ladder
+    assert [int(m) for m in misses] == [w["kmer_misses"] for w in want]
+    assert [float(m) for m in max_hit] == [float(np.float32(w["max_hit"])) for w in want]
+    o10 = SearchOracle(fx)
+    want10 = [o10.search(r, cap=1 << 20, first_bits=10) for r in reads]
+    o10.close()
+    for i, (w, g) in enumerate(zip(want10, got10)):
+        assert (w["n"] < 0 and g is None) or _same(g, w["loc"], w["score"], w["rev"]), i
+    assert [int(m) for m in misses10] == [w["kmer_misses"] for w in want10]
+    assert max(w["kmer_misses"] for w in want) >= 200 and any(w["table_bits"] > 16 and w["kmer_misses"] > 0 for w in want)   # foreign k-mers, also on a read that climbed the ladder
     assert max(w["table_bits"] for w in want if w["n"] >= 0) > 16            # the retry ladder was climbed
     for i, (w, g) in enumerate(zip(want, got)):
         if w["n"] < 0:

@@ -304,5 +304,9 @@ def synthetic_search_case(seed=41):
     lead = bytes(b"NNNN" + b[4:])
     short = bytes(b[:12])
     allN = b"N" * 40
-    reads = [base, with_n, tail2, tail1, lead, short, allN, heavy, bytes(b[:40]), b"", bytes(b[:13])]
+    # k-mers the table does not know (kCount, src/CS.cpp:67-69): a foreign read (all of them), a known read with a foreign
+    # tail, and the heavy read -- which climbs the ladder, so whatever it misses is counted once per attempt -- with one
+    foreign = synth.random_ref(rng, 256).tobytes()
+    reads = [base, with_n, tail2, tail1, lead, short, allN, heavy, bytes(b[:40]), b"", bytes(b[:13]),
+             foreign, bytes(b[:150]) + foreign[:106], foreign[:56] + heavy[:200]]
     return fx, reads

@@ -25,19 +25,35 @@ mkdir -p "$REPO/oracle/_ref"
 #   ngmlr_hip_pool     ngmlr_hip_full + Convex::AlignPool: processLongReadLIS / processShortRead run on K >> t alignment
 #                      contexts instead of on the CS thread (align_pool.h; SURVEY 8 f1's second half), the main loop polls
 #                      for the end of the run every 20 ms instead of every 2 s, SAM buffers flush at 1 MB instead of 10 MB
+#   ngmlr_hip_all      ngmlr_hip_pool + the candidate search of every CS thread's batch on the device (Convex::CandidateSearchHip,
+#                      cs_search_binding.inc at the top of CS::RunBatch, src/CS.cpp:400): alignment, sub-read scoring, k-mer vote
+#                      and SAM records on the drop-ins (SURVEY 8 f1 + f2 + f3 + f4's search half)
 #   ngmlr_pool_cpu     the reference's CPU aligners + the same pool: the pool's own correctness without a GPU (tests/test_pool_cpu.py)
 #   ngmlr_ref          (nothing changed)       the unmodified reference, for wall-clock comparison only
 build_variant() {
-local OUT_NAME=$1 CLASS=$2 SCORER=${3:-} SAM=${4:-} POOL=${5:-}
+local OUT_NAME=$1 CLASS=$2 SCORER=${3:-} SAM=${4:-} POOL=${5:-} SEARCH=${6:-}
 local T="$WORK/$OUT_NAME"
 cp -r /root/reference "$T"
 if [ "$CLASS" != "unmodified" ]; then
-python3 - "$T" "$REPO" "$CLASS" "$SCORER" "$SAM" "$POOL" <<'PY'
+python3 - "$T" "$REPO" "$CLASS" "$SCORER" "$SAM" "$POOL" "$SEARCH" <<'PY'
 import re, sys
-T, REPO, CLASS, SCORER, SAM, POOL = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6]
+T, REPO, CLASS, SCORER, SAM, POOL, SEARCH = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6], sys.argv[7]
 def sub1(s, old, new, what):
     assert s.count(old) == 1, (what, s.count(old))
     return s.replace(old, new, 1)
+if SEARCH:
+    # the k-mer vote of a CS thread's batch on the device (ngmlr_amd/csrc/candidate_search_hip.h, cs_search_binding.inc)
+    p = T + '/src/PrefixTable.h'
+    s = open(p).read()
+    s = sub1(s, '\tstatic int maxPrefixFreq;\n', '\tstatic int maxPrefixFreq;\n\t/* read access to the table units for the device search (what GetRefEntry reads) */\n'
+             '\tTableUnit const * cvxUnits(uint & count) const { count = m_UnitCount; return m_Units; }\n', 'PrefixTable.h accessor')
+    open(p, 'w').write(s)
+    p = T + '/src/CS.cpp'
+    s = open(p).read()
+    s = sub1(s, '#include "AlignmentBuffer.h"', '#include "AlignmentBuffer.h"\n#include "PrefixTable.h"\n#include "candidate_search_hip.h"', 'CS include (search)')
+    s = sub1(s, '\tint nScoresSum = 0;\n\tfor (size_t i = 0; i < m_CurrentBatch.size(); ++i) {', '#include "cs_search_binding.inc"\n\tint nScoresSum = 0;\n\tfor (size_t i = 0; i < m_CurrentBatch.size(); ++i) {', 'CS::RunBatch')
+    s = sub1(s, 'void CS::Cleanup() {', 'void CS::Cleanup() {\n\tConvex::CandidateSearchHip::Shutdown();', 'CS::Cleanup')
+    open(p, 'w').write(s)
 if POOL:
     # reads in flight decoupled from the CS threads (ngmlr_amd/csrc/align_pool.h)
     p = T + '/src/CS.cpp'
@@ -89,7 +105,7 @@ if CLASS != 'cpu':
     open(p, 'w').write(s)
 p = T + '/src/CMakeLists.txt'
 c = open(p).read()
-c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp\n%s/ngmlr_amd/csrc/batching_aligner.cpp\n%s/ngmlr_amd/csrc/stripped_sw_hip.cpp%s' % (REPO, REPO, REPO, REPO, REPO, ('\n%s/ngmlr_amd/csrc/align_pool.cpp' % REPO) if POOL else ''), 1)
+c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp\n%s/ngmlr_amd/csrc/batching_aligner.cpp\n%s/ngmlr_amd/csrc/stripped_sw_hip.cpp\n%s/ngmlr_amd/csrc/candidate_search_hip.cpp%s' % (REPO, REPO, REPO, REPO, REPO, REPO, ('\n%s/ngmlr_amd/csrc/align_pool.cpp' % REPO) if POOL else ''), 1)
 c = c.replace('TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})', 'TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})\nTARGET_LINK_LIBRARIES(ngmlr %s/ngmlr_amd/libcvxalign.so)\nset_target_properties(ngmlr PROPERTIES BUILD_RPATH "\\$ORIGIN/../../ngmlr_amd;/opt/rocm/lib" SKIP_BUILD_RPATH FALSE)' % REPO, 1)
 open(p, 'w').write(c)
 PY
@@ -107,8 +123,9 @@ build_variant ngmlr_hip_full Convex::SharedAligner StrippedSWHip sam &
 build_variant ngmlr_sam cpu "" sam &
 build_variant ngmlr_hip_pool Convex::SharedAligner StrippedSWHip sam pool &
 build_variant ngmlr_pool_cpu cpu "" "" pool &
+build_variant ngmlr_hip_all Convex::SharedAligner StrippedSWHip sam pool search &
 build_variant ngmlr_ref unmodified &     # the reference as it is: wall-clock yardstick of tools/e2e_rates.py
 wait
-test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched" && test -x "$REPO/oracle/_ref/ngmlr_hip_full" && test -x "$REPO/oracle/_ref/ngmlr_sam" && test -x "$REPO/oracle/_ref/ngmlr_hip_pool" && test -x "$REPO/oracle/_ref/ngmlr_pool_cpu"
+test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched" && test -x "$REPO/oracle/_ref/ngmlr_hip_full" && test -x "$REPO/oracle/_ref/ngmlr_sam" && test -x "$REPO/oracle/_ref/ngmlr_hip_pool" && test -x "$REPO/oracle/_ref/ngmlr_pool_cpu" && test -x "$REPO/oracle/_ref/ngmlr_hip_all"
 readelf -d "$REPO/oracle/_ref/ngmlr_hip" | grep -E "RPATH|RUNPATH|NEEDED" | head
 rm -rf "$WORK"

@@ -83,8 +83,9 @@ def run(name, t, ref, fq, extra_env=None):
     mp = re.search(r"Overall time for creating RefTable: ([0-9.]+)s", res.stderr)
     st = re.search(r"SharedAligner: \d+ workers over.*", res.stderr)
     sc = re.search(r"StrippedSWHip: \d+ scoring calls.*", res.stderr)
+    se = re.search(r"CandidateSearchHip: \d+ search calls.*", res.stderr)
     po = re.search(r"AlignPool: \d+ reads on.*", res.stderr)
-    return {"wall": dt, "cpu_note": cpu_note, "pool_stats": po.group(0) if po else None, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
+    return {"wall": dt, "search_stats": se.group(0) if se else None, "cpu_note": cpu_note, "pool_stats": po.group(0) if po else None, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
             "map_s": dt - float(mp.group(1)) if mp else None, "err": res.stderr[-400:], "full_err": res.stderr}
 
 
@@ -99,6 +100,8 @@ def line(name, t, r, same):
         print("    " + r["stats"], flush=True)
     if r.get("score_stats"):
         print("    " + r["score_stats"], flush=True)
+    if r.get("search_stats"):
+        print("    " + r["search_stats"], flush=True)
     if r.get("pool_stats"):
         print("    " + r["pool_stats"], flush=True)
     if os.environ.get("E2E_VERBOSE"):
@@ -175,6 +178,9 @@ def synthetic(n_reads, threads):
     runs = [(name, t, None, "") for name in ((only,) if only else () if os.environ.get("E2E_SKIP_OLD") else ("ngmlr_hip_batched", "ngmlr_hip_full")) for t in threads]
     for spec in [x for x in os.environ.get("E2E_POOL", "").split(",") if x]:
         f = spec.split(":")
+        binary = "ngmlr_hip_pool"                 # "all@16:512:..." = ngmlr_hip_all (the pool + the candidate search on the device)
+        if "@" in f[0]:
+            binary, f[0] = "ngmlr_hip_" + f[0].split("@")[0], f[0].split("@")[1]
         env = {"CVX_POOL_CONTEXTS": f[1]}
         if len(f) > 2 and int(f[2]) > 0:
             env["CVX_BATCH_TARGET"] = f[2]
@@ -183,7 +189,7 @@ def synthetic(n_reads, threads):
         for extra in f[4:]:
             k, v = extra.split("=")
             env[k] = v
-        runs.append(("ngmlr_hip_pool", int(f[0]), env, "  [" + " ".join("%s=%s" % kv for kv in sorted(env.items())) + "]"))
+        runs.append((binary, int(f[0]), env, "  [" + " ".join("%s=%s" % kv for kv in sorted(env.items())) + "]"))
     for name, t, env, note in runs:
         if True:
             r = run(name, t, fa, fq, env)
