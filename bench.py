@@ -43,6 +43,26 @@ PARITY_KEYS = ("ret", "score_bits", "position_offset", "qstart", "qend", "nm", "
                "cigar_op_count", "sv_type", "first_ref", "first_read", "last_ref", "last_read", "cigar", "md")
 
 
+def effective_cores():
+    """What this process may really use: hardware threads it can see, its affinity mask, and the cgroup's CPU quota
+    (cpu.max = quota / period; the GPU boxes behind gpurun expose 256 hardware threads and allow 16 cores' worth of time)."""
+    out = {"hardware_threads": os.cpu_count() or 1, "affinity": len(os.sched_getaffinity(0)), "cgroup_quota_cores": None}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        out["cgroup_quota_cores"] = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            out["cgroup_quota_cores"] = None if q < 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except Exception:
+            pass
+    eff = min(out["hardware_threads"], out["affinity"])
+    if out["cgroup_quota_cores"]:
+        eff = min(eff, out["cgroup_quota_cores"])
+    out["effective"] = eff
+    return out
+
+
 def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
     """The step's tiles through the CPU checker on the host cores of this box (bounded sample), and
     every one of those alignments compared with the GPU's.  The reference's own ConvexAlignFast
@@ -157,6 +177,7 @@ def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
         if diff is not None:
             n_bad += 1
             detail = detail or "tile %d: %s" % (i, diff)
+    eff = effective_cores()
     bases = int(ts.H[:n_sample].sum())
     cells = int(sum(int(ts.row_length[ts.qry_off[i]:ts.qry_off[i + 1]].astype(np.int64).sum()) for i in range(n_sample)))
     cpu = {
@@ -164,8 +185,10 @@ def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
         "unit": "Gbp/h",
         "cores": threads,
         "kind": kind,
-        "sample": "%d of the step's tiles (%.2f Mbp, %.2e cells) in %.1f s wall on %d %s threads (%d host cores)" % (
-            n_sample, bases / 1e6, cells, dt, threads, "C++ (best of a thread-count scan)" if kind == "reference" else "python", cores),
+        "sample": "%d of the step's tiles (%.2f Mbp, %.2e cells) in %.1f s wall on %d %s threads; host: %d hardware threads visible, %s" % (
+            n_sample, bases / 1e6, cells, dt, threads, "C++ (best of a thread-count scan)" if kind == "reference" else "python", cores,
+            ("a cgroup quota of %.1f cores' worth of CPU time -- the effective core count" % eff["cgroup_quota_cores"]) if eff["cgroup_quota_cores"] else "no CPU quota"),
+        "host_cores_effective": eff,
         "cells_per_s_per_core": cells / max(busy_sum, 1e-9),
         "thread_scan_Gbp_per_h": scan,
     }
@@ -185,8 +208,9 @@ def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
                 cpu["threads_in_one_process"] = {"value": cpu["value"], "cores": cpu["cores"]}
                 cpu["value"], cpu["cores"] = best["value"], best["processes"]
                 cpu["sample"] = ("%d of the step's tiles on %d single-threaded processes in %.1f s wall (the best of: one process with the best thread "
-                                 "count -- %.1f Gbp/h on %d threads, every tile of that run compared with the GPU --, and 1 process per core); %d host cores"
-                                 % (best["tiles"], best["processes"], best["seconds"], cpu["threads_in_one_process"]["value"], threads, cores))
+                                 "count -- %.1f Gbp/h on %d threads, every tile of that run compared with the GPU --, and 1 process per core); %d hardware threads visible, effective cores %s"
+                                 % (best["tiles"], best["processes"], best["seconds"], cpu["threads_in_one_process"]["value"], threads, cores,
+                                    ("%.1f (cgroup quota)" % eff["cgroup_quota_cores"]) if eff["cgroup_quota_cores"] else str(eff["effective"])))
     except Exception as e:        # the extra measurement must not break the contract line
         cpu["as_processes_error"] = str(e)
     return cpu, "%d/%d" % (n_sample - n_bad, n_sample), detail
@@ -264,16 +288,28 @@ def other_config(al, tiles, what, parity_n, parity_max_cells=3.0e8):
         res, ops = batch.download()
         n_valid = sum(1 for i in range(len(tiles)) if res[i].status == 0)
         kind = "reference" if have_ref() else "port"
-        orc = Oracle(kind)
-        # bounded sample: spread over the list, tiles whose CPU cost stays small (the 8192-column 100 kb tiles take the CPU ~10 s each)
+        # bounded sample: spread over the list, tiles whose CPU cost stays small (the 8192-column 100 kb tiles take the CPU ~10 s each);
+        # the reference runs on a few host threads (one checker instance each; the C call releases the interpreter lock)
         cand = [i for i in range(0, len(tiles), max(1, len(tiles) // (4 * parity_n))) if tiles[i].cells <= parity_max_cells][:parity_n]
         bad, first = 0, None
-        for i in cand:
-            d = same_alignment(orc.align(tiles[i]), format_alignment(al.lib, res[i], ops, tiles[i]))
+        n_thr = max(1, min(8, len(cand)))
+        want = [None] * len(cand)
+
+        def check(k):
+            orc = Oracle(kind)
+            for q in range(k, len(cand), n_thr):
+                want[q] = orc.align(tiles[cand[q]])
+            orc.close()
+        ths = [threading.Thread(target=check, args=(k,)) for k in range(n_thr)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        for q, i in enumerate(cand):
+            d = same_alignment(want[q], format_alignment(al.lib, res[i], ops, tiles[i]))
             if d is not None:
                 bad += 1
                 first = first or "tile %d (%s): %s" % (i, tiles[i].tag, d)
-        orc.close()
         return {"what": what, "tiles": len(tiles), "read_bases": int(bases), "Gbp_per_h": bases / best.total_ms * 3.6e-3,
                 "ms": {"plan": best.plan_ms, "fill": best.fill_ms, "backtrack": best.backtrack_ms, "total": best.total_ms},
                 "G_cells_per_s": best.cells / best.total_ms * 1e-6, "fill_classes": classes, "valid_alignments": "%d/%d" % (n_valid, len(tiles)),
@@ -281,6 +317,99 @@ def other_config(al, tiles, what, parity_n, parity_max_cells=3.0e8):
                 "measured": "device rate, inputs resident in HBM (cvx_batch_run, best of 3), closed-form corridors"}
     finally:
         batch.free()
+
+
+def index_stage_rates(al):
+    """SURVEY 8 f4 on the device, beside the line: candidate search (cvx_search_batch_ex over the recorded test_3 k-mer table,
+    resident in HBM) and reference decode (cvx_genome_decode over the recorded 4-bit genome) -- rate of the whole call, and every
+    result compared with what the unmodified reference produced for the same input (tests/golden/, tools/make_golden*.sh)."""
+    from ngmlr_amd.aligner import Genome, KmerIndex
+    from oracle.pyoracle import SearchFixture
+    out = {}
+    golden = os.path.join(ROOT, "tests", "golden")
+    try:
+        fx = SearchFixture(os.path.join(golden, "cs_test_3.npz"))
+        idx, locs = fx.index_arrays()
+        ix = KmerIndex(al, fx.k, idx, locs, fx.unit_offset)
+        try:
+            rep_n = 16
+            reads = list(fx.seqs) * rep_n
+            ix.search(reads[:256])
+            c0 = time.perf_counter()
+            got, max_hit, misses = ix.search(reads, extras=True)
+            dt = time.perf_counter() - c0
+        finally:
+            ix.free()
+        n0 = len(fx.seqs)
+        ok = sum(1 for r in range(rep_n) for i in range(n0)
+                 if got[r * n0 + i] is not None and len(got[r * n0 + i]) == len(fx.want[i][0]) and np.array_equal(got[r * n0 + i]["location"], fx.want[i][0])
+                 and np.array_equal(got[r * n0 + i]["score"], fx.want[i][1]) and np.array_equal(got[r * n0 + i]["reverse"], fx.want[i][2])
+                 and float(max_hit[r * n0 + i]) == float(fx.max_hit[i]))
+        bases = sum(len(x) for x in reads)
+        out["candidate_search"] = {
+            "sub_reads": len(reads), "seconds": dt, "sub_reads_per_s": len(reads) / dt, "Gbp_per_h_of_sub_read_bases": bases / dt * 3.6e-6,
+            "parity": "%d/%d lists equal to the recorded CS::RunRead calls of the unmodified reference (entries, order, maxHitNumber)" % (ok, len(reads)),
+            "bound": "latency: one lane per sub-read casts its votes serially in the reference's order (the candidate list depends on that order), each vote a "
+                     "chain of dependent updates of its own vote table in HBM; throughput comes from sub-reads in flight -- no HBM-roofline figure applies",
+            "what": "cvx_search_batch_ex, whole call (reads in host memory -> candidate lists, maxHitNumber, kCount back), recorded test_3 index (k = %d, %d locations), "
+                    "%d recorded sub-reads x %d" % (fx.k, len(fx.locs), n0, rep_n)}
+    except Exception as e:
+        out["candidate_search"] = {"error": str(e)}
+    try:
+        z = np.load(os.path.join(golden, "decode_test_3.npz"))
+        wins = [(int(z["pos"][i]), int(z["len"][i]), z["bytes"][int(z["off"][i]):int(z["off"][i + 1])].tobytes()) for i in range(int(z["n"]))]
+        g = Genome(al, z["binref"], int(z["nibbles"]), z["starts"])
+        try:
+            rep_n = max(1, 200000 // max(len(wins), 1))
+            pos = [w[0] for w in wins] * rep_n
+            ln = [w[1] for w in wins] * rep_n
+            g.decode(pos[:len(wins)], ln[:len(wins)])
+            c0 = time.perf_counter()
+            got = g.decode(pos, ln)
+            dt = time.perf_counter() - c0
+        finally:
+            g.free()
+        ok = sum(1 for k, o in enumerate(got) if o == wins[k % len(wins)][2])
+        chars = float(sum(ln))
+        out["reference_decode"] = {
+            "windows": len(pos), "characters": int(chars), "seconds": dt, "G_chars_per_s": chars / dt * 1e-9,
+            "parity": "%d/%d windows byte-identical to what the unmodified reference decoded (SequenceProvider::DecodeRefSequenceExact)" % (ok, len(pos)),
+            "bound": "hbm for the kernel alone (0.5 B read + 1 B written per character); the figure here is the whole call, i.e. the D2H copy of the decoded "
+                     "characters into pageable memory plus python -- in the product the windows are decoded straight into the batch's sequence arena (cvx_submit_windows) and never leave HBM",
+            "what": "cvx_genome_decode, whole call, recorded test_3 genome and windows x %d" % rep_n}
+    except Exception as e:
+        out["reference_decode"] = {"error": str(e)}
+    return out
+
+
+def catch_all_kernel_rate(dev, tiles, main_results):
+    """fill_generic_kernel<SSE> (cvx_generic.hip): the kernel every tile takes under scoring outside the scalar-equivalent
+    regime (and irregular corridors): its rate on a sample of the ONT mix with the default scoring forced through it
+    (CVX_TUNE_SSE_VARIANT=1 at handle creation), results compared with the ring kernels' for the same tiles."""
+    from ngmlr_amd.aligner import ConvexAlignHip
+    os.environ["CVX_TUNE_SSE_VARIANT"] = "1"
+    try:
+        al2 = ConvexAlignHip(device=dev)
+    finally:
+        os.environ.pop("CVX_TUNE_SSE_VARIANT", None)
+    try:
+        batch = al2.upload(tiles, closed_form=True)
+        try:
+            batch.run()
+            tm = batch.run()
+            res, _ = batch.download()
+            same = sum(1 for i in range(len(tiles)) if res[i].status == main_results[i].status and (res[i].status != 0 or (
+                np.float32(res[i].score).view(np.uint32) == np.float32(main_results[i].score).view(np.uint32) and res[i].n_ops == main_results[i].n_ops
+                and res[i].ref_position == main_results[i].ref_position and res[i].qstart == main_results[i].qstart and res[i].qend == main_results[i].qend)))
+            return {"tiles": len(tiles), "fill_ms": tm.fill_ms, "G_cells_per_s": tm.cells / max(tm.fill_ms, 1e-6) * 1e-6,
+                    "read_bases": int(sum(t.H for t in tiles)), "Gbp_per_h": float(sum(t.H for t in tiles)) / max(tm.total_ms, 1e-6) * 3.6e-3,
+                    "equal_to_the_ring_kernels": "%d/%d (status, score bits, path end points, op count)" % (same, len(tiles)),
+                    "what": "fill_generic_kernel<SSE = true>: the reference's SSE-path semantics cell by cell, slot state in a global scratch, one workgroup per tile; "
+                            "ONT-mix tiles, default scoring forced through it"}
+        finally:
+            batch.free()
+    finally:
+        al2.close()
 
 
 def subread_scoring_rates(lib, dev, n=32768):
@@ -353,6 +482,7 @@ class Worker:
         self.last = None                              # the last step's job (results kept for the checks)
         self.valid = 0
         self.host_s = np.zeros(2)                     # host wall time inside cvx_submit / cvx_wait (timed steps)
+        self.redone = 0                               # tiles the exact-tracking pass had to redo (timed steps)
 
     def steps(self, k, keep_last=False, record=True):
         jobs = []
@@ -363,6 +493,7 @@ class Worker:
             if record:
                 self.host_s[1] += time.perf_counter() - c0
                 tm = j.timing()
+                self.redone += int(tm.n_tiles_redone)
                 self.stage += (tm.plan_ms, tm.fill_ms, tm.backtrack_ms, tm.total_ms)
                 for li in j.launches():
                     key = (li["slots_per_lane"], li["waves"], li["wrap16"])
@@ -677,13 +808,30 @@ def main() -> int:
         others = None
         if extra_tiles:
             others = {}
-            for name_, what_, pn_ in (("ont", "configs[2]: ONT-like reads, 25 % error 4:4:2, tile mix median 1.3 kb up to 20 kb, widths 309-463, 10 % retries at 2x", 96),
-                                      ("ultralong_sv", "configs[4]: 100 kb reads, 95 % first-attempt anchors corridors (309+), 5 % widened to 2048 / 8192 columns or full-matrix inversion tiles", 6),
+            for name_, what_, pn_ in (("ont", "configs[2]: ONT-like reads, 25 % error 4:4:2, tile mix median 1.3 kb up to 20 kb, widths 309-463, 10 % retries at 2x", 256),
+                                      ("ultralong_sv", "configs[4]: 100 kb reads, 95 % first-attempt anchors corridors (309+), 5 % widened to 2048 / 8192 columns or full-matrix inversion tiles", 48),
                                       ("short", "short reads (<= 256 bp) on the linear corridor (src/AlignmentBuffer.cpp:2576-2594)", 256)):
                 try:
                     others[name_] = other_config(w0.al, extra_tiles[name_], what_, pn_)
                 except Exception as e:
                     others[name_] = {"error": str(e)}
+
+        # SURVEY 8 f4 on the device (candidate search, reference decode) and the catch-all fill kernel: rate + parity, beside the line
+        index_stage = generic_rate = None
+        if not args.no_cpu_baseline and args.gpus == 1 and not args.no_extras:
+            index_stage = index_stage_rates(w0.al)
+            try:
+                if extra_tiles.get("ont"):
+                    sample = extra_tiles["ont"][:4096]
+                    bm = w0.al.upload(sample, closed_form=True)
+                    try:
+                        bm.run()
+                        main_res, _ = bm.download()          # (a ctypes array owned by python: outlives the batch)
+                    finally:
+                        bm.free()
+                    generic_rate = catch_all_kernel_rate(devs[0], sample, main_res)
+            except Exception as e:
+                generic_rate = {"error": str(e)}
 
         value = bases * args.steps / dt * 3600.0 / 1e9
         launch_ms, launch_meta = w0.launch_ms, w0.launch_meta
@@ -770,6 +918,7 @@ def main() -> int:
                 "traffic_source": traffic_src,
                 "launch_ms": dms,
                 "launches_timed": len(launch_ms[dom]),
+                "tiles_redone_by_the_exact_pass": "%d of %d (two-phase best-cell tracking: a tile whose best cell is not in the exactly tracked tail is filled again)" % (w0.redone, args.steps * len(ts)),
                 "launch_tiles": meta["n_tiles"],
                 "alg_bytes_per_launch": meta["alg_bytes"],
                 "gcups": meta["cells"] / (dms * 1e-3) / 1e9,
@@ -791,6 +940,8 @@ def main() -> int:
             "text_stage_device": text_dev,
             "subread_scoring": subread,
             "other_configs": others,
+            "index_stage_device": index_stage,
+            "catch_all_fill_kernel": generic_rate,
             "tile_generation_s": t_gen,
         }
     for w in workers:

@@ -410,6 +410,9 @@ int cvx_job_text(cvx_handle h, cvx_job job, const int32_t *ext_qstart, const int
  * several GB for a full batch of long reads.  *kernel_ms (may be NULL): the kernel's own duration. */
 int cvx_job_nm_profile(cvx_handle h, cvx_job job, int32_t first, int32_t count, uint64_t *entry_off,
 		int32_t *triples, uint64_t cap_entries, double *kernel_ms);
+/* the entry offsets alone (entry_off[0 .. count], as above): what a caller needs to size `triples` -- no profile is
+ * computed and nothing is allocated for it */
+int cvx_job_nm_sizes(cvx_handle h, cvx_job job, int32_t first, int32_t count, uint64_t *entry_off);
 
 /* The same kernel over op lists the caller holds (someone who kept cvx_result + ops and released the job): tile i's
  * ops are ops_arena[results[i].ops_begin ... + n_ops), ops_total = ints in the arena.  entry_off[n + 1] as above;

@@ -222,10 +222,11 @@ class Job:
         off = np.zeros(count + 1, dtype=np.uint64)
         ms = C.c_double()
         lib = self.al.lib
-        # sizes first (a NULL buffer leaves the profile in HBM), then the real call when the caller wants it
-        capi.check(lib.cvx_job_nm_profile(self.al.h, self.j, first, count, off.ctypes.data, None, 0, C.byref(ms)))
-        if not to_host:
+        if not to_host:      # the profile stays in HBM (a NULL buffer), for a consumer on the device
+            capi.check(lib.cvx_job_nm_profile(self.al.h, self.j, first, count, off.ctypes.data, None, 0, C.byref(ms)))
             return off, None, ms.value
+        # sizes first (the offsets alone: no profile kernel, no arena), then the one real call
+        capi.check(lib.cvx_job_nm_sizes(self.al.h, self.j, first, count, off.ctypes.data))
         tri = np.zeros((int(off[count]), 3), dtype=np.int32)
         capi.check(lib.cvx_job_nm_profile(self.al.h, self.j, first, count, off.ctypes.data, tri.ctypes.data, int(off[count]), C.byref(ms)))
         return off, tri, ms.value

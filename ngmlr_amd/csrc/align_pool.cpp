@@ -40,7 +40,7 @@ struct Pool {
 	long long producerBlockedNs, busyNs;
 	std::chrono::steady_clock::time_point born;
 
-	Pool() : maxContexts(256), queueLimit(0), idle(0), busy(0), stop(false), items(0), maxQueued(0), maxBusy(0),
+	Pool() : maxContexts(512), queueLimit(0), idle(0), busy(0), stop(false), items(0), maxQueued(0), maxBusy(0),
 			producerBlockedNs(0), busyNs(0), born(std::chrono::steady_clock::now()) {
 		if (const char * e = getenv("CVX_POOL_CONTEXTS")) maxContexts = atoi(e) > 0 ? atoi(e) : 1;
 		queueLimit = 2 * maxContexts;

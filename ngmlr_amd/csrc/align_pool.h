@@ -15,7 +15,7 @@
  * AlignmentBuffer per thread, shared state behind NGM's own locks and atomics) are the reference's own.
  * Contexts spend their time parked in SharedAligner::SingleAlign (batching_aligner.h), so K of them cost K
  * stacks, not K cores; the CS threads stay at the host's real core count and keep searching and scoring.
- * With K = 256 ... 512 a launch carries hundreds of tiles instead of ~20.
+ * With K = 512 (CVX_POOL_CONTEXTS; they are created on demand) a launch carries hundreds of tiles instead of ~20.
  *
  * Binding (applied by tools/build_ngmlr_hip.sh to its /tmp copy of the reference, shown in INTEGRATION.md):
  *   src/CS.cpp  CS::DoRun      AlignPool::Attach() before the thread builds its own buffers,

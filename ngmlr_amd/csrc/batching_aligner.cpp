@@ -40,6 +40,12 @@ void BatchingAligner::WorkerDone() {
 	cvDispatch.notify_all();      /* the remaining workers may all be parked now */
 }
 
+void BatchingAligner::SetBatchTarget(int targetRequests, int holdMicroseconds) {
+	std::lock_guard<std::mutex> lk(mtx);
+	target = targetRequests > 0 ? targetRequests : 0;
+	holdUs = holdMicroseconds > 0 ? holdMicroseconds : 0;
+}
+
 void BatchingAligner::WorkerJoined() {
 	std::lock_guard<std::mutex> lk(mtx);
 	workers += 1;
@@ -263,6 +269,10 @@ SharedAligner::SharedAligner(int const stdOutMode, float const match, float cons
 		if (const char * e = getenv("CVX_BATCH_TIMEOUT_US")) timeoutUs = atoi(e);
 		g_backend[device] = new ConvexAlignHip(stdOutMode, match, mismatch, gapOpen, gapExtend, gapExtendMin, gapDecay, nPhysical > 0 ? device % nPhysical : device);   /* throws without a usable device */
 		g_shared[device] = new BatchingAligner(g_backend[device], 0, maxBatch, timeoutUs);   /* workers join one by one */
+		/* with alignment contexts off the CS threads (align_pool.h) a launch waits for 256 tiles, 30 ms at most: hundreds of
+		 * contexts hide that wait, and the device sees a few large launches instead of many small ones (CVX_BATCH_TARGET /
+		 * CVX_BATCH_HOLD_US override) */
+		if (perRead && !getenv("CVX_BATCH_TARGET")) g_shared[device]->SetBatchTarget(256, getenv("CVX_BATCH_HOLD_US") ? atoi(getenv("CVX_BATCH_HOLD_US")) : 30000);
 	}
 	if (perRead) tl_dispatcher = g_shared[device];
 	else g_shared[device]->WorkerJoined();

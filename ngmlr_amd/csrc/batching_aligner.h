@@ -72,6 +72,8 @@ public:
 	void WorkerDone();
 	/* a worker that joins after construction (SharedAligner: one per AlignmentBuffer) */
 	void WorkerJoined();
+	/* batch target of the dispatcher (see the rules above; 0 = none); before the first request */
+	void SetBatchTarget(int targetRequests, int holdMicroseconds);
 
 	/* statistics */
 	long Launches() const { return launches; }

@@ -1,0 +1,26 @@
+/*
+ * cs_search_binding.h -- ngmlr-tree side of the candidate-search binding (see cs_search_binding.inc): which table the
+ * device search can take.  Only meaningful inside ngmlr's tree (it names the reference's own types); included by the
+ * patched src/CS.cpp (tools/build_ngmlr_hip.sh).
+ */
+#ifndef CS_SEARCH_BINDING_H
+#define CS_SEARCH_BINDING_H
+
+#include "PrefixTable.h"
+#include "candidate_search_hip.h"
+
+/* the one table unit of a genome below 4 Gbp (src/PrefixTable.h:53-75), or 0: several units keep the reference's search */
+static inline TableUnit const * cvxSearchableUnit(IRefProvider const * rp) {
+	CompactPrefixTable const * table = dynamic_cast<CompactPrefixTable const *>(rp);
+	uint unitCount = 0;
+	TableUnit const * units = table ? table->cvxUnits(unitCount) : 0;
+	return (units != 0 && unitCount == 1) ? units : 0;
+}
+
+/* CS::DoRun sizes the thread's host vote table with this (src/CS.cpp:422-432: 2^24 entries + list = 320 MB per CS thread,
+ * written once at start-up): a thread whose votes run on the device never touches it */
+static inline int cvxHostVoteTableLen(IRefProvider const * rp, int referenceLen) {
+	return cvxSearchableUnit(rp) != 0 ? 1 : referenceLen;
+}
+
+#endif

@@ -878,7 +878,10 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	 * chains finish on a few waves the device has issue slots to spare: the other classes' walks run there instead of
 	 * behind everything (CVX_TUNE_BT_PER_CLASS=0: one walk behind all fills, as a batch of one class has it anyway). */
 	static const bool bt_per_class_env = !(getenv("CVX_TUNE_BT_PER_CLASS") && atoi(getenv("CVX_TUNE_BT_PER_CLASS")) == 0);
-	const bool per_class = bt_per_class_env && launch_tiles.size() > 1 && !h->overlap_post;
+	/* Only where the walk is issue-bound (>= 4096 tiles; measured, r04c: ONT mix 60 000 tiles 57.2 -> 56.0 ms, 24 000 tiles
+	 * 35.3 -> 34.2, C5 mix 6 144 tiles 397 -> 369 ms); a small batch's one-wave-per-tile walks are latency-bound chains that
+	 * gain nothing from starting early and cost the fills still running (C5 mix 2 048 tiles: 183.6 -> 187.2 ms). */
+	const bool per_class = bt_per_class_env && launch_tiles.size() > 1 && !h->overlap_post && n_walk >= 4096;
 	int launches = 0;
 	/* fill launches go round-robin over the two aux streams and the main stream itself (which has
 	 * nothing else to do until they are all done): three classes side by side */
@@ -1010,8 +1013,13 @@ int stage_results(cvx_context *h, cvx_batch_s *b) {
 	const int launches = b->timing.n_fill_launches;
 	for (int i = 0; i < launches; ++i) b->launches[(size_t) i].ms = ev_ms(b->lev[(size_t) i * 4], b->lev[(size_t) i * 4 + 1]);
 	b->timing.plan_ms = ev_ms(b->ev[0], b->ev[1]);
-	b->timing.fill_ms = ev_ms(b->ev[4], b->ev[2]);
-	b->timing.backtrack_ms = ev_ms(b->ev[2], b->ev[3]);
+	/* fill = until the last fill class has finished its exact pass; backtrack = what is left of the compute stage (when every
+	 * class is walked behind its own fill, the walks of the early classes lie inside `fill`: the two still add up) */
+	float fill_end = 0.0f;
+	for (int i = 0; i < launches; ++i) fill_end = std::max(fill_end, ev_ms(b->ev[4], b->lev[(size_t) i * 4 + 2]));
+	if (launches == 0) fill_end = ev_ms(b->ev[4], b->ev[2]);
+	b->timing.fill_ms = fill_end;
+	b->timing.backtrack_ms = std::max(0.0f, ev_ms(b->ev[4], b->ev[3]) - fill_end);
 	b->timing.total_ms = b->timing.plan_ms + ev_ms(b->ev[4], b->ev[3]);
 	b->timing.n_tiles_redone = s->n_redone;
 	b->state = kFinished;
@@ -1583,8 +1591,20 @@ int cvx_job_text(cvx_handle h, cvx_job j, const int32_t *ext_qstart, const int32
 	ABI_GUARD_END
 }
 
+static int nm_profile_common(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint64_t *entry_off,
+		int32_t *triples, uint64_t cap_entries, double *kernel_ms, bool sizes_only);
+
 int cvx_job_nm_profile(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint64_t *entry_off,
 		int32_t *triples, uint64_t cap_entries, double *kernel_ms) {
+	return nm_profile_common(h, j, first, count, entry_off, triples, cap_entries, kernel_ms, false);
+}
+
+int cvx_job_nm_sizes(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint64_t *entry_off) {
+	return nm_profile_common(h, j, first, count, entry_off, nullptr, 0, nullptr, true);
+}
+
+static int nm_profile_common(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint64_t *entry_off,
+		int32_t *triples, uint64_t cap_entries, double *kernel_ms, bool sizes_only) {
 	ABI_GUARD_BEGIN
 	if (kernel_ms) *kernel_ms = 0.0;
 	if (!h || !j || j->state < kFinished) { set_err("cvx_job_nm_profile: job not finished (call cvx_wait first)"); return CVX_ERR_ARG; }
@@ -1610,6 +1630,7 @@ int cvx_job_nm_profile(cvx_handle h, cvx_job j, int32_t first, int32_t count, ui
 	HIP_TRY(hipStreamSynchronize(st));
 	for (size_t i = 0; i <= c1; ++i) entry_off[i] = hoff[i];
 	const unsigned long long total = hoff[c1];
+	if (sizes_only) return CVX_OK;      /* the entry offsets alone: no 12-byte-per-column arena, no profile kernel */
 	if (triples && total > cap_entries) { set_err("cvx_job_nm_profile: %llu entries, room for %llu", total, (unsigned long long) cap_entries); return CVX_ERR_CAPACITY; }
 	RC_TRY(j->d_nm.ensure(3 * (size_t) total + 16));
 	HIP_TRY(hipEventRecord(j->ev_nm0, st));

@@ -47,10 +47,11 @@ struct RowDesc { int32_t off, len; }; /* the same pair under the host's names */
 static const int kSwitchMargin = 4;
 static const int kRingMax = 4096;      /* largest ring any fill kernel provides */
 /* two-phase best-cell tracking of the ring fill (cvx_kernels.hip): the last
- * max(kLateMinGroups, groups / 8) four-step groups are tracked exactly; TileOut::pad == kPadRedo
+ * max(kLateMinGroups, groups >> kLateShift) four-step groups are tracked exactly; TileOut::pad == kPadRedo
  * marks a tile whose best cell may lie before them (redone by the exact instantiation) */
 static const int kLateMinGroups = 128;
-static const int kLateShift = 3;
+static const int kLateShift = 5;       /* exactly tracked tail = max(kLateMinGroups, groups >> kLateShift): a 10 kb tile tracks its last 161 groups
+                                        * = 644 steps, two corridor widths (round 3: groups / 8; 109.1 -> 107.9 ms per 49 120 tiles, still no tile redone) */
 static const int kPadRedo = 2;
 static const int kChainChunk = 16;     /* chained row blocks: steps per boundary hand-off (multiple of 4, power of two, <= 64) */
 

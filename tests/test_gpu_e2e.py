@@ -108,9 +108,7 @@ def test_test_3_alignment_contexts_off_the_cs_threads(built, tmp_path, target):
     scoring and SAM records on the drop-ins; with and without a batch target for the dispatcher.  SAM records
     identical to the unmodified reference (sorted)."""
     import re
-    env = {"CVX_POOL_CONTEXTS": "256"}
-    if target:
-        env.update(CVX_BATCH_TARGET=str(target), CVX_BATCH_HOLD_US="20000")
+    env = {"CVX_POOL_CONTEXTS": "256", "CVX_BATCH_TARGET": str(target), "CVX_BATCH_HOLD_US": "20000"}      # (target 0 = none; the pool's default is 256)
     got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_POOL, env=env)
     assert sorted(got) == _test_3_want()
     m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", err)

@@ -50,7 +50,8 @@ if SEARCH:
     open(p, 'w').write(s)
     p = T + '/src/CS.cpp'
     s = open(p).read()
-    s = sub1(s, '#include "AlignmentBuffer.h"', '#include "AlignmentBuffer.h"\n#include "PrefixTable.h"\n#include "candidate_search_hip.h"', 'CS include (search)')
+    s = sub1(s, '#include "AlignmentBuffer.h"', '#include "AlignmentBuffer.h"\n#include "cs_search_binding.h"', 'CS include (search)')
+    s = sub1(s, 'int x_SrchTableLen = (int) pow(2, x_SrchTableBitLen);', 'int x_SrchTableLen = cvxHostVoteTableLen(NGM.GetRefProvider(m_TID), (int) pow(2, x_SrchTableBitLen));', 'CS::DoRun vote table')
     s = sub1(s, '\tint nScoresSum = 0;\n\tfor (size_t i = 0; i < m_CurrentBatch.size(); ++i) {', '#include "cs_search_binding.inc"\n\tint nScoresSum = 0;\n\tfor (size_t i = 0; i < m_CurrentBatch.size(); ++i) {', 'CS::RunBatch')
     s = sub1(s, 'void CS::Cleanup() {', 'void CS::Cleanup() {\n\tConvex::CandidateSearchHip::Shutdown();', 'CS::Cleanup')
     open(p, 'w').write(s)
