@@ -62,7 +62,8 @@ extern "C" {
 enum {
 	CVX_OK = 0,
 	CVX_ERR_NO_DEVICE = -1,      /* no HIP device / wrong device id */
-	CVX_ERR_PARAMS = -2,         /* scoring parameters outside the proven-equivalent regime */
+	CVX_ERR_PARAMS = -2,         /* scoring parameters that are not finite (any finite set is accepted: scoring outside the regime in
+	                              * which the reference's SSE path equals its scalar recurrence runs on the catch-all kernel's SSE variant) */
 	CVX_ERR_ARG = -3,            /* NULL pointer, negative size, height != strlen(qry) ... */
 	CVX_ERR_OOM = -4,            /* device or host allocation failed */
 	CVX_ERR_HIP = -5,            /* a HIP call failed; see cvx_last_error() */

@@ -536,7 +536,7 @@ enum FillMode { kFillTwoPhase = 0, kFillExact = 1, kFillChain = 2 };
  * behind on the same stream over the same list, redoes just the flagged tiles with exact
  * tracking from the first step.
  *
- * kFillChain: corridors with more live rows than the widest ring (need > 512: the retry loop's
+ * kFillChain: corridors with more live rows than the widest ring (need > 256: the retry loop's
  * widened corridors up to 8192 columns, full-matrix inversion tiles) are cut into blocks of N
  * consecutive read rows; block g is an ordinary ring tile whose first row takes its "up" inputs
  * from the boundary stream that block g-1 writes while it computes its last row.  Blocks of one
