@@ -10,8 +10,9 @@ namespace Convex {
 
 namespace {
 /* handles per device: a call is synchronous (reads in, lists out) and a chain of short kernels with host round trips in
- * between, so one handle behind one mutex would serialise the CS threads; they are dealt round-robin over kLanes handles */
-const int kLanes = 8;
+ * between, so one handle behind one mutex would serialise the CS threads; they are dealt round-robin over kLanes handles
+ * (a handle's persistent vote tables are ~0.4 GB for a batch of 400 sub-reads) */
+const int kLanes = 16;
 std::mutex g_mtx;                       /* creation / shutdown */
 std::mutex g_laneMtx[kLanes];
 cvx_handle g_handle[kLanes] = {0};

@@ -11,7 +11,7 @@
  * the kCount rule for the mapping quality, AllocScores with the LocationScore list in the reference's order, SendToBuffer
  * (the binding is ngmlr_amd/csrc/cs_search_binding.inc, inserted by tools/build_ngmlr_hip.sh and shown in INTEGRATION.md).
  *
- * One instance per process: the table unit is uploaded once; searching threads are dealt round-robin over a few device
+ * One instance per process: the table unit is uploaded once; searching threads are dealt round-robin over sixteen device
  * handles (own streams, own persistent staging), calls on different handles overlap, a call sleeps while the device works.
  * No CPU path: a device error throws (the CS thread ends, as it would on any other hard error).
  */

@@ -1555,6 +1555,9 @@ hipError_t launch_backtrack(const BacktrackArgs &a, const int32_t *order, int n_
 	if (group == 16 && order != nullptr) {
 		if (n_order <= 0) return hipSuccess;
 		hipLaunchKernelGGL(backtrack_grp_kernel<16>, dim3((n_order + 3) / 4), dim3(64), 0, st, a, order, n_order);   /* four tiles per wave */
+	} else if (group == 4 && order != nullptr) {
+		if (n_order <= 0) return hipSuccess;
+		hipLaunchKernelGGL(backtrack_grp_kernel<4>, dim3((n_order + 15) / 16), dim3(64), 0, st, a, order, n_order);  /* sixteen tiles per wave (CVX_TUNE_BT_GROUP=4 only) */
 	} else if (group == 8 && order != nullptr) {
 		if (n_order <= 0) return hipSuccess;
 		hipLaunchKernelGGL(backtrack_grp_kernel<8>, dim3((n_order + 7) / 8), dim3(64), 0, st, a, order, n_order);    /* eight tiles per wave */

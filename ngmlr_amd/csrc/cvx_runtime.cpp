@@ -742,9 +742,8 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 			for (int k = 0; k < kBuckets; ++k) count[(size_t) k + 1] += count[(size_t) k];
 			const size_t at = n_listed;
 			const int m = count[(size_t) kBuckets];
-			std::vector<int32_t> sorted_v(v->begin(), v->end());
-			std::sort(sorted_v.begin(), sorted_v.end());          /* tile order inside a bucket, as the single global pass had it */
-			for (int32_t ti : sorted_v) if (!hp.trun[(size_t) ti].skip) lists[at + (size_t) count[(size_t) bucket(ti)]++] = ti;
+			/* (stable: inside a bucket of equally long reads the class's own order, most cells first) */
+			for (int32_t ti : *v) if (!hp.trun[(size_t) ti].skip) lists[at + (size_t) count[(size_t) bucket(ti)]++] = ti;
 			n_listed += (size_t) m;
 			bt_seg.emplace_back(at, m);
 		}

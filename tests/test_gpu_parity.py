@@ -281,7 +281,7 @@ def test_two_phase_tracking_redo_path(built, port_oracle, monkeypatch, late_min)
         assert tm.n_tiles_redone >= 12, tm.n_tiles_redone      # at least the engineered ones (some end in row 0: invalid, but still redone)
 
 
-@pytest.mark.parametrize("env", [{"CVX_TUNE_BT_GROUP": "8"}, {"CVX_TUNE_BT_GROUP": "16"}, {"CVX_TUNE_BT_GROUP": "32"},
+@pytest.mark.parametrize("env", [{"CVX_TUNE_BT_GROUP": "4"}, {"CVX_TUNE_BT_GROUP": "8"}, {"CVX_TUNE_BT_GROUP": "16"}, {"CVX_TUNE_BT_GROUP": "32"},
                                  {"CVX_TUNE_BT_GROUP": "64"}, {"CVX_TUNE_OVERLAP_POST": "1"}, {"CVX_TUNE_BT_PER_CLASS": "0"}])
 def test_runtime_knobs_do_not_change_results(built, port_oracle, monkeypatch, env):
     """Every lanes-per-tile setting of the backtrack (the default picks 8 / 32 / 64 by batch shape), the
