@@ -60,10 +60,18 @@ struct SearchArgs {
 	float *scores;                   /* two floats per table entry: forward, reverse */
 	float sensitivity, min_hits;
 	int32_t bin_shift;
+	/* search_wave_kernel (one wave per read, vote table in LDS): candidates of read i at cand + cand_off[i] (a fixed
+	 * kSearchWaveCand entries per read); n_cand[i] = kSearchNeedsHbm when the read has more bins than the LDS table holds */
+	const uint64_t *cand_off;
 };
+static const int kSearchWaveSlots = 2048;            /* LDS table slots per read (entries <= half of them) */
+static const int kSearchWaveCand = kSearchWaveSlots; /* at most two candidates per entry, entries <= slots / 2 */
+static const int kSearchNeedsHbm = -2;
 hipError_t launch_search_count(const SearchArgs &a, hipStream_t st);
 hipError_t launch_search(const SearchArgs &a, hipStream_t st);
-hipError_t launch_search_compact(const SearchCandidate *sparse, const uint64_t *list_off, const int32_t *n_cand, const uint64_t *dst_begin,
+hipError_t launch_search_wave(const SearchArgs &a, hipStream_t st);
+/* dense[dst_begin[i] ...) = the n_cand[i] candidates of read i, which lie at sparse + src_off[i] */
+hipError_t launch_search_compact(const SearchCandidate *sparse, const uint64_t *src_off, const int32_t *n_cand, const uint64_t *dst_begin,
 		SearchCandidate *dense, int n, hipStream_t st);
 
 /* reference windows from the 4-bit genome resident in HBM (cvx_genome.hip) */

@@ -273,7 +273,8 @@ struct cvx_batch_s {
 struct cvx_search_state {
 	PinBuf h_seq, h_meta, h_out;       /* reads; offsets + lengths + list offsets + work list + dense begins; results coming back */
 	DevBuf<uint8_t> d_seq;
-	DevBuf<uint64_t> d_off, d_listoff, d_begin;
+	DevBuf<uint64_t> d_off, d_listoff, d_begin, d_srcoff;
+	PinBuf h_srcoff;
 	DevBuf<int32_t> d_len, d_ncand, d_work, d_miss;
 	DevBuf<unsigned long long> d_events;
 	DevBuf<float> d_maxhit, d_scores;
@@ -283,7 +284,7 @@ struct cvx_search_state {
 	hipEvent_t done = nullptr;
 	void release() {
 		h_seq.release(); h_meta.release(); h_out.release();
-		d_seq.release(); d_off.release(); d_listoff.release(); d_begin.release(); d_len.release(); d_ncand.release(); d_work.release(); d_miss.release();
+		d_seq.release(); d_off.release(); d_listoff.release(); d_begin.release(); d_srcoff.release(); h_srcoff.release(); d_len.release(); d_ncand.release(); d_work.release(); d_miss.release();
 		d_events.release(); d_maxhit.release(); d_scores.release(); d_rlist.release(); d_cand.release(); d_dense.release(); d_keys.release();
 		if (done) { (void) hipEventDestroy(done); done = nullptr; }
 	}
@@ -1918,47 +1919,95 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	HIP_TRY(hipMemcpyAsync(ss->d_len.p, h_len, n1 * 4, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(ss->d_miss.p, 0, n1 * 4, st));
 	HIP_TRY(hipMemsetAsync(ss->d_maxhit.p, 0, n1 * 4, st));
-	HIP_TRY(launch_search_count(a, st));
-	HIP_TRY(hipMemcpyAsync(h_events, ss->d_events.p, n1 * 8, hipMemcpyDeviceToHost, st));
-	RC_TRY(search_wait(ss, st));
+	/* Every read starts on the wave-per-read kernel (its vote table in LDS, cvx_search.hip); a read with more bins than that
+	 * table holds, or longer than its sequence buffer, is redone -- the same attempt, then the rest of the ladder -- by the
+	 * lane-per-read kernel over a table in HBM, which needs the vote count of the reads to size its lists.  Candidates of read i
+	 * lie at d_cand + src_off[i]: a fixed kSearchWaveCand entries for a wave-kernel read, the sparse region behind all of those
+	 * (two slots per vote) for the others.  CVX_TUNE_SEARCH_WAVE=0 sends every read to the HBM kernel (tests, A/B). */
+	const char *wave_env = getenv("CVX_TUNE_SEARCH_WAVE");      /* (read per call: the parity tests switch it inside one process) */
+	const bool use_wave = !(wave_env && atoi(wave_env) == 0);
+	const uint64_t fixed_total = (uint64_t) n * (uint64_t) kSearchWaveCand;
+	RC_TRY(ss->d_cand.ensure((size_t) fixed_total + 64));
+	RC_TRY(ss->d_srcoff.ensure(n1));
+	RC_TRY(ss->h_srcoff.ensure(n1 * 8));
+	uint64_t *h_srcoff = ss->h_srcoff.as<uint64_t>();
+	for (int i = 0; i < n; ++i) h_srcoff[i] = (uint64_t) i * (uint64_t) kSearchWaveCand;
+	HIP_TRY(hipMemcpyAsync(ss->d_srcoff.p, h_srcoff, n1 * 8, hipMemcpyHostToDevice, st));
+	bool counted = false;
 	uint64_t total = 0;
-	for (int i = 0; i < n; ++i) { h_listoff[i] = total; total += h_events[i]; }
-	RC_TRY(ss->d_rlist.ensure((size_t) total + 64));
-	RC_TRY(ss->d_cand.ensure((size_t) (2 * total) + 64));
-	a.rlist = ss->d_rlist.p; a.cand = ss->d_cand.p;
-	HIP_TRY(hipMemcpyAsync(ss->d_listoff.p, h_listoff, n1 * 8, hipMemcpyHostToDevice, st));
+	auto count_votes = [&]() -> int {      /* sizes of the HBM kernel's lists: votes per read (all reads: the pass is cheap) */
+		HIP_TRY(launch_search_count(a, st));
+		HIP_TRY(hipMemcpyAsync(h_events, ss->d_events.p, n1 * 8, hipMemcpyDeviceToHost, st));
+		RC_TRY(search_wait(ss, st));
+		total = 0;
+		for (int i = 0; i < n; ++i) { h_listoff[i] = total; total += h_events[i]; }
+		RC_TRY(ss->d_rlist.ensure((size_t) total + 64));
+		if (ss->d_cand.cap < (size_t) (fixed_total + 2 * total) + 64) {
+			/* (grow without losing the wave kernel's lists of this call) */
+			DevBuf<SearchCandidate> bigger;
+			RC_TRY(bigger.ensure((size_t) (fixed_total + 2 * total) + 64));
+			HIP_TRY(hipMemcpyAsync(bigger.p, ss->d_cand.p, (size_t) fixed_total * sizeof(SearchCandidate), hipMemcpyDeviceToDevice, st));
+			RC_TRY(search_wait(ss, st));
+			ss->d_cand.release();
+			ss->d_cand = bigger;
+		}
+		HIP_TRY(hipMemcpyAsync(ss->d_listoff.p, h_listoff, n1 * 8, hipMemcpyHostToDevice, st));
+		counted = true;
+		return CVX_OK;
+	};
 	/* the reference's retry ladder (CS.cpp:345-394): the current table size with a probe budget of a third of the table, then
 	 * that + 2, + 3, ... up to 2^20 entries with 0.777; first_bits = CS::c_SrchTableBitLen (16 when the thread starts; the
 	 * reference adapts it per batch, CS.cpp:482-489 -- the size only decides WHEN an attempt runs out of budget, a successful
-	 * attempt returns the same list at every size).  Reads in flight per launch bounded by the memory their vote tables take. */
+	 * attempt returns the same list at every size). */
 	const int bits0 = first_bits ? first_bits : 16;
-	std::vector<int32_t> work((size_t) n);
-	for (int i = 0; i < n; ++i) work[(size_t) i] = i;
-	for (int attempt = 0; !work.empty(); ++attempt) {
+	std::vector<int32_t> work_wave, work_hbm;
+	for (int i = 0; i < n; ++i) (use_wave ? work_wave : work_hbm).push_back(i);
+	for (int attempt = 0; !work_wave.empty() || !work_hbm.empty(); ++attempt) {
 		const int bits = attempt == 0 ? bits0 : bits0 + 1 + attempt;
 		if (bits > 20) break;
-		const size_t per_read = (size_t) 1 << bits;
-		const size_t chunk = std::max<size_t>(64, std::min<size_t>(work.size(), ((size_t) 8 << 30) / (per_read * 16)));     /* <= 8 GB of tables */
-		RC_TRY(ss->d_keys.ensure(chunk * per_read));
-		RC_TRY(ss->d_scores.ensure(chunk * per_read * 2));
 		a.bits = bits;
 		a.hpoc_factor = attempt == 0 ? 0.333f : 0.777f;
-		a.keys = ss->d_keys.p; a.scores = ss->d_scores.p; a.work = ss->d_work.p;
-		for (size_t w0 = 0; w0 < work.size(); w0 += chunk) {
-			const size_t m = std::min(chunk, work.size() - w0);
-			memcpy(h_work, work.data() + w0, m * 4);
-			HIP_TRY(hipMemcpyAsync(ss->d_work.p, h_work, m * 4, hipMemcpyHostToDevice, st));
-			HIP_TRY(hipMemsetAsync(ss->d_keys.p, 0xFF, m * per_read * 8, st));          /* every slot empty */
-			a.n_work = (int32_t) m;
-			HIP_TRY(launch_search(a, st));
-			if (w0 + chunk < work.size()) RC_TRY(search_wait(ss, st));      /* (the work list is reused by the next chunk) */
+		a.work = ss->d_work.p;
+		std::vector<int32_t> next_wave, next_hbm, hbm_now(work_hbm);
+		if (!work_wave.empty()) {
+			memcpy(h_work, work_wave.data(), work_wave.size() * 4);
+			HIP_TRY(hipMemcpyAsync(ss->d_work.p, h_work, work_wave.size() * 4, hipMemcpyHostToDevice, st));
+			a.n_work = (int32_t) work_wave.size();
+			a.cand = ss->d_cand.p; a.cand_off = ss->d_srcoff.p;
+			HIP_TRY(launch_search_wave(a, st));
+			HIP_TRY(hipMemcpyAsync(h_ncand, ss->d_ncand.p, n1 * 4, hipMemcpyDeviceToHost, st));
+			RC_TRY(search_wait(ss, st));
+			for (int32_t i : work_wave) {
+				if (h_ncand[i] == kSearchNeedsHbm) hbm_now.push_back(i);
+				else if (h_ncand[i] < 0) next_wave.push_back(i);
+			}
 		}
-		HIP_TRY(hipMemcpyAsync(h_ncand, ss->d_ncand.p, n1 * 4, hipMemcpyDeviceToHost, st));
-		RC_TRY(search_wait(ss, st));
-		std::vector<int32_t> again;
-		for (int32_t i : work) if (h_ncand[i] < 0) again.push_back(i);
-		work.swap(again);
+		if (!hbm_now.empty()) {
+			if (!counted) RC_TRY(count_votes());
+			for (int32_t i : hbm_now) h_srcoff[i] = fixed_total + 2 * h_listoff[i];
+			const size_t per_read = (size_t) 1 << bits;
+			const size_t chunk = std::max<size_t>(64, std::min<size_t>(hbm_now.size(), ((size_t) 8 << 30) / (per_read * 16)));     /* <= 8 GB of tables */
+			RC_TRY(ss->d_keys.ensure(chunk * per_read));
+			RC_TRY(ss->d_scores.ensure(chunk * per_read * 2));
+			a.keys = ss->d_keys.p; a.scores = ss->d_scores.p;
+			a.rlist = ss->d_rlist.p; a.cand = ss->d_cand.p + fixed_total;
+			for (size_t w0 = 0; w0 < hbm_now.size(); w0 += chunk) {
+				const size_t m = std::min(chunk, hbm_now.size() - w0);
+				memcpy(h_work, hbm_now.data() + w0, m * 4);
+				HIP_TRY(hipMemcpyAsync(ss->d_work.p, h_work, m * 4, hipMemcpyHostToDevice, st));
+				HIP_TRY(hipMemsetAsync(ss->d_keys.p, 0xFF, m * per_read * 8, st));          /* every slot empty */
+				a.n_work = (int32_t) m;
+				HIP_TRY(launch_search(a, st));
+				if (w0 + chunk < hbm_now.size()) RC_TRY(search_wait(ss, st));      /* (the work list is reused by the next chunk) */
+			}
+			HIP_TRY(hipMemcpyAsync(h_ncand, ss->d_ncand.p, n1 * 4, hipMemcpyDeviceToHost, st));
+			RC_TRY(search_wait(ss, st));
+			for (int32_t i : hbm_now) if (h_ncand[i] < 0) next_hbm.push_back(i);
+		}
+		work_wave.swap(next_wave);
+		work_hbm.swap(next_hbm);
 	}
+	/* (a read that left the ladder without a list keeps -1; one still flagged for the HBM kernel cannot remain: it was redone in its attempt) */
 	/* dense candidate list in read order, compacted on the device: only the entries come back (the sparse arena is
 	 * two slots per vote) */
 	uint64_t need = 0;
@@ -1976,7 +2025,8 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	if (need) {
 		RC_TRY(ss->d_dense.ensure((size_t) need + 64));
 		HIP_TRY(hipMemcpyAsync(ss->d_begin.p, h_begin, n1 * 8, hipMemcpyHostToDevice, st));
-		HIP_TRY(launch_search_compact(ss->d_cand.p, ss->d_listoff.p, ss->d_ncand.p, ss->d_begin.p, ss->d_dense.p, n, st));
+		HIP_TRY(hipMemcpyAsync(ss->d_srcoff.p, h_srcoff, n1 * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(launch_search_compact(ss->d_cand.p, ss->d_srcoff.p, ss->d_ncand.p, ss->d_begin.p, ss->d_dense.p, n, st));
 		/* (straight into the caller's memory: pageable unless it came from cvx_host_alloc, then the copy is staged by the runtime) */
 		HIP_TRY(hipMemcpyAsync(cands, ss->d_dense.p, (size_t) need * sizeof(SearchCandidate), hipMemcpyDeviceToHost, st));
 	}

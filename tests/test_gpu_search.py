@@ -19,8 +19,17 @@ def _same(got, loc, sc, rev):
         and np.array_equal(got["reverse"], rev)
 
 
+@pytest.fixture(params=["wave", "hbm"])
+def search_kernel(request, monkeypatch):
+    """Both device kernels of the vote: one wave per read with the vote table in LDS (the default; reads it cannot hold fall
+    back per read) and one lane per read with the table in HBM (CVX_TUNE_SEARCH_WAVE=0 sends every read there)."""
+    if request.param == "hbm":
+        monkeypatch.setenv("CVX_TUNE_SEARCH_WAVE", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("which", ["sample", "full"])
-def test_device_search_equals_recorded_reference_calls(hip_aligner, which):
+def test_device_search_equals_recorded_reference_calls(hip_aligner, which, search_kernel):
     path = os.path.join(util.GOLDEN, "cs_test_3.npz") if which == "sample" else util.full_golden_path("cs_test_3_full.npz")
     if path is None:
         pytest.skip("oracle/_ref/golden_full/cs_test_3_full.npz not generated")
@@ -45,7 +54,7 @@ def test_device_search_equals_recorded_reference_calls(hip_aligner, which):
     assert [int(misses[i]) for i in sample] == want_miss and max(want_miss) > 0
 
 
-def test_device_search_corners_against_the_checker(hip_aligner):
+def test_device_search_corners_against_the_checker(hip_aligner, search_kernel):
     fx, reads = util.synthetic_search_case()
     o = SearchOracle(fx)
     want = [o.search(r, cap=1 << 20) for r in reads]
