@@ -5,8 +5,51 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include <pthread.h>
+
+#ifdef CVX_IN_NGMLR_TREE
+/* Inside ngmlr the first device call of the run used to be made by the first CS thread, after the index had been built:
+ * the HIP runtime's initialisation, the first handle and the first use of every kernel (code objects are loaded on first
+ * launch) -- several hundred ms -- sat at the head of the mapping phase.  A thread started when the binary is loaded does all
+ * of that while ngmlr parses its arguments and builds or reads its index: it creates a handle, aligns one tiny tile, scores one
+ * pair and goes away.  CVX_PREWARM=0 switches it off. */
+namespace {
+struct Prewarm {
+	std::thread t;
+	/* (joined when the binary's statics go, i.e. before the HIP runtime's own: a run that ends at once -- `--help` -- must not
+	 * tear the runtime down under this thread) */
+	~Prewarm() { if (t.joinable()) t.join(); }
+	Prewarm() {
+		const char * e = getenv("CVX_PREWARM");
+		if (e && atoi(e) == 0) return;
+		t = std::thread([] {
+			cvx_params p = { 2.0f, -5.0f, -5.0f, -5.0f, -1.0f, 0.15f };
+			cvx_handle h = 0;
+			if (cvx_create(0, &p, 0, &h) != CVX_OK) return;      /* no device: the run will say so itself */
+			static const char ref[] = "ACGTTGCAAGGCTTAACCGGTTAAGGCCTTGACCATGGTACCAGTCAGTCGATCGATTGCA";
+			static const char qry[] = "ACGTTGCAAGGCTTAACCGGTTAAGGCCTTGACCATGGTACCAGTCAGTCGATCGATTGCA";
+			int32_t off[60], len[60];
+			for (int y = 0; y < 60; ++y) { off[y] = y - 16; len[y] = 32; }
+			cvx_tile t;
+			memset(&t, 0, sizeof(t));
+			t.ref = ref; t.qry = qry; t.ref_len = 60; t.qry_len = 60;
+			t.row_offset = off; t.row_length = len; t.row_stride_bytes = 4; t.corridor_kind = CVX_CORRIDOR_ROWS;
+			cvx_result r;
+			uint32_t ops[256];
+			uint64_t used = 0;
+			(void) cvx_align_batch(h, 1, &t, &r, ops, 256, &used);
+			const char * rr[1] = { ref };
+			const char * qq[1] = { qry };
+			float sc = 0.0f;
+			(void) cvx_score_batch(h, 1, rr, qq, &sc);
+			cvx_destroy(h);
+		});
+	}
+} g_prewarm;
+}
+#endif
 
 namespace Convex {
 
