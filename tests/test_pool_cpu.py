@@ -43,3 +43,24 @@ def test_pool_keeps_the_reference_sam(tmp_path, threads, contexts):
         want = [l.rstrip("\n") for l in f if l.strip() and not l.startswith("@")]
     assert sorted(got) == want and len(want) > 200
     assert "AlignPool: 142 reads on" in err, err[-600:]
+
+
+@pytest.mark.skipif(not os.path.exists(BINARY) or not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ngmlr_ref")),
+                    reason="oracle/_ref/ngmlr_pool_cpu / ngmlr_ref not built (tools/build_ngmlr_hip.sh needs /root/reference)")
+def test_pool_keeps_the_sam_of_split_reads(tmp_path):
+    """ONT-like reads with inversions / deletions / insertions (tools/e2e_rates.py write_sv_workload, -x ont): ngmlr's split-read
+    path -- several intervals and alignments per read, supplementary records -- through the alignment contexts against the
+    unmodified reference, both on the CPU aligners."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_rates
+    fa, fq = str(tmp_path / "sv_ref.fa"), str(tmp_path / "sv_reads.fq")
+    e2e_rates.write_sv_workload(fa, fq, 60, seed=78, L=1_000_000)
+    args = ["-x", "ont", "-t", "8", "-R", "0.01", "--no-progress", "-r", fa, "-q", fq]
+    res = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ngmlr_ref"), "--skip-write"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=900, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    want = _records(res.stdout)
+    got, err = _run(tmp_path, args, 96)
+    assert sorted(got) == sorted(want) and len(want) >= 60
+    assert any(int(l.split("\t")[1]) & 2048 for l in want)          # split reads among them

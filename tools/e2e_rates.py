@@ -4,6 +4,8 @@
                                            (CPU ConvexAlignFast), a private ConvexAlignHip per worker, all workers sharing
                                            one BatchingAligner (SURVEY 8 f1), and that plus the scoring plugin on the device;
                                            SAM compared with the recorded output of the unmodified reference.
+    e2e_rates.py --synthetic-sv N [threads]  ONT-like 8-30 kb reads (20 % error) with inversions / deletions / insertions against the
+                                           reference in a third of them, -x ont: ngmlr's split-read path (BASELINE.json configs[4]'s shape)
     e2e_rates.py --synthetic N [threads]   BASELINE.md section 2's workload: N synthetic PacBio-like 10 kb reads (15 % error,
                                            ins:del:sub 6:3:1, half of them reverse-complemented) on a 2 Mbp random reference;
                                            ngmlr_ref at -t nproc' (best of a few thread counts) against the batched drop-ins with
@@ -28,6 +30,46 @@ E2E = os.path.join(ROOT, "tests", "golden", "e2e")
 tmp = tempfile.mkdtemp()
 
 
+PRESET = "pacbio"      # -x preset of the runs (the SV workload uses ont)
+
+
+def write_sv_workload(path_fa, path_fq, n_reads, seed=2026, L=3_000_000):
+    """BASELINE.json configs[4]'s shape at a size a CPU reference run still finishes: ONT-like reads of 8-30 kb (20 % error,
+    ins:del:sub 4:4:2) on a random reference, a third of them carrying a structural variant against it -- an inverted segment of
+    1-3 kb, a deletion of 0.5-2 kb, or an insertion of 0.3-1 kb of foreign sequence -- so that ngmlr's split-read path runs
+    (several intervals per read, reverse-strand segments, realignment).  -> read bases"""
+    from ngmlr_amd import synth
+    rng = np.random.default_rng(seed)
+    ref = synth.random_ref(rng, L)
+    with open(path_fa, "w") as f:
+        f.write(">synthSV\n")
+        s_ = ref.tobytes().decode()
+        for i in range(0, L, 80):
+            f.write(s_[i:i + 80] + "\n")
+    bases = 0
+    with open(path_fq, "w") as f:
+        for i in range(n_reads):
+            n = int(rng.integers(8000, 30000))
+            a = int(rng.integers(0, L - n - 4000))
+            w = ref[a:a + n].copy()
+            kind = int(rng.integers(0, 6))
+            if kind == 0:                                   # inversion
+                m = int(rng.integers(1000, 3000)); p0 = int(rng.integers(2000, n - m - 2000))
+                w = np.concatenate([w[:p0], synth.revcomp(w[p0:p0 + m]), w[p0 + m:]])
+            elif kind == 1:                                 # deletion in the read
+                m = int(rng.integers(500, 2000)); p0 = int(rng.integers(2000, n - m - 2000))
+                w = np.concatenate([w[:p0], w[p0 + m:]])
+            elif kind == 2:                                 # insertion of foreign sequence
+                m = int(rng.integers(300, 1000)); p0 = int(rng.integers(2000, n - 2000))
+                w = np.concatenate([w[:p0], synth.random_ref(rng, m), w[p0:]])
+            q = synth.mutate(rng, w, 0.20, (4, 4, 2))
+            if rng.random() < 0.5:
+                q = synth.revcomp(q)
+            bases += len(q)
+            f.write("@sv%d_%d_%d\n%s\n+\n%s\n" % (i, a, kind, q.tobytes().decode(), "I" * len(q)))
+    return bases
+
+
 def run(name, t, ref, fq, extra_env=None):
     binary = os.path.join(ROOT, "oracle", "_ref", name)
     if not os.path.exists(binary):
@@ -43,7 +85,7 @@ def run(name, t, ref, fq, extra_env=None):
     cg0 = cgroup_cpu_stat()
     t0 = time.perf_counter()
     with open(out_path, "wb") as fo, open(err_path, "wb") as fe:
-        proc = subprocess.Popen([binary, "--skip-write", "-x", "pacbio", "-t", str(t), "-R", "0.01", "--no-progress", "-r", ref_copy, "-q", fq],
+        proc = subprocess.Popen([binary, "--skip-write", "-x", PRESET, "-t", str(t), "-R", "0.01", "--no-progress", "-r", ref_copy, "-q", fq],
                                 stdout=fo, stderr=fe, cwd=tmp, env=env)
         ticks = {}
         hz = os.sysconf("SC_CLK_TCK")
@@ -136,28 +178,35 @@ def effective_cores():
     return ", ".join(out)
 
 
-def synthetic(n_reads, threads):
+def synthetic(n_reads, threads, sv=False):
     from ngmlr_amd import synth
+    global PRESET
     rng = np.random.default_rng(2025)
     L = 2_000_000
-    ref = synth.random_ref(rng, L)
     fa = os.path.join(tmp, "synth_ref.fa")
-    with open(fa, "w") as f:
-        f.write(">synth2M\n")
-        s = ref.tobytes().decode()
-        for i in range(0, L, 80):
-            f.write(s[i:i + 80] + "\n")
     fq = os.path.join(tmp, "synth_reads.fq")
-    bases = 0
-    with open(fq, "w") as f:
-        for i in range(n_reads):
-            a = int(rng.integers(0, L - 11000))
-            w = ref[a:a + int(rng.integers(9000, 11000))]
-            q = synth.mutate(rng, w, 0.15, (6, 3, 1))
-            if rng.random() < 0.5:
-                q = synth.revcomp(q)
-            bases += len(q)
-            f.write("@r%d_%d\n%s\n+\n%s\n" % (i, a, q.tobytes().decode(), "I" * len(q)))
+    if sv:
+        PRESET = "ont"
+        L = 3_000_000
+        bases = write_sv_workload(fa, fq, n_reads, L=L)
+        print("SV workload (ONT-like 8-30 kb reads, 20 % error, a third with an inversion / deletion / insertion; -x ont):")
+    else:
+        ref = synth.random_ref(rng, L)
+        with open(fa, "w") as f:
+            f.write(">synth2M\n")
+            s = ref.tobytes().decode()
+            for i in range(0, L, 80):
+                f.write(s[i:i + 80] + "\n")
+        bases = 0
+        with open(fq, "w") as f:
+            for i in range(n_reads):
+                a = int(rng.integers(0, L - 11000))
+                w = ref[a:a + int(rng.integers(9000, 11000))]
+                q = synth.mutate(rng, w, 0.15, (6, 3, 1))
+                if rng.random() < 0.5:
+                    q = synth.revcomp(q)
+                bases += len(q)
+                f.write("@r%d_%d\n%s\n+\n%s\n" % (i, a, q.tobytes().decode(), "I" * len(q)))
     print("synthetic: %d reads, %.1f Mbp, reference %d bp; host has %d hardware threads, %s" % (n_reads, bases / 1e6, L, os.cpu_count(), effective_cores()))
     cores = os.cpu_count() or 8
     base = None
@@ -222,8 +271,8 @@ def test_3(threads):
 
 if __name__ == "__main__":
     args = sys.argv[1:]
-    if args and args[0] == "--synthetic":
+    if args and args[0] in ("--synthetic", "--synthetic-sv"):
         n = int(args[1]) if len(args) > 1 else 2000
-        synthetic(n, [int(x) for x in args[2:]] or [64, 256, 512])
+        synthetic(n, [int(x) for x in args[2:]] or [64, 256, 512], sv=args[0] == "--synthetic-sv")
     else:
         test_3([int(x) for x in args] or [1, 16, 64])
