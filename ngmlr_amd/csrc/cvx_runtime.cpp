@@ -357,7 +357,6 @@ struct cvx_context {
 	hipEvent_t sc_ev0 = nullptr, sc_ev1 = nullptr, sc_done = nullptr;
 	float sc_kernel_ms = 0.0f;
 	bool score_no_diag = false;   /* test knob (env CVX_TUNE_SCORE_NO_DIAG): always the row-by-row kernels */
-	uint64_t io_arena_rows = 0;   /* corridor rows (array form) of the batch uploaded last: what the corridor analysis queued on `io` will read */
 	struct cvx_search_state *search = nullptr;   /* candidate search (cvx_search_batch): persistent staging and device buffers */
 };
 
@@ -448,7 +447,6 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	b->ops_total = 0;
 	b->seq_total = L.seq_total;
 	b->n_rows = L.n_rows;
-	h->io_arena_rows = L.arena_rows;
 	memset(&b->timing, 0, sizeof(b->timing));
 	RC_TRY(b->make_events());
 	const size_t n1 = (size_t) std::max(n, 1);
@@ -1048,12 +1046,12 @@ int stage_ops(cvx_context *h, cvx_batch_s *b) {
 		 * fill's duration; two of them queued under one fill finish late and the next fill starts late: measured 150
 		 * instead of 124 ms per step with an event right behind the copy).  CVX_TUNE_OPS_EVENT=1 selects the event. */
 		HIP_TRY(hipMemcpyAsync(b->h_ops.p, b->d_dense.p, (size_t) b->ops_total * sizeof(uint32_t), hipMemcpyDeviceToHost, h->s_io));
-		/* Round 4: the pacing is needed only while the corridor analysis queued on `io` READS rows (batches whose corridors came as
-		 * arrays: 8 H bytes per tile, a handful of times); closed-form corridors are analysed in registers and the event-only form
-		 * measures the same (profiles/r04_ab.txt), so a caller with another submit pattern no longer depends on a wait placed for
-		 * this one.  CVX_TUNE_OPS_EVENT=1 / =0 force the event / the stream wait. */
-		static const int ops_event_env = getenv("CVX_TUNE_OPS_EVENT") ? atoi(getenv("CVX_TUNE_OPS_EVENT")) : -1;
-		const bool ops_event = ops_event_env >= 0 ? ops_event_env != 0 : h->io_arena_rows < (1ull << 22);
+		/* Round 4 tried to drop the pacing for closed-form batches (their corridor analysis reads nothing: 2.3 ms alone): over
+		 * 3 steps of 24 576 tiles the event-only form measured the same, over the driver's 20 steps of 49 152 tiles it costs
+		 * 146.5 instead of 118.7 ms per step (gpurun_out/r04g/pacing.txt) -- the analysis is starved beside a fill whatever it
+		 * reads (70-100 ms), and two of them queued under one fill still delay the fill after next.  The stream wait stays;
+		 * CVX_TUNE_OPS_EVENT=1 selects the event. */
+		static const bool ops_event = getenv("CVX_TUNE_OPS_EVENT") && atoi(getenv("CVX_TUNE_OPS_EVENT")) != 0;
 		if (ops_event) {
 			HIP_TRY(hipEventRecord(b->ev_ops, h->s_io));
 			HIP_TRY(hipEventSynchronize(b->ev_ops));
