@@ -260,9 +260,9 @@ def test_3(threads):
     fq = os.path.join(tmp, "test_3.fq")
     open(fq, "wb").write(gzip.open(os.path.join(E2E, "test_3_reads.fq.gz"), "rb").read())
     want = [l.rstrip("\n") for l in gzip.open(os.path.join(ROOT, "tests", "golden", "test_3.sorted.sam.gz"), "rt") if l.strip()]
-    for name in ("ngmlr_ref", "ngmlr_hip", "ngmlr_hip_batched", "ngmlr_hip_full"):
+    for name in ("ngmlr_ref", "ngmlr_hip", "ngmlr_hip_batched", "ngmlr_hip_full", "ngmlr_hip_pool", "ngmlr_hip_all"):
         for t in threads:
-            r = run(name, t, os.path.join(E2E, "test_3_reference.fasta.gz"), fq)
+            r = run(name, t, os.path.join(E2E, "test_3_reference.fasta.gz"), fq, {"CVX_POOL_CONTEXTS": "256"} if name in ("ngmlr_hip_pool", "ngmlr_hip_all") else None)
             if r is None:
                 print("%-18s not built" % name)
                 break
