@@ -324,12 +324,31 @@ def index_stage_rates(al):
     resident in HBM) and reference decode (cvx_genome_decode over the recorded 4-bit genome) -- rate of the whole call, and every
     result compared with what the unmodified reference produced for the same input (tests/golden/, tools/make_golden*.sh)."""
     from ngmlr_amd.aligner import Genome, KmerIndex
-    from oracle.pyoracle import SearchFixture
+    from types import SimpleNamespace
     out = {}
     golden = os.path.join(ROOT, "tests", "golden")
+
+    def recorded_search_calls(path):
+        """tests/golden/cs_test_3.npz (tools/make_golden_cs.sh): the k-mer table the unmodified reference searched, every recorded
+        sub-read and the LocationScore list CS::CollectResultsStd produced for it.  (A plain loader: nothing of oracle/ is used.)"""
+        z = np.load(path)
+        k = int(z["k"])
+        off = np.concatenate([[0], np.cumsum(z["seq_len"].astype(np.int64))])
+        raw = z["seqs"].tobytes()
+        seqs = [raw[int(off[i]):int(off[i + 1])] for i in range(len(z["seq_len"]))]
+        so = np.concatenate([[0], np.cumsum(z["n_scores"].astype(np.int64))])
+        want = [(z["loc"][int(so[i]):int(so[i + 1])], z["score"][int(so[i]):int(so[i + 1])], z["rev"][int(so[i]):int(so[i + 1])]) for i in range(len(seqs))]
+        # the table as ngmlr holds it: Index[4^k + 2] of 5 packed bytes (uint m_TabIndex; char m_RevCompIndex), Location[] (src/PrefixTable.h:15-31)
+        n = (1 << (2 * k)) + 2
+        cnt_full = np.zeros(n, dtype=np.int64)
+        cnt_full[z["prefix"]] = z["cnt"]
+        idx = np.zeros(n, dtype=np.dtype([("tab", "<u4"), ("rc", "i1")]))
+        idx["tab"] = (1 + np.concatenate([[0], np.cumsum(cnt_full)[:-1]])).astype(np.uint32)
+        idx["rc"][z["prefix"]] = z["rc"]
+        return SimpleNamespace(k=k, unit_offset=int(z["unit_offset"]), seqs=seqs, want=want, max_hit=z["max_hit"], locs=np.ascontiguousarray(z["locs"], dtype=np.uint32), index=idx)
     try:
-        fx = SearchFixture(os.path.join(golden, "cs_test_3.npz"))
-        idx, locs = fx.index_arrays()
+        fx = recorded_search_calls(os.path.join(golden, "cs_test_3.npz"))
+        idx, locs = fx.index, fx.locs
         ix = KmerIndex(al, fx.k, idx, locs, fx.unit_offset)
         try:
             rep_n = 16
