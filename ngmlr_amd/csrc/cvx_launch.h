@@ -70,6 +70,7 @@ static const int kSearchNeedsHbm = -2;
 hipError_t launch_search_count(const SearchArgs &a, hipStream_t st);
 hipError_t launch_search(const SearchArgs &a, hipStream_t st);
 hipError_t launch_search_wave(const SearchArgs &a, hipStream_t st);
+hipError_t launch_search_wave_hbm(const SearchArgs &a, hipStream_t st);      /* a wave per read over the real table in HBM */
 /* dense[dst_begin[i] ...) = the n_cand[i] candidates of read i, which lie at sparse + src_off[i] */
 hipError_t launch_search_compact(const SearchCandidate *sparse, const uint64_t *src_off, const int32_t *n_cand, const uint64_t *dst_begin,
 		SearchCandidate *dense, int n, hipStream_t st);

@@ -1146,6 +1146,16 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 		return CVX_ERR_NO_DEVICE;
 	}
 	HIP_TRY(hipSetDevice(device_id));
+	/* How a host thread waits for this device.  The runtime's default is to spin: hipStreamSynchronize and hipEventSynchronize
+	 * burn a core for as long as they wait -- an event created with hipEventBlockingSync included (tools/wait_probe.hip,
+	 * profiles/r04_wait_probe.txt: 50.0 ms of thread CPU per 50 ms wait in every form).  Inside ngmlr that is a core per CS
+	 * thread parked in a search or scoring call and one for the dispatcher, on a host that needs its cores for the reads'
+	 * own code.  With the device in blocking-sync mode the same waits cost 0.5 ms of CPU per 50 ms and return 0.04 ms later.
+	 * CVX_WAIT=spin keeps the runtime's default. */
+	{
+		const char *w = getenv("CVX_WAIT");
+		if (!(w && strcmp(w, "spin") == 0) && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void) hipGetLastError();
+	}
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, device_id));
 	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -1924,13 +1934,16 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	HIP_TRY(hipMemcpyAsync(ss->d_len.p, h_len, n1 * 4, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(ss->d_miss.p, 0, n1 * 4, st));
 	HIP_TRY(hipMemsetAsync(ss->d_maxhit.p, 0, n1 * 4, st));
-	/* Every read starts on the wave-per-read kernel (its vote table in LDS, cvx_search.hip); a read with more bins than that
-	 * table holds, or longer than its sequence buffer, is redone -- the same attempt, then the rest of the ladder -- by the
-	 * lane-per-read kernel over a table in HBM, which needs the vote count of the reads to size its lists.  Candidates of read i
-	 * lie at d_cand + src_off[i]: a fixed kSearchWaveCand entries for a wave-kernel read, the sparse region behind all of those
-	 * (two slots per vote) for the others.  CVX_TUNE_SEARCH_WAVE=0 sends every read to the HBM kernel (tests, A/B). */
+	/* Every read starts on the wave-per-read kernel with its vote table in LDS (cvx_search.hip); a read with more bins than that
+	 * table holds, or longer than its sequence buffer, is redone -- the same attempt, then the rest of the ladder -- by the same
+	 * kernel over the real table in HBM, which needs the vote count of the reads to size its lists.  Candidates of read i
+	 * lie at d_cand + src_off[i]: a fixed kSearchWaveCand entries for an LDS-table read, the sparse region behind all of those
+	 * (two slots per vote) for the others.  CVX_TUNE_SEARCH_WAVE=2 sends every read to the HBM-table form, =0 to the
+	 * lane-per-read kernel (one serial chain of votes per read; an independent implementation: tests, A/B). */
 	const char *wave_env = getenv("CVX_TUNE_SEARCH_WAVE");      /* (read per call: the parity tests switch it inside one process) */
-	const bool use_wave = !(wave_env && atoi(wave_env) == 0);
+	const int wave_mode = wave_env ? atoi(wave_env) : 1;
+	const bool use_wave = wave_mode == 1;
+	const bool lane_serial = wave_mode == 0;
 	const uint64_t fixed_total = (uint64_t) n * (uint64_t) kSearchWaveCand;
 	RC_TRY(ss->d_cand.ensure((size_t) fixed_total + 64));
 	RC_TRY(ss->d_srcoff.ensure(n1));
@@ -1965,6 +1978,10 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	 * reference adapts it per batch, CS.cpp:482-489 -- the size only decides WHEN an attempt runs out of budget, a successful
 	 * attempt returns the same list at every size). */
 	const int bits0 = first_bits ? first_bits : 16;
+	static const bool trace = getenv("CVX_SEARCH_TRACE") != nullptr;      /* one line per call on stderr: who ran where, for how long */
+	const std::chrono::steady_clock::time_point tr0 = std::chrono::steady_clock::now();
+	std::string tr;
+	auto tr_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
 	std::vector<int32_t> work_wave, work_hbm;
 	for (int i = 0; i < n; ++i) (use_wave ? work_wave : work_hbm).push_back(i);
 	for (int attempt = 0; !work_wave.empty() || !work_hbm.empty(); ++attempt) {
@@ -1986,6 +2003,7 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 				if (h_ncand[i] == kSearchNeedsHbm) hbm_now.push_back(i);
 				else if (h_ncand[i] < 0) next_wave.push_back(i);
 			}
+			if (trace) { char b[160]; snprintf(b, sizeof(b), " [bits %d wave %zu -> %zu to hbm, %zu retry, at %.2f ms]", bits, work_wave.size(), hbm_now.size() - work_hbm.size(), next_wave.size(), tr_ms()); tr += b; }
 		}
 		if (!hbm_now.empty()) {
 			if (!counted) RC_TRY(count_votes());
@@ -2002,12 +2020,13 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 				HIP_TRY(hipMemcpyAsync(ss->d_work.p, h_work, m * 4, hipMemcpyHostToDevice, st));
 				HIP_TRY(hipMemsetAsync(ss->d_keys.p, 0xFF, m * per_read * 8, st));          /* every slot empty */
 				a.n_work = (int32_t) m;
-				HIP_TRY(launch_search(a, st));
+				HIP_TRY(lane_serial ? launch_search(a, st) : launch_search_wave_hbm(a, st));
 				if (w0 + chunk < hbm_now.size()) RC_TRY(search_wait(ss, st));      /* (the work list is reused by the next chunk) */
 			}
 			HIP_TRY(hipMemcpyAsync(h_ncand, ss->d_ncand.p, n1 * 4, hipMemcpyDeviceToHost, st));
 			RC_TRY(search_wait(ss, st));
 			for (int32_t i : hbm_now) if (h_ncand[i] < 0) next_hbm.push_back(i);
+			if (trace) { char b[160]; snprintf(b, sizeof(b), " [bits %d hbm %zu (%llu votes in the call) -> %zu retry, at %.2f ms]", bits, hbm_now.size(), (unsigned long long) total, next_hbm.size(), tr_ms()); tr += b; }
 		}
 		work_wave.swap(next_wave);
 		work_hbm.swap(next_hbm);
@@ -2036,6 +2055,7 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 		HIP_TRY(hipMemcpyAsync(cands, ss->d_dense.p, (size_t) need * sizeof(SearchCandidate), hipMemcpyDeviceToHost, st));
 	}
 	RC_TRY(search_wait(ss, st));
+	if (trace) fprintf(stderr, "cvx_search_batch: %d reads, %llu bases, %llu candidates, %.2f ms:%s\n", n, (unsigned long long) bytes - (unsigned long long) n, (unsigned long long) need, tr_ms(), tr.c_str());
 	if (max_hit) memcpy(max_hit, h_maxhit, n1 * 4);
 	if (kmer_misses) memcpy(kmer_misses, h_miss, n1 * 4);
 	return CVX_OK;

@@ -187,154 +187,352 @@ search_kernel(const SearchArgs a) {
 }
 
 /*
- * search_wave_kernel -- one WAVE per read (round 4).  The lane-per-read kernel above keeps a read's vote table in HBM and
- * walks the read's votes as one chain of dependent global loads and stores (~1 us per link on a lane that has the memory
- * system almost to itself): a batch of a few hundred sub-reads -- what one of ngmlr's CS threads hands over per call -- is
- * seven waves chasing pointers.  Here a read owns a wave and its vote table lives in LDS:
+ * search_vote_kernel -- one WAVE per read, the votes cast 64 at a time (round 4).
  *
- *   - the reference's table of 2^bits entries is needed only for its COLLISION BEHAVIOUR (which probe step opens which
- *     entry, when the probe budget runs out): the table stays virtual, and the few hundred slots a 256-bp sub-read really
- *     occupies are kept in an LDS map  virtual slot -> (bin, forward score, reverse score, listed);  "is virtual slot e
- *     occupied, and by which bin" is one lookup in that map, so the probe sequence, the budget and with them the overflow
- *     / retry behaviour are the reference's, step by step (CS.cpp:101-149);
- *   - the k-mer walk stays serial (CSstatic.cpp:23-73 with its N rules) but only collects (position, prefix) pairs, 64 at
- *     a time; the table rows of those 64 k-mers and of their reverse complements are then looked up by 64 lanes at once
- *     (one memory round trip instead of 4 x 64 dependent ones), and the locations of a row are fetched 64 per load;
- *   - the votes are cast in the reference's order by the whole wave in lock step (every lane computes the same vote: the
- *     control flow is uniform, the LDS accesses are broadcasts), a vote costs a few LDS round trips instead of HBM ones.
+ * The lane-per-read kernel above walks a read's votes as one chain of dependent loads and stores (~1 us per link): fine for
+ * a sub-read with a few hundred votes when there are thousands of them in flight, hopeless for the sub-reads a real genome
+ * produces beside those -- one inside a repeat family or a microsatellite casts 10^4..10^5 votes (tools/e2e_rates.py
+ * --synthetic-rep: 100-900 ms for a call of 400 sub-reads, profiles/r04_e2e_rep.txt).  Here a read owns a wave, and a BATCH
+ * of 64 consecutive votes -- in the reference's order, across table rows and k-mers -- is cast by the 64 lanes at once with
+ * the sequential semantics of CS.cpp:101-149 reproduced by construction:
  *
- * A read with more bins than the LDS map holds (kSearchWaveSlots / 2; a read whose k-mers are all over the genome) is
- * flagged kSearchNeedsHbm and redone by search_kernel.  Same outputs as search_kernel; candidates at cand + cand_off[i].
+ *   - probing: every lane probes the table as it stood before the batch.  A vote's probe path consists of entries that were
+ *     occupied before the batch and ends at its own bin's entry or at the first free slot, so an earlier vote of the same
+ *     batch can change it in one way only: by opening a new entry in exactly that free slot.  Same slot, same bin: the later
+ *     vote joins the entry (a duplicate, below).  Same slot, different bin: a HAZARD -- the batch's new entries are taken
+ *     back and the batch is cast vote by vote (cast_serial; rare: the table of 2^16+ slots holds a few hundred entries);
+ *   - the probe budget (hpoc) is a sum over the votes; a batch that could exhaust it is cast serially as well, so the vote
+ *     at which the attempt overflows -- and with it kCount, the k-mers visited until then -- is the reference's;
+ *   - scores: votes of the batch for the same entry and orientation are ranked in lane order, vote j scores base + rank + 1
+ *     (float32 additions of 1.0f: exact);
+ *   - maxHitNumber before vote j is a prefix maximum over the lanes, the threshold of that moment maxHit * sensitivity in
+ *     float32; an entry enters rList at the first vote (in lane order) whose score reaches its threshold, and the order of
+ *     rList is the lane order of those votes (ballot + popcount).
+ *
+ * The k-mer walk stays serial (CSstatic.cpp:23-73 with its N rules) and collects (position, prefix) pairs 64 at a time; the
+ * table rows of those k-mers and their reverse complements are looked up by 64 lanes at once, a prefix sum over the 128 row
+ * lengths numbers the chunk's votes, and lane t of a batch finds its row by binary search and loads its location: one
+ * memory round trip per 64 votes.
+ *
+ * Two tables behind the same code (template parameter):
+ *   LdsVotes  the reference's table of 2^bits entries is needed only for its COLLISION BEHAVIOUR (which probe step opens
+ *             which entry, when the budget runs out): it stays virtual, and the slots a sub-read really occupies live in an
+ *             LDS map  virtual slot -> (bin, forward score, reverse score, listed).  A read with more bins than the map
+ *             holds (kSearchWaveSlots / 2), or longer than its sequence buffer, is flagged kSearchNeedsHbm and redone with
+ *   HbmVotes  the real table in HBM (keys / scores of search_kernel's layout), any number of bins, any read length.
+ * Same outputs as search_kernel: candidates at cand + cand_off[i] (LdsVotes) or cand + 2 * list_off[i] (HbmVotes).
  */
 namespace {
-const int kSearchWaveSeq = 4096;        /* longest read (with its NUL) the wave kernel takes; longer ones go to search_kernel */
-struct WaveTable {
-	uint32_t slot[kSearchWaveSlots];      /* virtual slot of the entry | listed << 31; 0xFFFFFFFF: free */
-	uint32_t bin_lo[kSearchWaveSlots], bin_hi[kSearchWaveSlots];
-	float f[kSearchWaveSlots], r[kSearchWaveSlots];
-	uint16_t rlist[kSearchWaveSlots / 2];
-	uint32_t c_prefix_lo[64], c_prefix_hi[64];      /* the chunk: k-mers in walk order */
+const int kSearchWaveSeq = 4096;        /* longest read (with its NUL) the LDS form takes */
+const uint32_t kFreeSlot = 0xFFFFFFFFu;
+enum { kProbeFree = 0, kProbeMatch = 1, kProbeOther = 2 };
+
+struct ChunkRows {                      /* the chunk of <= 64 k-mers being cast (LDS, both table forms) */
+	uint32_t c_prefix_lo[64], c_prefix_hi[64];      /* k-mers in walk order */
 	uint32_t c_pos[64];
-	uint32_t c_start[2][64], c_n[2][64];          /* their table rows, forward / reverse complement */
-	uint8_t seq[kSearchWaveSeq + 64];             /* the read and its NUL: the serial walk reads LDS, not HBM */
+	uint32_t c_start[2][64];                       /* where their table rows start, forward / reverse complement */
+	uint32_t row_first[129];                       /* votes before row 2 c + rev, in casting order; [128] = all of them */
+	uint16_t miss_upto[64];                        /* k-mers 0..c with neither row in the table (kCount) */
+	uint8_t scr[256];                              /* duplicate detection inside a batch */
 };
+
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, const int lane) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t u = (uint32_t) __shfl_up((int) v, d, 64); if (lane >= d) v += u; }
+	return v;
+}
+__device__ __forceinline__ float wave_incl_max(float v, const int lane) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const float u = __shfl_up(v, d, 64); if (lane >= d) v = u > v ? u : v; }
+	return v;
+}
+__device__ __forceinline__ uint64_t shfl_u64(const uint64_t v, const int src) {
+	const uint32_t lo = (uint32_t) __shfl((int) (uint32_t) v, src, 64), hi = (uint32_t) __shfl((int) (uint32_t) (v >> 32), src, 64);
+	return ((uint64_t) hi << 32) | lo;
 }
 
-__global__ void __launch_bounds__(64)
-search_wave_kernel(const SearchArgs a) {
-	__shared__ WaveTable T;
-	const int q = blockIdx.x;
-	if (q >= a.n_work) return;
-	const int lane = threadIdx.x;
-	const int i = a.work ? a.work[q] : q;
+struct LdsVotes {
+	static const bool kLds = true;
+	struct Store {
+		uint32_t slot[kSearchWaveSlots];      /* virtual slot of the entry | listed << 31; kFreeSlot: free */
+		uint32_t bin_lo[kSearchWaveSlots], bin_hi[kSearchWaveSlots];
+		float f[kSearchWaveSlots], r[kSearchWaveSlots];
+		uint16_t rlist[kSearchWaveSlots / 2];
+		uint8_t seq[kSearchWaveSeq + 64];     /* the read and its NUL: the serial walk reads LDS, not HBM */
+	};
+	Store *T;
+	int entries;
+	__device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+	__device__ int seq_at(const int p) { return T->seq[p]; }
+	/* what the virtual table holds at slot e, as far as a vote for `bin` cares */
+	__device__ int find(const uint32_t e, const uint64_t bin, int &idx, bool &listed) const {
+		static_assert(kSearchWaveSlots == 2048, "the map's hash keeps 11 bits");
+		int h = (int) ((e * 2654435761u) >> (32 - 11));
+		uint32_t sv;
+		for (;;) {
+			sv = T->slot[h];
+			if (sv == kFreeSlot || (sv & 0x7FFFFFFFu) == e) break;
+			h = (h + 1) & (kSearchWaveSlots - 1);
+		}
+		if (sv == kFreeSlot) return kProbeFree;
+		if (T->bin_lo[h] == (uint32_t) bin && T->bin_hi[h] == (uint32_t) (bin >> 32)) { idx = h; listed = (sv >> 31) != 0u; return kProbeMatch; }
+		return kProbeOther;
+	}
+	/* open (or join, when another lane of the batch just opened it) the entry of virtual slot e */
+	__device__ void claim(const uint32_t e, const uint64_t bin, int &idx, bool &creator, bool &hazard) {
+		int h = (int) ((e * 2654435761u) >> (32 - 11));
+		for (;;) {
+			const uint32_t old = atomicCAS(&T->slot[h], kFreeSlot, e);
+			if (old == kFreeSlot) { creator = true; T->bin_lo[h] = (uint32_t) bin; T->bin_hi[h] = (uint32_t) (bin >> 32); T->f[h] = 0.0f; T->r[h] = 0.0f; break; }
+			if ((old & 0x7FFFFFFFu) == e) break;
+			h = (h + 1) & (kSearchWaveSlots - 1);
+		}
+		idx = h;
+		hazard = false;         /* decided by verify() once the creators' bins are visible */
+	}
+	__device__ bool verify(const int idx, const uint64_t bin) const { return T->bin_lo[idx] == (uint32_t) bin && T->bin_hi[idx] == (uint32_t) (bin >> 32); }
+	__device__ void unclaim(const int idx, const uint32_t e) { (void) e; T->slot[idx] = kFreeSlot; }
+	__device__ float score(const int idx, const bool rev) const { return rev ? T->r[idx] : T->f[idx]; }
+	__device__ void set_score(const int idx, const bool rev, const float s) { if (rev) T->r[idx] = s; else T->f[idx] = s; }
+	__device__ void set_listed(const int idx, const uint32_t e) { T->slot[idx] = e | 0x80000000u; }
+	__device__ void list_put(const int pos, const int idx) { T->rlist[pos] = (uint16_t) idx; }
+	__device__ int list_at(const int pos) const { return T->rlist[pos]; }
+	__device__ uint64_t bin_of(const int idx) const { return ((uint64_t) T->bin_hi[idx] << 32) | T->bin_lo[idx]; }
+	__device__ float2 scores_of(const int idx) const { return make_float2(T->f[idx], T->r[idx]); }
+	__device__ bool room_for(const int n_new) const { return entries + n_new <= kSearchWaveSlots / 2; }
+};
+
+struct HbmVotes {
+	static const bool kLds = false;
+	uint64_t *keys;          /* 2^bits: bin | kListed, kEmptyKey = free (search_kernel's layout) */
+	float *fr;               /* 2 floats per slot */
+	uint32_t *rlist;
+	const uint8_t *gseq;     /* the read, seq_bytes of it readable (its NUL included) */
+	int seq_bytes;
+	uint8_t *win;            /* LDS: kSeqWindow bytes of the read around the walk's cursor */
+	int win_at;
+	int lane;
+	int entries;
+	static const int kSeqWindow = 512;
+	/* lanes of one wave share these through L2: every access is an agent-scope atomic (no stale L1 lines) */
+	__device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }
+	/* (called with the same p by every lane: the walk is uniform) */
+	__device__ int seq_at(const int p) {
+		if (p < win_at || p >= win_at + kSeqWindow) {
+			win_at = p & ~63;
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+			for (int s = lane; s < kSeqWindow; s += 64) win[s] = win_at + s < seq_bytes ? gseq[win_at + s] : (uint8_t) 0;
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+		}
+		return win[p - win_at];
+	}
+	__device__ int find(const uint32_t e, const uint64_t bin, int &idx, bool &listed) const {
+		const uint64_t key = __hip_atomic_load(&keys[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (key == kEmptyKey) return kProbeFree;
+		if ((key & ~kListed) == bin) { idx = (int) e; listed = (key & kListed) != 0ull; return kProbeMatch; }
+		return kProbeOther;
+	}
+	__device__ void claim(const uint32_t e, const uint64_t bin, int &idx, bool &creator, bool &hazard) {
+		unsigned long long expected = kEmptyKey;
+		const bool won = __hip_atomic_compare_exchange_strong((unsigned long long *) &keys[e], &expected, (unsigned long long) bin, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		idx = (int) e;
+		creator = won;
+		hazard = !won && (expected & ~kListed) != bin;
+		if (won) { __hip_atomic_store(&fr[2 * (size_t) e], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&fr[2 * (size_t) e + 1], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	}
+	__device__ bool verify(const int idx, const uint64_t bin) const { (void) idx; (void) bin; return true; }
+	__device__ void unclaim(const int idx, const uint32_t e) { (void) idx; __hip_atomic_store(&keys[e], kEmptyKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	__device__ float score(const int idx, const bool rev) const { return __hip_atomic_load(&fr[2 * (size_t) (uint32_t) idx + (rev ? 1 : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	__device__ void set_score(const int idx, const bool rev, const float s) { __hip_atomic_store(&fr[2 * (size_t) (uint32_t) idx + (rev ? 1 : 0)], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	__device__ void set_listed(const int idx, const uint32_t e) { (void) e; __hip_atomic_fetch_or((unsigned long long *) &keys[(uint32_t) idx], (unsigned long long) kListed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	__device__ void list_put(const int pos, const int idx) { rlist[pos] = (uint32_t) idx; }
+	__device__ int list_at(const int pos) const { return (int) __hip_atomic_load(&rlist[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	__device__ uint64_t bin_of(const int idx) const { return __hip_atomic_load(&keys[(uint32_t) idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~kListed; }
+	__device__ float2 scores_of(const int idx) const { return make_float2(score(idx, false), score(idx, true)); }
+	__device__ bool room_for(const int n_new) const { (void) n_new; return true; }
+};
+
+/* the running state of a read's vote (CS::RunRead's locals, CS.cpp:324-398) */
+struct VoteState {
+	long long hpoc;
+	float max_hit, thresh;
+	int rlen, misses;
+	bool overflow, too_many;
+};
+
+template <class TABLE>
+__device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, const int i, const int lane, SearchCandidate *out) {
 	const int bits = a.bits;
 	const uint32_t size = 1u << bits;
-	const uint8_t *gseq = a.seq + a.seq_off[i];
 	long long length = a.seq_len[i];
 	const int read_len = a.seq_len[i];
 	const int K = a.k;
 	const uint64_t mask = (1ull << (2 * K)) - 1ull;
-	long long hpoc = (long long) ((float) size * a.hpoc_factor);
-	float max_hit = 0.0f, thresh = 0.0f;
-	int rlen = 0, entries = 0, misses = 0;
-	bool overflow = false, too_many = false;
+	const uint64_t lt = (1ull << lane) - 1ull, gt = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+	VoteState S;
+	S.hpoc = (long long) ((float) size * a.hpoc_factor);       /* CS.cpp:352 / :379 */
+	S.max_hit = 0.0f; S.thresh = 0.0f; S.rlen = 0; S.misses = 0; S.overflow = false; S.too_many = false;
 	unsigned long long offset = 0;
-	if (read_len + 1 > kSearchWaveSeq) { if (lane == 0) a.n_cand[i] = kSearchNeedsHbm; return; }
+	int sb = 0;       /* the walk's cursor into the read (the reference's moving `sequence` pointer) */
 
-	for (int s = lane; s < kSearchWaveSlots; s += 64) T.slot[s] = 0xFFFFFFFFu;
-	for (int s = lane; s < read_len + 64; s += 64) T.seq[s] = s < read_len ? gseq[s] : (uint8_t) 0;      /* coalesced; NULs behind the read */
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-	int sb = 0;       /* the walk's cursor into T.seq (the reference's moving `sequence` pointer) */
-
-	/* every lane runs this with the same arguments (uniform control flow); lane 0 writes */
-	auto vote = [&](const uint64_t bin, const bool reverse) {
+	/* one vote, every lane with the same arguments (uniform control flow); lane 0 writes.  CS.cpp:101-149 */
+	auto vote_serial = [&](const uint64_t bin, const bool reverse) {
 		uint32_t e = (uint32_t) ((bin * 11400714819323199488ull) >> (64 - bits));
-		const uint32_t blo = (uint32_t) bin, bhi = (uint32_t) (bin >> 32);
-		int h;
-		uint32_t sv;
+		int idx = 0;
+		bool listed = false;
+		int st;
 		for (;;) {
-			/* is virtual slot e taken?  (multiplicative hash of e into the LDS map, linear probing there) */
-			h = (int) ((e * 2654435761u) >> (32 - 11));
-			static_assert(kSearchWaveSlots == 2048, "the map's hash keeps 11 bits");
-			for (;;) {
-				sv = T.slot[h];
-				if (sv == 0xFFFFFFFFu || (sv & 0x7FFFFFFFu) == e) break;
-				h = (h + 1) & (kSearchWaveSlots - 1);
-			}
-			if (sv == 0xFFFFFFFFu) break;                                   /* free in the virtual table: a new entry goes here */
-			if (T.bin_lo[h] == blo && T.bin_hi[h] == bhi) break;            /* this bin's entry */
+			st = tb.find(e, bin, idx, listed);
+			if (st != kProbeOther) break;
 			if (++e >= size) e = 0;                                         /* CS.cpp:107-114 */
-			if (--hpoc == 0) { overflow = true; return; }
+			if (--S.hpoc == 0) { S.overflow = true; return; }
 		}
 		float score = 1.0f;
-		bool listed = false;
-		if (sv == 0xFFFFFFFFu) {
-			if (entries >= kSearchWaveSlots / 2) { too_many = true; return; }
-			entries += 1;
-			if (lane == 0) { T.bin_lo[h] = blo; T.bin_hi[h] = bhi; T.f[h] = reverse ? 0.0f : 1.0f; T.r[h] = reverse ? 1.0f : 0.0f; }
+		if (st == kProbeFree) {
+			if (!tb.room_for(1)) { S.too_many = true; return; }
+			bool creator = false, hazard = false;
+			if (lane == 0) tb.claim(e, bin, idx, creator, hazard);
+			tb.fence();
+			idx = __shfl(idx, 0, 64);
+			tb.entries += 1;
+			listed = false;
 		} else {
-			listed = (sv >> 31) != 0u;
-			if (reverse) { score = T.r[h] + 1.0f; if (lane == 0) T.r[h] = score; }
-			else { score = T.f[h] + 1.0f; if (lane == 0) T.f[h] = score; }
+			score = tb.score(idx, reverse) + 1.0f;
 		}
-		if (score > max_hit) { max_hit = score; thresh = max_hit * a.sensitivity; }
-		if (!listed && score >= thresh) {
-			listed = true;
-			if (lane == 0) T.rlist[rlen] = (uint16_t) h;
-			rlen += 1;
+		if (lane == 0) tb.set_score(idx, reverse, score);
+		if (score > S.max_hit) { S.max_hit = score; S.thresh = S.max_hit * a.sensitivity; }
+		if (!listed && score >= S.thresh) {
+			if (lane == 0) { tb.list_put(S.rlen, idx); tb.set_listed(idx, e); }
+			S.rlen += 1;
 		}
-		if (lane == 0) T.slot[h] = e | (listed ? 0x80000000u : 0u);
+		tb.fence();
+	};
+
+	/* the batch's votes one by one (lane j holds vote j: bin, orientation, k-mer index in the chunk) */
+	auto cast_serial = [&](const int m, const uint64_t bin, const bool rev, const int c) {
+		for (int j = 0; j < m; ++j) {
+			vote_serial(shfl_u64(bin, j), __shfl((int) rev, j, 64) != 0);
+			if (S.overflow) { S.misses += C.miss_upto[__shfl(c, j, 64)]; return; }
+			if (S.too_many) return;
+		}
+	};
+
+	/* <= 64 consecutive votes at once; `active` lanes hold them in casting order */
+	auto cast_batch = [&](const bool active, const uint64_t bin, const bool rev, const int c) {
+		const int m = __popcll(__ballot(active));
+		/* probe the table as it stands */
+		uint32_t e = (uint32_t) ((bin * 11400714819323199488ull) >> (64 - bits));
+		uint32_t steps = 0;
+		int idx = 0, st = kProbeOther;
+		bool listed = false;
+		if (active) {
+			for (;;) {
+				st = tb.find(e, bin, idx, listed);
+				if (st != kProbeOther) break;
+				if (++e >= size) e = 0;
+				if ((long long) ++steps >= S.hpoc) break;               /* this vote alone exhausts the budget */
+			}
+		}
+		const uint32_t total_steps = (uint32_t) __shfl((int) wave_incl_sum(active ? steps : 0u, lane), 63, 64);
+		const int n_free = __popcll(__ballot(active && st == kProbeFree));
+		if ((long long) total_steps >= S.hpoc || !tb.room_for(n_free)) { cast_serial(m, bin, rev, c); return; }
+		/* new entries; two votes of the batch that open the same slot for different bins cannot be ordered here */
+		bool creator = false, hazard = false;
+		if (active && st == kProbeFree) tb.claim(e, bin, idx, creator, hazard);
+		tb.fence();
+		if (active && st == kProbeFree && !creator && !tb.verify(idx, bin)) hazard = true;
+		if (__ballot(hazard) != 0ull) {
+			if (creator) tb.unclaim(idx, e);
+			tb.fence();
+			cast_serial(m, bin, rev, c);
+			return;
+		}
+		S.hpoc -= (long long) total_steps;
+		tb.entries += __popcll(__ballot(creator));
+		/* votes of the batch for the same entry: ranked in lane order per orientation, listed once */
+		uint64_t grp_h = 1ull << lane, grp_hr = 1ull << lane;
+		if (active) C.scr[(uint32_t) idx & 255u] = (uint8_t) lane;
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+		uint64_t todo = __ballot(active && C.scr[(uint32_t) idx & 255u] != (uint8_t) lane);
+		while (todo != 0ull) {
+			const int l = __ffsll((unsigned long long) todo) - 1;
+			const int kh = __shfl(idx, l, 64);
+			const uint64_t same_h = __ballot(active && idx == kh);
+			const uint64_t same_f = __ballot(active && idx == kh && !rev);
+			if (active && idx == kh) { grp_h = same_h; grp_hr = rev ? (same_h & ~same_f) : same_f; }
+			todo &= ~same_h;
+		}
+		float s = 0.0f;
+		if (active) s = tb.score(idx, rev) + (float) (__popcll(grp_hr & lt) + 1);
+		const float pm = wave_incl_max(s, lane);
+		const float mh = pm > S.max_hit ? pm : S.max_hit;                 /* maxHitNumber right after this vote */
+		const bool qual = active && s >= mh * a.sensitivity;
+		const uint64_t qb = __ballot(qual);
+		const bool lister = qual && !listed && (qb & grp_h & lt) == 0ull;
+		const uint64_t lb = __ballot(lister);
+		if (lister) { tb.list_put(S.rlen + __popcll(lb & lt), idx); tb.set_listed(idx, e); }
+		S.rlen += __popcll(lb);
+		if (active && (grp_hr & gt) == 0ull) tb.set_score(idx, rev, s);
+		const float last = __shfl(pm, 63, 64);
+		if (last > S.max_hit) { S.max_hit = last; S.thresh = S.max_hit * a.sensitivity; }
+		tb.fence();
 	};
 
 	/* the votes of the chunk's first `cn` k-mers, in order */
 	auto cast_chunk = [&](const int cn) {
-		/* table rows of all its k-mers, both orientations: one round trip for the wave */
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      /* lane 0's chunk entries -> every lane */
+		uint32_t n0 = 0, n1 = 0;
+		bool miss = false;
 		if (lane < cn) {
-			const uint64_t pr = ((uint64_t) T.c_prefix_hi[lane] << 32) | T.c_prefix_lo[lane];
+			/* table rows of all its k-mers, both orientations: one round trip for the wave */
+			const uint64_t pr = ((uint64_t) C.c_prefix_hi[lane] << 32) | C.c_prefix_lo[lane];
 			const uint64_t rc = rev_comp13(pr, K);
 			const bool uf = a.used[pr] != 0, ur = a.used[rc] != 0;
-			uint32_t sf = 0, nf = 0, sr = 0, nr = 0;
-			if (uf) { sf = a.tab[pr] - 1u; nf = a.tab[pr + 1] - 1u - sf; }
-			if (ur) { sr = a.tab[rc] - 1u; nr = a.tab[rc + 1] - 1u - sr; }
-			T.c_start[0][lane] = sf; T.c_n[0][lane] = uf ? nf : 0xFFFFFFFFu;      /* 0xFFFFFFFF: row not in the table */
-			T.c_start[1][lane] = sr; T.c_n[1][lane] = ur ? nr : 0xFFFFFFFFu;
+			uint32_t sf = 0, sr = 0;
+			if (uf) { sf = a.tab[pr] - 1u; n0 = a.tab[pr + 1] - 1u - sf; }
+			if (ur) { sr = a.tab[rc] - 1u; n1 = a.tab[rc + 1] - 1u - sr; }
+			C.c_start[0][lane] = sf; C.c_start[1][lane] = sr;
+			miss = !uf && !ur;                  /* entries[0].refTotal == 0 (PrefixTable.cpp:489-525): kCount, CS.cpp:67-69 */
 		}
+		const uint32_t incl = wave_incl_sum(n0 + n1, lane);
+		C.row_first[2 * lane] = incl - n0 - n1;
+		C.row_first[2 * lane + 1] = incl - n1;
+		if (lane == 63) C.row_first[128] = incl;
+		C.miss_upto[lane] = (uint16_t) wave_incl_sum(miss ? 1u : 0u, lane);
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-		for (int c = 0; c < cn && !overflow && !too_many; ++c) {
-			const unsigned long long pos = T.c_pos[c];
-			const uint32_t n0 = T.c_n[0][c], n1 = T.c_n[1][c];
-			if (n0 == 0xFFFFFFFFu && n1 == 0xFFFFFFFFu) misses += 1;          /* kCount, counted before the k-mer's votes */
-			for (int rev = 0; rev < 2 && !overflow && !too_many; ++rev) {
-				const uint32_t nloc = rev ? n1 : n0;
-				if (nloc == 0xFFFFFFFFu) continue;
-				const uint32_t start = T.c_start[rev][c];
+		const uint32_t votes = C.row_first[128];
+		for (uint32_t v0 = 0; v0 < votes && !S.overflow && !S.too_many; v0 += 64) {
+			const uint32_t v = v0 + (uint32_t) lane;
+			const bool active = v < votes;
+			uint64_t bin = 0;
+			bool rev = false;
+			int c = 0;
+			if (active) {
+				int lo = 0, hi = 128;             /* the last row that starts at or before vote v (empty rows start where the next one does) */
+				while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (C.row_first[mid] <= v) lo = mid; else hi = mid; }
+				c = lo >> 1; rev = (lo & 1) != 0;
+				const unsigned long long loc = (unsigned long long) a.locs[C.c_start[lo & 1][c] + (v - C.row_first[lo])] + a.unit_offset;
+				const unsigned long long pos = C.c_pos[c];
 				const unsigned long long corr = rev ? (unsigned long long) read_len - (pos + (unsigned long long) K) : pos;
-				for (uint32_t j0 = 0; j0 < nloc && !overflow && !too_many; j0 += 64) {
-					const uint32_t m = nloc - j0 < 64u ? nloc - j0 : 64u;
-					const uint32_t mine = (uint32_t) lane < m ? a.locs[start + j0 + (uint32_t) lane] : 0u;      /* 64 locations per load */
-					for (uint32_t j = 0; j < m && !overflow && !too_many; ++j) {
-						const unsigned long long loc = (unsigned long long) (uint32_t) __shfl((int) mine, (int) j, 64) + a.unit_offset;
-						vote((loc - corr) >> a.bin_shift, rev != 0);
-					}
-				}
+				bin = (loc - corr) >> a.bin_shift;
 			}
+			cast_batch(active, bin, rev, c);
 		}
+		if (!S.overflow && !S.too_many) S.misses += C.miss_upto[63];
 	};
 
 	/* CSstatic.cpp:23-73: the walk, collecting k-mers 64 at a time */
 	int cn = 0;
 	auto push = [&](const uint64_t prefix, const unsigned long long pos) {
-		if (lane == 0) { T.c_prefix_lo[cn] = (uint32_t) prefix; T.c_prefix_hi[cn] = (uint32_t) (prefix >> 32); T.c_pos[cn] = (uint32_t) pos; }
+		if (lane == 0) { C.c_prefix_lo[cn] = (uint32_t) prefix; C.c_prefix_hi[cn] = (uint32_t) (prefix >> 32); C.c_pos[cn] = (uint32_t) pos; }
 		cn += 1;
 		if (cn == 64) { cast_chunk(64); cn = 0; }
 	};
-	for (; !overflow && !too_many;) {
+	for (; !S.overflow && !S.too_many;) {
 		if (length < K) break;
-		if (T.seq[sb] == 'N') {
+		if (tb.seq_at(sb) == 'N') {
 			int n_skip = 1;
-			while (T.seq[sb + n_skip] == 'N') ++n_skip;
+			while (tb.seq_at(sb + n_skip) == 'N') ++n_skip;
 			sb += n_skip;
 			if (n_skip >= length - K) break;
 			length -= n_skip;
@@ -343,52 +541,88 @@ search_wave_kernel(const SearchArgs a) {
 		uint64_t prefix = 0;
 		bool restart = false;
 		for (int p = 0; p < K - 1; ++p) {
-			const int ch = T.seq[sb + p];
+			const int ch = tb.seq_at(sb + p);
 			if (ch == 'N') { sb += p + 1; length -= p + 1; offset += (unsigned long long) (p + 1); restart = true; break; }
 			prefix = (prefix << 2) | (uint64_t) ((ch >> 1) & 3);
 		}
 		if (restart) continue;
-		for (int p = K - 1; p < length && !overflow && !too_many; ++p) {
-			const int ch = T.seq[sb + p];
+		for (int p = K - 1; p < length && !S.overflow && !S.too_many; ++p) {
+			const int ch = tb.seq_at(sb + p);
 			if (ch == 'N') { sb += p + 1; length -= p + 1; offset += (unsigned long long) (p + 1); restart = true; break; }
 			prefix = ((prefix << 2) | (uint64_t) ((ch >> 1) & 3)) & mask;
 			push(prefix, offset + (unsigned long long) p + 1ull - (unsigned long long) K);
 		}
 		if (!restart) break;
 	}
-	if (cn > 0 && !overflow && !too_many) cast_chunk(cn);
+	if (cn > 0 && !S.overflow && !S.too_many) cast_chunk(cn);
 
-	if (too_many) { if (lane == 0) a.n_cand[i] = kSearchNeedsHbm; return; }      /* redone by search_kernel: nothing of this attempt counts */
-	if (lane == 0 && a.kmer_misses) a.kmer_misses[i] += misses;
-	if (overflow) { if (lane == 0) a.n_cand[i] = -1; return; }
+	if (S.too_many) { if (lane == 0) a.n_cand[i] = kSearchNeedsHbm; return; }      /* redone over a table in HBM: nothing of this attempt counts */
+	/* kCount is reset per read, not per attempt (CS.cpp:338): the k-mers an overflowed attempt visited stay counted */
+	if (lane == 0 && a.kmer_misses) a.kmer_misses[i] += S.misses;
+	if (S.overflow) { if (lane == 0) a.n_cand[i] = -1; return; }
 	/* CollectResultsStd, CS.cpp:219-268: rList order, forward before reverse; 64 list entries per pass */
-	const float thr = a.min_hits > thresh ? a.min_hits : thresh;
+	const float thr = a.min_hits > S.thresh ? a.min_hits : S.thresh;
 	const unsigned long long half = a.bin_shift > 0 ? 1ull << (a.bin_shift - 1) : 0ull;
-	SearchCandidate *out = a.cand + a.cand_off[i];
 	int n = 0;
-	for (int r0 = 0; r0 < rlen; r0 += 64) {
+	for (int r0 = 0; r0 < S.rlen; r0 += 64) {
 		const int r = r0 + lane;
 		int cnt = 0;
 		float vf = 0.0f, vr = 0.0f;
 		unsigned long long bin = 0;
-		if (r < rlen) {
-			const int h = T.rlist[r];
-			vf = T.f[h]; vr = T.r[h];
-			bin = ((unsigned long long) T.bin_hi[h] << 32) | T.bin_lo[h];
+		if (r < S.rlen) {
+			const int h = tb.list_at(r);
+			const float2 sc = tb.scores_of(h);
+			vf = sc.x; vr = sc.y;
+			bin = tb.bin_of(h);
 			cnt = (vf >= thr ? 1 : 0) + (vr >= thr ? 1 : 0);
 		}
-		int incl = cnt;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const int u = __shfl_up(incl, d, 64);
-			if (lane >= d) incl += u;
-		}
+		const int incl = (int) wave_incl_sum((uint32_t) cnt, lane);
 		int at = n + incl - cnt;
-		if (vf >= thr && r < rlen) { SearchCandidate c; c.location = (bin << a.bin_shift) + half; c.score = vf; c.reverse = 0; out[at++] = c; }
-		if (vr >= thr && r < rlen) { SearchCandidate c; c.location = (bin << a.bin_shift) + half; c.score = vr; c.reverse = 1; out[at++] = c; }
+		if (vf >= thr && r < S.rlen) { SearchCandidate cd; cd.location = (bin << a.bin_shift) + half; cd.score = vf; cd.reverse = 0; out[at++] = cd; }
+		if (vr >= thr && r < S.rlen) { SearchCandidate cd; cd.location = (bin << a.bin_shift) + half; cd.score = vr; cd.reverse = 1; out[at++] = cd; }
 		n += __shfl(incl, 63, 64);
 	}
-	if (lane == 0) { a.n_cand[i] = n; a.max_hit[i] = max_hit; }
+	if (lane == 0) { a.n_cand[i] = n; a.max_hit[i] = S.max_hit; }
+}
+}  // namespace
+
+__global__ void __launch_bounds__(64)
+search_wave_kernel(const SearchArgs a) {
+	__shared__ LdsVotes::Store T;
+	__shared__ ChunkRows C;
+	const int q = blockIdx.x;
+	if (q >= a.n_work) return;
+	const int lane = threadIdx.x;
+	const int i = a.work ? a.work[q] : q;
+	const int read_len = a.seq_len[i];
+	if (read_len + 1 > kSearchWaveSeq) { if (lane == 0) a.n_cand[i] = kSearchNeedsHbm; return; }
+	const uint8_t *gseq = a.seq + a.seq_off[i];
+	for (int s = lane; s < kSearchWaveSlots; s += 64) T.slot[s] = kFreeSlot;
+	for (int s = lane; s < read_len + 64; s += 64) T.seq[s] = s < read_len ? gseq[s] : (uint8_t) 0;      /* coalesced; NULs behind the read */
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	LdsVotes tb;
+	tb.T = &T; tb.entries = 0;
+	search_vote_read(a, tb, C, i, lane, a.cand + a.cand_off[i]);
+}
+
+/* the same over the real table in HBM (table q of the launch: keys / scores as search_kernel lays them out, emptied by the host) */
+__global__ void __launch_bounds__(64)
+search_wave_hbm_kernel(const SearchArgs a) {
+	__shared__ ChunkRows C;
+	__shared__ uint8_t window[HbmVotes::kSeqWindow];
+	const int q = blockIdx.x;
+	if (q >= a.n_work) return;
+	const int lane = threadIdx.x;
+	const int i = a.work ? a.work[q] : q;
+	const size_t size = (size_t) 1 << a.bits;
+	HbmVotes tb;
+	tb.win = window; tb.win_at = -(1 << 30); tb.lane = lane; tb.seq_bytes = a.seq_len[i] + 1;
+	tb.keys = a.keys + (size_t) q * size;
+	tb.fr = a.scores + 2 * (size_t) q * size;
+	tb.rlist = a.rlist + a.list_off[i];
+	tb.gseq = a.seq + a.seq_off[i];
+	tb.entries = 0;
+	search_vote_read(a, tb, C, i, lane, a.cand + 2ull * a.list_off[i]);
 }
 
 /* dense[dst_begin[i] ...) = the n_cand[i] candidates of read i, which lie at sparse + src_off[i] */
@@ -413,6 +647,12 @@ hipError_t launch_search_compact(const SearchCandidate *sparse, const uint64_t *
 hipError_t launch_search_wave(const SearchArgs &a, hipStream_t st) {
 	if (a.n_work <= 0) return hipSuccess;
 	hipLaunchKernelGGL(search_wave_kernel, dim3(a.n_work), dim3(64), 0, st, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_search_wave_hbm(const SearchArgs &a, hipStream_t st) {
+	if (a.n_work <= 0) return hipSuccess;
+	hipLaunchKernelGGL(search_wave_hbm_kernel, dim3(a.n_work), dim3(64), 0, st, a);
 	return hipGetLastError();
 }
 

@@ -19,11 +19,14 @@ def _same(got, loc, sc, rev):
         and np.array_equal(got["reverse"], rev)
 
 
-@pytest.fixture(params=["wave", "hbm"])
+@pytest.fixture(params=["wave", "wave_hbm", "lane"])
 def search_kernel(request, monkeypatch):
-    """Both device kernels of the vote: one wave per read with the vote table in LDS (the default; reads it cannot hold fall
-    back per read) and one lane per read with the table in HBM (CVX_TUNE_SEARCH_WAVE=0 sends every read there)."""
-    if request.param == "hbm":
+    """The device kernels of the vote: one wave per read casting 64 votes at a time, with the vote table in LDS (the default; reads
+    it cannot hold fall back per read) or with the real table in HBM (CVX_TUNE_SEARCH_WAVE=2 sends every read there), and one lane
+    per read casting its votes one by one over a table in HBM (=0: an independent implementation of the same contract)."""
+    if request.param == "wave_hbm":
+        monkeypatch.setenv("CVX_TUNE_SEARCH_WAVE", "2")
+    if request.param == "lane":
         monkeypatch.setenv("CVX_TUNE_SEARCH_WAVE", "0")
     return request.param
 
@@ -39,12 +42,14 @@ def test_device_search_equals_recorded_reference_calls(hip_aligner, which, searc
     try:
         got, max_hit, misses = ix.search(fx.seqs, extras=True)
         got12 = ix.search(fx.seqs[:600], first_bits=12)        # CS::c_SrchTableBitLen adapted down (src/CS.cpp:482-489): same lists
+        got8 = ix.search(fx.seqs[:600], first_bits=8)          # ... and a table so small that every read climbs the ladder
     finally:
         ix.free()
     bad = [i for i in range(len(fx.seqs)) if not _same(got[i], *fx.want[i])]
     assert not bad, (len(bad), bad[:5])
     assert sum(len(g) for g in got) == sum(len(w[0]) for w in fx.want) > 1000
     assert all(_same(got12[i], *fx.want[i]) for i in range(len(got12)))
+    assert all(_same(got8[i], *fx.want[i]) for i in range(len(got8)))
     # maxHitNumber as the reference recorded it (MappedRead::s), kCount against the checker's restatement of src/CS.cpp:67-69
     assert np.array_equal(max_hit, fx.max_hit.astype(np.float32))
     o = SearchOracle(fx)
@@ -65,6 +70,7 @@ def test_device_search_corners_against_the_checker(hip_aligner, search_kernel):
         got, max_hit, misses = ix.search(reads, extras=True)
         got2 = ix.search(reads, sensitivity=0.5, min_kmer_hits=2.0, bin_shift=2)
         got10, max_hit10, misses10 = ix.search(reads, first_bits=10, extras=True)
+        got8, max_hit8, misses8 = ix.search(reads, first_bits=8, extras=True)
     finally:
         ix.free()
     # what CS::RunRead leaves behind beside the list: maxHitNumber, and kCount summed over the attempts of the ladder
@@ -76,6 +82,15 @@ def test_device_search_corners_against_the_checker(hip_aligner, search_kernel):
     for i, (w, g) in enumerate(zip(want10, got10)):
         assert (w["n"] < 0 and g is None) or _same(g, w["loc"], w["score"], w["rev"]), i
     assert [int(m) for m in misses10] == [w["kmer_misses"] for w in want10]
+    # 256 slots for a few hundred bins: probe paths run into each other all the time (two votes of one 64-vote batch opening the same
+    # slot for different bins, budgets running out in mid-batch) -- the wave kernels' vote-by-vote path
+    o8 = SearchOracle(fx)
+    want8 = [o8.search(r, cap=1 << 20, first_bits=8) for r in reads]
+    o8.close()
+    for i, (w, g) in enumerate(zip(want8, got8)):
+        assert (w["n"] < 0 and g is None) or _same(g, w["loc"], w["score"], w["rev"]), i
+    assert [int(m) for m in misses8] == [w["kmer_misses"] for w in want8]
+    assert [float(m) for m in max_hit8] == [float(np.float32(w["max_hit"])) for w in want8]
     assert max(w["kmer_misses"] for w in want) >= 200 and any(w["table_bits"] > 16 and w["kmer_misses"] > 0 for w in want)   # foreign k-mers, also on a read that climbed the ladder
     assert max(w["table_bits"] for w in want if w["n"] >= 0) > 16            # the retry ladder was climbed
     for i, (w, g) in enumerate(zip(want, got)):

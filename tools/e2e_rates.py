@@ -6,6 +6,8 @@
                                            SAM compared with the recorded output of the unmodified reference.
     e2e_rates.py --synthetic-sv N [threads]  ONT-like 8-30 kb reads (20 % error) with inversions / deletions / insertions against the
                                            reference in a third of them, -x ont: ngmlr's split-read path (BASELINE.json configs[4]'s shape)
+    e2e_rates.py --synthetic-rep N [threads] PacBio-like 10 kb reads on a reference with repeat families and microsatellites: several
+                                           candidate regions per sub-read, close scores (what the candidate search and MAPQ see on a real genome)
     e2e_rates.py --synthetic N [threads]   BASELINE.md section 2's workload: N synthetic PacBio-like 10 kb reads (15 % error,
                                            ins:del:sub 6:3:1, half of them reverse-complemented) on a 2 Mbp random reference;
                                            ngmlr_ref at -t nproc' (best of a few thread counts) against the batched drop-ins with
@@ -67,6 +69,49 @@ def write_sv_workload(path_fa, path_fq, n_reads, seed=2026, L=3_000_000):
                 q = synth.revcomp(q)
             bases += len(q)
             f.write("@sv%d_%d_%d\n%s\n+\n%s\n" % (i, a, kind, q.tobytes().decode(), "I" * len(q)))
+    return bases
+
+
+def write_repeat_workload(path_fa, path_fq, n_reads, seed=2027, L=3_000_000):
+    """A reference a k-mer vote has to work on: six repeat families (a 6-15 kb unit copied 8-20 times, every copy 1-4 % diverged from
+    the unit), 150 microsatellite stretches of 200-800 bp and the rest random -- sub-reads then have several candidate regions, reads
+    several scored locations with close scores (MAPQ < 60, the retry ladder of the vote tables, max-cmrs).  PacBio-like 10 kb reads,
+    a third of them started inside a repeat copy.  -> read bases"""
+    from ngmlr_amd import synth
+    rng = np.random.default_rng(seed)
+    ref = synth.random_ref(rng, L)
+    copies = []
+    for fam in range(6):
+        unit = synth.random_ref(rng, int(rng.integers(6000, 15000)))
+        for c in range(int(rng.integers(8, 21))):
+            v = synth.mutate(rng, unit, float(rng.uniform(0.01, 0.04)), (1, 1, 8))
+            a = int(rng.integers(20000, L - 40000))
+            ref[a:a + len(v)] = v
+            copies.append((a, len(v)))
+    for i in range(150):
+        motif = synth.random_ref(rng, int(rng.integers(1, 5)))
+        n = int(rng.integers(200, 800))
+        a = int(rng.integers(20000, L - 40000))
+        ref[a:a + n] = np.tile(motif, n // len(motif) + 1)[:n]
+    with open(path_fa, "w") as f:
+        f.write(">synthRep\n")
+        s_ = ref.tobytes().decode()
+        for i in range(0, L, 80):
+            f.write(s_[i:i + 80] + "\n")
+    bases = 0
+    with open(path_fq, "w") as f:
+        for i in range(n_reads):
+            n = int(rng.integers(9000, 11000))
+            if i % 3 == 0:
+                ca, cl = copies[int(rng.integers(0, len(copies)))]
+                a = max(0, min(L - n - 1, ca + int(rng.integers(-3000, max(cl - 3000, 1)))))
+            else:
+                a = int(rng.integers(0, L - n - 1))
+            q = synth.mutate(rng, ref[a:a + n], 0.15, (6, 3, 1))
+            if rng.random() < 0.5:
+                q = synth.revcomp(q)
+            bases += len(q)
+            f.write("@rep%d_%d\n%s\n+\n%s\n" % (i, a, q.tobytes().decode(), "I" * len(q)))
     return bases
 
 
@@ -148,7 +193,7 @@ def line(name, t, r, same):
         print("    " + r["pool_stats"], flush=True)
     if os.environ.get("E2E_VERBOSE"):
         for l in r["full_err"].splitlines():
-            if "library loaded" in l or "time" in l.lower() or "Done" in l:
+            if "library loaded" in l or "time" in l.lower() or "Done" in l or l.startswith("cvx_search_batch:"):
                 print("      | " + l[:200], flush=True)
 
 
@@ -178,7 +223,7 @@ def effective_cores():
     return ", ".join(out)
 
 
-def synthetic(n_reads, threads, sv=False):
+def synthetic(n_reads, threads, sv=False, rep=False):
     from ngmlr_amd import synth
     global PRESET
     rng = np.random.default_rng(2025)
@@ -190,6 +235,10 @@ def synthetic(n_reads, threads, sv=False):
         L = 3_000_000
         bases = write_sv_workload(fa, fq, n_reads, L=L)
         print("SV workload (ONT-like 8-30 kb reads, 20 % error, a third with an inversion / deletion / insertion; -x ont):")
+    elif rep:
+        L = 3_000_000
+        bases = write_repeat_workload(fa, fq, n_reads, L=L)
+        print("repeat workload (six repeat families of 8-20 diverged copies, microsatellites; PacBio-like 10 kb reads, a third from inside a copy):")
     else:
         ref = synth.random_ref(rng, L)
         with open(fa, "w") as f:
@@ -271,8 +320,8 @@ def test_3(threads):
 
 if __name__ == "__main__":
     args = sys.argv[1:]
-    if args and args[0] in ("--synthetic", "--synthetic-sv"):
+    if args and args[0] in ("--synthetic", "--synthetic-sv", "--synthetic-rep"):
         n = int(args[1]) if len(args) > 1 else 2000
-        synthetic(n, [int(x) for x in args[2:]] or [64, 256, 512], sv=args[0] == "--synthetic-sv")
+        synthetic(n, [int(x) for x in args[2:]] or [64, 256, 512], sv=args[0] == "--synthetic-sv", rep=args[0] == "--synthetic-rep")
     else:
         test_3([int(x) for x in args] or [1, 16, 64])
