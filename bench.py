@@ -368,9 +368,10 @@ def index_stage_rates(al):
         out["candidate_search"] = {
             "sub_reads": len(reads), "seconds": dt, "sub_reads_per_s": len(reads) / dt, "Gbp_per_h_of_sub_read_bases": bases / dt * 3.6e-6,
             "parity": "%d/%d lists equal to the recorded CS::RunRead calls of the unmodified reference (entries, order, maxHitNumber)" % (ok, len(reads)),
-            "bound": "latency: the votes of a sub-read are cast serially in the reference's order (the candidate list depends on that order), each vote a "
-                     "chain of dependent updates of the sub-read's vote table -- one wave per sub-read with the table's occupied slots in LDS (search_wave_kernel), "
-                     "one lane per sub-read with the table in HBM for the reads LDS cannot hold; throughput comes from sub-reads in flight -- no HBM-roofline figure applies",
+            "bound": "latency: a sub-read's candidate list depends on the order of its votes, so a sub-read stays on one wave, which casts 64 consecutive "
+                     "votes per batch with the reference's sequential semantics (search_wave_kernel: the vote table's occupied slots in LDS; the real table in "
+                     "HBM for the reads LDS cannot hold); a batch is a handful of dependent LDS / memory round trips, throughput comes from sub-reads in "
+                     "flight -- no HBM-roofline figure applies",
             "what": "cvx_search_batch_ex, whole call (reads in host memory -> candidate lists, maxHitNumber, kCount back), recorded test_3 index (k = %d, %d locations), "
                     "%d recorded sub-reads x %d" % (fx.k, len(fx.locs), n0, rep_n)}
     except Exception as e:
