@@ -113,9 +113,11 @@ struct Pool {
 			while (!(queue.empty() && busy == 0)) cvDrained.wait(lk);
 			stop = true;
 		}
+		double const drained = std::chrono::duration<double>(std::chrono::steady_clock::now() - born).count();
 		cvWork.notify_all();
 		for (std::thread & t : threads) t.join();
 		double const wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - born).count();
+		if (getenv("CVX_TIMELINE")) fprintf(stderr, "cvx timeline: AlignPool drained %.2f s after its first producer, contexts joined (SAM buffers flushed) at %.2f s\n", drained, wall);
 		fprintf(stderr, "AlignPool: %ld reads on %zu contexts (limit %d) over %.2f s: at most %ld reads in flight, %ld queued; "
 				"contexts held a read %.1f %% of their time, CS threads waited %.2f s for room in the queue\n",
 				items, threads.size(), maxContexts, wall, maxBusy, maxQueued,

@@ -20,14 +20,19 @@ struct Prewarm {
 	std::thread t;
 	/* (joined when the binary's statics go, i.e. before the HIP runtime's own: a run that ends at once -- `--help` -- must not
 	 * tear the runtime down under this thread) */
-	~Prewarm() { if (t.joinable()) t.join(); }
+	std::chrono::steady_clock::time_point const loaded = std::chrono::steady_clock::now();
+	~Prewarm() {
+		if (t.joinable()) t.join();
+		if (getenv("CVX_TIMELINE")) fprintf(stderr, "cvx timeline: the binary's statics go %.2f s after the library was loaded\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - loaded).count());
+	}
 	Prewarm() {
 		const char * e = getenv("CVX_PREWARM");
 		if (e && atoi(e) == 0) return;
-		t = std::thread([] {
+		t = std::thread([this] {
 			cvx_params p = { 2.0f, -5.0f, -5.0f, -5.0f, -1.0f, 0.15f };
 			cvx_handle h = 0;
 			if (cvx_create(0, &p, 0, &h) != CVX_OK) return;      /* no device: the run will say so itself */
+			struct Done { Prewarm * w; ~Done() { if (getenv("CVX_TIMELINE")) fprintf(stderr, "cvx timeline: device warm-up done %.2f s after the library was loaded\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - w->loaded).count()); } } done{this};
 			static const char ref[] = "ACGTTGCAAGGCTTAACCGGTTAAGGCCTTGACCATGGTACCAGTCAGTCGATCGATTGCA";
 			static const char qry[] = "ACGTTGCAAGGCTTAACCGGTTAAGGCCTTGACCATGGTACCAGTCAGTCGATCGATTGCA";
 			int32_t off[60], len[60];

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 namespace Convex {
@@ -52,6 +53,9 @@ void CandidateSearchHip::Shutdown() {
 	std::lock_guard<std::mutex> g(g_mtx);
 	if (g_instance == 0) return;
 	for (int l = 0; l < kLanes; ++l) g_laneMtx[l].lock();
+	std::chrono::steady_clock::time_point const s0 = std::chrono::steady_clock::now();
+	/* (leaving the 32 scoring and search handles to the end of the process instead saves nothing: measured, the runtime's own
+	 * teardown at exit then takes the 0.5 s these calls take, profiles/r04_timeline_e2e.txt) */
 	cvx_index_free(g_handle[0], g_instance->index);
 	for (int l = 0; l < kLanes; ++l) { cvx_destroy(g_handle[l]); g_handle[l] = 0; }
 	for (int l = 0; l < kLanes; ++l) g_laneMtx[l].unlock();
@@ -59,6 +63,7 @@ void CandidateSearchHip::Shutdown() {
 			"(%.3f ms per call, %.1f us per read)\n", g_calls.load(), g_reads.load(), g_calls.load() ? (double) g_reads.load() / (double) g_calls.load() : 0.0,
 			g_lists.load(), (double) g_ns.load() * 1e-9, g_calls.load() ? (double) g_ns.load() * 1e-6 / (double) g_calls.load() : 0.0,
 			g_reads.load() ? (double) g_ns.load() * 1e-3 / (double) g_reads.load() : 0.0);
+	if (getenv("CVX_TIMELINE")) fprintf(stderr, "cvx timeline: CandidateSearchHip freed its index and handles in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count());
 	delete g_instance;
 	g_instance = 0;
 }

@@ -2,6 +2,7 @@
 #include "stripped_sw_hip.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 #include <atomic>
 #include <chrono>

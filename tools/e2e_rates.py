@@ -193,7 +193,7 @@ def line(name, t, r, same):
         print("    " + r["pool_stats"], flush=True)
     if os.environ.get("E2E_VERBOSE"):
         for l in r["full_err"].splitlines():
-            if "library loaded" in l or "time" in l.lower() or "Done" in l or l.startswith("cvx_search_batch:"):
+            if "library loaded" in l or "time" in l.lower() or "Done" in l or l.startswith("cvx_search_batch:") or l.startswith("cvx timeline"):
                 print("      | " + l[:200], flush=True)
 
 
