@@ -162,6 +162,30 @@ def test_split_reads_with_structural_variants(built, tmp_path):
     assert "CandidateSearchHip:" in err and "AlignPool: 160 reads" in err, err[-1500:]
 
 
+def test_repeat_rich_reference(built, tmp_path):
+    """What a k-mer vote sees on a real genome: repeat families of 8-20 diverged copies and microsatellites, so that sub-reads cast
+    10^4..10^5 votes, overflow the wave kernel's LDS map (the HBM-table form runs) and reads get several close candidates (MAPQ
+    spread over 10..60).  The unmodified reference against the binary with everything on the drop-ins: every SAM record identical."""
+    import re
+    import sys
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ngmlr_ref")
+    if not os.path.exists(ref_bin) or not os.path.exists(BIN_ALL):
+        pytest.skip("oracle/_ref/ngmlr_ref / ngmlr_hip_all not built")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_rates
+    fa, fq = str(tmp_path / "rep_ref.fa"), str(tmp_path / "rep_reads.fq")
+    e2e_rates.write_repeat_workload(fa, fq, 240, seed=91)
+    args = ["-x", "pacbio", "-R", "0.01", "--no-progress", "-r", fa, "-q", fq]
+    want, _ = _run(["-t", "16"] + args, tmp_path, binary=ref_bin)
+    got, err = _run(["-t", "8"] + args, tmp_path, binary=BIN_ALL, env={"CVX_POOL_CONTEXTS": "128", "CVX_SEARCH_TRACE": "1"})
+    assert sorted(got) == sorted(want)
+    mapq = [int(l.split("\t")[4]) for l in want]
+    assert sum(1 for q in mapq if q < 40) >= 20 and sum(1 for q in mapq if q >= 40) >= 20, "the workload must produce ambiguous and unambiguous reads"
+    to_hbm = sum(int(x) for x in re.findall(r"wave \d+ -> (\d+) to hbm", err))
+    assert to_hbm >= 1, "no sub-read overflowed the LDS map: the HBM-table form of the vote did not run"
+    assert "CandidateSearchHip:" in err and "AlignPool: 240 reads" in err, err[-1500:]
+
+
 def test_binary_links_the_device_library(built):
     if not os.path.exists(BIN):
         pytest.skip("ngmlr_hip not built")
