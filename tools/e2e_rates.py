@@ -247,10 +247,11 @@ def synthetic(n_reads, threads, sv=False, rep=False):
             for i in range(0, L, 80):
                 f.write(s[i:i + 80] + "\n")
         bases = 0
+        lo, hi = [int(x) for x in os.environ.get("E2E_READ_LEN", "9000:11000").split(":")]      # E2E_READ_LEN=50000:120000: ultra-long reads
         with open(fq, "w") as f:
             for i in range(n_reads):
-                a = int(rng.integers(0, L - 11000))
-                w = ref[a:a + int(rng.integers(9000, 11000))]
+                a = int(rng.integers(0, L - hi))
+                w = ref[a:a + int(rng.integers(lo, hi))]
                 q = synth.mutate(rng, w, 0.15, (6, 3, 1))
                 if rng.random() < 0.5:
                     q = synth.revcomp(q)
