@@ -241,17 +241,26 @@ def synthetic(n_reads, threads, sv=False, rep=False):
         print("repeat workload (six repeat families of 8-20 diverged copies, microsatellites; PacBio-like 10 kb reads, a third from inside a copy):")
     else:
         ref = synth.random_ref(rng, L)
+        n_ctg = int(os.environ.get("E2E_CONTIGS", "1"))      # E2E_CONTIGS=16: the reference as 16 sequences, a fifth of the reads flush with a contig's start or end
+        clen = L // n_ctg
         with open(fa, "w") as f:
-            f.write(">synth2M\n")
             s = ref.tobytes().decode()
-            for i in range(0, L, 80):
-                f.write(s[i:i + 80] + "\n")
+            for c in range(n_ctg):
+                f.write(">synth2M\n" if n_ctg == 1 else ">ctg%d\n" % c)
+                for i in range(c * clen, (c + 1) * clen if n_ctg > 1 else L, 80):
+                    f.write(s[i:min(i + 80, (c + 1) * clen if n_ctg > 1 else L)] + "\n")
         bases = 0
         lo, hi = [int(x) for x in os.environ.get("E2E_READ_LEN", "9000:11000").split(":")]      # E2E_READ_LEN=50000:120000: ultra-long reads
         with open(fq, "w") as f:
             for i in range(n_reads):
-                a = int(rng.integers(0, L - hi))
-                w = ref[a:a + int(rng.integers(lo, hi))]
+                n = int(rng.integers(lo, hi))
+                if n_ctg == 1:
+                    a = int(rng.integers(0, L - hi))
+                else:
+                    c = int(rng.integers(0, n_ctg))
+                    edge = int(rng.integers(0, 10))
+                    a = c * clen + (0 if edge == 0 else clen - n if edge == 1 else int(rng.integers(0, clen - n)))
+                w = ref[a:a + n]
                 q = synth.mutate(rng, w, 0.15, (6, 3, 1))
                 if rng.random() < 0.5:
                     q = synth.revcomp(q)
