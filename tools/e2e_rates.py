@@ -227,7 +227,7 @@ def synthetic(n_reads, threads, sv=False, rep=False):
     from ngmlr_amd import synth
     global PRESET
     rng = np.random.default_rng(2025)
-    L = 2_000_000
+    L = int(os.environ.get("E2E_REF_LEN", "2000000"))      # (plain synthetic workload only)
     fa = os.path.join(tmp, "synth_ref.fa")
     fq = os.path.join(tmp, "synth_reads.fq")
     if sv:
