@@ -314,8 +314,9 @@ struct HbmVotes {
 	int lane;
 	int entries;
 	static const int kSeqWindow = 512;
-	/* lanes of one wave share these through L2: every access is an agent-scope atomic (no stale L1 lines) */
-	__device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }
+	/* lanes of one wave share these through L2: every access is an agent-scope atomic (no stale L1 lines), so ordering them
+	 * needs no more than the wave's own memory operations completing -- a workgroup fence; an agent-scope one would write L2 back */
+	__device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 	/* (called with the same p by every lane: the walk is uniform) */
 	__device__ int seq_at(const int p) {
 		if (p < win_at || p >= win_at + kSeqWindow) {
