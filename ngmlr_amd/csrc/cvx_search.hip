@@ -13,11 +13,14 @@
  *
  * The list a read gets depends on the ORDER of its votes (a bin enters rList when one of its scores reaches the
  * threshold of that moment, and the threshold grows with the votes), and what follows the search sorts candidates with
- * an unstable sort: a drop-in has to produce the list in the reference's order.  The vote is therefore kept serial per
- * read -- one LANE owns a read, its vote table (same multiplicative hash, same linear probing, same probe budget, so that
- * the overflow / retry behaviour is the reference's too) and its rList -- and the device's width goes into the batch:
- * hundreds of thousands of reads in flight hide the dependent loads of each.  Integer and float32 arithmetic as in the
- * reference (votes are +1.0f, the threshold is maxHitNumber * sensitivity in float32).
+ * an unstable sort: a drop-in has to produce the list in the reference's order, with the reference's vote table (same
+ * multiplicative hash, same linear probing, same probe budget, so that the overflow / retry behaviour is the reference's
+ * too).  Integer and float32 arithmetic as in the reference (votes are +1.0f, the threshold is maxHitNumber * sensitivity
+ * in float32).  Two implementations of that contract:
+ *   search_wave_kernel / search_wave_hbm_kernel   the product path: a read owns a wave, which casts 64 consecutive votes at
+ *       once with the sequential semantics reproduced by construction (further down);
+ *   search_kernel                                  round 3's form and the independent check (CVX_TUNE_SEARCH_WAVE=0): a read
+ *       owns a LANE, which casts its votes one by one over its own table in HBM -- the device's width goes into the batch.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -187,7 +190,7 @@ search_kernel(const SearchArgs a) {
 }
 
 /*
- * search_vote_kernel -- one WAVE per read, the votes cast 64 at a time (round 4).
+ * search_vote_read (search_wave_kernel, search_wave_hbm_kernel) -- one WAVE per read, the votes cast 64 at a time (round 4).
  *
  * The lane-per-read kernel above walks a read's votes as one chain of dependent loads and stores (~1 us per link): fine for
  * a sub-read with a few hundred votes when there are thousands of them in flight, hopeless for the sub-reads a real genome
