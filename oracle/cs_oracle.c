@@ -6,10 +6,11 @@
  *
  * Parity status: PINNED -- tests/test_search_cpu.py checks it against every candidate-search call recorded from
  * the unmodified reference on its own test_3 reads (tools/make_golden_cs.sh: 5 663 sub-reads, LocationScore lists
- * in the reference's own order, maxHitNumber and the threshold).  One output is NOT among the recorded fields and is
- * pinned by restatement only: kmer_misses (kCount, CS.cpp:26,67-69,221-224,338 -- in the reference a global that all CS
- * threads increment without synchronisation, so a recording at -t > 1 would not even be well defined; restated here
- * with the meaning it has for one thread).  The reference's CS class itself cannot be
+ * in the reference's own order, maxHitNumber, the threshold, and kmer_misses = kCount as the reference left it -- CS.cpp:26,
+ * 67-69,221-224,338: summed over the attempts of the retry ladder, which is why the recording also holds the table size of
+ * each read's first attempt (the reference adapts it per batch, CS.cpp:482-489: 2^8 .. 2^16 on test_3).  kCount is a global
+ * that all CS threads increment without synchronisation; the recording is a -t 1 run, where it is the read's own count, and
+ * that is the meaning restated here).  The reference's CS class itself cannot be
  * compiled on its own (it drags NGM, the task system, the read providers and the output writers along), so there
  * is no oracle/_ref build of it; the recorded calls are the anchor.
  *

@@ -225,6 +225,8 @@ class SearchFixture:
         self.want = [(z["loc"][int(so[i]):int(so[i + 1])], z["score"][int(so[i]):int(so[i + 1])], z["rev"][int(so[i]):int(so[i + 1])])
                      for i in range(len(self.seqs))]
         self.max_hit, self.thresh, self.rlist_len = z["max_hit"], z["thresh"], z["rlist_len"]
+        # kCount as the reference left it (summed over the attempts of the retry ladder) and the table size its first attempt ran with
+        self.kmer_misses, self.first_bits = z["kmer_misses"], z["first_bits"]
 
     def index_arrays(self):
         """The table as ngmlr holds it (src/PrefixTable.h:17-31 Index, packed 5 bytes: uint m_TabIndex, char m_RevCompIndex;

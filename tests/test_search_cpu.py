@@ -1,7 +1,9 @@
 """CPU: the candidate-search oracle (oracle/cs_oracle.c, a restatement of CS::RunRead: src/CS.cpp:57-149, 219-268, 324-398,
 src/CSstatic.cpp:23-73, src/PrefixTable.cpp:476-532) against every candidate-search call recorded from the unmodified
 reference on its own test_3 reads (tools/make_golden_cs.sh): the LocationScore list in the reference's own order, maxHitNumber,
-the threshold applied and the length of rList.  This is what pins the oracle the device kernel is checked against."""
+the threshold applied, the length of rList, and kCount (the k-mers found in neither orientation, summed over the attempts of the
+retry ladder -- each read searched with the table size the reference's first attempt had, which the recording holds).  This is
+what pins the oracle the device kernel is checked against."""
 import os
 
 import numpy as np
@@ -14,10 +16,15 @@ from tests import util
 def _check(fx, o, idx):
     bad = []
     for i in idx:
-        g = o.search(fx.seqs[i])
         loc, sc, rev = fx.want[i]
-        if not (g["n"] == len(loc) and np.array_equal(g["loc"], loc) and np.array_equal(g["score"], sc) and np.array_equal(g["rev"], rev)
-                and g["max_hit"] == fx.max_hit[i] and g["thresh"] == fx.thresh[i] and g["rlist_len"] == fx.rlist_len[i]):
+        # at the thread's starting table size (what the drop-in's binding uses) and at the size the reference's first attempt had:
+        # the same list either way; kCount only with the latter (it counts the failed attempts' k-mers as well)
+        for bits in (16, int(fx.first_bits[i])):
+            g = o.search(fx.seqs[i], first_bits=bits)
+            if not (g["n"] == len(loc) and np.array_equal(g["loc"], loc) and np.array_equal(g["score"], sc) and np.array_equal(g["rev"], rev)
+                    and g["max_hit"] == fx.max_hit[i] and g["thresh"] == fx.thresh[i] and g["rlist_len"] == fx.rlist_len[i]):
+                bad.append(i)
+        if g["kmer_misses"] != int(fx.kmer_misses[i]):
             bad.append(i)
     return bad
 
@@ -25,6 +32,7 @@ def _check(fx, o, idx):
 def test_oracle_reproduces_recorded_candidate_searches(built):
     fx = SearchFixture(os.path.join(util.GOLDEN, "cs_test_3.npz"))
     assert len(fx.seqs) > 900 and sum(len(w[0]) for w in fx.want) > 1000
+    assert int(fx.first_bits.min()) == 8 and int(fx.first_bits.max()) == 16 and int(fx.kmer_misses.max()) > 256      # ladder sums are in the recording
     o = SearchOracle(fx)
     assert _check(fx, o, range(len(fx.seqs))) == []
     o.close()

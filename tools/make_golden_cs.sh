@@ -3,7 +3,12 @@
 #
 # A fresh /tmp copy of /root/reference gets two pass-through recorder hooks, switched on by environment variables:
 #   CS::CollectResultsStd (src/CS.cpp:219-268)   every sub-read it was called for and the LocationScore list it produced
-#                                                 (in list order), plus maxHitNumber / the threshold it applied
+#                                                 (in list order), plus maxHitNumber / the threshold it applied, kCount -- the
+#                                                 k-mers of the read found in neither orientation, summed over the attempts of
+#                                                 the retry ladder (src/CS.cpp:26,67-69,338; a global the CS threads share: the
+#                                                 run is -t 1, where it is the read's own count) -- and the table size the
+#                                                 read's first attempt ran with (c_SrchTableBitLen at src/CS.cpp:338, which the
+#                                                 reference adapts per batch, :482-489)
 #   CompactPrefixTable::CompactPrefixTable        the k-mer table the search ran on, in compact form: the used prefixes with
 #   (src/PrefixTable.cpp:97-131)                  their slot counts and the RefTable (the 4^13 + 1 entry index is a running
 #                                                 sum over those, GetRefEntry reads nothing else: src/PrefixTable.cpp:476-532)
@@ -27,10 +32,10 @@ s = s.replace(anchor, """\tif (getenv("CVX_RECORD_CS")) {   /* recorder hook (to
 		static pthread_mutex_t cvx_m = PTHREAD_MUTEX_INITIALIZER;
 		pthread_mutex_lock(&cvx_m);
 		FILE * cf = fopen(getenv("CVX_RECORD_CS"), "ab");
-		int len = read->length, nn = index, rl = rListLength;
+		int len = read->length, nn = index, rl = rListLength, kc = kCount, fb = cvx_first_bits;
 		float mh = maxHitNumber, th = mi_Threshhold;
 		fwrite(&len, 4, 1, cf); fwrite(read->Seq, 1, (size_t) len, cf);
-		fwrite(&mh, 4, 1, cf); fwrite(&th, 4, 1, cf); fwrite(&rl, 4, 1, cf); fwrite(&nn, 4, 1, cf);
+		fwrite(&mh, 4, 1, cf); fwrite(&th, 4, 1, cf); fwrite(&rl, 4, 1, cf); fwrite(&nn, 4, 1, cf); fwrite(&kc, 4, 1, cf); fwrite(&fb, 4, 1, cf);
 		for (int q = 0; q < nn; ++q) {
 			unsigned long long l = tmp[q].Location.m_Location; float f = tmp[q].Score.f; int r = tmp[q].Location.isReverse() ? 1 : 0;
 			fwrite(&l, 8, 1, cf); fwrite(&f, 4, 1, cf); fwrite(&r, 4, 1, cf);
@@ -39,7 +44,10 @@ s = s.replace(anchor, """\tif (getenv("CVX_RECORD_CS")) {   /* recorder hook (to
 		pthread_mutex_unlock(&cvx_m);
 	}
 """ + anchor)
-s = s.replace('#include <memory.h>', '#include <memory.h>\n#include <pthread.h>', 1)
+s = s.replace('#include <memory.h>', '#include <memory.h>\n#include <pthread.h>\nstatic int cvx_first_bits = 0;   /* recorder: table size of the read\'s first attempt */', 1)
+anchor = '\tkCount = 0;'
+assert s.count(anchor) == 1
+s = s.replace(anchor, anchor + ' cvx_first_bits = c_SrchTableBitLen;   /* recorder hook */')
 open(p, 'w').write(s)
 p = src + '/PrefixTable.cpp'
 s = open(p).read()

@@ -1,6 +1,6 @@
 """tools/pack_golden_cs.py CS_DUMP TABLE_DUMP SAMPLE.npz FULL.npz -- the recorder dumps of tools/make_golden_cs.sh as fixtures:
 the k-mer table in compact form (used prefixes, slot counts, RefTable, unit offset) and the recorded candidate-search calls
-(sub-read -> LocationScore list in the reference's order, maxHitNumber, threshold).  SAMPLE keeps every `stride`-th sub-read."""
+(sub-read -> LocationScore list in the reference's order, maxHitNumber, threshold, kCount, table size of the first attempt).  SAMPLE keeps every `stride`-th sub-read."""
 import struct
 import sys
 
@@ -26,10 +26,10 @@ def read_cs(path):
     while pos < len(d):
         n, = struct.unpack_from('<i', d, pos); pos += 4
         seq = d[pos:pos + n]; pos += n
-        mh, th, rl, nn = struct.unpack_from('<ffii', d, pos); pos += 16
+        mh, th, rl, nn, kc, fb = struct.unpack_from('<ffiiii', d, pos); pos += 24
         rec = np.frombuffer(d, dtype=np.dtype([('loc', '<u8'), ('score', '<f4'), ('rev', '<i4')]), count=nn, offset=pos).copy()
         pos += 16 * nn
-        out.append((seq, mh, th, rl, rec))
+        out.append((seq, mh, th, rl, rec, kc, fb))
     return out
 
 
@@ -42,7 +42,8 @@ def pack(table, calls, out):
                         prefix=table['prefix'], tab=table['tab'], cnt=table['cnt'], rc=table['rc'], locs=table['locs'],
                         seqs=np.frombuffer(seqs, dtype=np.uint8), seq_len=lens, max_hit=np.array([c[1] for c in calls], dtype=np.float32),
                         thresh=np.array([c[2] for c in calls], dtype=np.float32), rlist_len=np.array([c[3] for c in calls], dtype=np.int32),
-                        n_scores=cnt, loc=recs['loc'], score=recs['score'], rev=recs['rev'])
+                        n_scores=cnt, loc=recs['loc'], score=recs['score'], rev=recs['rev'],
+                        kmer_misses=np.array([c[5] for c in calls], dtype=np.int32), first_bits=np.array([c[6] for c in calls], dtype=np.int32))
 
 
 if __name__ == '__main__':
