@@ -14,6 +14,10 @@
                                            many more workers than cores (reads in flight are what fills a launch); SAM of the
                                            drop-in compared with the SAM ngmlr_ref produced in this very run.
 
+Environment: E2E_POOL="[all@]t:K:target:hold_us[:ENV=v...],..." (pool binaries: CS threads, contexts, batch target / hold, extra environment),
+E2E_ONLY=binary (no reference run), E2E_QUICK / E2E_SKIP_OLD (fewer runs), E2E_VERBOSE (timeline and trace lines of the run's stderr),
+and for --synthetic: E2E_READ_LEN=lo:hi, E2E_REF_LEN=bases, E2E_CONTIGS=n (reference as n sequences, a fifth of the reads flush with a contig end).
+
 Wall clock includes ngmlr's start-up (reference encoding + index); `map` is the wall clock minus the
 index construction time ngmlr reports (thread start-up + mapping + exit).  Says how the drop-in behaves inside the real pipeline, not how fast the kernels are."""
 import gzip
