@@ -183,7 +183,11 @@ def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
     cpu = {
         "value": bases / dt * 3600.0 / 1e9,
         "unit": "Gbp/h",
-        "cores": threads,
+        # `cores` = what the host lets this job use (the cgroup quota when there is one), `threads` = the workers that
+        # ran: the box shows 256 hardware threads, allows 16 cores' worth of CPU time, and the reference is fastest on 32 threads
+        "cores": (int(round(eff["effective"])) if eff["effective"] >= 1 else 1),
+        "threads": threads,
+        "Gbp_per_h_per_core": bases / dt * 3600.0 / 1e9 / max(float(eff["effective"]), 1.0),
         "kind": kind,
         "sample": "%d of the step's tiles (%.2f Mbp, %.2e cells) in %.1f s wall on %d %s threads; host: %d hardware threads visible, %s" % (
             n_sample, bases / 1e6, cells, dt, threads, "C++ (best of a thread-count scan)" if kind == "reference" else "python", cores,
@@ -205,8 +209,9 @@ def cpu_baseline_and_parity(al, ts, results, ops, seconds_budget: float):
                     if best is None or r["value"] > best["value"]:
                         best = r
             if best is not None and best["value"] > cpu["value"]:
-                cpu["threads_in_one_process"] = {"value": cpu["value"], "cores": cpu["cores"]}
-                cpu["value"], cpu["cores"] = best["value"], best["processes"]
+                cpu["threads_in_one_process"] = {"value": cpu["value"], "threads": cpu["threads"]}
+                cpu["value"], cpu["threads"] = best["value"], best["processes"]
+                cpu["Gbp_per_h_per_core"] = best["value"] / max(float(eff["effective"]), 1.0)
                 cpu["sample"] = ("%d of the step's tiles on %d single-threaded processes in %.1f s wall (the best of: one process with the best thread "
                                  "count -- %.1f Gbp/h on %d threads, every tile of that run compared with the GPU --, and 1 process per core); %d hardware threads visible, effective cores %s"
                                  % (best["tiles"], best["processes"], best["seconds"], cpu["threads_in_one_process"]["value"], threads, cores,
@@ -292,7 +297,7 @@ def other_config(al, tiles, what, parity_n, parity_max_cells=3.0e8):
         # the reference runs on a few host threads (one checker instance each; the C call releases the interpreter lock)
         cand = [i for i in range(0, len(tiles), max(1, len(tiles) // (4 * parity_n))) if tiles[i].cells <= parity_max_cells][:parity_n]
         bad, first = 0, None
-        n_thr = max(1, min(8, len(cand)))
+        n_thr = max(1, min(16, len(cand)))
         want = [None] * len(cand)
 
         def check(k):
@@ -324,6 +329,7 @@ def index_stage_rates(al):
     resident in HBM) and reference decode (cvx_genome_decode over the recorded 4-bit genome) -- rate of the whole call, and every
     result compared with what the unmodified reference produced for the same input (tests/golden/, tools/make_golden*.sh)."""
     from ngmlr_amd.aligner import Genome, KmerIndex
+    from ngmlr_amd import capi as capi_mod
     from types import SimpleNamespace
     out = {}
     golden = os.path.join(ROOT, "tests", "golden")
@@ -357,6 +363,7 @@ def index_stage_rates(al):
             c0 = time.perf_counter()
             got, max_hit, misses = ix.search(reads, extras=True)
             dt = time.perf_counter() - c0
+            k_ms = al.stage_kernel_ms(capi_mod.STAGE_SEARCH)
         finally:
             ix.free()
         n0 = len(fx.seqs)
@@ -367,6 +374,7 @@ def index_stage_rates(al):
         bases = sum(len(x) for x in reads)
         out["candidate_search"] = {
             "sub_reads": len(reads), "seconds": dt, "sub_reads_per_s": len(reads) / dt, "Gbp_per_h_of_sub_read_bases": bases / dt * 3.6e-6,
+            "kernel_ms": k_ms, "kernel_sub_reads_per_s": len(reads) / max(k_ms * 1e-3, 1e-9),
             "parity": "%d/%d lists equal to the recorded CS::RunRead calls of the unmodified reference (entries, order, maxHitNumber)" % (ok, len(reads)),
             "bound": "latency: a sub-read's candidate list depends on the order of its votes, so a sub-read stays on one wave, which casts 64 consecutive "
                      "votes per batch with the reference's sequential semantics (search_wave_kernel: the vote table's occupied slots in LDS; the real table in "
@@ -388,12 +396,15 @@ def index_stage_rates(al):
             c0 = time.perf_counter()
             got = g.decode(pos, ln)
             dt = time.perf_counter() - c0
+            k_ms = al.stage_kernel_ms(capi_mod.STAGE_DECODE)
         finally:
             g.free()
         ok = sum(1 for k, o in enumerate(got) if o == wins[k % len(wins)][2])
         chars = float(sum(ln))
         out["reference_decode"] = {
             "windows": len(pos), "characters": int(chars), "seconds": dt, "G_chars_per_s": chars / dt * 1e-9,
+            # the kernel alone (HIP events on its stream): 0.5 B read + 1 B written per character against the 8 TB/s peak
+            "kernel_ms": k_ms, "kernel_GB_per_s": chars * 1.5 / max(k_ms * 1e-3, 1e-9) * 1e-9, "kernel_frac_of_hbm_peak": chars * 1.5 / max(k_ms * 1e-3, 1e-9) * 1e-9 / HBM_PEAK_GBS,
             "parity": "%d/%d windows byte-identical to what the unmodified reference decoded (SequenceProvider::DecodeRefSequenceExact)" % (ok, len(pos)),
             "bound": "hbm for the kernel alone (0.5 B read + 1 B written per character); the figure here is the whole call, i.e. the D2H copy of the decoded "
                      "characters into pageable memory plus python -- in the product the windows are decoded straight into the batch's sequence arena (cvx_submit_windows) and never leave HBM",
@@ -558,6 +569,8 @@ def main() -> int:
     ap.add_argument("--no-pin", action="store_true", help="keep the sequences in ordinary (pageable) memory: cvx_submit packs them into its own staging")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs (ONT mix, ultra-long + SV, short reads) reported beside the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the e2e_pipeline extra (the reference's ngmlr with every drop-in bound against the unmodified build)")
+    ap.add_argument("--e2e-reads", type=int, default=4000, help="synthetic 10 kb reads of the e2e_pipeline extra")
     ap.add_argument("--alias-device", type=int, default=-1, metavar="D",
                     help="run the --gpus N code path (N handles, N host threads, one shared pack pool; --strong too) with every handle on physical "
                          "device D: exercises the N-device path on a one-GPU box -- NOT a scaling measurement (N batches' arenas share one HBM: "
@@ -829,9 +842,9 @@ def main() -> int:
         others = None
         if extra_tiles:
             others = {}
-            for name_, what_, pn_ in (("ont", "configs[2]: ONT-like reads, 25 % error 4:4:2, tile mix median 1.3 kb up to 20 kb, widths 309-463, 10 % retries at 2x", 256),
-                                      ("ultralong_sv", "configs[4]: 100 kb reads, 95 % first-attempt anchors corridors (309+), 5 % widened to 2048 / 8192 columns or full-matrix inversion tiles", 48),
-                                      ("short", "short reads (<= 256 bp) on the linear corridor (src/AlignmentBuffer.cpp:2576-2594)", 256)):
+            for name_, what_, pn_ in (("ont", "configs[2]: ONT-like reads, 25 % error 4:4:2, tile mix median 1.3 kb up to 20 kb, widths 309-463, 10 % retries at 2x", 1024),
+                                      ("ultralong_sv", "configs[4]: 100 kb reads, 95 % first-attempt anchors corridors (309+), 5 % widened to 2048 / 8192 columns or full-matrix inversion tiles", 256),
+                                      ("short", "short reads (<= 256 bp) on the linear corridor (src/AlignmentBuffer.cpp:2576-2594)", 1024)):
                 try:
                     others[name_] = other_config(w0.al, extra_tiles[name_], what_, pn_)
                 except Exception as e:
@@ -969,6 +982,17 @@ def main() -> int:
         w.al.close()
     for ts in tilesets:
         ts.unpin()
+    if out is not None and args.gpus == 1 and not (args.no_e2e or args.no_extras or args.no_cpu_baseline):
+        # ngmlr's own pipeline (the reference's only published metric is end to end, README.md:25), outside the timed region and
+        # after this process has given its device memory back: the reference's binary built with every drop-in (oracle/_ref/ngmlr_hip_all)
+        # against the unmodified build (ngmlr_ref) on the same synthetic reads -- wall, mapping time, SAM identical, tiles per
+        # launch, launch-in-flight share, CPU seconds by thread class, peak RSS of both
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import e2e_rates
+            out["e2e_pipeline"] = e2e_rates.pipeline_summary(args.e2e_reads)
+        except Exception as e:        # never let the extra measurement break the contract line
+            out["e2e_pipeline"] = {"error": str(e)}
     if out is not None:
         print(json.dumps(out))
     if dist is not None:

@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define CVX_ABI_VERSION 5
+#define CVX_ABI_VERSION 6
 
 /* return codes */
 enum {
@@ -195,7 +195,14 @@ const char *cvx_build_id(void);
  * hipDeviceSynchronize behind the C ABI, for callers that bracket a timed region. */
 int cvx_device_synchronize(int device_id);
 
-/* max_matrix_mb: IConfig::maxMatrixSizeMB (src/IConfig.h:47), 0 -> 10000. */
+/* max_matrix_mb: IConfig::maxMatrixSizeMB (src/IConfig.h:47), 0 -> 10000.
+ *
+ * Process-wide side effects, stated here because they reach beyond the handle:
+ *   - the first cvx_create on a device puts that device into hipDeviceScheduleBlockingSync mode (host threads that wait for
+ *     it sleep instead of spinning; this also governs the host application's own HIP waits on that device).  CVX_WAIT=spin
+ *     leaves the runtime's default; a runtime that refuses the flag is reported on stderr.
+ *   - loading the library sets GPU_MAX_HW_QUEUES=8 in the environment unless the variable is already set (the HIP runtime
+ *     reads it at its first call): the streams of several handles in one process must not share hardware queues. */
 int cvx_create(int device_id, const cvx_params *params, uint64_t max_matrix_mb, cvx_handle *out);
 void cvx_destroy(cvx_handle h);
 
@@ -334,6 +341,16 @@ typedef struct {
 int cvx_index_upload(cvx_handle h, int32_t kmer_len, const void *ref_table_index, const uint32_t *ref_table, uint32_t n_locations,
 		uint64_t unit_offset, cvx_index *out);
 void cvx_index_free(cvx_handle h, cvx_index ix);
+/* One table unit built on the host from an encoded genome (cvx_genome_encode's output or ngmlr's own binRef): what
+ * CompactPrefixTable::CreateTable leaves behind (src/PrefixTable.cpp:265-352, :372-463), byte for byte -- for callers without
+ * an ngmlr at hand and for measurements on genome-sized tables (ngmlr itself builds and caches its table; production feeds
+ * that to cvx_index_upload).  start_table[i] / seq_lengths[i]: first nibble and number of bases of the i-th kept sequence;
+ * ref_skip = --kmer-skip (2), bin_shift = --bin-size (4).  ref_table_index: room for 4^kmer_len + 2 records of 5 bytes;
+ * ref_table: room for ref_table_capacity locations -- CVX_ERR_CAPACITY with *n_locations = the need when that is too few
+ * (the index records are complete by then).  Host only, one thread, ~20 ns per sampled position. */
+int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table, const uint64_t *seq_lengths, int32_t n_seqs,
+		int32_t kmer_len, int32_t ref_skip, int32_t bin_shift, void *ref_table_index, uint32_t *ref_table, uint64_t ref_table_capacity,
+		uint64_t *n_locations);
 int cvx_search_batch(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
 		float sensitivity, float min_kmer_hits, int32_t bin_shift,
 		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used);
@@ -341,6 +358,11 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 		float sensitivity, float min_kmer_hits, int32_t bin_shift, int32_t first_bits,
 		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used,
 		float *max_hit, int32_t *kmer_misses);
+
+/* attempts[i] = vote-table sizes tried for read i in the handle's last cvx_search_batch(_ex) call (ABI 6): 1 = the first attempt
+ * produced the list; more = the first attempt ran out of its probe budget -- the event CS::RunRead counts in m_Overflows
+ * (src/CS.cpp:359-364), which CS::DoRun's per-batch adaptation of the table size reads (src/CS.cpp:482-489). */
+int cvx_search_last_attempts(cvx_handle h, int32_t n, int32_t *attempts);
 
 /* Sub-read scoring: what StrippedSW::BatchScore / SingleScore return
  * (reference src/StrippedSW.cpp:118-203 over ssw.c): refs/qrys are NUL-terminated strings,
@@ -351,6 +373,12 @@ int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char
 /* duration of the scoring kernel of the handle's last cvx_score_batch (HIP events on its stream): the device-resident
  * rate, beside the rate of the whole call (strings in host memory in, scores out) */
 int cvx_score_kernel_ms(cvx_handle h, float *ms);
+/* The same for every next-row stage (ABI 6): device time of the kernels of the handle's last call of that stage, from HIP
+ * events on the stream they ran on -- CVX_STAGE_SCORE: cvx_score_batch; CVX_STAGE_DECODE: decode_windows_kernel of
+ * cvx_genome_decode; CVX_STAGE_SEARCH: every kernel of cvx_search_batch(_ex) (count, vote batches of each attempt of the
+ * ladder, compaction) summed, without the host round trips between them. */
+enum { CVX_STAGE_SCORE = 0, CVX_STAGE_DECODE = 1, CVX_STAGE_SEARCH = 2 };
+int cvx_stage_kernel_ms(cvx_handle h, int32_t stage, float *ms);
 
 /* Host-side text stage (convertCigar, src/ConvexAlignFast.cpp:112-333, and the
  * N-clip flags of :493-528).  Pure host code, no device needed. */

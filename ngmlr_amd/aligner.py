@@ -32,6 +32,13 @@ class ConvexAlignHip:
         self.h = C.c_void_p()
         capi.check(self.lib.cvx_create(device, C.byref(self.params), max_matrix_mb, C.byref(self.h)))
 
+    def stage_kernel_ms(self, stage: int) -> float:
+        """cvx_stage_kernel_ms: device time (HIP events) of the kernels of the handle's last call of a next-row stage
+        (capi.STAGE_SCORE / STAGE_DECODE / STAGE_SEARCH)."""
+        ms = C.c_float()
+        capi.check(self.lib.cvx_stage_kernel_ms(self.h, stage, C.byref(ms)))
+        return float(ms.value)
+
     def close(self) -> None:
         if getattr(self, "h", None):
             self.lib.cvx_destroy(self.h)

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CVX_LIB") or os.path.join(HERE, "libcvxalign.so")   # CVX_LIB: A/B builds while tuning
 
 CVX_OK = 0
+STAGE_SCORE, STAGE_DECODE, STAGE_SEARCH = 0, 1, 2      # cvx_stage_kernel_ms
 ERR_NAMES = {0: "CVX_OK", -1: "CVX_ERR_NO_DEVICE", -2: "CVX_ERR_PARAMS", -3: "CVX_ERR_ARG",
              -4: "CVX_ERR_OOM", -5: "CVX_ERR_HIP", -6: "CVX_ERR_CAPACITY"}
 TILE_STATUS = {0: "ok", 1: "invalid-row0", 2: "invalid-edge", 3: "invalid-length", 4: "too-large",
@@ -27,7 +28,7 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_genome_decode", "cvx_submit_windows", "cvx_job_text",
            "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id", "cvx_job_poll", "cvx_score_kernel_ms",
            "cvx_index_upload", "cvx_index_free", "cvx_search_batch", "cvx_search_batch_ex", "cvx_job_nm_profile", "cvx_job_nm_sizes", "cvx_nm_profile_ops",
-           "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch")
+           "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch", "cvx_stage_kernel_ms", "cvx_search_last_attempts", "cvx_index_build")
 
 
 class CvxParams(C.Structure):
@@ -183,6 +184,10 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_search_batch_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]
     lib.cvx_score_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.cvx_stage_kernel_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
+    lib.cvx_search_last_attempts.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.cvx_index_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.cvx_score_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p]
     lib.cvx_format_alignment.argtypes = [C.POINTER(CvxResult), C.c_void_p, C.c_char_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,

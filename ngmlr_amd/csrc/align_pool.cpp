@@ -35,12 +35,14 @@ struct Pool {
 	int maxContexts, queueLimit;
 	int idle, busy;
 	bool stop;
+	bool feedDone;          /* no producer is left (drainAndStop has begun): what is queued is all there will ever be */
+	long failed;            /* reads whose long-read stage threw (reported by the last Detach, which then throws) */
 	/* statistics */
 	long items, maxQueued, maxBusy;
 	long long producerBlockedNs, busyNs;
 	std::chrono::steady_clock::time_point born;
 
-	Pool() : maxContexts(512), queueLimit(0), idle(0), busy(0), stop(false), items(0), maxQueued(0), maxBusy(0),
+	Pool() : maxContexts(512), queueLimit(0), idle(0), busy(0), stop(false), feedDone(false), failed(0), items(0), maxQueued(0), maxBusy(0),
 			producerBlockedNs(0), busyNs(0), born(std::chrono::steady_clock::now()) {
 		if (const char * e = getenv("CVX_POOL_CONTEXTS")) maxContexts = atoi(e) > 0 ? atoi(e) : 1;
 		queueLimit = 2 * maxContexts;
@@ -64,6 +66,9 @@ struct Pool {
 			if (queue.empty()) break;      /* stop, and nothing left */
 			Item const it = queue.front();
 			queue.pop_front();
+			/* the last queued read has been taken and nobody will bring another: from here on a dispatcher must not hold a
+			 * launch back "for company" once every context that holds a read is parked (batching_aligner.cpp, shouldCut) */
+			if (feedDone && queue.empty()) SharedAligner::SetFeedActive(false);
 			busy += 1;
 			if (busy > maxBusy) maxBusy = busy;
 			lk.unlock();
@@ -72,15 +77,19 @@ struct Pool {
 			/* this thread counts as a worker of its device's dispatcher only while it holds a read: "every worker is
 			 * parked" then means every context that could still add a tile to the launch */
 			SharedAligner::ThreadBegin();
+			bool threw = false;
 			try {
 				if (it.group != 0) buffer->processLongReadLIS(it.group);
 				else buffer->processShortRead(it.read);
 			} catch (...) {
-				/* the reference would have lost the CS thread here (NGMTask::Run rethrows); a context only loses the read */
-				fprintf(stderr, "AlignPool: exception while processing a read (dropped)\n");
+				/* the reference loses the CS thread here and the run fails (NGMTask::Run logs and rethrows); a context finishes
+				 * the other reads first, then the last Detach fails the run just as loudly (it used to exit 0) */
+				fprintf(stderr, "AlignPool: exception while processing a read\n");
+				threw = true;
 			}
 			SharedAligner::ThreadEnd();
 			lk.lock();
+			if (threw) failed += 1;
 			busyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 			busy -= 1;
 			if (busy == 0 && queue.empty()) cvDrained.notify_all();
@@ -107,9 +116,12 @@ struct Pool {
 		}
 	}
 
-	void drainAndStop() {
+	/* -> reads that failed */
+	long drainAndStop() {
 		{
 			std::unique_lock<std::mutex> lk(mtx);
+			feedDone = true;
+			if (queue.empty()) SharedAligner::SetFeedActive(false);
 			while (!(queue.empty() && busy == 0)) cvDrained.wait(lk);
 			stop = true;
 		}
@@ -122,6 +134,7 @@ struct Pool {
 				"contexts held a read %.1f %% of their time, CS threads waited %.2f s for room in the queue\n",
 				items, threads.size(), maxContexts, wall, maxBusy, maxQueued,
 				threads.empty() ? 0.0 : 100.0 * (double) busyNs * 1e-9 / (wall * (double) threads.size()), (double) producerBlockedNs * 1e-9);
+		return failed;
 	}
 };
 
@@ -145,6 +158,7 @@ void AlignPool::Attach() {
 	SharedAligner::UsePoolAccounting(true);
 	if (g_pool == 0) g_pool = new Pool();
 	g_producers += 1;
+	SharedAligner::SetFeedActive(true);
 }
 
 void AlignPool::Detach() {
@@ -159,8 +173,12 @@ void AlignPool::Detach() {
 		}
 	}
 	if (last != 0) {
-		last->drainAndStop();
+		long const failed = last->drainAndStop();
 		delete last;
+		if (failed > 0) {
+			fprintf(stderr, "AlignPool: %ld read(s) failed in their long-read stage: the run is incomplete\n", failed);
+			throw "AlignPool: reads failed";      /* into NGMTask::Run of the last CS thread: logged and rethrown, as for a CS thread's own exception */
+		}
 	}
 }
 

@@ -61,7 +61,7 @@ namespace Convex {
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
 		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0),
 		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), stop(false), launches(0), requests(0), maxInFlight(0),
-		target(0), holdUs(20000), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000) {
+		target(0), holdUs(20000), feedActive(true), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000) {
 	if (const char * e = getenv("CVX_BATCH_TARGET")) target = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_HOLD_US")) holdUs = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_LEAD_US")) leadUs = atoi(e);      /* < 0: the plain timeout rule while a launch runs */
@@ -94,6 +94,14 @@ void BatchingAligner::SetBatchTarget(int targetRequests, int holdMicroseconds) {
 	holdUs = holdMicroseconds > 0 ? holdMicroseconds : 0;
 }
 
+void BatchingAligner::SetFeedActive(bool active) {
+	{
+		std::lock_guard<std::mutex> lk(mtx);
+		feedActive = active;
+	}
+	cvDispatch.notify_all();
+}
+
 void BatchingAligner::WorkerJoined() {
 	std::lock_guard<std::mutex> lk(mtx);
 	workers += 1;
@@ -113,7 +121,10 @@ bool BatchingAligner::shouldCut(bool deviceIdle) const {
 		/* Many more contexts than cores (align_pool.h): the host stages, not the device, bound the throughput, a launch
 		 * lasts about as long as its slowest tile whatever it carries, and every launch costs the dispatcher, the pack
 		 * threads and `its` workers' wake-ups the same -- so a request may wait for company while other contexts keep
-		 * the cores busy.  Bounded by holdUs, and never when nobody is left to add to the launch (rule above). */
+		 * the cores busy.  Bounded by holdUs -- and over at once when nobody is left to add to the launch: every worker that
+		 * holds a read is parked and the pool has no producer and no queued read any more (the tail of a run, sparse input;
+		 * each of a read's dependent intervals paid the full hold there: ADVICE r4). */
+		if (!feedActive && parked >= workers) return true;
 		return now - oldest >= std::chrono::microseconds(holdUs);
 	}
 	if (deviceIdle) return true;                             /* nothing to overlap with: latency first */
@@ -286,12 +297,18 @@ double g_lastParked = 0.0, g_lastFinish = 0.0, g_lastBusy = 0.0;
 std::chrono::steady_clock::time_point g_firstJoin;
 std::chrono::steady_clock::time_point const g_loaded = std::chrono::steady_clock::now();      /* ~ process start */
 bool g_poolAccounting = false;                       /* under g_sharedMtx */
+bool g_feedActive = true;                            /* under g_sharedMtx: handed to dispatchers created later */
 thread_local BatchingAligner * tl_dispatcher = 0;    /* the dispatcher of the SharedAligner this thread constructed (pool accounting) */
 }
 
 void SharedAligner::UsePoolAccounting(bool on) {
 	std::lock_guard<std::mutex> g(g_sharedMtx);
 	g_poolAccounting = on;
+}
+void SharedAligner::SetFeedActive(bool active) {
+	std::lock_guard<std::mutex> g(g_sharedMtx);
+	g_feedActive = active;
+	for (int d = 0; d < kMaxDevices; ++d) if (g_shared[d]) g_shared[d]->SetFeedActive(active);
 }
 void SharedAligner::ThreadBegin() { if (tl_dispatcher) tl_dispatcher->WorkerJoined(); }
 void SharedAligner::ThreadEnd() { if (tl_dispatcher) tl_dispatcher->WorkerDone(); }
@@ -320,6 +337,7 @@ SharedAligner::SharedAligner(int const stdOutMode, float const match, float cons
 		/* with alignment contexts off the CS threads (align_pool.h) a launch waits for 256 tiles, 30 ms at most: hundreds of
 		 * contexts hide that wait, and the device sees a few large launches instead of many small ones (CVX_BATCH_TARGET /
 		 * CVX_BATCH_HOLD_US override) */
+		g_shared[device]->SetFeedActive(g_feedActive);
 		if (perRead && !getenv("CVX_BATCH_TARGET")) g_shared[device]->SetBatchTarget(256, getenv("CVX_BATCH_HOLD_US") ? atoi(getenv("CVX_BATCH_HOLD_US")) : 30000);
 	}
 	if (perRead) tl_dispatcher = g_shared[device];

@@ -18,7 +18,8 @@
  *                   or   every registered worker is parked (nobody else can add to it),
  *                   or   (only with a batch target, CVX_BATCH_TARGET > 0: many more alignment contexts than cores,
  *                        align_pool.h) -- while fewer than `target` requests wait, only once the oldest has waited
- *                        holdUs (CVX_BATCH_HOLD_US); from `target` requests on the rules below apply,
+ *                        holdUs (CVX_BATCH_HOLD_US), or at once when every registered worker is parked and nobody is left
+ *                        to feed the contexts (SetFeedActive(false)); from `target` requests on the rules below apply,
  *                   or   the oldest request has waited timeoutUs (while no launch has been timed yet), resp. the launch
  *                        that is running is expected to end within leadUs (the time an upload + corridor analysis
  *                        take: what arrives before that travels for free),
@@ -74,6 +75,10 @@ public:
 	void WorkerJoined();
 	/* batch target of the dispatcher (see the rules above; 0 = none); before the first request */
 	void SetBatchTarget(int targetRequests, int holdMicroseconds);
+	/* whether anybody outside the registered workers may still bring requests (align_pool.h: CS threads attached, or reads
+	 * queued for a context).  While that is so a launch below the batch target waits for company up to holdUs; once it is
+	 * not, "every registered worker is parked" cuts the launch at once (tail of a run, sparse input: ADVICE r4) */
+	void SetFeedActive(bool active);
 
 	/* statistics */
 	long Launches() const { return launches; }
@@ -118,6 +123,7 @@ private:
 	int timeoutUs;
 	int target;                                 /* batch target (CVX_BATCH_TARGET, 0 = none) and how long the oldest request may */
 	int holdUs;                                 /* wait for it (CVX_BATCH_HOLD_US) */
+	bool feedActive;                            /* see SetFeedActive (true until told otherwise) */
 	bool stop;
 	long launches, requests, maxInFlight;
 	long long parkedNs, finishNs, busyNs;       /* under mtx */
@@ -175,6 +181,8 @@ public:
 	static void UsePoolAccounting(bool on);
 	static void ThreadBegin();
 	static void ThreadEnd();
+	/* the pool's producers are gone and its queue is empty (false) / a producer attached (true): passed on to every dispatcher */
+	static void SetFeedActive(bool active);
 
 private:
 	BatchingAligner * shared;

@@ -70,7 +70,7 @@ void CandidateSearchHip::Shutdown() {
 
 void CandidateSearchHip::Search(Batch & b, float sensitivity, float minKmerHits, int binShift, int firstTableBits) {
 	size_t const n = b.seqs.size();
-	b.nCand.assign(n, 0); b.begin.assign(n, 0); b.maxHit.assign(n, 0.0f); b.kmerMisses.assign(n, 0);
+	b.nCand.assign(n, 0); b.begin.assign(n, 0); b.maxHit.assign(n, 0.0f); b.kmerMisses.assign(n, 0); b.attempts.assign(n, 1);
 	if (n == 0) return;
 	if (tl_lane < 0) tl_lane = g_nextLane.fetch_add(1) % kLanes;
 	std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
@@ -88,6 +88,7 @@ void CandidateSearchHip::Search(Batch & b, float sensitivity, float minKmerHits,
 			fprintf(stderr, "CandidateSearchHip: %s\n", cvx_last_error());
 			throw 1;
 		}
+		(void) cvx_search_last_attempts(g_handle[tl_lane], (int32_t) n, b.attempts.data());
 		break;
 	}
 	g_calls += 1; g_reads += (long) n; g_lists += (long) used;

@@ -44,6 +44,7 @@ public:
 		std::vector<cvx_candidate> cands;    /* (location, score, reverse) in the order CollectResultsStd produces */
 		std::vector<float> maxHit;           /* maxHitNumber -> MappedRead::s */
 		std::vector<int32_t> kmerMisses;     /* kCount: k-mers of the read the table knows in neither orientation */
+		std::vector<int32_t> attempts;       /* table sizes tried: > 1 = the first attempt overflowed (CS::m_Overflows counts those) */
 	};
 	/* throws 1 on a device error */
 	void Search(Batch & b, float sensitivity, float minKmerHits, int binShift, int firstTableBits = 16);

@@ -7,6 +7,9 @@
  * builds from its own test genomes (tests/test_decode_cpu.py, fixtures from tools/make_golden.sh).
  */
 #include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
 
 #include "cvx_align.h"
 
@@ -60,6 +63,163 @@ int cvx_genome_encode(int32_t n, const char *const *seqs, const uint64_t *length
 	if (kept == 0) { *n_starts = 0; return CVX_ERR_ARG; }
 	start_table[kept] = start_table[kept - 1] + last_len + 1000;   /* upper bound for positions on the last sequence */
 	*n_starts = kept + 1;
+	return CVX_OK;
+}
+
+/*
+ * cvx_index_build -- one unit of ngmlr's k-mer table from the encoded genome, on the host: what
+ * CompactPrefixTable::CreateTable leaves in TableUnit::RefTableIndex / RefTable (reference src/PrefixTable.cpp:324-352:
+ * createRefTableIndex :265-322 over CountKmerFreq / CountKmer :199-226, 372-393; Generate / BuildPrefixTable /
+ * SaveToRefTable :228-263, 405-463; the walk over a sequence is CS::PrefixIteration, src/CSstatic.cpp:23-73).  The
+ * library does not need it in production -- ngmlr builds (and caches) its own table and cvx_index_upload takes that --
+ * but a table the size of a real genome's is needed to measure the device search where its accesses miss every cache,
+ * and ngmlr takes minutes to build one.  Restated with the reference's quirks, all of which shape the table:
+ *   - a sequence is decoded with DecodeRefSequence(seq, id, start, len) into a buffer of len bytes, which decodes len - 2
+ *     characters (:569), turns the last of them into 'x' when that count is odd (:609-611) and leaves the rest NUL; the walk
+ *     then runs over all len bytes and encodes every byte that is not 'N' as (c >> 1) & 3 -- 'x' and NUL count as A;
+ *   - of a run of equal k-mers at consecutive sampled positions only the first one per bin (position >> bin_shift) is
+ *     kept (lastPrefix / lastBin, reset per sequence and by every other k-mer);
+ *   - a k-mer is indexed while it and its reverse complement occur fewer than 1000 times together, its weight byte is
+ *     (char) ((1000 - total) * 100.0f / 1000) -- which is 0, i.e. "unused", from 991 occurrences on although the slots
+ *     stay reserved.
+ * Pinned byte for byte against the table the unmodified reference writes to <ref>-ht-13-2.2.ngm (tests/test_index_cpu.py).
+ */
+int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table, const uint64_t *seq_lengths, int32_t n_seqs,
+		int32_t kmer_len, int32_t ref_skip, int32_t bin_shift, void *ref_table_index, uint32_t *ref_table, uint64_t ref_table_capacity,
+		uint64_t *n_locations) {
+	if (!bin_ref || !start_table || !seq_lengths || n_seqs <= 0 || kmer_len < 4 || kmer_len > 15 || ref_skip < 0 || bin_shift < 0 || bin_shift > 30 ||
+			!ref_table_index || !n_locations) return CVX_ERR_ARG;
+	const uint64_t n_prefix = 1ull << (2 * kmer_len);
+	const uint64_t length = n_prefix + 1;                 /* indexLength (:102) */
+	const uint64_t mask = n_prefix - 1;
+	const int kMaxFreq = 1000;                            /* CompactPrefixTable::maxPrefixFreq (:28) */
+	static const char dec4[] = { 'A', 'T', 'G', 'C', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N' };
+	uint64_t longest = 0;
+	for (int32_t s = 0; s < n_seqs; ++s) {
+		if (start_table[s] & 1ull) return CVX_ERR_ARG;     /* sequences start on a byte (SeqStart = binRefIndex * 2, :350) */
+		if (start_table[s] + seq_lengths[s] > n_nibbles) return CVX_ERR_ARG;
+		if (seq_lengths[s] > longest) longest = seq_lengths[s];
+	}
+	std::vector<char> buf;
+	std::vector<int32_t> freq;
+	try { buf.resize((size_t) longest + 2); freq.assign((size_t) length, 0); } catch (const std::bad_alloc &) { return CVX_ERR_OOM; }
+
+	/* DecodeRefSequence(buf, id, start, len): len - 2 characters, the rest NUL */
+	auto decode = [&](int32_t s) {
+		const uint64_t len = seq_lengths[s], pos = start_table[s];
+		memset(buf.data(), 0, (size_t) len + 2);
+		if (len < 2) return;
+		const uint64_t n = len - 2, first = pos / 2;
+		uint64_t at = 0;
+		for (uint64_t i = 0; i < (n + 1) / 2; ++i) {
+			const uint8_t b = bin_ref[first + i];
+			buf[(size_t) at++] = dec4[b >> 4];
+			buf[(size_t) at++] = dec4[b & 15];
+		}
+		if (n & 1) buf[(size_t) at - 1] = 'x';
+	};
+	/* CS::PrefixIteration(seq, len, fn, 0, 0, data, ref_skip, offset), its recursion on N written as a loop */
+	auto walk = [&](const char *seq, uint64_t len, uint64_t offset, auto &&fn) {
+		const uint64_t k = (uint64_t) kmer_len;
+		for (;;) {
+			if (len < k) return;
+			if (*seq == 'N') {
+				uint64_t n_skip = 1;
+				while (seq[n_skip] == 'N') ++n_skip;
+				seq += n_skip;
+				if (n_skip >= len - k) return;
+				len -= n_skip; offset += n_skip;
+			}
+			uint64_t prefix = 0, i = 0;
+			bool restart = false;
+			for (; i < k - 1; ++i) {
+				const char c = seq[i];
+				if (c == 'N') { restart = true; break; }
+				prefix = (prefix << 2) | (uint64_t) ((c >> 1) & 3);
+			}
+			if (!restart) {
+				uint32_t skipcount = (uint32_t) ref_skip;
+				for (i = k - 1; i < len; ++i) {
+					const char c = seq[i];
+					if (c == 'N') { restart = true; break; }
+					prefix = ((prefix << 2) | (uint64_t) ((c >> 1) & 3)) & mask;
+					if (skipcount == (uint32_t) ref_skip) { fn(prefix, offset + i + 1 - k); skipcount = 0; }
+					else ++skipcount;
+				}
+				if (!restart) return;
+			}
+			seq += i + 1; len -= i + 1; offset += i + 1;      /* PrefixIteration(sequence + i + 1, length - i - 1, ..., offset + i + 1) */
+		}
+	};
+	/* revComp (:69-89): complement is xor 2 per base (A 0, C 1, T 2, G 3), then the bases in reverse order */
+	auto rev_comp = [&](uint64_t p) {
+		uint64_t c = (p ^ 0xAAAAAAAAAAAAAAAAull) & mask, r = 0;
+		for (int b = 0; b < kmer_len; ++b) { r = (r << 2) | (c & 3); c >>= 2; }
+		return r;
+	};
+
+	/* pass 1: CountKmer */
+	for (int32_t s = 0; s < n_seqs; ++s) {
+		decode(s);
+		uint64_t last_prefix = 111111;
+		int64_t last_bin = -1;
+		walk(buf.data(), seq_lengths[s], start_table[s], [&](uint64_t prefix, uint64_t pos) {
+			if (prefix == last_prefix) {
+				const int64_t bin = (int64_t) (pos >> bin_shift);
+				if (bin != last_bin || last_bin == -1) freq[(size_t) prefix] += 1;
+				last_bin = bin;
+			} else {
+				last_bin = -1;
+				freq[(size_t) prefix] += 1;
+			}
+			last_prefix = prefix;
+		});
+	}
+	/* createRefTableIndex: 5-byte records (uint m_TabIndex; char m_RevCompIndex), length + 1 of them, zero-initialised (Index()) */
+	uint8_t *idx = static_cast<uint8_t *>(ref_table_index);
+	memset(idx, 0, (size_t) (length + 1) * 5);
+	uint64_t next = 0;
+	std::vector<uint32_t> cursor;                          /* SaveToRefTable's "first unused slot" per prefix */
+	try { cursor.assign((size_t) n_prefix, 0u); } catch (const std::bad_alloc &) { return CVX_ERR_OOM; }
+	auto put_tab = [&](uint64_t i, uint64_t v) { const uint32_t t = (uint32_t) v; memcpy(idx + 5 * i, &t, 4); };
+	uint64_t i = 0;
+	for (; i < length - 1; ++i) {
+		const int f = freq[(size_t) i];
+		const int total = f + freq[(size_t) rev_comp(i)];
+		put_tab(i, next + 1);
+		if (f > 0 && total < kMaxFreq) {
+			idx[5 * i + 4] = (uint8_t) (char) ((float) (kMaxFreq - total) * 100.0f / (float) kMaxFreq);
+			next += (uint64_t) f;
+		}
+	}
+	put_tab(i, next + 1);
+	*n_locations = next;
+	if (next > 0xFFFFFFFFull) return CVX_ERR_ARG;          /* one table unit */
+	if (next > ref_table_capacity || (next > 0 && !ref_table)) return CVX_ERR_CAPACITY;
+	if (next) memset(ref_table, 0, (size_t) next * 4);
+	/* pass 2: BuildPrefixTable (positions relative to the unit's offset 0) */
+	for (int32_t s = 0; s < n_seqs; ++s) {
+		decode(s);
+		uint64_t last_prefix = 111111;
+		int64_t last_bin = -1;
+		walk(buf.data(), seq_lengths[s], start_table[s], [&](uint64_t prefix, uint64_t pos) {
+			auto save = [&]() {
+				if (idx[5 * prefix + 4] == 0) return;          /* RefTableIndex[prefix].used() */
+				uint32_t tab;
+				memcpy(&tab, idx + 5 * prefix, 4);
+				ref_table[(size_t) (tab - 1) + cursor[(size_t) prefix]++] = (uint32_t) pos;
+			};
+			if (prefix == last_prefix) {
+				const int64_t bin = (int64_t) (pos >> bin_shift);
+				if (bin != last_bin || last_bin == -1) save();
+				last_bin = bin;
+			} else {
+				last_bin = -1;
+				save();
+			}
+			last_prefix = prefix;
+		});
+	}
 	return CVX_OK;
 }
 

@@ -453,7 +453,14 @@ inline void plan_chain_tile(int tile, int m, const TilePlan &p, const TileIn &in
 		t.y0 = y0;
 		t.rows = y1 - y0;
 		if (ge_max > gs_min) {
-			t.r0 = p.r0 + (int) ((gs_min - p.r0) & ~31ll);       /* planes of all blocks share the tile's bit phase */
+			/* planes of all blocks share the tile's bit phase: a block begins on a multiple of 32 steps behind the tile's first.
+			 * A block below another begins at least ONE step before its first cell: the diagonal input of that cell -- the score
+			 * of the row above one column to the left -- reaches the slot as the `up` score of the step before (round 5: a block
+			 * whose first cell fell exactly on such a multiple took 0 for it; one block in 32, and visible only where the best
+			 * path runs down the corridor's first column, i.e. in tiles validPath rejects -- found on the C5 mix, where the raw
+			 * fill score of 6 of 4 096 chained tiles differed from the ring kernels' and the reference's) */
+			const long long lead = g > 0 ? 1 : 0;
+			t.r0 = p.r0 + (int) ((gs_min - lead - p.r0) & ~31ll);
 			t.nsteps = (int) (ge_max - t.r0);
 		} else {
 			t.r0 = p.r0;
@@ -523,6 +530,7 @@ struct PlanTuning {
 	int force_generic = 0; /* every tile to the catch-all kernel (scoring that needs its SSE-variant instantiation) */
 	int long_steps = 0;    /* > 0: replaces kLongTileSteps (a tile of a small batch with at least this many steps is chained) */
 	int small_batch = 0;   /* > 0: replaces kSmallBatchTiles */
+	int long_need = 0;     /* > 0: replaces the 128 live rows from which a very long tile of a small batch is chained */
 };
 
 /* rows_of(i, tmp) -> the (offset, length) rows of tile i (may fill and return tmp), or an empty function /
@@ -579,7 +587,7 @@ inline void host_plan_rows(int n, const TilePlan *plan, const TileIn *tin, RowsO
 		r.ops_off = hp.ops_ints;
 		hp.ops_ints += (uint64_t) r.ops_cap;
 		hp.active += p.active;
-		const bool long_tile = small_batch && p.need >= 128 && (p.rend - p.r0) >= (tune.long_steps > 0 ? tune.long_steps : kLongTileSteps);
+		const bool long_tile = small_batch && p.need >= (tune.long_need > 0 ? tune.long_need : 128) && (p.rend - p.r0) >= (tune.long_steps > 0 ? tune.long_steps : kLongTileSteps);
 		if ((k < 0 || long_tile) && regular && have_rows && tune_min_slots == 0 && !tune.force_generic) {
 			/* more live rows than any ring (or one very long tile in a batch too small to fill the
 			 * device with whole tiles): row blocks chained through boundary streams */

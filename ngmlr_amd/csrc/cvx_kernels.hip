@@ -499,6 +499,12 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 		(M) == 3 ? CVX_FILL_WAVES_PER_EU : ((M) == 4 ? CVX_FILL_WAVES_M4 : 1), \
 		(M) == 3 ? CVX_FILL_WAVES_PER_EU : ((M) == 4 && CVX_FILL_WAVES_M4 > 1 ? CVX_FILL_WAVES_M4 : 8))))
 
+/* TAB instantiation: 1 = the penalty read of a cell is consumed one step later, where the cell's offers to its two
+ * consumers (V, Hc) are first needed -- the LDS round trip then has most of a step to come back; 0 = consumed at once */
+#ifndef CVX_FILL_TAB_LAZY
+#define CVX_FILL_TAB_LAZY 1
+#endif
+
 /* instruction-order experiments on the cell update (0: leave it to the compiler) */
 #ifndef CVX_FILL_SCHED
 #define CVX_FILL_SCHED 0
@@ -549,13 +555,15 @@ enum FillMode { kFillTwoPhase = 0, kFillExact = 1, kFillChain = 2 };
  * steps ahead of their use -- no counter, no release fence in the producer, no round trip to memory on
  * the consumer's critical path while the producer is ahead (it starts 2 N anti-diagonals earlier).
  */
-template <int M, bool WRAP, int MODE>
+template <int M, bool WRAP, int MODE, bool TAB = false>
 __global__ void __launch_bounds__(64) CVX_FILL_OCC(M)
 fill_ring_kernel(const FillArgs a) {
 	constexpr int N = 64 * M;
 	constexpr bool EXACT = (MODE != kFillTwoPhase);
 	constexpr bool CHAIN = (MODE == kFillChain);
-	typedef typename RunT<WRAP>::type run_t;   /* gap run: float (exact small ints) or int16-emulating int */
+	static_assert(!TAB || (!WRAP && MODE == kFillTwoPhase), "the penalty table serves the two-phase float-score instantiation only");
+	/* gap run: float (exact small ints), int16-emulating int, or (TAB) the byte address 4 * run of the run's penalty in s_pen */
+	typedef typename RunT<WRAP || TAB>::type run_t;
 	const int tid = threadIdx.x;
 	const int lane = tid;
 	const float go = a.sp.go;
@@ -573,6 +581,14 @@ fill_ring_kernel(const FillArgs a) {
 	__shared__ int4 s_rec[CHAIN ? 1 : M][64];
 	__shared__ int s_besty[M][64];
 	__shared__ BoundaryVal s_bnd[CHAIN ? kChainChunk : 1];      /* the predecessor's boundary records of the current chunk of steps */
+	/* TAB: the convex penalty min(gem, gext + run * decay) (src/ConvexAlignFast.cpp:672-674) takes 28 distinct values under
+	 * every preset; entry `run` of this table holds it, computed once per wave with the very operations the arithmetic form
+	 * uses (binary32 multiply, add, min, each rounded on its own).  The run register of a slot is then the entry's byte
+	 * address and the cell update reads its penalty with one ds_read_b32 -- the LDS pipe is otherwise idle in the step
+	 * loop -- instead of v_mul + v_add + v_min.  A run that walks off the table (kPenEntries and more: a gap of 500+ bases)
+	 * flags the tile for the arithmetic exact pass, like a tile whose best cell was not tracked (FillArgs::pen_limit, a power
+	 * of two <= kPenEntries: the test is on the OR of the run addresses seen at group ends). */
+	__shared__ float s_pen[TAB ? kPenEntries + kPenGuard : 1];
 
 	int t;                          /* tile */
 	int task_id = 0, y0 = 0;        /* chain: task index, first read row of the block */
@@ -629,6 +645,8 @@ fill_ring_kernel(const FillArgs a) {
 	int qch[M];        /* read character of the row                                  */
 	unsigned xa[M];    /* seq-arena offset of the next reference dword to prefetch   */
 	unsigned cwn[M];   /* reference characters of the NEXT 4-step group              */
+	float penp[M];     /* TAB (lazy form): the penalty an extension of the slot's latest cell pays, on its way from LDS */
+	constexpr bool LAZY = TAB && (CVX_FILL_TAB_LAZY != 0);
 	float best[M];
 	int best_r[M];
 	float lbest = 0.0f;          /* early phase: running maximum of this lane's cells */
@@ -687,12 +705,18 @@ fill_ring_kernel(const FillArgs a) {
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      /* one wave: LDS write -> read order across lanes */
 	};
 
+	if (TAB) {
+		for (int i = lane; i < kPenEntries + kPenGuard; i += 64) s_pen[i] = fminf(gem, gext + (float) i * decay);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	}
+	unsigned run_seen = 0u;         /* TAB: OR of the run addresses stored at group ends (a run grows by one entry per step) */
 #pragma unroll
 	for (int j = 0; j < M; ++j) {
 		s_besty[j][tid] = 0;
 		S[j] = 0.0f; Hc[j] = go; V[j] = go; dg[j] = 0.0f;
 		drun[j] = 0; irun[j] = 0;
 		best[j] = 0.0f; best_r[j] = 0;
+		penp[j] = gem;
 		accA[j] = accB[j] = 0u;
 		mD[j] = 0; mI[j] = 0;
 		cwn[j] = 0u;
@@ -791,10 +815,18 @@ fill_ring_kernel(const FillArgs a) {
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			/* lane boundary: previous lane's last slot, values of step r-1 */
-			float uV0 = rot1_f(V[M - 1]);
+			/* (lazy TAB form: what a slot's latest cell offers -- E to an extension, O to an opening -- is worked out here, one
+			 * step after the cell, from its score, the penalty that has come back from LDS meanwhile and its two masks) */
+			float p_E[M], p_O[M];
+			auto offers = [&](const int j) {
+				p_E[j] = fmaxf(S[j] + penp[j], S[j] * -0x1p100f);
+				p_O[j] = S[j] + go;
+			};
+			if (LAZY) offers(M - 1);
+			float uV0 = LAZY ? rot1_f(lanes(mI[M - 1]) ? p_E[M - 1] : p_O[M - 1]) : rot1_f(V[M - 1]);
 			float uS0 = rot1_f(S[M - 1]);
 			run_t uI0;
-			if (WRAP) uI0 = (run_t) rot1_i((int) irun[M - 1]);
+			if (WRAP || TAB) uI0 = (run_t) rot1_i((int) irun[M - 1]);
 			else uI0 = (run_t) rot1_f((float) irun[M - 1]);
 			u64 mIu0 = rot1_m(mI[M - 1]);
 			if (CHAIN) {
@@ -818,13 +850,21 @@ fill_ring_kernel(const FillArgs a) {
 			u64 p_eL[M], p_eU[M], p_eG[M], p_act[M], p_isDl[M], p_isIu[M];
 			u64 p_nD[M], p_nI[M], p_gap[M], p_cread[M];
 			auto phase1 = [&](const int j) {
-				const float uV = (j > 0) ? V[j > 0 ? j - 1 : 0] : uV0;
+				float uV = (j > 0) ? V[j > 0 ? j - 1 : 0] : uV0;
 				const run_t uI = (j > 0) ? irun[j > 0 ? j - 1 : 0] : uI0;
 				const u64 mIu = (j > 0) ? mI[j > 0 ? j - 1 : 0] : mIu0;
+				float lcv = Hc[j];
+				if (LAZY) {
+					if (j > 0) {
+						offers(j > 0 ? j - 1 : 0);
+						uV = lanes(mIu) ? p_E[j > 0 ? j - 1 : 0] : p_O[j > 0 ? j - 1 : 0];
+					}
+					lcv = lanes(mD[j]) ? p_E[j] : p_O[j];
+				}
 				const int refc = (int) ((cw[j] >> (8 * i)) & 0xffu);
 				const bool eq = (refc == qch[j]);
 				const float diag_cell = dg[j] + (eq ? vmat : vmis);
-				float lc = Hc[j], dc = diag_cell, uc = uV;
+				float lc = lcv, dc = diag_cell, uc = uV;
 				const float mx = fmaxf(fmaxf(fmaxf(lc, dc), uc), 0.0f);
 				p_lc[j] = lc; p_dc[j] = dc; p_uc[j] = uc; p_mx[j] = mx;
 				p_eL[j] = ballot(mx == lc);
@@ -856,8 +896,20 @@ fill_ring_kernel(const FillArgs a) {
 				/* outside the row the new "cell" is the empty element: score 0 */
 				const float sc = lanes(p_act[j]) ? mx : 0.0f;
 				run_t nd, ni;
-				float runf;
-				if (WRAP) {
+				float runf = 0.0f;
+				float E;
+				if (TAB) {
+					/* the registers hold 4 * (run + 1), the table address of the penalty a cell that extends this one pays
+					 * for; as in the float form they are only ever read through the masks (isDl, isIu) */
+					const u64 extD = nD & isDl, extI = nI & isIu;
+					const int t1 = lanes(extI) ? (int) uI : 4;
+					const int ra = lanes(extD) ? (int) drun[j] : t1;
+					nd = (run_t) (ra + 4);
+					ni = nd;
+					const float pen = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s_pen) + ra);
+					if (LAZY) penp[j] = pen;
+					E = fmaxf(sc + pen, sc * -0x1p100f);      /* gap_extend_value with the penalty looked up (dead code in the lazy form) */
+				} else if (WRAP) {
 					/* indelRun is a short in the reference (src/AlignmentMatrixFast.h:43) */
 					nd = lanes(nD) ? (lanes(isDl) ? (run_t) (short) ((int) drun[j] + 1) : (run_t) 1) : (run_t) 0;
 					ni = lanes(nI) ? (lanes(isIu) ? (run_t) (short) ((int) uI + 1) : (run_t) 1) : (run_t) 0;
@@ -875,15 +927,17 @@ fill_ring_kernel(const FillArgs a) {
 					nd = (run_t) (runf + 1.0f);
 					ni = nd;
 				}
-				const float E = gap_extend_value(sc, runf, gem, gext, decay);
+				if (!TAB) E = gap_extend_value(sc, runf, gem, gext, decay);
 				const float O = sc + go;
 
 				dg[j] = uS;
 				S[j] = sc;
 				drun[j] = nd;
 				irun[j] = ni;
-				V[j] = lanes(nI) ? E : O;
-				Hc[j] = lanes(nD) ? E : O;
+				if (!LAZY) {
+					V[j] = lanes(nI) ? E : O;
+					Hc[j] = lanes(nD) ? E : O;
+				}
 				if (TRACK) {
 					const u64 better = ballot(sc > best[j]);   /* sc is 0 outside the row, best >= 0 */
 					best[j] = lanes(better) ? mx : best[j];
@@ -954,6 +1008,10 @@ fill_ring_kernel(const FillArgs a) {
 				take_row(j, s_rec[CHAIN ? 0 : j][tid], r, false);
 			}
 		}
+		if (TAB) {
+#pragma unroll
+			for (int j = 0; j < M; ++j) run_seen |= (unsigned) (int) drun[j];
+		}
 		if (stage_now) {
 			stage_rows(stage_next, stage_slot);
 			stage_next += kStage;
@@ -999,6 +1057,8 @@ fill_ring_kernel(const FillArgs a) {
 		if (ob > b || (ob == b && (oy < by || (oy == by && ox < bx)))) { b = ob; by = oy; bx = ox; }
 		if (!EXACT) be = fmaxf(be, __shfl_xor(be, off, 64));
 	}
+	/* (every run address stored at a group end; inside a group a run grows by at most four entries: kPenGuard) */
+	const bool pen_overflow = TAB && ballot(run_seen >= 4u * (unsigned) a.pen_limit) != 0ull;
 	if (CHAIN) {
 		if (lane == 0) {
 			ChainOut co;
@@ -1025,6 +1085,7 @@ fill_ring_kernel(const FillArgs a) {
 		/* be under-estimates the early maximum by at most `match` (steps 0 and 1 of a group are not sampled);
 		 * 2 * match + 1 also covers the rounding of the float adds behind that bound */
 		o.pad = (!EXACT && gswitch > 0 && !(b > be + 2.0f * a.sp.mat + 1.0f)) ? kPadRedo : 0;
+		if (TAB && pen_overflow) o.pad = kPadRedo;      /* a gap run left the penalty table: the arithmetic exact pass redoes the tile */
 		a.tout[t] = o;
 	}
 }
@@ -1504,6 +1565,7 @@ static hipError_t launch_fill_t(const FillArgs &a, int mode, size_t pad_lds, hip
 		if constexpr (M == 1 || M == 2 || M == 4) hipLaunchKernelGGL((fill_ring_kernel<M, WRAP, kFillChain>), dim3(a.list_n), dim3(64), pad_lds, st, a);
 		else return hipErrorInvalidValue;
 	} else if (mode == kFillExact) hipLaunchKernelGGL((fill_ring_kernel<M, WRAP, kFillExact>), dim3(a.list_n), dim3(64), 0, st, a);
+	else if (!WRAP && a.pen_table) hipLaunchKernelGGL((fill_ring_kernel<M, false, kFillTwoPhase, true>), dim3(a.list_n), dim3(64), 0, st, a);
 	else hipLaunchKernelGGL((fill_ring_kernel<M, WRAP, kFillTwoPhase>), dim3(a.list_n), dim3(64), 0, st, a);
 	return hipGetLastError();
 }

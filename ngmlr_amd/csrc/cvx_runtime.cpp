@@ -282,7 +282,19 @@ struct cvx_search_state {
 	DevBuf<SearchCandidate> d_cand, d_dense;
 	DevBuf<uint64_t> d_keys;
 	hipEvent_t done = nullptr;
+	/* kernel time of the last call (cvx_stage_kernel_ms): an event pair around every kernel launch of the call, summed when it ends */
+	std::vector<int32_t> attempts;     /* per read of the last call: table sizes tried (cvx_search_last_attempts) */
+	std::vector<hipEvent_t> kev;
+	size_t kev_used = 0;
+	float kernel_ms = 0.0f;
+	int kmark(hipStream_t st) {
+		if (kev_used == kev.size()) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); kev.push_back(e); }
+		HIP_TRY(hipEventRecord(kev[kev_used++], st));
+		return CVX_OK;
+	}
 	void release() {
+		for (hipEvent_t e : kev) (void) hipEventDestroy(e);
+		kev.clear(); kev_used = 0;
 		h_seq.release(); h_meta.release(); h_out.release();
 		d_seq.release(); d_off.release(); d_listoff.release(); d_begin.release(); d_srcoff.release(); h_srcoff.release(); d_len.release(); d_ncand.release(); d_work.release(); d_miss.release();
 		d_events.release(); d_maxhit.release(); d_scores.release(); d_rlist.release(); d_cand.release(); d_dense.release(); d_keys.release();
@@ -328,6 +340,7 @@ struct cvx_context {
 	int tune_late_min = kLateMinGroups;  /* test knob (env CVX_TUNE_LATE_MIN): groups of the exactly tracked tail (huge: exact everywhere) */
 	int tune_late_shift = kLateShift;    /* tuning knob (env CVX_TUNE_LATE_SHIFT): the exactly tracked tail is groups >> this (at least tune_late_min) */
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
+	int tune_long_need = 0;   /* tuning knob (env CVX_TUNE_LONG_NEED): see PlanTuning */
 	int tune_long_steps = 0, tune_small_batch = 0;   /* tuning knobs (env CVX_TUNE_LONG_STEPS / CVX_TUNE_SMALL_BATCH): see PlanTuning */
 	bool single_lane = true;  /* experiment (env CVX_TUNE_TWO_LANES=1 clears it): small streaming jobs alternate between two stream sets.
 	                           * Measured with the batching dispatcher at four launches in flight: no gain -- 20 000 reads 25.1 s against
@@ -336,6 +349,8 @@ struct cvx_context {
 	int tune_chain_prio = -1; /* tuning knob (env CVX_TUNE_CHAIN_PRIO = 0 / 1): wave priority of chained blocks; -1 = the default (raised) */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
+	int tune_pen_limit = kPenEntries;   /* test knob (env CVX_TUNE_PEN_LIMIT, a power of two <= kPenEntries): gap runs from which a tile leaves the table */
+	int tune_pen_table = 1;   /* tuning knob (env CVX_TUNE_PEN_TABLE = 0 / 1): convex penalty from the LDS table in the two-phase float-score fills */
 	int test_fail_compute = 0; /* test knob (env CVX_TUNE_FAIL_COMPUTE = k): the k-th compute stage of this handle fails (error-path tests) */
 	int bt_group = 0;          /* lanes per tile in the backtrack: 0 = auto (8 for the bulk, 32 for the much-longer-than-average
 	                            * reads), 8 / 16 / 32 = that many for all, 64 = the one-wave-per-tile walk (env CVX_TUNE_BT_GROUP) */
@@ -356,6 +371,7 @@ struct cvx_context {
 	DevBuf<float> sc_out;
 	hipEvent_t sc_ev0 = nullptr, sc_ev1 = nullptr, sc_done = nullptr;
 	float sc_kernel_ms = 0.0f;
+	float decode_kernel_ms = 0.0f;     /* decode_windows_kernel of the last cvx_genome_decode (cvx_stage_kernel_ms) */
 	bool score_no_diag = false;   /* test knob (env CVX_TUNE_SCORE_NO_DIAG): always the row-by-row kernels */
 	struct cvx_search_state *search = nullptr;   /* candidate search (cvx_search_batch): persistent staging and device buffers */
 };
@@ -428,8 +444,25 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
 }
 
 /* ---- stage 1: pack into pinned staging and copy to the device, piece by piece (stream `io`) */
+/* the streams of an aligning handle beside `main` (cvx_create makes only that one) */
+int ensure_streams(cvx_context *c) {
+	if (c->s_io) return CVX_OK;
+	int prio_lo = 0, prio_hi = 0;
+	(void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     /* numerically lower = higher priority */
+	hipError_t e = hipStreamCreateWithFlags(&c->s_post, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_text, hipStreamNonBlocking);
+	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_main2, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_post2, hipStreamNonBlocking);
+	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux2[i], hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->s_io, hipStreamNonBlocking, prio_hi);      /* last: its existence says "all of them" */
+	if (e != hipSuccess) { set_err("hipStreamCreate failed: %s", hipGetErrorString(e)); return CVX_ERR_HIP; }
+	return CVX_OK;
+}
+
 int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tiles,
 		const cvx_genome_s *genome = nullptr, const uint64_t *ref_position = nullptr) {
+	RC_TRY(ensure_streams(h));
 	UploadLayout L;
 	std::vector<TileIn> tin;
 	int bad = -1;
@@ -668,7 +701,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	PlanTuning tune;
 	tune.min_slots = h->tune_min_slots; tune.max_slots = h->tune_max_slots; tune.force_wrap = h->tune_force_wrap; tune.chain_m = h->tune_chain_m;
 	tune.force_generic = h->sse_variant ? 1 : 0;
-	tune.long_steps = h->tune_long_steps; tune.small_batch = h->tune_small_batch;
+	tune.long_steps = h->tune_long_steps; tune.small_batch = h->tune_small_batch; tune.long_need = h->tune_long_need;
 	/* (a tile that gets chained needs its rows on the host: rebuilt from the step stream the batch still owns) */
 	const RowSrc *rsrc = b->h_rsrc.as<RowSrc>();
 	host_plan_rows(n, b->plan(), b->tin(), [&](int i, std::vector<RowDesc> &tmp) -> const RowDesc * {
@@ -814,6 +847,8 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		a.redo_count = b->d_counters.p;
 		a.late_min_groups = h->tune_late_min;
 		a.late_shift = h->tune_late_shift;
+		a.pen_table = h->tune_pen_table;
+		a.pen_limit = h->tune_pen_limit;
 		a.tasks = nullptr; a.chain_ticket = nullptr; a.bnd = nullptr; a.chain_out = nullptr; a.bnd_epoch = 0; a.chain_prio = 0;
 		a.ops = b->d_regions.p;
 		a.sp = h->sp;
@@ -1090,6 +1125,17 @@ namespace cvx {
 void pack_pool_run(int n_tasks, const std::function<void(int)> &fn) { PackPool::get().run(n_tasks, fn); }
 }
 
+/* Before the HIP runtime reads its settings (it does at the first HIP call of the process, which for ngmlr and for bench.py is
+ * one of ours): eight hardware queues per device instead of the runtime's four.  A handle runs its fill classes side by side
+ * on three streams beside the upload stream, and a process holds several handles (ngmlr: the aligner, sixteen search handles,
+ * the scoring plugin's); with four hardware queues the streams of a later handle share queues, and two fill classes that
+ * share a queue run one after the other -- measured (gpurun_out/r05b): the ONT mix 45 ms per batch on the first handle of a
+ * process, 59 ms on every later one (C5 mix: 195 / 288 ms); with eight queues every handle gets the 45 / 195.  Not
+ * overridden when the user has set GPU_MAX_HW_QUEUES. */
+__attribute__((constructor)) static void cvx_process_settings() {
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 extern "C" {
 
 const char *cvx_last_error(void) { return g_err.c_str(); }
@@ -1153,8 +1199,19 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	 * own code.  With the device in blocking-sync mode the same waits cost 0.5 ms of CPU per 50 ms and return 0.04 ms later.
 	 * CVX_WAIT=spin keeps the runtime's default. */
 	{
-		const char *w = getenv("CVX_WAIT");
-		if (!(w && strcmp(w, "spin") == 0) && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void) hipGetLastError();
+		/* once per device and process, by whichever thread gets here first (the others wait in call_once): the flag is a
+		 * process-wide property of the device, documented as such in cvx_align.h; a runtime that refuses it (a context that is
+		 * already active with another policy) is reported, the waits then spin */
+		static std::once_flag once[64];
+		std::call_once(once[device_id & 63], [&] {
+			const char *w = getenv("CVX_WAIT");
+			if (w && strcmp(w, "spin") == 0) return;
+			const hipError_t fe = hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+			if (fe != hipSuccess) {
+				(void) hipGetLastError();
+				fprintf(stderr, "cvx_create: device %d stays in its current scheduling mode (%s): host threads that wait for it will spin\n", device_id, hipGetErrorString(fe));
+			}
+		});
 	}
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, device_id));
@@ -1176,6 +1233,8 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	c->pack_threads = PackPool::get().size();      /* the process's shared pack threads (CVX_PACK_THREADS) */
 	if (const char *e = getenv("CVX_TUNE_MIN_M")) c->tune_min_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_FORCE_WRAP16")) c->tune_force_wrap = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_PEN_TABLE")) c->tune_pen_table = atoi(e) != 0;
+	if (const char *e = getenv("CVX_TUNE_PEN_LIMIT")) { int v = atoi(e), p2 = 4; while (p2 * 2 <= v && p2 * 2 <= kPenEntries) p2 *= 2; c->tune_pen_limit = p2; }
 	if (const char *e = getenv("CVX_TUNE_FAIL_COMPUTE")) c->test_fail_compute = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_SCORE_NO_DIAG")) c->score_no_diag = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
@@ -1185,18 +1244,14 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_TWO_LANES")) c->single_lane = atoi(e) == 0;
 	if (const char *e = getenv("CVX_TUNE_LONG_STEPS")) c->tune_long_steps = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_SMALL_BATCH")) c->tune_small_batch = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_LONG_NEED")) c->tune_long_need = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
 	if (const char *e = getenv("CVX_TUNE_LATE_SHIFT")) c->tune_late_shift = std::min(16, std::max(0, atoi(e)));
-	int prio_lo = 0, prio_hi = 0;
-	(void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     /* numerically lower = higher priority */
+	/* One stream now; the seven others an aligning handle uses (upload, post, text, the fill classes' side streams and the second
+	 * set for small jobs) are created by its first alignment call (ensure_streams).  ngmlr holds 32 handles that only ever
+	 * score or search on `main`: 224 streams that were created at start-up and destroyed at exit for nothing
+	 * (0.8 s between the last alignment and the process's exit, profiles/r04_timeline_e2e.txt). */
 	hipError_t e = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_post, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_text, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->s_io, hipStreamNonBlocking, prio_hi);
-	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_main2, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_post2, hipStreamNonBlocking);
-	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux2[i], hipStreamNonBlocking);
 	if (e != hipSuccess) {
 		set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
 		cvx_destroy(c);
@@ -1664,6 +1719,7 @@ int cvx_nm_profile_ops(cvx_handle h, int32_t n, const cvx_result *results, const
 	if (!h || n < 0 || (n > 0 && (!results || !entry_off)) || (ops_total > 0 && !ops_arena)) { set_err("cvx_nm_profile_ops: bad argument"); return CVX_ERR_ARG; }
 	if (n == 0) return CVX_OK;
 	HIP_TRY(hipSetDevice(h->device));
+	RC_TRY(ensure_streams(h));
 	const size_t n1 = (size_t) n;
 	std::vector<TileOut> tout(n1);
 	std::vector<TileRun> trun(n1);
@@ -1797,9 +1853,17 @@ int cvx_genome_decode(cvx_handle h, cvx_genome g, int32_t n, const uint64_t *pos
 	hipStream_t st = h->s_main;
 	hipError_t e = hipMemsetAsync(d_out.p, 0, (size_t) total, st);   /* the NUL that ends every window */
 	if (e == hipSuccess) e = hipMemcpyAsync(d_win.p, win.data(), (size_t) n * sizeof(WindowDesc), hipMemcpyHostToDevice, st);
+	hipEvent_t k0 = nullptr, k1 = nullptr;      /* the kernel alone, on its own stream */
+	if (e == hipSuccess) e = hipEventCreate(&k0);
+	if (e == hipSuccess) e = hipEventCreate(&k1);
+	if (e == hipSuccess) e = hipEventRecord(k0, st);
 	if (e == hipSuccess) e = launch_decode_windows(g->d_bin.p, g->d_starts.p, g->n_starts, d_win.p, n, d_out.p, st);
+	if (e == hipSuccess) e = hipEventRecord(k1, st);
 	if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out.p, (size_t) total, hipMemcpyDeviceToHost, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e == hipSuccess) h->decode_kernel_ms = ev_ms(k0, k1);
+	if (k0) (void) hipEventDestroy(k0);
+	if (k1) (void) hipEventDestroy(k1);
 	d_out.release();
 	d_win.release();
 	if (e != hipSuccess) { set_err("cvx_genome_decode: %s", hipGetErrorString(e)); return CVX_ERR_HIP; }
@@ -1952,25 +2016,45 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	for (int i = 0; i < n; ++i) h_srcoff[i] = (uint64_t) i * (uint64_t) kSearchWaveCand;
 	HIP_TRY(hipMemcpyAsync(ss->d_srcoff.p, h_srcoff, n1 * 8, hipMemcpyHostToDevice, st));
 	bool counted = false;
-	uint64_t total = 0;
-	auto count_votes = [&]() -> int {      /* sizes of the HBM kernel's lists: votes per read (all reads: the pass is cheap) */
+	uint64_t total = 0;             /* votes of the reads that took the HBM-table form so far: their rList / candidate regions */
+	std::vector<uint8_t> has_region(n1, 0);
+	ss->kev_used = 0;
+	ss->kernel_ms = 0.0f;
+	auto count_votes = [&]() -> int {      /* votes per read (all reads: the pass is cheap): sizes of the HBM kernel's lists */
+		RC_TRY(ss->kmark(st));
 		HIP_TRY(launch_search_count(a, st));
+		RC_TRY(ss->kmark(st));
 		HIP_TRY(hipMemcpyAsync(h_events, ss->d_events.p, n1 * 8, hipMemcpyDeviceToHost, st));
 		RC_TRY(search_wait(ss, st));
-		total = 0;
-		for (int i = 0; i < n; ++i) { h_listoff[i] = total; total += h_events[i]; }
+		counted = true;
+		return CVX_OK;
+	};
+	/* Regions only for the reads that really go to the HBM-table form, handed out when a read first gets there and kept for its
+	 * retries (sizing them by the votes of all n reads cost a repeat-rich call gigabytes per handle).  The
+	 * candidate arena grows without losing the lists already in it. */
+	auto give_regions = [&](const std::vector<int32_t> &reads) -> int {
+		bool grew = false;
+		for (int32_t i : reads) {
+			if (has_region[(size_t) i]) continue;
+			has_region[(size_t) i] = 1;
+			h_listoff[i] = total;
+			total += h_events[i];
+			grew = true;
+		}
+		if (!grew) return CVX_OK;
 		RC_TRY(ss->d_rlist.ensure((size_t) total + 64));
 		if (ss->d_cand.cap < (size_t) (fixed_total + 2 * total) + 64) {
-			/* (grow without losing the wave kernel's lists of this call) */
 			DevBuf<SearchCandidate> bigger;
-			RC_TRY(bigger.ensure((size_t) (fixed_total + 2 * total) + 64));
-			HIP_TRY(hipMemcpyAsync(bigger.p, ss->d_cand.p, (size_t) fixed_total * sizeof(SearchCandidate), hipMemcpyDeviceToDevice, st));
-			RC_TRY(search_wait(ss, st));
+			RC_TRY(bigger.ensure((size_t) (fixed_total + 2 * total) + (size_t) total / 2 + 64));
+			hipError_t e = hipMemcpyAsync(bigger.p, ss->d_cand.p, ss->d_cand.cap * sizeof(SearchCandidate), hipMemcpyDeviceToDevice, st);
+			int rc = CVX_OK;
+			if (e != hipSuccess) { set_err("cvx_search_batch: %s", hipGetErrorString(e)); rc = CVX_ERR_HIP; }
+			if (rc == CVX_OK) rc = search_wait(ss, st);
+			if (rc != CVX_OK) { bigger.release(); return rc; }      /* (this buffer leaked on the error paths) */
 			ss->d_cand.release();
 			ss->d_cand = bigger;
 		}
 		HIP_TRY(hipMemcpyAsync(ss->d_listoff.p, h_listoff, n1 * 8, hipMemcpyHostToDevice, st));
-		counted = true;
 		return CVX_OK;
 	};
 	/* the reference's retry ladder (CS.cpp:345-394): the current table size with a probe budget of a third of the table, then
@@ -1984,9 +2068,12 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	auto tr_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
 	std::vector<int32_t> work_wave, work_hbm;
 	for (int i = 0; i < n; ++i) (use_wave ? work_wave : work_hbm).push_back(i);
+	ss->attempts.assign(n1, 0);
 	for (int attempt = 0; !work_wave.empty() || !work_hbm.empty(); ++attempt) {
 		const int bits = attempt == 0 ? bits0 : bits0 + 1 + attempt;
 		if (bits > 20) break;
+		for (int32_t i : work_wave) ss->attempts[(size_t) i] += 1;
+		for (int32_t i : work_hbm) ss->attempts[(size_t) i] += 1;
 		a.bits = bits;
 		a.hpoc_factor = attempt == 0 ? 0.333f : 0.777f;
 		a.work = ss->d_work.p;
@@ -1996,7 +2083,9 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 			HIP_TRY(hipMemcpyAsync(ss->d_work.p, h_work, work_wave.size() * 4, hipMemcpyHostToDevice, st));
 			a.n_work = (int32_t) work_wave.size();
 			a.cand = ss->d_cand.p; a.cand_off = ss->d_srcoff.p;
+			RC_TRY(ss->kmark(st));
 			HIP_TRY(launch_search_wave(a, st));
+			RC_TRY(ss->kmark(st));
 			HIP_TRY(hipMemcpyAsync(h_ncand, ss->d_ncand.p, n1 * 4, hipMemcpyDeviceToHost, st));
 			RC_TRY(search_wait(ss, st));
 			for (int32_t i : work_wave) {
@@ -2007,9 +2096,10 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 		}
 		if (!hbm_now.empty()) {
 			if (!counted) RC_TRY(count_votes());
+			RC_TRY(give_regions(hbm_now));
 			for (int32_t i : hbm_now) h_srcoff[i] = fixed_total + 2 * h_listoff[i];
 			const size_t per_read = (size_t) 1 << bits;
-			const size_t chunk = std::max<size_t>(64, std::min<size_t>(hbm_now.size(), ((size_t) 8 << 30) / (per_read * 16)));     /* <= 8 GB of tables */
+			const size_t chunk = std::max<size_t>(1, std::min<size_t>(hbm_now.size(), ((size_t) 8 << 30) / (per_read * 16)));     /* <= 8 GB of tables, and no more tables than reads */
 			RC_TRY(ss->d_keys.ensure(chunk * per_read));
 			RC_TRY(ss->d_scores.ensure(chunk * per_read * 2));
 			a.keys = ss->d_keys.p; a.scores = ss->d_scores.p;
@@ -2020,7 +2110,9 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 				HIP_TRY(hipMemcpyAsync(ss->d_work.p, h_work, m * 4, hipMemcpyHostToDevice, st));
 				HIP_TRY(hipMemsetAsync(ss->d_keys.p, 0xFF, m * per_read * 8, st));          /* every slot empty */
 				a.n_work = (int32_t) m;
+				RC_TRY(ss->kmark(st));
 				HIP_TRY(lane_serial ? launch_search(a, st) : launch_search_wave_hbm(a, st));
+				RC_TRY(ss->kmark(st));
 				if (w0 + chunk < hbm_now.size()) RC_TRY(search_wait(ss, st));      /* (the work list is reused by the next chunk) */
 			}
 			HIP_TRY(hipMemcpyAsync(h_ncand, ss->d_ncand.p, n1 * 4, hipMemcpyDeviceToHost, st));
@@ -2050,16 +2142,26 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 		RC_TRY(ss->d_dense.ensure((size_t) need + 64));
 		HIP_TRY(hipMemcpyAsync(ss->d_begin.p, h_begin, n1 * 8, hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemcpyAsync(ss->d_srcoff.p, h_srcoff, n1 * 8, hipMemcpyHostToDevice, st));
+		RC_TRY(ss->kmark(st));
 		HIP_TRY(launch_search_compact(ss->d_cand.p, ss->d_srcoff.p, ss->d_ncand.p, ss->d_begin.p, ss->d_dense.p, n, st));
+		RC_TRY(ss->kmark(st));
 		/* (straight into the caller's memory: pageable unless it came from cvx_host_alloc, then the copy is staged by the runtime) */
 		HIP_TRY(hipMemcpyAsync(cands, ss->d_dense.p, (size_t) need * sizeof(SearchCandidate), hipMemcpyDeviceToHost, st));
 	}
 	RC_TRY(search_wait(ss, st));
+	for (size_t q = 0; q + 1 < ss->kev_used; q += 2) ss->kernel_ms += ev_ms(ss->kev[q], ss->kev[q + 1]);
 	if (trace) fprintf(stderr, "cvx_search_batch: %d reads, %llu bases, %llu candidates, %.2f ms:%s\n", n, (unsigned long long) bytes - (unsigned long long) n, (unsigned long long) need, tr_ms(), tr.c_str());
 	if (max_hit) memcpy(max_hit, h_maxhit, n1 * 4);
 	if (kmer_misses) memcpy(kmer_misses, h_miss, n1 * 4);
 	return CVX_OK;
 	ABI_GUARD_END
+}
+
+int cvx_search_last_attempts(cvx_handle h, int32_t n, int32_t *attempts) {
+	if (!h || n < 0 || (n > 0 && !attempts)) { set_err("cvx_search_last_attempts: bad argument"); return CVX_ERR_ARG; }
+	if (!h->search || (size_t) n > h->search->attempts.size()) { set_err("cvx_search_last_attempts: the handle's last search had fewer than %d reads", n); return CVX_ERR_ARG; }
+	if (n) memcpy(attempts, h->search->attempts.data(), (size_t) n * sizeof(int32_t));
+	return CVX_OK;
 }
 
 int cvx_search_batch(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
@@ -2125,6 +2227,16 @@ int cvx_score_batch(cvx_handle h, int32_t n, const char *const *refs, const char
 	h->sc_kernel_ms = ev_ms(h->sc_ev0, h->sc_ev1);
 	return CVX_OK;
 	ABI_GUARD_END
+}
+
+int cvx_stage_kernel_ms(cvx_handle h, int32_t stage, float *ms) {
+	if (!h || !ms) { set_err("cvx_stage_kernel_ms: NULL argument"); return CVX_ERR_ARG; }
+	switch (stage) {
+	case CVX_STAGE_SCORE: *ms = h->sc_kernel_ms; return CVX_OK;
+	case CVX_STAGE_DECODE: *ms = h->decode_kernel_ms; return CVX_OK;
+	case CVX_STAGE_SEARCH: *ms = h->search ? h->search->kernel_ms : 0.0f; return CVX_OK;
+	default: set_err("cvx_stage_kernel_ms: unknown stage %d", stage); return CVX_ERR_ARG;
+	}
 }
 
 int cvx_score_kernel_ms(cvx_handle h, float *ms) {

@@ -503,6 +503,8 @@ void oracle_port_set_spec_fill(void *h, int on) { ((oracle_t *) h)->use_spec_fil
 
 /* Port-only: forward results of the last call (for kernel-level parity checks). */
 static __thread int g_last_best_x, g_last_best_y, g_last_ref_position, g_last_qstart, g_last_qend;
+static __thread float g_last_fill_score;      /* curr_max of the last call's forward fill, valid path or not */
+float oracle_port_last_fill_score(void) { return g_last_fill_score; }
 static __thread int *g_last_ops; static __thread int g_last_nops;
 /* Port-only: run-length ops (len<<4|op, forward order, clips excluded) of the last valid call. */
 int oracle_port_last_ops(int32_t *out, int32_t cap) {
@@ -555,6 +557,7 @@ int oracle_align(void *h, const char *ref, const char *qry,
 		float score = o->use_spec_fill ? fill_spec(o, &m, &f, ref, qry)
 				: fill_sse_semantics(o, &m, &f, ref, qry);
 
+		g_last_fill_score = score;
 		int bc_len = 200000; /* defaultMaxBinaryCigarLength, :36 */
 		if (bc_len < m.H) bc_len = m.H + 1; /* :480-485 */
 		int *bc = (int *) malloc(sizeof(int) * (size_t) bc_len);

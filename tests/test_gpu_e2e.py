@@ -139,12 +139,14 @@ def test_candidate_search_bound_in_the_pipeline(built, tmp_path):
     assert re.search(r"SharedAligner: 985 alignments", err), err[-1500:]
 
 
-def test_split_reads_with_structural_variants(built, tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--subread-corridor", "80"]])
+def test_split_reads_with_structural_variants(built, tmp_path, extra):
     """BASELINE.json configs[4]'s shape end to end: ONT-like reads of 8-30 kb (20 % error) on a random reference, a third of them
     with an inverted segment, a deletion or a foreign insertion, `-x ont` -- ngmlr's split-read path (several intervals per read,
     reverse-strand segments, realignment, supplementary records).  The unmodified reference (CPU, in this very test) against
     the binary with alignment, scoring, candidate search and SAM records on the drop-ins and the alignment contexts: every SAM
-    record identical."""
+    record identical.  Second case: configs[4]'s own flag, `--subread-corridor 80` (reference src/ScoreBuffer.h:65-72: the
+    scoring windows grow to 256 + 80 + 12 characters, so StrippedSWHip scores 348-character windows)."""
     import sys
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "ngmlr_ref")
     if not os.path.exists(ref_bin) or not os.path.exists(BIN_ALL):
@@ -153,10 +155,11 @@ def test_split_reads_with_structural_variants(built, tmp_path):
     import e2e_rates
     fa, fq = str(tmp_path / "sv_ref.fa"), str(tmp_path / "sv_reads.fq")
     e2e_rates.write_sv_workload(fa, fq, 160, seed=77)
-    args = ["-x", "ont", "-R", "0.01", "--no-progress", "-r", fa, "-q", fq]
+    args = ["-x", "ont", "-R", "0.01", "--no-progress"] + extra + ["-r", fa, "-q", fq]
     want, _ = _run(["-t", "16"] + args, tmp_path, binary=ref_bin)
     got, err = _run(["-t", "8"] + args, tmp_path, binary=BIN_ALL, env={"CVX_POOL_CONTEXTS": "128"})
     assert sorted(got) == sorted(want)
+    assert "StrippedSWHip:" in err, err[-1500:]
     flags = [int(l.split("\t")[1]) for l in want]
     assert sum(1 for f in flags if f & 2048) >= 20 and any(f & 16 for f in flags), "the workload must exercise split and reverse-strand records"
     assert "CandidateSearchHip:" in err and "AlignPool: 160 reads" in err, err[-1500:]

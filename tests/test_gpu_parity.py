@@ -124,6 +124,96 @@ def test_long_gap_runs(hip_aligner, port_oracle):
     assert longest >= 257
 
 
+def _edge_hugging_tiles(rng, n):
+    """Tiles whose true alignment runs down the first (or last) column of the corridor rows: the anchors corridor shifted
+    sideways by about its own half-width.  validPath rejects most of them -- and the raw fill result (best score, best cell)
+    of exactly such tiles is where a wrong input at a row's first cell shows."""
+    from ngmlr_amd import synth
+    tiles = []
+    for i in range(n):
+        W = int(rng.integers(500, 2600))
+        ref = synth.random_ref(rng, W)
+        q = synth.mutate(rng, ref, float(rng.choice([0.02, 0.08, 0.15])), (6, 3, 1))
+        off, ln = synth.corridor_anchors(len(q), W)
+        w, right = int(ln[0]), -int(off[0])
+        edge = i % 3
+        shift = (right + int(rng.integers(-12, 6))) if edge == 0 else (right - w + int(rng.integers(-6, 12))) if edge == 1 else int(rng.integers(-40, 40))
+        tiles.append(synth.Tile(ref=ref.tobytes(), qry=q.tobytes(), row_offset=(off + shift).astype(np.int32), row_length=ln, tag="edge%d shift %d" % (edge, shift)))
+    return tiles
+
+
+@pytest.mark.parametrize("env", [{}, {"CVX_TUNE_MAX_M": "1"}, {"CVX_TUNE_MAX_M": "1", "CVX_TUNE_CHAIN_M": "2"}, {"CVX_TUNE_MAX_M": "2", "CVX_TUNE_CHAIN_M": "4"}])
+def test_raw_fill_result_on_corridor_edge_paths(built, port_oracle, monkeypatch, env):
+    """cvx_result.score / best cell are the fill's curr_max and argmax whether or not validPath accepts the path.  On tiles whose
+    best path hugs a corridor edge (almost all invalid, so the text-level parity checks never see their scores) the raw fill
+    result must equal the oracle's forward fill bit for bit -- whole-tile rings and chained row blocks of every height.
+    Round 5: a chained block whose first cell fell on a multiple of 32 steps took 0 for that cell's diagonal input (6 of
+    4 096 tiles of the C5 mix, 6 of 200 such tiles here)."""
+    import ctypes as C
+    from ngmlr_amd.aligner import ConvexAlignHip
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tiles = _edge_hugging_tiles(np.random.default_rng(99), 600)
+    port_oracle.lib.oracle_port_last_fill_score.restype = C.c_float
+    want = []
+    for t in tiles:
+        port_oracle.align(t, want_nm=False)
+        f = port_oracle.last_fwd()
+        want.append((int(np.float32(port_oracle.lib.oracle_port_last_fill_score()).view(np.uint32)), f["best_x"], f["best_y"]))
+    al = ConvexAlignHip(device=0)
+    b = al.upload(tiles)
+    tm = b.run()
+    res, _ = b.download()
+    b.free()
+    al.close()
+    assert (tm.n_tiles_chained > 0) == bool(env)
+    bad = [(t.tag, t.H, got, w) for t, got, w in ((t, (int(np.float32(res[i].score).view(np.uint32)), res[i].best_ref_index, res[i].best_read_index), want[i])
+                                                for i, t in enumerate(tiles)) if got != w and w[0] != 0xBF800000]
+    assert not bad, bad[:5]
+    assert sum(1 for i in range(len(tiles)) if res[i].status == 2) >= 100      # the workload does what it is for
+
+
+@pytest.mark.parametrize("table,limit", [("1", None), ("1", "32"), ("0", None)])
+def test_penalty_table_and_its_overflow(built, port_oracle, monkeypatch, table, limit):
+    """The two-phase fill reads the convex gap penalty from an LDS table (cvx_kernels.hip, TAB instantiation: 512 runs); a
+    tile in which a gap run walks off the table is flagged and redone by the arithmetic exact pass.  Whole-tile rings with
+    engineered gap runs around the point where the penalty stops shrinking (27) and, with the table cut to 32 runs
+    (CVX_TUNE_PEN_LIMIT), just below, at and far beyond its end, both kinds; the same tiles with the table switched off
+    (CVX_TUNE_PEN_TABLE=0): equal to the oracle every time, and the long runs really are on the paths."""
+    from ngmlr_amd import synth
+    from ngmlr_amd.aligner import ConvexAlignHip
+    monkeypatch.setenv("CVX_TUNE_PEN_TABLE", table)
+    if limit is not None:
+        monkeypatch.setenv("CVX_TUNE_PEN_LIMIT", limit)
+    rng = np.random.default_rng(5150)
+    tiles = []
+    for g in (5, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 40, 64, 90, 120):
+        for dels, inss in (([g], []), ([], [g]), ([g, 3], [2, g])):
+            ref_parts, qry_parts = [], []
+            for k in range(max(len(dels), len(inss)) + 1):
+                f = synth.random_ref(rng, 500)
+                ref_parts.append(f)
+                qry_parts.append(synth.mutate(rng, f, 0.03, (1, 1, 1)))
+                if k < len(dels):
+                    ref_parts.append(synth.random_ref(rng, dels[k]))
+                if k < len(inss):
+                    qry_parts.append(synth.random_ref(rng, inss[k]))
+            ref, qry = np.concatenate(ref_parts), np.concatenate(qry_parts)
+            off, ln = synth.corridor_endpoints(len(qry), len(ref), 420, realign=True)      # 420 columns: a whole tile on a 256-slot ring
+            tiles.append(synth.Tile(ref=ref.tobytes(), qry=qry.tobytes(), row_offset=off, row_length=ln, tag="pen d%s i%s" % (dels, inss)))
+    tiles += util.tile_zoo(seed=33, n=24, max_w=2500)
+    al = ConvexAlignHip(device=0)
+    got = _check(al, port_oracle, tiles)
+    longest = max(int(m) for g in got if g["ret"] >= 0 for m in re.findall(r"(\d+)[ID]", g["cigar"]))
+    assert longest >= 120
+    batch = al.upload(tiles)
+    tm = batch.run()
+    batch.free()
+    al.close()
+    if limit == "32":
+        assert tm.n_tiles_redone >= 20, tm.n_tiles_redone      # every tile with a run of 32 and more left the table
+
+
 def test_every_ring_class(hip_aligner, port_oracle):
     """Corridor widths chosen to land in each fill kernel class (rings 64 ... 256) and, beyond
     those, in the chained row-block class (corridors with more than 256 live rows)."""

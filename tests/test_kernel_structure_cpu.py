@@ -58,14 +58,15 @@ def test_fill_kernels_have_flat_uniform_step_loops(device_asm):
                     "%s: step loop closed by %s (divergent?)" % (name, m.group(1))
         assert step_loops >= 1, name
         seen += 1
-    assert seen == 22          # 4 ring classes x {float, int16 runs} x {two-phase, exact} + 3 chain classes x {float, int16}
+    # 4 ring classes x {float, int16 runs} x {two-phase, exact} + 4 x the two-phase float form with the penalty table (TAB) + 3 chain classes x {float, int16}
+    assert seen == 26
 
 
 def test_register_budgets(device_asm):
     def vgprs(body):
         return int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
     fill = dict(_kernels(device_asm, "_ZN3cvx16fill_ring_kernelILi3ELb0E"))
-    assert len(fill) == 2                                # two-phase and exact instantiation
+    assert len(fill) == 3                                # two-phase (arithmetic penalty and LDS penalty table) and exact instantiation
     for body in fill.values():
         assert vgprs(body) <= 80                         # six waves per SIMD
     walk = dict(_kernels(device_asm, "_ZN3cvx16backtrack_kernel"))

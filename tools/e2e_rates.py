@@ -119,6 +119,79 @@ def write_repeat_workload(path_fa, path_fq, n_reads, seed=2027, L=3_000_000):
     return bases
 
 
+def write_plain_workload(fa, fq, n_reads, rng, L):
+    """BASELINE.md section 2's workload: PacBio-like reads (15 % error, ins:del:sub 6:3:1, half of them reverse-complemented) of
+    E2E_READ_LEN bases (default 9-11 kb) on a random reference of L bases in E2E_CONTIGS sequences.  -> read bases"""
+    from ngmlr_amd import synth
+    ref = synth.random_ref(rng, L)
+    n_ctg = int(os.environ.get("E2E_CONTIGS", "1"))      # E2E_CONTIGS=16: the reference as 16 sequences, a fifth of the reads flush with a contig's start or end
+    clen = L // n_ctg
+    with open(fa, "w") as f:
+        s = ref.tobytes().decode()
+        for c in range(n_ctg):
+            f.write(">synth2M\n" if n_ctg == 1 else ">ctg%d\n" % c)
+            for i in range(c * clen, (c + 1) * clen if n_ctg > 1 else L, 80):
+                f.write(s[i:min(i + 80, (c + 1) * clen if n_ctg > 1 else L)] + "\n")
+    bases = 0
+    lo, hi = [int(x) for x in os.environ.get("E2E_READ_LEN", "9000:11000").split(":")]      # E2E_READ_LEN=50000:120000: ultra-long reads
+    with open(fq, "w") as f:
+        for i in range(n_reads):
+            n = int(rng.integers(lo, hi))
+            if n_ctg == 1:
+                a = int(rng.integers(0, L - hi))
+            else:
+                c = int(rng.integers(0, n_ctg))
+                edge = int(rng.integers(0, 10))
+                a = c * clen + (0 if edge == 0 else clen - n if edge == 1 else int(rng.integers(0, clen - n)))
+            w = ref[a:a + n]
+            q = synth.mutate(rng, w, 0.15, (6, 3, 1))
+            if rng.random() < 0.5:
+                q = synth.revcomp(q)
+            bases += len(q)
+            f.write("@r%d_%d\n%s\n+\n%s\n" % (i, a, q.tobytes().decode(), "I" * len(q)))
+    return bases
+
+
+def pipeline_summary(n_reads=4000, t_ref=32, spec=(32, 512, 256, 30000), extra_env=None):
+    """What bench.py puts beside its line as `e2e_pipeline`: the reference's own ngmlr, unmodified (ngmlr_ref, CPU) against the
+    build with every drop-in bound (ngmlr_hip_all: alignment, sub-read scoring, candidate search, SAM records on the device
+    path, alignment contexts off the CS threads), same synthetic reads, SAM compared record by record.  -> dict (or a dict
+    with `skipped` when the binaries are not there: they are built from /root/reference by tools/build_ngmlr_hip.sh)."""
+    for b_ in ("ngmlr_ref", "ngmlr_hip_all"):
+        if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", b_)):
+            return {"skipped": "oracle/_ref/%s not built (tools/build_ngmlr_hip.sh needs /root/reference)" % b_}
+    rng = np.random.default_rng(2025)
+    L = 2000000
+    fa, fq = os.path.join(tmp, "ps_ref.fa"), os.path.join(tmp, "ps_reads.fq")
+    bases = write_plain_workload(fa, fq, n_reads, rng, L)
+    t, ctx, target, hold = spec
+    env = {"CVX_POOL_CONTEXTS": str(ctx), "CVX_BATCH_TARGET": str(target), "CVX_BATCH_HOLD_US": str(hold)}
+    env.update(extra_env or {})
+    r0 = run("ngmlr_ref", t_ref, fa, fq)
+    r1 = run("ngmlr_hip_all", t, fa, fq, env)
+
+    def side(r, threads):
+        infl = re.search(r"a launch was in flight ([0-9.]+) %", r["stats"] or "")
+        parked = re.search(r"\(([0-9.]+) ms per alignment\)", r["stats"] or "")
+        return {"threads": threads, "rc": r["rc"], "wall_s": r["wall"], "map_s": r["map_s"], "sam_records": len(r["recs"]),
+                "mapped_Gbp_per_h": (bases / r["map_s"] * 3.6e-6) if r["map_s"] else None,
+                "alignments": r["launch"][0] if r["launch"] else None, "device_launches": r["launch"][1] if r["launch"] else None,
+                "tiles_per_launch": (r["launch"][0] / max(r["launch"][1], 1)) if r["launch"] else None,
+                "launch_in_flight_share": float(infl.group(1)) / 100.0 if infl else None,
+                "ms_parked_per_alignment": float(parked.group(1)) if parked else None,
+                "cpu_seconds": r["cpu_total_s"], "cpu_seconds_by_thread_class": r["cpu_by_class"], "peak_rss_mb": r["peak_rss_mb"]}
+    out = {"reads": n_reads, "read_bases": bases, "reference_bases": L, "host": effective_cores(),
+           "ngmlr_ref": side(r0, t_ref), "ngmlr_hip_all": side(r1, t),
+           "sam_identical": bool(r0["rc"] == 0 and r1["rc"] == 0 and r0["recs"] == r1["recs"]),
+           "wall_ratio": r1["wall"] / max(r0["wall"], 1e-9),
+           "map_ratio": (r1["map_s"] / r0["map_s"]) if (r0["map_s"] and r1["map_s"]) else None,
+           "settings": "ngmlr_hip_all -t %d, %d alignment contexts, batch target %d tiles / %d us; ngmlr_ref -t %d" % (t, ctx, target, hold, t_ref),
+           "what": "the reference's ngmlr binary built from /root/reference with the drop-ins (tools/build_ngmlr_hip.sh) against the unmodified build, "
+                   "-x pacbio, synthetic 10 kb reads on a 2 Mbp random reference; wall includes ngmlr's index construction, map = wall - index time; "
+                   "CPU seconds sampled from /proc/<pid>/task by thread name; peak RSS = VmHWM"}
+    return out
+
+
 def run(name, t, ref, fq, extra_env=None):
     binary = os.path.join(ROOT, "oracle", "_ref", name)
     if not os.path.exists(binary):
@@ -137,8 +210,16 @@ def run(name, t, ref, fq, extra_env=None):
         proc = subprocess.Popen([binary, "--skip-write", "-x", PRESET, "-t", str(t), "-R", "0.01", "--no-progress", "-r", ref_copy, "-q", fq],
                                 stdout=fo, stderr=fe, cwd=tmp, env=env)
         ticks = {}
+        peak_rss_kb = 0
         hz = os.sysconf("SC_CLK_TCK")
         while proc.poll() is None:
+            try:
+                for l_ in open("/proc/%d/status" % proc.pid):
+                    if l_.startswith("VmHWM:"):
+                        peak_rss_kb = max(peak_rss_kb, int(l_.split()[1]))
+                        break
+            except (OSError, ValueError):
+                pass
             try:
                 for tid in os.listdir("/proc/%d/task" % proc.pid):
                     try:
@@ -176,7 +257,8 @@ def run(name, t, ref, fq, extra_env=None):
     sc = re.search(r"StrippedSWHip: \d+ scoring calls.*", res.stderr)
     se = re.search(r"CandidateSearchHip: \d+ search calls.*", res.stderr)
     po = re.search(r"AlignPool: \d+ reads on.*", res.stderr)
-    return {"wall": dt, "search_stats": se.group(0) if se else None, "cpu_note": cpu_note, "pool_stats": po.group(0) if po else None, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
+    cpu_by_class = {k: round(c, 2) for k, (c, n) in by.items()}
+    return {"peak_rss_mb": peak_rss_kb / 1024.0, "cpu_by_class": cpu_by_class, "cpu_total_s": sum(c for c, _ in by.values()), "wall": dt, "search_stats": se.group(0) if se else None, "cpu_note": cpu_note, "pool_stats": po.group(0) if po else None, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
             "map_s": dt - float(mp.group(1)) if mp else None, "err": res.stderr[-400:], "full_err": res.stderr}
 
 
@@ -244,32 +326,7 @@ def synthetic(n_reads, threads, sv=False, rep=False):
         bases = write_repeat_workload(fa, fq, n_reads, L=L)
         print("repeat workload (six repeat families of 8-20 diverged copies, microsatellites; PacBio-like 10 kb reads, a third from inside a copy):")
     else:
-        ref = synth.random_ref(rng, L)
-        n_ctg = int(os.environ.get("E2E_CONTIGS", "1"))      # E2E_CONTIGS=16: the reference as 16 sequences, a fifth of the reads flush with a contig's start or end
-        clen = L // n_ctg
-        with open(fa, "w") as f:
-            s = ref.tobytes().decode()
-            for c in range(n_ctg):
-                f.write(">synth2M\n" if n_ctg == 1 else ">ctg%d\n" % c)
-                for i in range(c * clen, (c + 1) * clen if n_ctg > 1 else L, 80):
-                    f.write(s[i:min(i + 80, (c + 1) * clen if n_ctg > 1 else L)] + "\n")
-        bases = 0
-        lo, hi = [int(x) for x in os.environ.get("E2E_READ_LEN", "9000:11000").split(":")]      # E2E_READ_LEN=50000:120000: ultra-long reads
-        with open(fq, "w") as f:
-            for i in range(n_reads):
-                n = int(rng.integers(lo, hi))
-                if n_ctg == 1:
-                    a = int(rng.integers(0, L - hi))
-                else:
-                    c = int(rng.integers(0, n_ctg))
-                    edge = int(rng.integers(0, 10))
-                    a = c * clen + (0 if edge == 0 else clen - n if edge == 1 else int(rng.integers(0, clen - n)))
-                w = ref[a:a + n]
-                q = synth.mutate(rng, w, 0.15, (6, 3, 1))
-                if rng.random() < 0.5:
-                    q = synth.revcomp(q)
-                bases += len(q)
-                f.write("@r%d_%d\n%s\n+\n%s\n" % (i, a, q.tobytes().decode(), "I" * len(q)))
+        bases = write_plain_workload(fa, fq, n_reads, rng, L)
     print("synthetic: %d reads, %.1f Mbp, reference %d bp; host has %d hardware threads, %s" % (n_reads, bases / 1e6, L, os.cpu_count(), effective_cores()))
     cores = os.cpu_count() or 8
     base = None
