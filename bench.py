@@ -315,7 +315,12 @@ def other_config(al, tiles, what, parity_n, parity_max_cells=3.0e8):
             if d is not None:
                 bad += 1
                 first = first or "tile %d (%s): %s" % (i, tiles[i].tag, d)
-        return {"what": what, "tiles": len(tiles), "read_bases": int(bases), "Gbp_per_h": bases / best.total_ms * 3.6e-3,
+        chain = None
+        if best.n_tiles_chained:
+            chain = {"tiles": int(best.n_tiles_chained), "poll_share": best.chain_poll_ticks / max(best.chain_task_ticks, 1),
+                     "what": "share of the chained waves' lifetime (s_memtime ticks summed over the row-block tasks) spent polling for a boundary "
+                             "record the block above had not written yet"}
+        return {"what": what, "tiles": len(tiles), "read_bases": int(bases), "Gbp_per_h": bases / best.total_ms * 3.6e-3, "chained_row_blocks": chain,
                 "ms": {"plan": best.plan_ms, "fill": best.fill_ms, "backtrack": best.backtrack_ms, "total": best.total_ms},
                 "G_cells_per_s": best.cells / best.total_ms * 1e-6, "fill_classes": classes, "valid_alignments": "%d/%d" % (n_valid, len(tiles)),
                 "parity": "%d/%d vs oracle/_ref (%s)" % (len(cand) - bad, len(cand), kind), "parity_detail": first,
@@ -515,6 +520,7 @@ class Worker:
         self.valid = 0
         self.host_s = np.zeros(2)                     # host wall time inside cvx_submit / cvx_wait (timed steps)
         self.redone = 0                               # tiles the exact-tracking pass had to redo (timed steps)
+        self.wall_s = 0.0                             # this device's wall time of the last run_on_all call
 
     def steps(self, k, keep_last=False, record=True):
         jobs = []
@@ -679,7 +685,9 @@ def main() -> int:
 
         def wrap(w):
             try:
+                c0 = time.perf_counter()
                 fn(w)
+                w.wall_s = time.perf_counter() - c0      # this device's own wall time for the call (device_skew_ms)
             except BaseException as e:  # surface worker failures in the main thread
                 errs.append(e)
 
@@ -702,6 +710,14 @@ def main() -> int:
     sync_all()
     dt = time.perf_counter() - t0
     bases = float(sum(ts.read_bases for ts in tilesets))
+
+    def device_line(w):
+        """the dominant fill launch of one device (HIP events on its stream) and that device's own timed wall"""
+        if not w.launch_ms:
+            return [float(w.dev), 0.0, 0.0, 0.0, float(w.wall_s)]
+        dom_ = max(w.launch_ms, key=lambda k_: w.launch_meta[k_]["alg_bytes"])
+        return [float(w.dev), float(np.mean(w.launch_ms[dom_])), float(w.launch_meta[dom_]["alg_bytes"]), float(w.launch_meta[dom_]["n_tiles"]), float(w.wall_s)]
+    per_dev = [device_line(w) for w in workers]
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -709,6 +725,12 @@ def main() -> int:
         tb = torch.tensor([bases], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         bases = float(tb.item())
+        mine_ = torch.tensor(per_dev[0], dtype=torch.float64, device="cuda:%d" % local_rank)
+        all_ = [torch.zeros_like(mine_) for _ in range(world)]
+        dist.all_gather(all_, mine_)
+        per_dev = [[float(x) for x in t_.tolist()] for t_ in all_]
+        for r_, row_ in enumerate(per_dev):
+            row_[0] = float(r_)                                  # (rank = device of the node)
 
     out = None
     if rank == 0:
@@ -958,6 +980,12 @@ def main() -> int:
                 "gcups": meta["cells"] / (dms * 1e-3) / 1e9,
                 "all_fill_launches": {"M%d_NW%d_wrap%d" % k_: {"ms": float(np.mean(v)), "tiles": launch_meta[k_]["n_tiles"]} for k_, v in launch_ms.items()},
             },
+            # every device of the run: its own dominant fill launch against the roofline and its own timed wall, so that a scaling run
+            # explains itself (one straggling device shows as skew, a slower launch on every device as a lower `frac`)
+            "per_device": [{"device": int(r_[0]), "roofline": {"launch_ms": r_[1], "launch_tiles": int(r_[3]), "achieved": (r_[2] / (r_[1] * 1e-3) / 1e9) if r_[1] > 0 else None,
+                                                               "frac": (r_[2] / (r_[1] * 1e-3) / 1e9 / HBM_PEAK_GBS) if r_[1] > 0 else None, "unit": "GB/s"},
+                            "timed_wall_s": r_[4]} for r_ in per_dev],
+            "device_skew_ms": (max(r_[4] for r_ in per_dev) - min(r_[4] for r_ in per_dev)) * 1e3,
             "stage_ms_per_step": ({"plan": resident["plan_ms"], "fill": resident["fill_ms"], "backtrack": resident["backtrack_ms"],
                                    "what": "HIP-event stage times of the device-resident steps (in the pipelined steps the stages of neighbouring batches overlap)"}
                                   if resident and "fill_ms" in resident else None),

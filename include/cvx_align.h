@@ -170,6 +170,10 @@ typedef struct {
 	int32_t n_tiles_fast; /* tiles taken whole by one wave */
 	int32_t n_tiles_redone; /* tiles whose best cell was not in the exactly tracked tail (second fill pass) */
 	int32_t n_tiles_chained; /* wide tiles cut into chained row blocks */
+	/* ABI 6: chained row blocks -- ticks of the device's constant clock (s_memtime) their waves ran for, summed over the tasks,
+	 * and the part of it spent waiting for boundary records of the block above (chain_poll_ticks / chain_task_ticks = the share
+	 * of a chained wave's life in which it holds a wave slot without issuing the recurrence) */
+	uint64_t chain_task_ticks, chain_poll_ticks;
 } cvx_timing;
 
 /* One forward-fill launch of the last cvx_batch_run (HIP-event timed on the stream). */

@@ -59,7 +59,8 @@ class CvxTiming(C.Structure):
     _fields_ = [("plan_ms", C.c_float), ("fill_ms", C.c_float), ("backtrack_ms", C.c_float),
                 ("total_ms", C.c_float), ("cells", C.c_uint64), ("active_cells", C.c_uint64),
                 ("dir_bytes", C.c_uint64), ("n_fill_launches", C.c_int32), ("n_tiles_fast", C.c_int32),
-                ("n_tiles_redone", C.c_int32), ("n_tiles_chained", C.c_int32)]
+                ("n_tiles_redone", C.c_int32), ("n_tiles_chained", C.c_int32),
+                ("chain_task_ticks", C.c_uint64), ("chain_poll_ticks", C.c_uint64)]
 
 
 class CvxLaunchInfo(C.Structure):

@@ -6,6 +6,8 @@
 #ifndef CS_SEARCH_BINDING_H
 #define CS_SEARCH_BINDING_H
 
+#include <stdlib.h>
+
 #include "PrefixTable.h"
 #include "candidate_search_hip.h"
 
@@ -21,6 +23,14 @@ static inline TableUnit const * cvxSearchableUnit(IRefProvider const * rp) {
  * written once at start-up): a thread whose votes run on the device never touches it */
 static inline int cvxHostVoteTableLen(IRefProvider const * rp, int referenceLen) {
 	return cvxSearchableUnit(rp) != 0 ? 1 : referenceLen;
+}
+
+/* reads per CS batch (src/CS.cpp:34: 10, "reduced batch size for low read number PacBio samples") -- with the vote on the device
+ * it is also the size of a search call.  The reference's value unless CVX_CS_BATCH is set (measurements: a call of 100 reads
+ * amortises the host round trips of the ladder ten times over; DoRun's per-batch adaptation thresholds scale with it) */
+static inline int cvxCsBatchSize(int referenceValue) {
+	const char * e = getenv("CVX_CS_BATCH");
+	return (e && atoi(e) > 0) ? atoi(e) : referenceValue;
 }
 
 #endif

@@ -6,9 +6,15 @@
  * refStartPos table of :415-424; checked byte for byte against the binRef the unmodified reference
  * builds from its own test genomes (tests/test_decode_cpu.py, fixtures from tools/make_golden.sh).
  */
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "cvx_align.h"
@@ -100,14 +106,21 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 		if (start_table[s] + seq_lengths[s] > n_nibbles) return CVX_ERR_ARG;
 		if (seq_lengths[s] > longest) longest = seq_lengths[s];
 	}
-	std::vector<char> buf;
 	std::vector<int32_t> freq;
-	try { buf.resize((size_t) longest + 2); freq.assign((size_t) length, 0); } catch (const std::bad_alloc &) { return CVX_ERR_OOM; }
+	try { freq.assign((size_t) length, 0); } catch (const std::bad_alloc &) { return CVX_ERR_OOM; }
+	/* sequences are independent (the walk's lastPrefix / lastBin state is reset per sequence): one host thread per sequence
+	 * at a time, counters shared through relaxed atomic adds.  CVX_INDEX_THREADS overrides min(sequences, hardware threads, 16). */
+	int n_threads = (int) std::thread::hardware_concurrency();
+	if (n_threads > 16) n_threads = 16;
+	if (const char *e = getenv("CVX_INDEX_THREADS")) n_threads = atoi(e);
+	if (n_threads > n_seqs) n_threads = n_seqs;
+	if (n_threads < 1) n_threads = 1;
+	bool oom = false;
 
 	/* DecodeRefSequence(buf, id, start, len): len - 2 characters, the rest NUL */
-	auto decode = [&](int32_t s) {
+	auto decode = [&](int32_t s, std::vector<char> &buf) {
 		const uint64_t len = seq_lengths[s], pos = start_table[s];
-		memset(buf.data(), 0, (size_t) len + 2);
+		buf.assign((size_t) len + 2, 0);
 		if (len < 2) return;
 		const uint64_t n = len - 2, first = pos / 2;
 		uint64_t at = 0;
@@ -151,75 +164,126 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 			seq += i + 1; len -= i + 1; offset += i + 1;      /* PrefixIteration(sequence + i + 1, length - i - 1, ..., offset + i + 1) */
 		}
 	};
-	/* revComp (:69-89): complement is xor 2 per base (A 0, C 1, T 2, G 3), then the bases in reverse order */
-	auto rev_comp = [&](uint64_t p) {
-		uint64_t c = (p ^ 0xAAAAAAAAAAAAAAAAull) & mask, r = 0;
-		for (int b = 0; b < kmer_len; ++b) { r = (r << 2) | (c & 3); c >>= 2; }
-		return r;
+	/* every sequence once, on n_threads threads; fn(prefix, pos) sees only the occurrences the reference keeps */
+	auto for_kept_kmers = [&](auto &&fn) {
+		std::atomic<int32_t> next_seq(0);
+		auto work = [&]() {
+			std::vector<char> buf;
+			for (;;) {
+				const int32_t s = next_seq.fetch_add(1);
+				if (s >= n_seqs) return;
+				try { decode(s, buf); } catch (const std::bad_alloc &) { oom = true; return; }
+				uint64_t last_prefix = 111111;
+				int64_t last_bin = -1;
+				walk(buf.data(), seq_lengths[s], start_table[s], [&](uint64_t prefix, uint64_t pos) {
+					if (prefix == last_prefix) {
+						const int64_t bin = (int64_t) (pos >> bin_shift);
+						if (bin != last_bin || last_bin == -1) fn(prefix, pos);
+						last_bin = bin;
+					} else {
+						last_bin = -1;
+						fn(prefix, pos);
+					}
+					last_prefix = prefix;
+				});
+			}
+		};
+		std::vector<std::thread> ths;
+		for (int t = 1; t < n_threads; ++t) ths.emplace_back(work);
+		work();
+		for (std::thread &t : ths) t.join();
+	};
+	auto parallel_ranges = [&](uint64_t n, auto &&fn) {      /* fn(begin, end) over [0, n) in n_threads pieces */
+		std::vector<std::thread> ths;
+		const uint64_t per = (n + (uint64_t) n_threads - 1) / (uint64_t) n_threads;
+		for (int t = 1; t < n_threads; ++t) ths.emplace_back([&, t] { fn(std::min(n, per * (uint64_t) t), std::min(n, per * (uint64_t) (t + 1))); });
+		fn(0, std::min(n, per));
+		for (std::thread &t : ths) t.join();
 	};
 
+	const bool trace = getenv("CVX_INDEX_TRACE") != nullptr;
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!trace) return;
+		const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
+		fprintf(stderr, "cvx_index_build: %s %.2f s (%d threads)\n", what, std::chrono::duration<double>(t1 - t0).count(), n_threads);
+		t0 = t1;
+	};
 	/* pass 1: CountKmer */
-	for (int32_t s = 0; s < n_seqs; ++s) {
-		decode(s);
-		uint64_t last_prefix = 111111;
-		int64_t last_bin = -1;
-		walk(buf.data(), seq_lengths[s], start_table[s], [&](uint64_t prefix, uint64_t pos) {
-			if (prefix == last_prefix) {
-				const int64_t bin = (int64_t) (pos >> bin_shift);
-				if (bin != last_bin || last_bin == -1) freq[(size_t) prefix] += 1;
-				last_bin = bin;
-			} else {
-				last_bin = -1;
-				freq[(size_t) prefix] += 1;
+	if (n_threads == 1) for_kept_kmers([&](uint64_t prefix, uint64_t) { freq[(size_t) prefix] += 1; });
+	else for_kept_kmers([&](uint64_t prefix, uint64_t) { __atomic_fetch_add(&freq[(size_t) prefix], 1, __ATOMIC_RELAXED); });
+	if (oom) return CVX_ERR_OOM;
+	lap("count");
+	/* createRefTableIndex: 5-byte records (uint m_TabIndex; char m_RevCompIndex), length + 1 of them, zero-initialised (Index()).
+	 * revComp (:69-89): complement is xor 2 per base (A 0, C 1, T 2, G 3), then the bases in reverse order.  freq[revComp(i)]
+	 * for i in order is a cache miss per entry (the last base of i is the first of its reverse complement); the sums are
+	 * therefore formed middle bases outermost: with the k-mer split into head | middle | tail, i = head middle tail and its
+	 * reverse complement rc(tail) rc(middle) rc(head) both stay inside two small windows while head and tail vary. */
+	std::vector<int32_t> total;
+	try { total.assign((size_t) n_prefix, 0); } catch (const std::bad_alloc &) { return CVX_ERR_OOM; }
+	{
+		const int nt = kmer_len >= 8 ? 4 : kmer_len / 2;          /* bases in the tail and in the head */
+		const int nm = kmer_len - 2 * nt;                          /* bases in the middle */
+		auto rc_bits = [](uint64_t v, int bases) { uint64_t c = v ^ 0xAAAAAAAAAAAAAAAAull, r = 0; for (int b = 0; b < bases; ++b) { r = (r << 2) | (c & 3); c >>= 2; } return r; };
+		const uint64_t n_t = 1ull << (2 * nt), n_m = 1ull << (2 * nm);
+		std::vector<uint32_t> rc_t((size_t) n_t);
+		for (uint64_t v = 0; v < n_t; ++v) rc_t[(size_t) v] = (uint32_t) rc_bits(v, nt);
+		parallel_ranges(n_m, [&](uint64_t m0, uint64_t m1) {
+			for (uint64_t m = m0; m < m1; ++m) {
+				const uint64_t rm = rc_bits(m, nm);
+				for (uint64_t h = 0; h < n_t; ++h)
+					for (uint64_t t = 0; t < n_t; ++t) {
+						const uint64_t i = (h << (2 * (nm + nt))) | (m << (2 * nt)) | t;
+						const uint64_t r = ((uint64_t) rc_t[(size_t) t] << (2 * (nm + nt))) | (rm << (2 * nt)) | (uint64_t) rc_t[(size_t) h];
+						total[(size_t) i] = freq[(size_t) i] + freq[(size_t) r];
+					}
 			}
-			last_prefix = prefix;
 		});
 	}
-	/* createRefTableIndex: 5-byte records (uint m_TabIndex; char m_RevCompIndex), length + 1 of them, zero-initialised (Index()) */
 	uint8_t *idx = static_cast<uint8_t *>(ref_table_index);
 	memset(idx, 0, (size_t) (length + 1) * 5);
 	uint64_t next = 0;
-	std::vector<uint32_t> cursor;                          /* SaveToRefTable's "first unused slot" per prefix */
-	try { cursor.assign((size_t) n_prefix, 0u); } catch (const std::bad_alloc &) { return CVX_ERR_OOM; }
 	auto put_tab = [&](uint64_t i, uint64_t v) { const uint32_t t = (uint32_t) v; memcpy(idx + 5 * i, &t, 4); };
 	uint64_t i = 0;
 	for (; i < length - 1; ++i) {
 		const int f = freq[(size_t) i];
-		const int total = f + freq[(size_t) rev_comp(i)];
 		put_tab(i, next + 1);
-		if (f > 0 && total < kMaxFreq) {
-			idx[5 * i + 4] = (uint8_t) (char) ((float) (kMaxFreq - total) * 100.0f / (float) kMaxFreq);
+		if (f > 0 && total[(size_t) i] < kMaxFreq) {
+			idx[5 * i + 4] = (uint8_t) (char) ((float) (kMaxFreq - total[(size_t) i]) * 100.0f / (float) kMaxFreq);
 			next += (uint64_t) f;
 		}
 	}
 	put_tab(i, next + 1);
+	total = std::vector<int32_t>();
+	lap("index");
 	*n_locations = next;
 	if (next > 0xFFFFFFFFull) return CVX_ERR_ARG;          /* one table unit */
 	if (next > ref_table_capacity || (next > 0 && !ref_table)) return CVX_ERR_CAPACITY;
 	if (next) memset(ref_table, 0, (size_t) next * 4);
-	/* pass 2: BuildPrefixTable (positions relative to the unit's offset 0) */
-	for (int32_t s = 0; s < n_seqs; ++s) {
-		decode(s);
-		uint64_t last_prefix = 111111;
-		int64_t last_bin = -1;
-		walk(buf.data(), seq_lengths[s], start_table[s], [&](uint64_t prefix, uint64_t pos) {
-			auto save = [&]() {
-				if (idx[5 * prefix + 4] == 0) return;          /* RefTableIndex[prefix].used() */
+	/* pass 2: BuildPrefixTable (positions relative to the unit's offset 0).  SaveToRefTable takes the first unused slot of the
+	 * k-mer's run, i.e. the run fills in the order of the walk: ascending positions.  With several threads the slots are
+	 * handed out by an atomic cursor per k-mer (the counter array of pass 1, reused) and every run is sorted afterwards. */
+	std::fill(freq.begin(), freq.end(), 0);
+	for_kept_kmers([&](uint64_t prefix, uint64_t pos) {
+		if (idx[5 * prefix + 4] == 0) return;              /* RefTableIndex[prefix].used() */
+		uint32_t tab;
+		memcpy(&tab, idx + 5 * prefix, 4);
+		const int32_t slot = n_threads == 1 ? freq[(size_t) prefix]++ : __atomic_fetch_add(&freq[(size_t) prefix], 1, __ATOMIC_RELAXED);
+		ref_table[(size_t) (tab - 1) + (size_t) slot] = (uint32_t) pos;
+	});
+	if (oom) return CVX_ERR_OOM;
+	if (n_threads > 1) {
+		parallel_ranges(n_prefix, [&](uint64_t p0, uint64_t p1) {
+			for (uint64_t p = p0; p < p1; ++p) {
+				const int32_t n = freq[(size_t) p];
+				if (n < 2) continue;
 				uint32_t tab;
-				memcpy(&tab, idx + 5 * prefix, 4);
-				ref_table[(size_t) (tab - 1) + cursor[(size_t) prefix]++] = (uint32_t) pos;
-			};
-			if (prefix == last_prefix) {
-				const int64_t bin = (int64_t) (pos >> bin_shift);
-				if (bin != last_bin || last_bin == -1) save();
-				last_bin = bin;
-			} else {
-				last_bin = -1;
-				save();
+				memcpy(&tab, idx + 5 * p, 4);
+				std::sort(ref_table + (tab - 1), ref_table + (tab - 1) + n);
 			}
-			last_prefix = prefix;
 		});
 	}
+	lap("fill");
 	return CVX_OK;
 }
 

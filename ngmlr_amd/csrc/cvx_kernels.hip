@@ -592,6 +592,7 @@ fill_ring_kernel(const FillArgs a) {
 
 	int t;                          /* tile */
 	int task_id = 0, y0 = 0;        /* chain: task index, first read row of the block */
+	u64 chain_t0 = 0ull, chain_polled = 0ull;      /* chain: s_memtime at the task's start; ticks spent polling for boundary records */
 	ChainTask ct;
 	if (CHAIN) {
 		int tk = 0;
@@ -607,6 +608,7 @@ fill_ring_kernel(const FillArgs a) {
 		 * (ONT, 60 000 tiles: 7 660-7 770 -> 8 320-8 450 Gbp/h; C5 mix, 2 048 tiles: 2 860-2 930 -> 3 140).  The host
 		 * can switch it off (CVX_TUNE_CHAIN_PRIO=0). */
 		if (a.chain_prio) __builtin_amdgcn_s_setprio(3);
+		chain_t0 = __builtin_amdgcn_s_memtime();
 	} else {
 		t = a.list[blockIdx.x];
 #if CVX_FILL_PRIO
@@ -760,6 +762,8 @@ fill_ring_kernel(const FillArgs a) {
 			u64 q = bpre;
 			bool ok = !mine || (unsigned) (q >> 49) == epoch;
 			int spins = 0;
+			const bool must_poll = !chain_failed && ballot(!ok) != 0ull;
+			const u64 poll_t0 = must_poll ? __builtin_amdgcn_s_memtime() : 0ull;      /* (statistics: cvx_timing.chain_poll_ticks) */
 			while (!chain_failed && ballot(!ok) != 0ull) {     /* (wave-uniform) the producer has not got there yet */
 				if (!ok) {
 					q = __hip_atomic_load(bnd_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -772,6 +776,7 @@ fill_ring_kernel(const FillArgs a) {
 				else if (spins < 64) __builtin_amdgcn_s_sleep(32);
 				else __builtin_amdgcn_s_sleep(127);
 			}
+			if (must_poll) chain_polled += __builtin_amdgcn_s_memtime() - poll_t0;
 			BoundaryVal br;
 			br.V = go; br.S = 0.0f; br.run = 0u; br.is_ins = 0u;     /* outside the row above: the empty element */
 			if (mine && ok) {
@@ -1067,6 +1072,9 @@ fill_ring_kernel(const FillArgs a) {
 			co.best_x = (b > -1.0f) ? bx - y0 : 0;      /* bx was computed against block-local rows */
 			co.failed = chain_failed;
 			a.chain_out[ct.blk] = co;
+			unsigned long long *ticks = reinterpret_cast<unsigned long long *>(a.redo_count + kCtrChainTicks);
+			atomicAdd(ticks, (unsigned long long) (__builtin_amdgcn_s_memtime() - chain_t0));
+			if (chain_polled) atomicAdd(ticks + 1, (unsigned long long) chain_polled);
 		}
 		return;
 	}
@@ -1495,6 +1503,8 @@ finalize_kernel(const TileOut *tout, const TilePlan *plan, uint64_t *dst_off, Re
 		b.dense_cap = dense_cap;
 		b.n_valid = s_valid;
 		b.n_redone = counters ? counters[0] : 0;
+		b.chain_task_ticks = counters ? reinterpret_cast<const unsigned long long *>(counters + kCtrChainTicks)[0] : 0ull;
+		b.chain_poll_ticks = counters ? reinterpret_cast<const unsigned long long *>(counters + kCtrChainTicks)[1] : 0ull;
 		*sum = b;
 	}
 	/* last reader of the batch's counters (redo statistics, chain tickets): leave them zeroed for the

@@ -1057,6 +1057,8 @@ int stage_results(cvx_context *h, cvx_batch_s *b) {
 	b->timing.backtrack_ms = std::max(0.0f, ev_ms(b->ev[4], b->ev[3]) - fill_end);
 	b->timing.total_ms = b->timing.plan_ms + ev_ms(b->ev[4], b->ev[3]);
 	b->timing.n_tiles_redone = s->n_redone;
+	b->timing.chain_task_ticks = s->chain_task_ticks;
+	b->timing.chain_poll_ticks = s->chain_poll_ticks;
 	b->state = kFinished;
 	return CVX_OK;
 }

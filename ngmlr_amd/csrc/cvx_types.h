@@ -53,7 +53,10 @@ static const int kLateMinGroups = 128;
 static const int kLateShift = 5;       /* exactly tracked tail = max(kLateMinGroups, groups >> kLateShift): a 10 kb tile tracks its last 161 groups
                                         * = 644 steps, two corridor widths (round 3: groups / 8; 109.1 -> 107.9 ms per 49 120 tiles, still no tile redone) */
 static const int kPadRedo = 2;
-static const int kPenEntries = 512;    /* fill_ring_kernel<.., TAB>: gap runs whose penalty comes from the LDS table (longer runs: the tile is redone arithmetically) */
+#ifndef CVX_PEN_ENTRIES
+#define CVX_PEN_ENTRIES 512
+#endif
+static const int kPenEntries = CVX_PEN_ENTRIES;    /* fill_ring_kernel<.., TAB>: gap runs whose penalty comes from the LDS table (longer runs: the tile is redone arithmetically) */
 static const int kPenGuard = 8;        /* entries a run may walk past the table between two checks (one per 4-step group) */
 static const int kChainChunk = 16;     /* chained row blocks: steps per boundary hand-off (multiple of 4, power of two, <= 64) */
 
@@ -229,7 +232,11 @@ struct BatchSummary {      /* follows the result records in the same buffer */
 	uint64_t dense_cap;    /* capacity the compaction ran with (ops_total > dense_cap: compact again) */
 	int32_t n_valid;
 	int32_t n_redone;      /* tiles that needed the exact-tracking fill pass */
+	/* chained row blocks: s_memtime ticks (a constant ~100 MHz clock) the tasks of the launch ran for in total, and the part
+	 * of that spent polling for a boundary record their predecessor had not written yet (cvx_timing.chain_*) */
+	uint64_t chain_task_ticks, chain_poll_ticks;
 };
+static const int kCtrChainTicks = 16;  /* int32 index of the two uint64 tick counters inside the batch's counter block */
 
 struct WindowDesc {        /* one reference window to decode from the resident genome (cvx_genome.hip) */
 	uint64_t position;     /* first base, concatenated-genome coordinates (ngmlr's onRefStart) */

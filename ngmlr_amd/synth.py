@@ -485,3 +485,72 @@ def pacbio_tileset(n_tiles: int, seed: int = 7, read_len: int = 10000, err: floa
     return TileSet(cat(0, np.uint8), np.concatenate([[0], np.cumsum(W)]).astype(np.int64),
                    cat(1, np.uint8), np.concatenate([[0], np.cumsum(H)]).astype(np.int64),
                    cat(2, np.int32), cat(3, np.int32), tag="pacbio", desc=cat(6, DESC_DTYPE))
+
+
+# --------------------------------------------------------------------------- genome-sized reference for the candidate search
+
+def big_reference(total_bases: int = 512 << 20, n_contigs: int = 8, seed: int = 5, families: int = 24, microsats: int = 600) -> List[np.ndarray]:
+    """A reference whose k-mer table cannot sit in any cache (SURVEY 8 f4 at the scale of a genome): `total_bases` of uniform
+    ACGT in `n_contigs` sequences, with what makes a real genome hard for a k-mer vote -- `families` repeat families (a 3-12 kb
+    unit copied 10-40 times over all contigs, each copy 1-5 % diverged) and `microsats` microsatellite stretches of 200-800 bp."""
+    rng = np.random.default_rng(seed)
+    per = total_bases // n_contigs
+    contigs = [_ACGT[rng.integers(0, 4, size=per, dtype=np.uint8)].astype(np.uint8) for _ in range(n_contigs)]
+    for _ in range(families):
+        unit = random_ref(rng, int(rng.integers(3000, 12000)))
+        for _c in range(int(rng.integers(10, 41))):
+            v = mutate(rng, unit, float(rng.uniform(0.01, 0.05)), (1, 1, 8))
+            c = contigs[int(rng.integers(0, n_contigs))]
+            a = int(rng.integers(1000, per - len(v) - 1000))
+            c[a:a + len(v)] = v
+    for _ in range(microsats):
+        motif = random_ref(rng, int(rng.integers(1, 6)))
+        n = int(rng.integers(200, 800))
+        c = contigs[int(rng.integers(0, n_contigs))]
+        a = int(rng.integers(1000, per - n - 1000))
+        c[a:a + n] = np.tile(motif, n // len(motif) + 1)[:n]
+    return contigs
+
+
+def kmer_table(lib, contigs: Sequence[np.ndarray], k: int = 13, skip: int = 2, bin_shift: int = 4):
+    """-> (index bytes [(4^k + 2) * 5], locations uint32[], start table uint64[]) for `contigs`: cvx_genome_encode + cvx_index_build,
+    i.e. what ngmlr's SequenceProvider and CompactPrefixTable build from the same sequences (host only)."""
+    import ctypes as C
+    from . import capi
+    n = len(contigs)
+    lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+    lib.cvx_genome_encoded_bytes.restype = C.c_uint64
+    binref = np.zeros(int(lib.cvx_genome_encoded_bytes(n, lens.ctypes.data_as(C.c_void_p))), dtype=np.uint8)
+    arr = (C.c_char_p * n)()
+    for i, c in enumerate(contigs):
+        arr[i] = C.cast(np.ascontiguousarray(c).ctypes.data, C.c_char_p)
+    nn, ns = C.c_uint64(), C.c_int32()
+    starts = np.zeros(n + 1, dtype=np.uint64)
+    capi.check(lib.cvx_genome_encode(n, arr, lens.ctypes.data_as(C.c_void_p), binref.ctypes.data_as(C.c_void_p), C.byref(nn),
+                                     starts.ctypes.data_as(C.c_void_p), C.byref(ns)))
+    kept = np.ascontiguousarray(lens[lens > 10])
+    idx = np.zeros(((1 << (2 * k)) + 2) * 5, dtype=np.uint8)
+    cap = int(kept.sum()) // (skip + 1) + 64
+    locs = np.zeros(cap, dtype=np.uint32)
+    nl = C.c_uint64()
+    capi.check(lib.cvx_index_build(binref.ctypes.data, nn.value, starts.ctypes.data, kept.ctypes.data, len(kept), k, skip, bin_shift,
+                                   idx.ctypes.data, locs.ctypes.data, cap, C.byref(nl)))
+    return idx, locs[:nl.value], starts[:ns.value]
+
+
+def sample_subreads(contigs: Sequence[np.ndarray], n: int, length: int = 256, err: float = 0.15, seed: int = 9) -> List[bytes]:
+    """n sub-reads of `length` bases (ngmlr's --subread-length) cut from PacBio-like reads of the reference (15 % error 6:3:1, half
+    of them reverse-complemented), positions uniform over the contigs -- so repeat copies and microsatellites are hit in proportion."""
+    rng = np.random.default_rng(seed)
+    out = []
+    per_read = 40                                         # sub-reads cut from one 10 kb read
+    while len(out) < n:
+        c = contigs[int(rng.integers(0, len(contigs)))]
+        a = int(rng.integers(0, len(c) - 12000))
+        q = mutate(rng, c[a:a + 10400], err, (6, 3, 1))
+        if rng.random() < 0.5:
+            q = revcomp(q)
+        raw = q.tobytes()
+        for j in range(min(per_read, len(raw) // length)):
+            out.append(raw[j * length:(j + 1) * length])
+    return out[:n]

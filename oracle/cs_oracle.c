@@ -74,6 +74,25 @@ void *cs_table_create(int k, uint64_t unit_offset, uint32_t n_used, const uint32
 	return t;
 }
 
+/* the table as ngmlr holds it (and cvx_index_upload takes it): 4^k + 2 packed 5-byte Index records (uint m_TabIndex; char
+ * m_RevCompIndex, src/PrefixTable.h:15-31) and the locations */
+void *cs_table_create_raw(int k, uint64_t unit_offset, const uint8_t *index5, const uint32_t *locs, uint32_t n_locs) {
+	cs_table *t = (cs_table *) calloc(1, sizeof(cs_table));
+	t->k = k;
+	t->unit_offset = unit_offset;
+	t->n_index = (1u << (2 * k)) + 1u;
+	t->tab = (uint32_t *) malloc(((size_t) t->n_index + 1) * 4);
+	t->used = (uint8_t *) calloc((size_t) t->n_index + 1, 1);
+	t->locs = (uint32_t *) malloc(((size_t) n_locs + 1) * 4);
+	memcpy(t->locs, locs, (size_t) n_locs * 4);
+	t->n_locs = n_locs;
+	for (uint32_t p = 0; p <= t->n_index; ++p) {
+		memcpy(&t->tab[p], index5 + 5 * (size_t) p, 4);
+		t->used[p] = index5[5 * (size_t) p + 4] != 0;
+	}
+	return t;
+}
+
 void cs_table_destroy(void *h) {
 	cs_table *t = (cs_table *) h;
 	if (!t) return;

@@ -246,7 +246,9 @@ class SearchFixture:
 class SearchOracle:
     """cs_oracle.c: one CS::RunRead (reference src/CS.cpp:324-398) per call."""
 
-    def __init__(self, fx: "SearchFixture"):
+    def __init__(self, fx: "SearchFixture" = None, raw=None):
+        """fx: a recorded fixture (compact table form); raw = (k, unit_offset, index bytes [(4^k + 2) * 5], locations uint32[]): the
+        table as ngmlr holds it."""
         if not os.path.exists(CS_SO):
             build("port")
         self.lib = C.CDLL(CS_SO)
@@ -257,6 +259,15 @@ class SearchOracle:
                                        C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         self.lib.cs_search_ex.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        if raw is not None:
+            k, unit_offset, idx5, locs = raw
+            self.lib.cs_table_create_raw.restype = C.c_void_p
+            self.lib.cs_table_create_raw.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32]
+            i5 = np.ascontiguousarray(idx5).view(np.uint8)
+            assert len(i5) == ((1 << (2 * k)) + 2) * 5
+            l = np.ascontiguousarray(locs, dtype=np.uint32)
+            self.t = self.lib.cs_table_create_raw(k, unit_offset, i5.ctypes.data, l.ctypes.data, len(l))
+            return
         p = np.ascontiguousarray(fx.prefix, dtype=np.uint32)
         c = np.ascontiguousarray(fx.cnt, dtype=np.uint32)
         l = np.ascontiguousarray(fx.locs, dtype=np.uint32)

@@ -54,6 +54,8 @@ if SEARCH:
     s = sub1(s, 'int x_SrchTableLen = (int) pow(2, x_SrchTableBitLen);', 'int x_SrchTableLen = cvxHostVoteTableLen(NGM.GetRefProvider(m_TID), (int) pow(2, x_SrchTableBitLen));', 'CS::DoRun vote table')
     s = sub1(s, '\tint nScoresSum = 0;\n\tfor (size_t i = 0; i < m_CurrentBatch.size(); ++i) {', '#include "cs_search_binding.inc"\n\tint nScoresSum = 0;\n\tfor (size_t i = 0; i < m_CurrentBatch.size(); ++i) {', 'CS::RunBatch')
     s = sub1(s, 'void CS::Cleanup() {', 'void CS::Cleanup() {\n\tConvex::CandidateSearchHip::Shutdown();', 'CS::Cleanup')
+    # reads per CS batch = reads per device search / scoring call: the reference's 10 unless CVX_CS_BATCH says otherwise (a measurement knob)
+    s = sub1(s, 'int const cBatchSize = 10;', 'int const cBatchSize = cvxCsBatchSize(10);', 'cBatchSize')
     open(p, 'w').write(s)
 if POOL:
     # reads in flight decoupled from the CS threads (ngmlr_amd/csrc/align_pool.h)
