@@ -389,6 +389,29 @@ def index_stage_rates(al):
                     "%d recorded sub-reads x %d" % (fx.k, len(fx.locs), n0, rep_n)}
     except Exception as e:
         out["candidate_search"] = {"error": str(e)}
+    # the same search over a table the size of a genome's (512 Mbp synthetic reference with repeat families: 1 GB of index records and
+    # locations, far beyond L2 + MALL): kernel time from HIP events, votes per sub-read, a sample of the lists against the CPU restatement
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import search_rates
+        bpv, bpv_src = None, "no profiles/r*_pmc.json of this build carries a candidate_search_big entry"
+        try:
+            import glob
+            al.lib.cvx_build_id.restype = C_char_p
+            bid = al.lib.cvx_build_id().decode()
+            for pm_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+                pm = json.load(open(pm_path))
+                ent = pm.get("candidate_search_big")
+                if pm.get("build_id") == bid and ent:
+                    bpv = ent["hbm_bytes_per_vote"]
+                    bpv_src = "%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/search_rates.py --big on build %s)" % (os.path.relpath(pm_path, ROOT), bid)
+                    break
+        except Exception as e:
+            bpv_src = "unavailable: %s" % e
+        out["candidate_search_big"] = search_rates.big_index_rates(al, 512, 100000, 2000, pmc_bytes_per_vote=bpv)
+        out["candidate_search_big"]["bytes_per_vote_source"] = bpv_src
+    except Exception as e:
+        out["candidate_search_big"] = {"error": str(e)}
     try:
         z = np.load(os.path.join(golden, "decode_test_3.npz"))
         wins = [(int(z["pos"][i]), int(z["len"][i]), z["bytes"][int(z["off"][i]):int(z["off"][i + 1])].tobytes()) for i in range(int(z["n"]))]

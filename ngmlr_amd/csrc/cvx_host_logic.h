@@ -28,15 +28,18 @@ namespace cvx {
 /* ------------------------------------------------------------------ kernel classes */
 
 struct KernelClass {
-	int m;                           /* slots per lane; one wave per tile */
-	int ring() const { return 64 * m; }
+	int m;                           /* slots per lane */
+	int gang;                        /* waves per tile (1; 2 or 3: a gang of waves on one ring, float runs only) */
+	int ring() const { return 64 * m * gang; }
 };
 
 /* fill_ring_kernel instantiations the runtime dispatches whole tiles to, smallest ring first.
  * Rings of more than 256 slots need so many registers (M = 6: 133, M = 8: 170 VGPRs) that only two
  * or three waves fit a SIMD; such tiles are chained instead (ONT mix, 60 000 tiles: 5 950 -> 7 180
  * Gbp/h when everything above M = 4 goes to 64-row blocks). */
-static const KernelClass kClasses[] = { {1}, {2}, {3}, {4} };
+/* Round 5: rings of 384 and 576 slots as GANGS of two / three M = 3 waves in one workgroup (the lane boundary between the
+ * waves goes through LDS, cvx_kernels.hip): the retry loop's doubled corridors (257-576 live rows) are whole tiles again. */
+static const KernelClass kClasses[] = { {1, 1}, {2, 1}, {3, 1}, {4, 1}, {3, 2}, {3, 3} };
 static const int kNumClasses = (int) (sizeof(kClasses) / sizeof(kClasses[0]));
 
 /* Corridors with more live rows than the widest single-wave ring are cut into row blocks that run
@@ -531,6 +534,7 @@ struct PlanTuning {
 	int long_steps = 0;    /* > 0: replaces kLongTileSteps (a tile of a small batch with at least this many steps is chained) */
 	int small_batch = 0;   /* > 0: replaces kSmallBatchTiles */
 	int long_need = 0;     /* > 0: replaces the 128 live rows from which a very long tile of a small batch is chained */
+	int no_gangs = 0;      /* != 0: no gang classes (corridors with more than 256 live rows are chained, as before round 5) */
 };
 
 /* rows_of(i, tmp) -> the (offset, length) rows of tile i (may fill and return tmp), or an empty function /
@@ -578,7 +582,8 @@ inline void host_plan_rows(int n, const TilePlan *plan, const TileIn *tin, RowsO
 		if (regular && !tune.force_generic) {
 			for (int c = 0; c < kNumClasses; ++c)
 				if (kClasses[c].ring() >= p.need && kClasses[c].m >= tune_min_slots &&
-						(tune.max_slots <= 0 || kClasses[c].m <= tune.max_slots)) { k = c; break; }
+						(tune.max_slots <= 0 || kClasses[c].m <= tune.max_slots) &&
+						(kClasses[c].gang == 1 || (!wrap && !tune.no_gangs))) { k = c; break; }
 		}
 		r.skip = 0;
 		r.chain_blk0 = -1;

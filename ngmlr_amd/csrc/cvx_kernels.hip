@@ -495,14 +495,24 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 #ifndef CVX_FILL_WAVES_M4
 #define CVX_FILL_WAVES_M4 1
 #endif
-#define CVX_FILL_OCC(M) __attribute__((amdgpu_waves_per_eu( \
-		(M) == 3 ? CVX_FILL_WAVES_PER_EU : ((M) == 4 ? CVX_FILL_WAVES_M4 : 1), \
-		(M) == 3 ? CVX_FILL_WAVES_PER_EU : ((M) == 4 && CVX_FILL_WAVES_M4 > 1 ? CVX_FILL_WAVES_M4 : 8))))
+#ifndef CVX_FILL_WAVES_TAB
+#define CVX_FILL_WAVES_TAB 7
+#endif
+/* (round 5: the two-phase M = 3 instantiation with the penalty table -- the PacBio launch -- fits seven waves per SIMD: 72 VGPRs,
+ * 4 KB of LDS per wave; 104.95 -> 101.7 ms per 49 108 tiles.  The exact and the gang instantiations keep six.) */
+#define CVX_FILL_OCC(M, SEVEN) __attribute__((amdgpu_waves_per_eu( \
+		(M) == 3 ? ((SEVEN) ? CVX_FILL_WAVES_TAB : CVX_FILL_WAVES_PER_EU) : ((M) == 4 ? CVX_FILL_WAVES_M4 : 1), \
+		(M) == 3 ? ((SEVEN) ? CVX_FILL_WAVES_TAB : CVX_FILL_WAVES_PER_EU) : ((M) == 4 && CVX_FILL_WAVES_M4 > 1 ? CVX_FILL_WAVES_M4 : 8))))
 
 /* TAB instantiation: 1 = the penalty read of a cell is consumed one step later, where the cell's offers to its two
  * consumers (V, Hc) are first needed -- the LDS round trip then has most of a step to come back; 0 = consumed at once */
 #ifndef CVX_FILL_TAB_LAZY
 #define CVX_FILL_TAB_LAZY 1
+#endif
+
+/* gang: s_sleep argument of a wave that waits for its neighbour's record (x 64 clocks; 0 = spin) */
+#ifndef CVX_GANG_SLEEP
+#define CVX_GANG_SLEEP 1
 #endif
 
 /* instruction-order experiments on the cell update (0: leave it to the compiler) */
@@ -555,17 +565,29 @@ enum FillMode { kFillTwoPhase = 0, kFillExact = 1, kFillChain = 2 };
  * steps ahead of their use -- no counter, no release fence in the producer, no round trip to memory on
  * the consumer's critical path while the producer is ahead (it starts 2 N anti-diagonals earlier).
  */
-template <int M, bool WRAP, int MODE, bool TAB = false>
-__global__ void __launch_bounds__(64) CVX_FILL_OCC(M)
+template <int M, bool WRAP, int MODE, bool TAB = false, int G = 1>
+__global__ void __launch_bounds__(64 * G) CVX_FILL_OCC(M, TAB && G == 1)
 fill_ring_kernel(const FillArgs a) {
-	constexpr int N = 64 * M;
+	/* G > 1: a GANG of G waves shares one ring of N = 64 M G slots -- wave w holds the slots [64 M w, 64 M (w + 1)), i.e.
+	 * every G-th stretch of 64 M consecutive read rows.  Inside a wave nothing changes; the lane boundary between the last
+	 * lane of wave w and the first lane of wave w + 1 (and from the last wave back to the first: the ring) goes through one
+	 * self-validating 8-byte record per step in LDS instead of the DPP rotate.  The waves of a gang are never more than
+	 * G - 1 steps apart (each needs its predecessor's record of the step before), so they run in lock step on their own
+	 * SIMDs: a corridor with 257-576 live rows -- the retry loop's doubled corridors, src/AlignmentBuffer.cpp:291-294 -- is
+	 * a whole tile on a ring again (M = 3 per wave: the cheapest cell update there is) instead of 64-row blocks chained
+	 * through L2 at 1.6 x the instructions per cell. */
+	constexpr int N = 64 * M * G;
+	constexpr int NW = 64 * M;             /* slots of one wave */
 	constexpr bool EXACT = (MODE != kFillTwoPhase);
 	constexpr bool CHAIN = (MODE == kFillChain);
+	constexpr bool GANG = G > 1;
+	static_assert(!GANG || (!WRAP && !CHAIN), "gangs serve whole tiles with float runs");
 	static_assert(!TAB || (!WRAP && MODE == kFillTwoPhase), "the penalty table serves the two-phase float-score instantiation only");
 	/* gap run: float (exact small ints), int16-emulating int, or (TAB) the byte address 4 * run of the run's penalty in s_pen */
 	typedef typename RunT<WRAP || TAB>::type run_t;
-	const int tid = threadIdx.x;
-	const int lane = tid;
+	const int tid = threadIdx.x;           /* = ring slot / M of the thread's first slot */
+	const int lane = GANG ? (tid & 63) : tid;
+	const int wv = GANG ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;      /* wave inside the gang */
 	const float go = a.sp.go;
 	const float gext = a.sp.ge, gem = a.sp.gem, decay = a.sp.decay;
 	/* keep match / mismatch in VGPRs: v_cndmask cannot take two SGPR values plus a mask */
@@ -578,17 +600,24 @@ fill_ring_kernel(const FillArgs a) {
 	 * reference characters) and ~25 VALU instructions executed by the whole wave for one or two lanes --
 	 * round 2's counters had the wave parked on s_waitcnt for a quarter of its time, most of it here.
 	 * The row of a slot's best cell (changes only at a hand-over) lives in LDS too, to keep VGPRs for occupancy. */
-	__shared__ int4 s_rec[CHAIN ? 1 : M][64];
-	__shared__ int s_besty[M][64];
+	__shared__ int4 s_rec[CHAIN ? 1 : M * G][64];      /* (gang: wave w's records at [w * M + ...]) */
+	__shared__ int s_besty[M][64 * G];
+	/* gang: what the last slot of wave w offers the first slot of wave w + 1, one record per step in a ring of kGangDepth
+	 * (BoundaryRec layout: score bits | run16 | insertion bit | 15-bit step tag), and the waves' partial results at the end */
+	__shared__ u64 s_gx[GANG ? G : 1][GANG ? kGangDepth : 1];
+	__shared__ float s_gred[GANG ? G : 1][4];
+	__shared__ int s_gfail[GANG ? G : 1];
 	__shared__ BoundaryVal s_bnd[CHAIN ? kChainChunk : 1];      /* the predecessor's boundary records of the current chunk of steps */
 	/* TAB: the convex penalty min(gem, gext + run * decay) (src/ConvexAlignFast.cpp:672-674) takes 28 distinct values under
 	 * every preset; entry `run` of this table holds it, computed once per wave with the very operations the arithmetic form
 	 * uses (binary32 multiply, add, min, each rounded on its own).  The run register of a slot is then the entry's byte
 	 * address and the cell update reads its penalty with one ds_read_b32 -- the LDS pipe is otherwise idle in the step
-	 * loop -- instead of v_mul + v_add + v_min.  A run that walks off the table (kPenEntries and more: a gap of 500+ bases)
-	 * flags the tile for the arithmetic exact pass, like a tile whose best cell was not tracked (FillArgs::pen_limit, a power
-	 * of two <= kPenEntries: the test is on the OR of the run addresses seen at group ends). */
-	__shared__ float s_pen[TAB ? kPenEntries + kPenGuard : 1];
+	 * loop -- instead of v_mul + v_add + v_min.  The penalty is constant from some run on (27 with the default scoring:
+	 * gext + run * decay has reached gem); the host enables this form only when that run is below kPenClamp
+	 * (FillArgs::pen_table), and the run registers are clamped to kPenClamp at every group end -- a run register only ever
+	 * selects a penalty, so the clamp changes nothing, and the table needs kPenClamp + 5 entries whatever the corridor
+	 * (gap runs through zero-score cells are as long as a row is wide). */
+	__shared__ float s_pen[TAB ? kPenEntries : 1];
 
 	int t;                          /* tile */
 	int task_id = 0, y0 = 0;        /* chain: task index, first read row of the block */
@@ -618,6 +647,10 @@ fill_ring_kernel(const FillArgs a) {
 		 * tiles fill in behind them.  (A batch of equal tiles -- the PacBio bench -- is unaffected.) */
 		if (blockIdx.x < (unsigned) (a.list_n >> 4)) __builtin_amdgcn_s_setprio(2);
 #endif
+		/* a gang's tiles are the widest corridors of the batch -- the retry loop's second and third attempts, twice and three
+		 * times the steps per row -- and, like the chained blocks, the long pole of a mixed launch: raised priority for all of them
+		 * (FillArgs::chain_prio; CVX_TUNE_GANG_PRIO=0 switches it off) */
+		if (GANG && a.chain_prio) __builtin_amdgcn_s_setprio(2);
 		if (MODE == kFillExact) {
 			if (a.tout[t].pad != kPadRedo) return;   /* block-uniform */
 			if (tid == 0) atomicAdd(a.redo_count, 1);
@@ -696,22 +729,21 @@ fill_ring_kernel(const FillArgs a) {
 		 * ring without slack hands a slot over less than a group before its row starts. */
 		if (fetch_now || cnt[j] > -4) cwn[j] = *reinterpret_cast<const unsigned *>(seq + (xa[j] - 4u));
 	};
-	/* the wave writes the records of rows [Y, Y + 16 M) to their slots (sY = Y mod N, wave-uniform) */
+	/* the wave writes the records of rows [Y, Y + 16 M) to their slots (sY = the first one's slot inside the wave, wave-uniform) */
 	constexpr int kStage = 16 * M;
 	auto stage_rows = [&](const int Y, const int sY) {
 		if (lane < kStage) {
 			const int4 rec = make_rec(Y + lane);
 			const int sl = sY + lane;
-			s_rec[CHAIN ? 0 : sl % M][sl / M] = rec;
+			s_rec[CHAIN ? 0 : wv * M + sl % M][sl / M] = rec;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      /* one wave: LDS write -> read order across lanes */
 	};
 
 	if (TAB) {
-		for (int i = lane; i < kPenEntries + kPenGuard; i += 64) s_pen[i] = fminf(gem, gext + (float) i * decay);
+		for (int i = lane; i < kPenEntries; i += 64) s_pen[i] = fminf(gem, gext + (float) i * decay);
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	}
-	unsigned run_seen = 0u;         /* TAB: OR of the run addresses stored at group ends (a run grows by one entry per step) */
 #pragma unroll
 	for (int j = 0; j < M; ++j) {
 		s_besty[j][tid] = 0;
@@ -727,11 +759,25 @@ fill_ring_kernel(const FillArgs a) {
 	/* rows [N, 2N - 16 M) are staged up front; from then on the hand-over of every row that is a multiple
 	 * of 16 M (slot 0 of lanes 0, 16, 32, 48) stages the 16 M rows that end one ring further on: their slots
 	 * were all handed over before it (rows end in order), and the first of them is needed only when the row
-	 * 16 M above the triggering one ends, N - 16 M row ends later. */
-	int stage_next = N, stage_slot = 0;
+	 * 16 M above the triggering one ends, N - 16 M row ends later.  (A gang's wave stages its own stretches of 64 M rows:
+	 * three of the four chunks of its next stretch up front, then one chunk per trigger, a stretch every N rows.) */
+	int stage_next = N + wv * NW, stage_slot = 0;
+	auto stage_advance = [&]() {
+		stage_next += kStage;
+		stage_slot += kStage;
+		if (stage_slot >= NW) { stage_slot = 0; stage_next += N - NW; }
+	};
 	if (!CHAIN) {
-		for (; stage_next < 2 * N - kStage; stage_next += kStage, stage_slot += kStage) stage_rows(stage_next, stage_slot);
+		for (int c = 0; c < NW / kStage - 1; ++c) { stage_rows(stage_next, stage_slot); stage_advance(); }
 	}
+
+	int gang_failed = 0;
+	if (GANG) {
+		/* no record is valid yet (tag 0x7fff is the one of step 32767, by when every entry has long been rewritten) */
+		if (lane < kGangDepth) s_gx[wv][lane] = ~0ull;
+		__syncthreads();
+	}
+	const int gang_pred = GANG ? (wv + G - 1) % G : 0;      /* the wave whose last slot holds the row above this wave's first */
 
 	const int ngroups = (nsteps + 3) >> 2;
 	int late = ngroups >> a.late_shift;
@@ -834,6 +880,45 @@ fill_ring_kernel(const FillArgs a) {
 			if (WRAP || TAB) uI0 = (run_t) rot1_i((int) irun[M - 1]);
 			else uI0 = (run_t) rot1_f((float) irun[M - 1]);
 			u64 mIu0 = rot1_m(mI[M - 1]);
+			u64 gq = 0ull;
+			if (GANG && r != r0) gq = __hip_atomic_load(&s_gx[gang_pred][(r - r0 - 1) & (kGangDepth - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			/* gang: the first slot of the wave has the last slot of the wave before it above it.  The record of the step before
+			 * was asked for at the top of this step and is looked at only here, in front of slot 0, the last slot of the step --
+			 * the waves of a gang run in lock step, it has been there for most of a step (a spin otherwise, bounded) */
+			auto gang_take = [&]() {
+				float sc = 0.0f, vv = go;
+				unsigned run16 = 0u, ins = 0u;
+				if (r != r0) {
+					const unsigned want_tag = (unsigned) (r - r0 - 1) & 0x7fffu;
+					int spins = 0;
+					while (!gang_failed && (((unsigned) __builtin_amdgcn_readfirstlane((int) (gq >> 32))) >> 17) != want_tag) {
+						if (++spins > (1 << 22)) { gang_failed = 1; break; }      /* never hang the device */
+#if CVX_GANG_SLEEP > 0
+						__builtin_amdgcn_s_sleep(CVX_GANG_SLEEP);
+#endif
+						gq = __hip_atomic_load(&s_gx[gang_pred][(r - r0 - 1) & (kGangDepth - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+					const unsigned meta = (unsigned) __builtin_amdgcn_readfirstlane((int) (gq >> 32));
+					sc = __uint_as_float((unsigned) __builtin_amdgcn_readfirstlane((int) gq));
+					run16 = meta & 0xffffu;
+					ins = (meta >> 16) & 1u;
+					/* the up candidate is a function of (score, run, insertion): rebuilt with the cell update's own operations */
+					vv = ins ? gap_extend_value(sc, (float) run16 - 1.0f, gem, gext, decay) : sc + go;
+				}
+				if (lane == 0) {
+					uV0 = vv;
+					uS0 = sc;
+					uI0 = TAB ? (run_t) (int) (run16 << 2) : (run_t) (float) run16;
+				}
+				mIu0 = (mIu0 & ~1ull) | (u64) ins;
+			};
+			/* ... and offers its own last slot's new cell to the wave after it: lane 63, right after that slot (the first of the step) */
+			auto gang_give = [&]() {
+				const unsigned run16 = TAB ? (((unsigned) (int) irun[M - 1]) >> 2) & 0xffffu : ((unsigned) (int) (float) irun[M - 1]) & 0xffffu;
+				const unsigned meta = run16 | (unsigned) (((mI[M - 1] >> 63) & 1ull) << 16) | (((unsigned) (r - r0) & 0x7fffu) << 17);
+				if (lane == 63)
+					__hip_atomic_store(&s_gx[wv][(r - r0) & (kGangDepth - 1)], ((u64) meta << 32) | (u64) __float_as_uint(S[M - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			};
 			if (CHAIN) {
 				/* the block's first row (lane 0, slot 0) has the previous block's last row above it */
 				/* (the record was fetched from LDS one step ago: its latency is off the step's critical path) */
@@ -981,9 +1066,11 @@ fill_ring_kernel(const FillArgs a) {
 #pragma unroll
 			for (int j = M - 1; j >= 0; --j) {
 #if CVX_FILL_SCHED == 0 || CVX_FILL_SCHED == 3
+				if (GANG && j == 0) gang_take();
 				phase1(j); phase2(j);
 #endif
 				phase3(j);
+				if (GANG && j == M - 1) gang_give();
 #if CVX_FILL_SCHED == 3
 				__builtin_amdgcn_sched_barrier(0);
 #endif
@@ -1010,18 +1097,17 @@ fill_ring_kernel(const FillArgs a) {
 					const int yy = (int) (ref_base - (xa[j] - (unsigned) r - 4u));
 					if (best_r[j] >= r - cnt[j]) s_besty[j][tid] = yy;
 				}
-				take_row(j, s_rec[CHAIN ? 0 : j][tid], r, false);
+				take_row(j, s_rec[CHAIN ? 0 : wv * M + j][lane], r, false);
 			}
 		}
 		if (TAB) {
+			/* (one register per slot: the deletion and the insertion run of a cell share it in this form) */
 #pragma unroll
-			for (int j = 0; j < M; ++j) run_seen |= (unsigned) (int) drun[j];
+			for (int j = 0; j < M; ++j) { const int c = min((int) drun[j], 4 * kPenClamp); drun[j] = (run_t) c; irun[j] = (run_t) c; }
 		}
 		if (stage_now) {
 			stage_rows(stage_next, stage_slot);
-			stage_next += kStage;
-			stage_slot += kStage;
-			if (stage_slot >= N) stage_slot = 0;
+			stage_advance();
 		}
 	};
 
@@ -1062,8 +1148,6 @@ fill_ring_kernel(const FillArgs a) {
 		if (ob > b || (ob == b && (oy < by || (oy == by && ox < bx)))) { b = ob; by = oy; bx = ox; }
 		if (!EXACT) be = fmaxf(be, __shfl_xor(be, off, 64));
 	}
-	/* (every run address stored at a group end; inside a group a run grows by at most four entries: kPenGuard) */
-	const bool pen_overflow = TAB && ballot(run_seen >= 4u * (unsigned) a.pen_limit) != 0ull;
 	if (CHAIN) {
 		if (lane == 0) {
 			ChainOut co;
@@ -1077,6 +1161,23 @@ fill_ring_kernel(const FillArgs a) {
 			if (chain_polled) atomicAdd(ticks + 1, (unsigned long long) chain_polled);
 		}
 		return;
+	}
+	if (GANG) {
+		/* the waves' partial results, combined by wave 0 in wave order with the same tie-break */
+		if (lane == 0) {
+			s_gred[wv][0] = b; s_gred[wv][1] = __int_as_float(by); s_gred[wv][2] = __int_as_float(bx);
+			s_gred[wv][3] = EXACT ? 0.0f : be;
+			s_gfail[wv] = gang_failed;
+		}
+		__syncthreads();
+		if (wv != 0) return;
+#pragma unroll
+		for (int w = 1; w < G; ++w) {
+			const float ob = s_gred[w][0];
+			const int oy = __float_as_int(s_gred[w][1]), ox = __float_as_int(s_gred[w][2]);
+			if (ob > b || (ob == b && (oy < by || (oy == by && ox < bx)))) { b = ob; by = oy; bx = ox; }
+			if (!EXACT) be = fmaxf(be, s_gred[w][3]);
+		}
 	}
 	if (lane == 0) {
 		/* b == -1: no positive score among the tracked cells.  If there is none anywhere either,
@@ -1093,7 +1194,12 @@ fill_ring_kernel(const FillArgs a) {
 		/* be under-estimates the early maximum by at most `match` (steps 0 and 1 of a group are not sampled);
 		 * 2 * match + 1 also covers the rounding of the float adds behind that bound */
 		o.pad = (!EXACT && gswitch > 0 && !(b > be + 2.0f * a.sp.mat + 1.0f)) ? kPadRedo : 0;
-		if (TAB && pen_overflow) o.pad = kPadRedo;      /* a gap run left the penalty table: the arithmetic exact pass redoes the tile */
+		if (GANG) {
+			/* a wave that gave up waiting for its neighbour's record: CVX_TILE_UNSUPPORTED, loud, never a hang or a wrong answer */
+			bool failed = gang_failed != 0;
+			for (int w = 1; w < G; ++w) failed = failed || s_gfail[w] != 0;
+			if (failed) { o.status = -1; o.pad = 0; }
+		}
 		a.tout[t] = o;
 	}
 }
@@ -1567,6 +1673,16 @@ chain_reduce_kernel(const int32_t *tiles, int n_tiles, const TileRun *trun, cons
 	}
 }
 
+/* gangs: G waves per tile on one ring of 64 * 3 * G slots (two-phase with the penalty table when the scoring allows, else
+ * arithmetic; and the exact pass) */
+template <int G>
+static hipError_t launch_fill_gang(const FillArgs &a, int mode, hipStream_t st) {
+	if (mode == kFillExact) hipLaunchKernelGGL((fill_ring_kernel<3, false, kFillExact, false, G>), dim3(a.list_n), dim3(64 * G), 0, st, a);
+	else if (a.pen_table) hipLaunchKernelGGL((fill_ring_kernel<3, false, kFillTwoPhase, true, G>), dim3(a.list_n), dim3(64 * G), 0, st, a);
+	else hipLaunchKernelGGL((fill_ring_kernel<3, false, kFillTwoPhase, false, G>), dim3(a.list_n), dim3(64 * G), 0, st, a);
+	return hipGetLastError();
+}
+
 template <int M, bool WRAP>
 static hipError_t launch_fill_t(const FillArgs &a, int mode, size_t pad_lds, hipStream_t st) {
 	/* one wave per tile of the list (per task for chained tiles; pad_lds = unused dynamic LDS that
@@ -1585,8 +1701,12 @@ static hipError_t launch_fill_w(const FillArgs &a, bool wrap, int mode, size_t p
 	return wrap ? launch_fill_t<M, true>(a, mode, pad_lds, st) : launch_fill_t<M, false>(a, mode, pad_lds, st);
 }
 
-hipError_t launch_fill(int m, bool wrap, int mode, const FillArgs &a, size_t pad_lds, hipStream_t st) {
+hipError_t launch_fill(int m, int gang, bool wrap, int mode, const FillArgs &a, size_t pad_lds, hipStream_t st) {
 	if (a.list_n <= 0) return hipSuccess;
+	if (gang > 1) {
+		if (m != 3 || wrap || mode == kFillChain) return hipErrorInvalidValue;
+		return gang == 2 ? launch_fill_gang<2>(a, mode, st) : gang == 3 ? launch_fill_gang<3>(a, mode, st) : hipErrorInvalidValue;
+	}
 	switch (m) {
 	case 1: return launch_fill_w<1>(a, wrap, mode, pad_lds, st);
 	case 2: return launch_fill_w<2>(a, wrap, mode, pad_lds, st);

@@ -12,7 +12,8 @@ namespace cvx {
 /* m in {1,2,3,4}.  mode (cvx_kernels.hip FillMode): 0 two-phase best-cell tracking (flags
  * undecided tiles), 1 the exact pass that redoes the flagged tiles of the same list (launch both, in
  * this order, on one stream), 2 chained row blocks (a.tasks, list_n = number of tasks). */
-hipError_t launch_fill(int m, bool wrap, int mode, const FillArgs &a, size_t pad_lds, hipStream_t st);
+/* gang > 1 (2 or 3; m = 3, float runs, modes 0 / 1): that many waves share the tile's ring (cvx_kernels.hip, GANG) */
+hipError_t launch_fill(int m, int gang, bool wrap, int mode, const FillArgs &a, size_t pad_lds, hipStream_t st);
 hipError_t launch_chain_reduce(const int32_t *tiles, int n_tiles, const TileRun *trun, const ChainOut *cout, TileOut *tout, hipStream_t st);
 /* sub-read scoring (cvx_score.hip) */
 struct ScorePair {

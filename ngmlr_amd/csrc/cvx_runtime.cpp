@@ -150,7 +150,7 @@ bool in_pinned_block(const void *p, uint64_t bytes) {
  * (by default) four hardware queues, and two streams that land on the same queue serialise --
  * measured: with seven streams the 18-tile M = 4 launch ran alone for 11 ms in front of the
  * 24 558-tile M = 3 launch instead of beside it. */
-static const int kAuxStreams = 1;
+static const int kAuxStreams = 2;      /* (round 5: a batch has up to four fill classes -- chained, gangs, M = 4, M = 3 -- and each wants a stream of its own) */
 static const size_t kPoolBatches = 4;
 
 enum BatchState { kFailed = -1, kEmpty = 0, kUploaded = 1, kPlanned = 2, kComputed = 3, kFinished = 4 };
@@ -341,6 +341,12 @@ struct cvx_context {
 	int tune_late_shift = kLateShift;    /* tuning knob (env CVX_TUNE_LATE_SHIFT): the exactly tracked tail is groups >> this (at least tune_late_min) */
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
 	int tune_long_need = 0;   /* tuning knob (env CVX_TUNE_LONG_NEED): see PlanTuning */
+	int tune_gang_prio = 0;   /* tuning knob (env CVX_TUNE_GANG_PRIO = 0 / 1): gang tiles at raised wave priority (measured: 26.9 against 24.0 ms, a loss) */
+	int tune_gangs = 0;       /* tuning knob (env CVX_TUNE_GANGS = 0 / 1): rings of 384 / 576 slots as gangs of two / three waves instead of chained row
+	                           * blocks.  Off: measured, the gangs lose -- the ONT mix's retry tiles alone 24.0 ms against 21.4 ms chained, the whole mix
+	                           * equal within noise (profiles/r05_gang_ab.txt): short tiles leave a 576-slot ring idle through its ramps (60 % slot use
+	                           * against 85 % for 64-row blocks), which eats the 1.6 x cheaper cell update, and three waves in lock step on three SIMDs
+	                           * wait for the slowest of them every step */
 	int tune_long_steps = 0, tune_small_batch = 0;   /* tuning knobs (env CVX_TUNE_LONG_STEPS / CVX_TUNE_SMALL_BATCH): see PlanTuning */
 	bool single_lane = true;  /* experiment (env CVX_TUNE_TWO_LANES=1 clears it): small streaming jobs alternate between two stream sets.
 	                           * Measured with the batching dispatcher at four launches in flight: no gain -- 20 000 reads 25.1 s against
@@ -349,7 +355,6 @@ struct cvx_context {
 	int tune_chain_prio = -1; /* tuning knob (env CVX_TUNE_CHAIN_PRIO = 0 / 1): wave priority of chained blocks; -1 = the default (raised) */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
-	int tune_pen_limit = kPenEntries;   /* test knob (env CVX_TUNE_PEN_LIMIT, a power of two <= kPenEntries): gap runs from which a tile leaves the table */
 	int tune_pen_table = 1;   /* tuning knob (env CVX_TUNE_PEN_TABLE = 0 / 1): convex penalty from the LDS table in the two-phase float-score fills */
 	int test_fail_compute = 0; /* test knob (env CVX_TUNE_FAIL_COMPUTE = k): the k-th compute stage of this handle fails (error-path tests) */
 	int bt_group = 0;          /* lanes per tile in the backtrack: 0 = auto (8 for the bulk, 32 for the much-longer-than-average
@@ -702,6 +707,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	tune.min_slots = h->tune_min_slots; tune.max_slots = h->tune_max_slots; tune.force_wrap = h->tune_force_wrap; tune.chain_m = h->tune_chain_m;
 	tune.force_generic = h->sse_variant ? 1 : 0;
 	tune.long_steps = h->tune_long_steps; tune.small_batch = h->tune_small_batch; tune.long_need = h->tune_long_need;
+	tune.no_gangs = h->tune_gangs ? 0 : 1;
 	/* (a tile that gets chained needs its rows on the host: rebuilt from the step stream the batch still owns) */
 	const RowSrc *rsrc = b->h_rsrc.as<RowSrc>();
 	host_plan_rows(n, b->plan(), b->tin(), [&](int i, std::vector<RowDesc> &tmp) -> const RowDesc * {
@@ -848,7 +854,6 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		a.late_min_groups = h->tune_late_min;
 		a.late_shift = h->tune_late_shift;
 		a.pen_table = h->tune_pen_table;
-		a.pen_limit = h->tune_pen_limit;
 		a.tasks = nullptr; a.chain_ticket = nullptr; a.bnd = nullptr; a.chain_out = nullptr; a.bnd_epoch = 0; a.chain_prio = 0;
 		a.ops = b->d_regions.p;
 		a.sp = h->sp;
@@ -967,7 +972,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		const size_t per_cu = (size_t) ((resident + (uint64_t) h->num_cus - 1) / (uint64_t) h->num_cus);
 		size_t pad_lds = per_cu >= 32 ? 0 : (size_t) (160 * 1024) / per_cu - 4096;
 		pad_lds = std::min<size_t>(pad_lds, 60 * 1024) / 256 * 256;
-		HIP_TRY(launch_fill(m, (c & 1) != 0, 2, a, pad_lds, ls));
+		HIP_TRY(launch_fill(m, 1, (c & 1) != 0, 2, a, pad_lds, ls));
 		HIP_TRY(launch_chain_reduce(reinterpret_cast<const int32_t *>(b->d_chain.p + chain_tile_off[c]), (int) hp.chain_tiles[c].size(),
 				b->d_trun.p, b->d_chain_out.p, b->d_tout.p, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 1], ls));
@@ -978,19 +983,21 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		const size_t c = (size_t) cc;
 		if (cls[c].empty()) continue;
 		const KernelClass &kc = kClasses[c / 2];
-		launch_stats(cls[c], kc.m, 1, (int) (c & 1));
+		launch_stats(cls[c], kc.m, kc.gang, (int) (c & 1));      /* `waves` = waves per tile (a gang's size) */
 		hipStream_t ls = fill_streams[launches % n_fill_streams];
 		RC_TRY(begin_launch(ls));
 		if (n_direct[c] > 0) {
 			/* the very long tiles of the class, exact from the first step (flagged above), before everything else */
-			const FillArgs ad = fill_args(b->d_lists.p + seg_begin[c], n_direct[c]);
-			HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 1, ad, 0, ls));
+			FillArgs ad = fill_args(b->d_lists.p + seg_begin[c], n_direct[c]);
+			if (kc.gang > 1) ad.chain_prio = h->tune_gang_prio;
+			HIP_TRY(launch_fill(kc.m, kc.gang, (c & 1) != 0, 1, ad, 0, ls));
 		}
-		const FillArgs a = fill_args(b->d_lists.p + seg_begin[c] + n_direct[c], (int) cls[c].size() - n_direct[c]);
-		if (a.list_n > 0) HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 0, a, 0, ls));
+		FillArgs a = fill_args(b->d_lists.p + seg_begin[c] + n_direct[c], (int) cls[c].size() - n_direct[c]);
+		if (kc.gang > 1) a.chain_prio = h->tune_gang_prio;
+		if (a.list_n > 0) HIP_TRY(launch_fill(kc.m, kc.gang, (c & 1) != 0, 0, a, 0, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 1], ls));
 		/* exact-tracking pass over the tiles the two-phase pass flagged (usually none) */
-		if (a.list_n > 0) HIP_TRY(launch_fill(kc.m, (c & 1) != 0, 1, a, 0, ls));
+		if (a.list_n > 0) HIP_TRY(launch_fill(kc.m, kc.gang, (c & 1) != 0, 1, a, 0, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 2], ls));
 		RC_TRY(end_launch(ls));
 	}
@@ -1236,7 +1243,16 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_MIN_M")) c->tune_min_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_FORCE_WRAP16")) c->tune_force_wrap = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_PEN_TABLE")) c->tune_pen_table = atoi(e) != 0;
-	if (const char *e = getenv("CVX_TUNE_PEN_LIMIT")) { int v = atoi(e), p2 = 4; while (p2 * 2 <= v && p2 * 2 <= kPenEntries) p2 *= 2; c->tune_pen_limit = p2; }
+	{
+		/* the table form needs the penalty min(gem, gext + run * decay) to be constant from run kPenClamp on.  With decay >= 0 the sum
+		 * never shrinks as the run grows (binary32 multiply and add are monotone), so that is the case exactly when the penalty of run
+		 * kPenClamp has already reached gem, or decay is 0 (it is from run 27 on with the default scoring); anything else -- a tiny
+		 * decay -- keeps the arithmetic form */
+		volatile float prod = (float) kPenClamp * p->gap_decay;
+		volatile float at_clamp = p->gap_extend + prod;
+		const bool reached = !(at_clamp < p->gap_extend_min);
+		if (!(p->gap_decay >= 0.0f) || !(reached || p->gap_decay == 0.0f)) c->tune_pen_table = 0;
+	}
 	if (const char *e = getenv("CVX_TUNE_FAIL_COMPUTE")) c->test_fail_compute = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_SCORE_NO_DIAG")) c->score_no_diag = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
@@ -1247,6 +1263,8 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_LONG_STEPS")) c->tune_long_steps = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_SMALL_BATCH")) c->tune_small_batch = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LONG_NEED")) c->tune_long_need = atoi(e);
+	if (const char *e = getenv("CVX_TUNE_GANGS")) c->tune_gangs = atoi(e) != 0;
+	if (const char *e = getenv("CVX_TUNE_GANG_PRIO")) c->tune_gang_prio = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
 	if (const char *e = getenv("CVX_TUNE_LATE_SHIFT")) c->tune_late_shift = std::min(16, std::max(0, atoi(e)));
 	/* One stream now; the seven others an aligning handle uses (upload, post, text, the fill classes' side streams and the second

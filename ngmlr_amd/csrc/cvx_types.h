@@ -53,11 +53,11 @@ static const int kLateMinGroups = 128;
 static const int kLateShift = 5;       /* exactly tracked tail = max(kLateMinGroups, groups >> kLateShift): a 10 kb tile tracks its last 161 groups
                                         * = 644 steps, two corridor widths (round 3: groups / 8; 109.1 -> 107.9 ms per 49 120 tiles, still no tile redone) */
 static const int kPadRedo = 2;
-#ifndef CVX_PEN_ENTRIES
-#define CVX_PEN_ENTRIES 512
-#endif
-static const int kPenEntries = CVX_PEN_ENTRIES;    /* fill_ring_kernel<.., TAB>: gap runs whose penalty comes from the LDS table (longer runs: the tile is redone arithmetically) */
-static const int kPenGuard = 8;        /* entries a run may walk past the table between two checks (one per 4-step group) */
+/* fill_ring_kernel<.., TAB>: entries of the LDS penalty table, and the run from which the run registers are clamped (the
+ * penalty must be constant from kPenClamp on: checked by the host per scoring; a run grows by at most four between two clamps) */
+static const int kPenEntries = 64;
+static const int kPenClamp = kPenEntries - 8;
+static const int kGangDepth = 8;       /* fill_ring_kernel<.., G > 1>: steps of lane-boundary records a wave keeps for its successor (> G) */
 static const int kChainChunk = 16;     /* chained row blocks: steps per boundary hand-off (multiple of 4, power of two, <= 64) */
 
 struct ScoreParams {
@@ -291,7 +291,6 @@ struct FillArgs {
 	int32_t late_min_groups; /* exactly tracked tail, in 4-step groups (kLateMinGroups; a test knob raises it) */
 	int32_t late_shift;      /* ... or groups >> late_shift of them if that is more (kLateShift) */
 	int32_t pen_table;       /* != 0: the two-phase float-score launches read the convex penalty from an LDS table (TAB instantiation) */
-	int32_t pen_limit;       /* ... and redo a tile in which a gap run reaches this many bases (kPenEntries; a test knob lowers it; power of two) */
 	int32_t *ops;          /* per-tile op regions */
 	ScoreParams sp;
 };

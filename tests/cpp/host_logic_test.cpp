@@ -226,7 +226,10 @@ int main() {
 		CHECK(r.nsteps == p.rend - p.r0 && r.r0 == p.r0 && r.ops_cap == pin[i].H + pin[i].W + 8);
 		dir += (uint64_t) ((r.nsteps + 31) / 32) * (uint64_t) r.ring * 2ull;
 		ops += (uint64_t) r.ops_cap;
-		if ((p.flags & kPlanIrregular) || p.need > kClasses[kNumClasses - 1].ring()) {    /* (no rows given: no chaining) */
+		/* (gangs of waves -- rings of 384 / 576 slots -- take float-run tiles only: an int16-run tile's widest ring is one wave's 256) */
+		int widest = 0;
+		for (int c = 0; c < kNumClasses; ++c) if (kClasses[c].gang == 1 || !(p.flags & kPlanWrap16)) widest = std::max(widest, kClasses[c].ring());
+		if ((p.flags & kPlanIrregular) || p.need > widest) {    /* (no rows given: no chaining) */
 			CHECK(where[i] == 1000 && r.mnw == 0 && r.ring % 64 == 0);
 			CHECK(r.ring >= ((p.flags & kPlanIrregular) ? pin[i].H : p.need));
 		} else {

@@ -124,7 +124,7 @@ def test_long_gap_runs(hip_aligner, port_oracle):
     assert longest >= 257
 
 
-def _edge_hugging_tiles(rng, n):
+def _edge_hugging_tiles(rng, n, mult=1):
     """Tiles whose true alignment runs down the first (or last) column of the corridor rows: the anchors corridor shifted
     sideways by about its own half-width.  validPath rejects most of them -- and the raw fill result (best score, best cell)
     of exactly such tiles is where a wrong input at a row's first cell shows."""
@@ -134,7 +134,7 @@ def _edge_hugging_tiles(rng, n):
         W = int(rng.integers(500, 2600))
         ref = synth.random_ref(rng, W)
         q = synth.mutate(rng, ref, float(rng.choice([0.02, 0.08, 0.15])), (6, 3, 1))
-        off, ln = synth.corridor_anchors(len(q), W)
+        off, ln = synth.corridor_anchors(len(q), W, mult=mult)      # mult 2 / 3: the retry loop's widened corridors (rings of 384 / 576 slots: gangs)
         w, right = int(ln[0]), -int(off[0])
         edge = i % 3
         shift = (right + int(rng.integers(-12, 6))) if edge == 0 else (right - w + int(rng.integers(-6, 12))) if edge == 1 else int(rng.integers(-40, 40))
@@ -142,18 +142,20 @@ def _edge_hugging_tiles(rng, n):
     return tiles
 
 
-@pytest.mark.parametrize("env", [{}, {"CVX_TUNE_MAX_M": "1"}, {"CVX_TUNE_MAX_M": "1", "CVX_TUNE_CHAIN_M": "2"}, {"CVX_TUNE_MAX_M": "2", "CVX_TUNE_CHAIN_M": "4"}])
-def test_raw_fill_result_on_corridor_edge_paths(built, port_oracle, monkeypatch, env):
+@pytest.mark.parametrize("env,mult", [({}, 1), ({"CVX_TUNE_MAX_M": "1"}, 1), ({"CVX_TUNE_MAX_M": "1", "CVX_TUNE_CHAIN_M": "2"}, 1), ({"CVX_TUNE_MAX_M": "2", "CVX_TUNE_CHAIN_M": "4"}, 1),
+                                      ({"CVX_TUNE_GANGS": "1"}, 2), ({"CVX_TUNE_GANGS": "1"}, 3), ({"CVX_TUNE_GANGS": "1", "CVX_TUNE_GANG_PRIO": "1"}, 2), ({}, 2)])
+def test_raw_fill_result_on_corridor_edge_paths(built, port_oracle, monkeypatch, env, mult):
     """cvx_result.score / best cell are the fill's curr_max and argmax whether or not validPath accepts the path.  On tiles whose
     best path hugs a corridor edge (almost all invalid, so the text-level parity checks never see their scores) the raw fill
-    result must equal the oracle's forward fill bit for bit -- whole-tile rings and chained row blocks of every height.
+    result must equal the oracle's forward fill bit for bit -- whole-tile rings, gangs of two and three waves on one ring
+    (corridor multipliers 2 and 3) and chained row blocks of every height.
     Round 5: a chained block whose first cell fell on a multiple of 32 steps took 0 for that cell's diagonal input (6 of
     4 096 tiles of the C5 mix, 6 of 200 such tiles here)."""
     import ctypes as C
     from ngmlr_amd.aligner import ConvexAlignHip
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    tiles = _edge_hugging_tiles(np.random.default_rng(99), 600)
+    tiles = _edge_hugging_tiles(np.random.default_rng(99 + mult), 600 if mult == 1 else 240, mult)
     port_oracle.lib.oracle_port_last_fill_score.restype = C.c_float
     want = []
     for t in tiles:
@@ -166,28 +168,26 @@ def test_raw_fill_result_on_corridor_edge_paths(built, port_oracle, monkeypatch,
     res, _ = b.download()
     b.free()
     al.close()
-    assert (tm.n_tiles_chained > 0) == bool(env)
+    assert (tm.n_tiles_chained > 0) == (("CVX_TUNE_MAX_M" in env) or (mult > 1 and "CVX_TUNE_GANGS" not in env))
     bad = [(t.tag, t.H, got, w) for t, got, w in ((t, (int(np.float32(res[i].score).view(np.uint32)), res[i].best_ref_index, res[i].best_read_index), want[i])
                                                 for i, t in enumerate(tiles)) if got != w and w[0] != 0xBF800000]
     assert not bad, bad[:5]
-    assert sum(1 for i in range(len(tiles)) if res[i].status == 2) >= 100      # the workload does what it is for
+    assert sum(1 for i in range(len(tiles)) if res[i].status == 2) >= len(tiles) // 6      # the workload does what it is for
 
 
-@pytest.mark.parametrize("table,limit", [("1", None), ("1", "32"), ("0", None)])
-def test_penalty_table_and_its_overflow(built, port_oracle, monkeypatch, table, limit):
-    """The two-phase fill reads the convex gap penalty from an LDS table (cvx_kernels.hip, TAB instantiation: 512 runs); a
-    tile in which a gap run walks off the table is flagged and redone by the arithmetic exact pass.  Whole-tile rings with
-    engineered gap runs around the point where the penalty stops shrinking (27) and, with the table cut to 32 runs
-    (CVX_TUNE_PEN_LIMIT), just below, at and far beyond its end, both kinds; the same tiles with the table switched off
-    (CVX_TUNE_PEN_TABLE=0): equal to the oracle every time, and the long runs really are on the paths."""
+@pytest.mark.parametrize("table", ["1", "0"])
+def test_penalty_table_and_long_gap_runs(built, port_oracle, monkeypatch, table):
+    """The two-phase fill reads the convex gap penalty from an LDS table of 64 runs and clamps its run registers to 56 at every
+    group end (cvx_kernels.hip, TAB instantiation): exact because the penalty is constant from run 27 on.  Whole-tile rings
+    with engineered gap runs around the point where the penalty stops shrinking (27), around the clamp (56) and far beyond
+    it, both kinds -- and every wide corridor carries runs of hundreds through its zero-score cells anyway; the same tiles
+    with the table switched off (CVX_TUNE_PEN_TABLE=0): equal to the oracle either way, the long runs really on the paths."""
     from ngmlr_amd import synth
     from ngmlr_amd.aligner import ConvexAlignHip
     monkeypatch.setenv("CVX_TUNE_PEN_TABLE", table)
-    if limit is not None:
-        monkeypatch.setenv("CVX_TUNE_PEN_LIMIT", limit)
     rng = np.random.default_rng(5150)
     tiles = []
-    for g in (5, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 40, 64, 90, 120):
+    for g in (5, 26, 27, 28, 29, 40, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 64, 90, 120):
         for dels, inss in (([g], []), ([], [g]), ([g, 3], [2, g])):
             ref_parts, qry_parts = [], []
             for k in range(max(len(dels), len(inss)) + 1):
@@ -204,14 +204,30 @@ def test_penalty_table_and_its_overflow(built, port_oracle, monkeypatch, table, 
     tiles += util.tile_zoo(seed=33, n=24, max_w=2500)
     al = ConvexAlignHip(device=0)
     got = _check(al, port_oracle, tiles)
+    al.close()
     longest = max(int(m) for g in got if g["ret"] >= 0 for m in re.findall(r"(\d+)[ID]", g["cigar"]))
     assert longest >= 120
-    batch = al.upload(tiles)
-    tm = batch.run()
-    batch.free()
+
+
+@pytest.mark.parametrize("decay,gext,gem", [(0.0, -5.0, -1.0), (0.0, -2.0, -2.0), (0.01, -5.0, -1.0), (0.5, -3.0, -1.0), (0.07, -5.0, -1.0)])
+def test_penalty_table_under_other_scorings(built, decay, gext, gem):
+    """The table form is used only while the penalty is constant from the clamped run on (decided per handle from the scoring,
+    cvx_runtime.cpp): no decay at all (constant), decay 0.5 (constant from run 4), 0.07 (from run 58: just beyond the clamp, so
+    the arithmetic form), 0.01 (from run 400: the arithmetic form).  Each against the reference-semantics oracle with the same
+    scoring; gap runs of 30-90 on the paths."""
+    from ngmlr_amd import synth
+    from ngmlr_amd.aligner import ConvexAlignHip
+    from oracle.pyoracle import Oracle
+    rng = np.random.default_rng(808)
+    tiles = util.tile_zoo(seed=71, n=18, max_w=1800)
+    for g in (30, 57, 90):
+        tiles.append(_sv_tile(rng, 300, [g], [], "endpoints"))
+        tiles.append(_sv_tile(rng, 300, [], [g], "endpoints"))
+    sc = dict(match=2.0, mismatch=-5.0, gap_open=-5.0, gap_extend=gext, gap_extend_min=gem, gap_decay=decay)
+    orc = Oracle("port", (sc["match"], sc["mismatch"], sc["gap_open"], sc["gap_extend"], sc["gap_extend_min"], sc["gap_decay"]))
+    al = ConvexAlignHip(device=0, **sc)
+    _check(al, orc, tiles)
     al.close()
-    if limit == "32":
-        assert tm.n_tiles_redone >= 20, tm.n_tiles_redone      # every tile with a run of 32 and more left the table
 
 
 def test_every_ring_class(hip_aligner, port_oracle):
@@ -231,7 +247,38 @@ def test_every_ring_class(hip_aligner, port_oracle):
     batch.run()
     rings = sorted({(li["slots_per_lane"], li["waves"]) for li in batch.launches()})
     batch.free()
-    assert len(rings) >= 5 and any(nw > 1 for _, nw in rings), rings      # chained launches report their task count
+    assert len(rings) >= 5 and any(nw > 3 for _, nw in rings), rings      # chained launches report their task count
+
+
+def test_gangs_of_waves(built, port_oracle, monkeypatch):
+    """CVX_TUNE_GANGS=1: corridors with 257-576 live rows as whole tiles on a ring of 384 / 576 slots shared by two / three
+    waves of one workgroup, the lane boundary between the waves going through one LDS record per step (cvx_kernels.hip,
+    GANG) instead of chained row blocks.  Selectable, not the default (measured slower on the ONT mix's short retries,
+    profiles/r05_gang_ab.txt) -- and bit-exact: widths that land in both gang classes, two-phase and exact instantiations,
+    with and without the penalty table, engineered gaps that cross the boundary between two waves."""
+    from ngmlr_amd import synth
+    from ngmlr_amd.aligner import ConvexAlignHip
+    rng = np.random.default_rng(4321)
+    tiles = []
+    for width in (530, 560, 620, 700, 760, 800, 900, 1000, 1100):
+        for W in (1400, 3100):
+            tiles.append(synth.make_tile(rng, W, err=0.15, corridor="endpoints", width=width, realign=True, tag="gang-w%d" % width))
+    for g in (60, 191, 192, 193, 400):
+        tiles.append(_sv_tile(rng, 700, [g], [g + 1], "endpoints"))
+    tiles += _early_best_tiles(rng)[:6]
+    for env in ({"CVX_TUNE_GANGS": "1"}, {"CVX_TUNE_GANGS": "1", "CVX_TUNE_PEN_TABLE": "0"}, {"CVX_TUNE_GANGS": "1", "CVX_TUNE_LATE_MIN": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        al = ConvexAlignHip(device=0)
+        _check(al, port_oracle, tiles, need_valid=False)
+        batch = al.upload(tiles)
+        batch.run()
+        rings = sorted({(li["slots_per_lane"], li["waves"]) for li in batch.launches()})
+        batch.free()
+        al.close()
+        assert (3, 2) in rings and (3, 3) in rings, rings                 # rings of 384 and 576 slots
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def test_chained_row_blocks(built, port_oracle, monkeypatch):
@@ -257,7 +304,7 @@ def test_chained_row_blocks(built, port_oracle, monkeypatch):
         batch = al.upload(tiles)
         tm = batch.run()
         assert tm.n_tiles_chained >= 12, tm.n_tiles_chained
-        assert {li["slots_per_lane"] for li in batch.launches() if li["waves"] > 1} == {chain_m or 1}
+        assert {li["slots_per_lane"] for li in batch.launches() if li["waves"] > 3} == {chain_m or 1}      # (a chained launch reports its row-block tasks)
         batch.free()
         al.close()
 

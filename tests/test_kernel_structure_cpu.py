@@ -41,7 +41,9 @@ def test_fill_kernels_have_flat_uniform_step_loops(device_asm):
     seen = 0
     for name, body in _kernels(device_asm, "_ZN3cvx16fill_ring_kernel"):
         depths = re.findall(r"Loop Header: Depth=(\d+)", body)
-        assert depths and set(depths) == {"1"}, "%s: loop levels %s" % (name, depths)
+        # (a gang's wave spins -- bounded -- on its neighbour's record in front of the step's last slot: one wave-uniform loop inside each step)
+        gang = re.search(r"ELi[23]EEEvNS_8FillArgsE$", name) is not None
+        assert depths and set(depths) <= ({"1", "2"} if gang else {"1"}), "%s: loop levels %s" % (name, depths)
         lines = body.split("\n")
         labels = {l.split(":")[0]: i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)}
         step_loops = 0
@@ -50,6 +52,10 @@ def test_fill_kernels_have_flat_uniform_step_loops(device_asm):
             if not m or m.group(2) not in labels or labels[m.group(2)] >= i:
                 continue
             seg = lines[labels[m.group(2)]:i]
+            # (a backward jump to a block that only ends the program -- the shared exit of an early return -- is not a loop)
+            tgt = [q.strip() for q in lines[labels[m.group(2)] + 1:labels[m.group(2)] + 4] if q.strip() and not q.strip().startswith(";")]
+            if tgt and tgt[0] == "s_endpgm":
+                continue
             if sum(1 for q in seg if "v_addc_co_u32_e64" in q) >= 8:      # holds the plane updates of a group
                 step_loops += 1
                 # (vccz / vccnz test the whole VCC for zero -- a ballot -- and are as wave-uniform as scc; EXEC-based
@@ -59,16 +65,19 @@ def test_fill_kernels_have_flat_uniform_step_loops(device_asm):
         assert step_loops >= 1, name
         seen += 1
     # 4 ring classes x {float, int16 runs} x {two-phase, exact} + 4 x the two-phase float form with the penalty table (TAB) + 3 chain classes x {float, int16}
-    assert seen == 26
+    # + gangs of 2 and 3 waves x {two-phase, two-phase with the table, exact}
+    assert seen == 32
 
 
 def test_register_budgets(device_asm):
     def vgprs(body):
         return int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
     fill = dict(_kernels(device_asm, "_ZN3cvx16fill_ring_kernelILi3ELb0E"))
-    assert len(fill) == 3                                # two-phase (arithmetic penalty and LDS penalty table) and exact instantiation
-    for body in fill.values():
-        assert vgprs(body) <= 80                         # six waves per SIMD
+    assert len(fill) == 9                                # {one wave, gangs of 2 and 3} x {two-phase arithmetic, two-phase with the LDS penalty table, exact}
+    for name, body in fill.items():
+        assert vgprs(body) <= 80, name                   # six waves per SIMD
+    tab = dict(_kernels(device_asm, "_ZN3cvx16fill_ring_kernelILi3ELb0ELi0ELb1ELi1E"))
+    assert len(tab) == 1 and vgprs(next(iter(tab.values()))) <= 72      # the PacBio launch: seven waves per SIMD
     walk = dict(_kernels(device_asm, "_ZN3cvx16backtrack_kernel"))
     assert len(walk) == 1
     assert vgprs(next(iter(walk.values()))) <= 32

@@ -4,7 +4,7 @@ CVX_LIB=ngmlr_amd/variants/libcvxalign_X.so) can be compared alignment by alignm
 
     ab_knobs.py WORKLOAD[,WORKLOAD...] [N_TILES] -- "K=V K=V" "K=V" ...
 
-WORKLOAD: pacbio | ont | c5 | short.  An empty setting ("") is the default configuration.  The first setting is the yardstick:
+WORKLOAD: pacbio | ont | ont_wide | c5 | short.  An empty setting ("") is the default configuration.  The first setting is the yardstick:
 every later one reports how many of its result records (status, score bits, best cell, path end points, op count, ops) differ."""
 import hashlib
 import os
@@ -23,6 +23,8 @@ def gen(what, n, pool):
         return synth.parallel_workload("pacbio", n or 24576, 7, pool, chunk=64)
     if what == "ont":
         return synth.parallel_workload("ont", n or 60000, 11, pool)
+    if what == "ont_wide":      # the ONT mix's retries alone (corridor multiplier 2: 257-576 live rows -- gangs of waves, or chained row blocks)
+        return [t for t in synth.parallel_workload("ont", n or 60000, 11, pool) if int(t.row_length[0]) > 520]
     if what == "c5":
         return synth.parallel_workload("ultralong_mix", n or 4096, 19, pool, chunk=16)
     if what == "short":

@@ -23,7 +23,17 @@ for c in SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CY
 done
 echo "second SQ pass:$SQ2"
 timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $SQ2 -d $OUT/${TAG}_sq2 -o p -- python $R/bench.py --tiles 12288 --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_sq2.log 2>&1
-for p in stats fetch write sq sq2; do
+# round 5: the other BASELINE configs' fill classes (ONT mix: chained retries / M = 4 / M = 3; C5 mix) -- kernel trace and the SQ pass
+# per class (tools/ab_knobs.py: one batch, inputs resident, four runs), and the genome-scale candidate search with its HBM traffic
+for W in ont c5; do
+	timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_${W}_stats -o p -- python $R/tools/ab_knobs.py $W -- "" > $OUT/${TAG}_${W}_stats.log 2>&1
+	timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/${TAG}_${W}_sq -o p -- python $R/tools/ab_knobs.py $W -- "" > $OUT/${TAG}_${W}_sq.log 2>&1
+done
+timeout -s KILL 300 python $R/tools/search_rates.py --big 512 100000 > $OUT/${TAG}_search_big.json 2> $OUT/${TAG}_search_big.err
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_search_stats -o p -- python $R/tools/search_rates.py --big 512 100000 > $OUT/${TAG}_search_stats.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_search_fetch -o p -- python $R/tools/search_rates.py --big 512 100000 > $OUT/${TAG}_search_fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_search_write -o p -- python $R/tools/search_rates.py --big 512 100000 > $OUT/${TAG}_search_write.log 2>&1
+for p in stats fetch write sq sq2 ont_stats ont_sq c5_stats c5_sq search_stats search_fetch search_write; do
 	db=$(ls $OUT/${TAG}_$p/*.db 2>/dev/null | head -1)
 	[ -n "$db" ] && python $R/tools/rocpd_summary.py $db > $OUT/${TAG}_$p.txt 2>&1
 done

@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOM = "void cvx::fill_ring_kernel<3, false, 0>(cvx::FillArgs)"
+DOM = "void cvx::fill_ring_kernel<3, false, 0, true>(cvx::FillArgs)"      # the two-phase float-score instantiation with the LDS penalty table
 
 
 def counters(path, kernel=DOM):
@@ -21,6 +21,56 @@ def counters(path, kernel=DOM):
                 out[f[0]] = float(f[4])            # largest dispatch
             elif len(f) >= 8 and "ms" not in out:
                 out["ms"] = float(f[3]) / 1e3       # median duration, us -> ms
+    return out
+
+
+def all_kernels(path, prefix):
+    """{kernel name: {counter: largest dispatch, "ms": median duration}} for every kernel whose name starts with prefix"""
+    out = {}
+    for line in open(path):
+        if not line.startswith(prefix):
+            continue
+        m = re.match(r"^(.*?\))\s+(.*)$", line)
+        if not m:
+            continue
+        name, f = m.group(1), m.group(2).split()
+        e = out.setdefault(name, {})
+        if len(f) == 5 and re.match(r"^[A-Z_0-9]+$", f[0]):
+            e[f[0]] = float(f[4])
+        elif len(f) >= 8 and "ms" not in e:
+            e["ms"] = float(f[3]) / 1e3
+            e["calls"] = int(f[0])
+    return out
+
+
+def class_report(stats_txt, sq_txt, ab_log):
+    """per fill kernel of one of the other configs: duration, instructions per slot-step, wave-state shares"""
+    cells = {}
+    for l in open(ab_log):
+        m = re.match(r"\s+M=(\d) tasks/waves=(\d+) wrap=(\d):\s+(\d+) tiles\s+([0-9.]+) ms\s+(\d+) G cells/s", l)
+        if m:
+            cells[(int(m.group(1)), int(m.group(2)) > 1)] = {"tiles": int(m.group(4)), "ms_in_the_batch": float(m.group(5)), "G_cells_per_s_in_the_batch": float(m.group(6))}
+    sq = all_kernels(sq_txt, "void cvx::fill_ring_kernel")
+    st = all_kernels(stats_txt, "void cvx::fill_ring_kernel")
+    out = {}
+    for name, c in sq.items():
+        m = re.search(r"<(\d), (true|false), (\d)(?:, (true|false))?>", name)
+        if not m or "SQ_WAVE_CYCLES" not in c:
+            continue
+        M, mode = int(m.group(1)), int(m.group(3))
+        key = "M=%d %s%s" % (M, {0: "two-phase", 1: "exact", 2: "chained row blocks"}[mode], " (int16 runs)" if m.group(2) == "true" else "")
+        e = {"kernel": name, "kernel_ms_alone_in_the_trace": st.get(name, {}).get("ms"),
+             "valu_wave_insts": c.get("SQ_INSTS_VALU"), "salu_wave_insts": c.get("SQ_INSTS_SALU"),
+             "valu_per_salu": (c["SQ_INSTS_VALU"] / c["SQ_INSTS_SALU"]) if c.get("SQ_INSTS_SALU") else None,
+             "wave_state_share": {k: c[k] / c["SQ_WAVE_CYCLES"] for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if k in c},
+             "valu_insts_per_wave_quad_cycle": c.get("SQ_INSTS_VALU", 0.0) / c["SQ_WAVE_CYCLES"]}
+        e.update(cells.get((M, mode == 2), {}))
+        if e.get("tiles") and "G_cells_per_s_in_the_batch" in e:
+            cells_total = e["G_cells_per_s_in_the_batch"] * 1e9 * e["ms_in_the_batch"] * 1e-3
+            # wave-instructions per 64 corridor cells (one per cell and lane if every slot-step were a real cell)
+            e["valu_wave_insts_per_64_cells"] = c.get("SQ_INSTS_VALU", 0.0) / (cells_total / 64.0)
+            e["salu_wave_insts_per_64_cells"] = c.get("SQ_INSTS_SALU", 0.0) / (cells_total / 64.0)
+        out[key] = e
     return out
 
 
@@ -64,6 +114,31 @@ def main():
             e["valu_busy_frac"] = busy / (sq2["ms"] * 1e-3 * 2.4e9 * 1024)
             e["valu_clocks_per_inst"] = busy / sq2["SQ_INSTS_VALU"]
         d["sq_pass"] = e
+    for w in ("ont", "c5"):
+        if os.path.exists(g("%s_sq.txt" % w)) and os.path.exists(g("%s_stats.txt" % w)):
+            d["%s_mix_fill_classes" % w] = class_report(g("%s_stats.txt" % w), g("%s_sq.txt" % w), g("%s_sq.log" % w))
+            d["%s_mix_fill_classes" % w]["_comment"] = ("tools/ab_knobs.py %s (one batch, inputs resident, four runs) under rocprofv3: largest dispatch per fill kernel; "
+                                                        "*_wave_insts_per_64_cells = wave-instructions per 64 corridor cells (idle slots and ramps included: 1 slot-step = 64 cells at best); the classes "
+                                                        "of a batch run side by side on three streams" % w)
+    if os.path.exists(g("search_fetch.txt")) and os.path.exists(g("search_big.json")):
+        try:
+            sb = json.load(open(g("search_big.json")))
+            f = all_kernels(g("search_fetch.txt"), "cvx::search")
+            f.update(all_kernels(g("search_fetch.txt"), "void cvx::search"))
+            wr = all_kernels(g("search_write.txt"), "cvx::search")
+            wr.update(all_kernels(g("search_write.txt"), "void cvx::search"))
+            fetch_kib = sum(v.get("FETCH_SIZE", 0.0) for v in f.values())
+            write_kib = sum(v.get("WRITE_SIZE", 0.0) for v in wr.values())
+            votes = sb["votes_per_sub_read"] * sb["sub_reads"]
+            hbm = (2.0 * fetch_kib + write_kib) * 1024
+            d["candidate_search_big"] = {"sub_reads": sb["sub_reads"], "votes": votes, "fetch_size_kib": fetch_kib, "write_size_kib": write_kib, "fetch_correction": 2.0,
+                                         "hbm_bytes": hbm, "hbm_bytes_per_vote": hbm / votes, "hbm_bytes_per_sub_read": hbm / sb["sub_reads"],
+                                         "kernel_ms": sb["kernel_ms"], "hbm_GB_per_s_over_kernel_time": hbm / (sb["kernel_ms"] * 1e-3) / 1e9,
+                                         "kernels": {k: {"fetch_kib": v.get("FETCH_SIZE"), "ms": v.get("ms")} for k, v in f.items()},
+                                         "_comment": "tools/search_rates.py --big 512 100000 under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; largest dispatch "
+                                                     "of every search kernel = the 100 000-read call), FETCH doubled as for the fill"}
+        except Exception as e:
+            d["candidate_search_big"] = {"error": str(e)}
     json.dump(d, open(out, "w"), indent=1)
     print(json.dumps(d, indent=1))
 
