@@ -928,9 +928,14 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	/* (the `post` stream carries a fill class too unless the post-fill overlap experiment owns it) */
 	hipStream_t fill_streams[kAuxStreams + 2];
 	int n_fill_streams = 0;
-	for (int i = 0; i < kAuxStreams; ++i) fill_streams[n_fill_streams++] = S_aux[i];
+	/* (order: first side stream, post, main -- the assignment of rounds 2-4 for up to three classes -- and the second side stream
+	 * only for a fourth class, i.e. with gangs.  Which class rides on which stream is not neutral: with the three whole-tile
+	 * classes of the C5 mix on side / side / post instead of side / post / main the same batch takes 181 or 236 ms depending on the
+	 * handle, on side / post / main 194 every time: gpurun_out r05u, profiles/r05_fill_stream_order.txt) */
+	fill_streams[n_fill_streams++] = S_aux[0];
 	if (!h->overlap_post) fill_streams[n_fill_streams++] = S_post;
 	fill_streams[n_fill_streams++] = st;
+	for (int i = 1; i < kAuxStreams; ++i) fill_streams[n_fill_streams++] = S_aux[i];
 	auto begin_launch = [&](hipStream_t ls) -> int {
 		while (b->lev.size() < (size_t) (launches + 1) * 4) {
 			hipEvent_t e;
@@ -2082,7 +2087,7 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	 * reference adapts it per batch, CS.cpp:482-489 -- the size only decides WHEN an attempt runs out of budget, a successful
 	 * attempt returns the same list at every size). */
 	const int bits0 = first_bits ? first_bits : 16;
-	static const bool trace = getenv("CVX_SEARCH_TRACE") != nullptr;      /* one line per call on stderr: who ran where, for how long */
+	const bool trace = getenv("CVX_SEARCH_TRACE") != nullptr;      /* one line per call on stderr: who ran where, for how long (read per call: tests switch it on inside a process) */
 	const std::chrono::steady_clock::time_point tr0 = std::chrono::steady_clock::now();
 	std::string tr;
 	auto tr_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };

@@ -67,6 +67,34 @@ def test_device_search_equals_recorded_reference_calls(hip_aligner, which, searc
         ix.free()
 
 
+def test_device_search_on_a_repeat_rich_reference(hip_aligner, search_kernel, capfd, monkeypatch):
+    """Recorded from the unmodified reference on a repeat-rich reference (tools/make_golden_cs.sh, round 5): sub-reads with thousands
+    of votes, hundreds of listed bins, reads from a 400-bp unit with 700 copies -- more bins than the wave kernel's LDS vote map
+    holds, so the same attempt is redone over the real table in HBM and the rest of the ladder follows there.  All three kernel
+    forms, lists / maxHitNumber at 2^16 and lists + kCount at the table size the reference's first attempt had."""
+    import re
+    fx = SearchFixture(os.path.join(util.GOLDEN, "cs_rep.npz"))
+    idx, locs = fx.index_arrays()
+    monkeypatch.setenv("CVX_SEARCH_TRACE", "1")
+    ix = KmerIndex(hip_aligner, fx.k, idx, locs, fx.unit_offset)
+    try:
+        got, max_hit, misses = ix.search(fx.seqs, extras=True)
+        bad = [i for i in range(len(fx.seqs)) if not _same(got[i], *fx.want[i])]
+        assert not bad, (len(bad), bad[:5])
+        assert np.array_equal(max_hit, fx.max_hit.astype(np.float32))
+        for b in sorted(set(int(x) for x in fx.first_bits)):
+            grp = [i for i in range(len(fx.seqs)) if int(fx.first_bits[i]) == b]
+            g_lists, g_max, g_miss = ix.search([fx.seqs[i] for i in grp], first_bits=b, extras=True)
+            assert all(_same(g_lists[j], *fx.want[i]) for j, i in enumerate(grp)), b
+            assert [int(x) for x in g_miss] == [int(fx.kmer_misses[i]) for i in grp], b
+    finally:
+        ix.free()
+    err = capfd.readouterr().err
+    if search_kernel == "wave":
+        to_hbm = sum(int(x) for x in re.findall(r"wave \d+ -> (\d+) to hbm", err))
+        assert to_hbm >= 10, "no sub-read overflowed the LDS vote map: the transition to the HBM-table form was not exercised\n" + err[-600:]
+
+
 def test_device_search_corners_against_the_checker(hip_aligner, search_kernel):
     fx, reads = util.synthetic_search_case()
     o = SearchOracle(fx)

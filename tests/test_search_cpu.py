@@ -49,6 +49,27 @@ def test_oracle_reproduces_every_recorded_candidate_search(built):
     o.close()
 
 
+def test_oracle_reproduces_recorded_searches_on_a_repeat_rich_reference(built):
+    """The same on a reference a k-mer vote has to work on (tools/make_golden_cs.sh, round 5: repeat families of diverged copies,
+    microsatellites, one 400-bp unit in 700 copies): sub-reads with thousands of votes and hundreds of listed bins, table sizes
+    the reference had adapted to (2^12 .. 2^16), kCount summed over ladders that really climbed."""
+    fx = SearchFixture(os.path.join(util.GOLDEN, "cs_rep.npz"))
+    assert len(fx.seqs) >= 1000 and max(len(w[0]) for w in fx.want) >= 300 and int(fx.rlist_len.max()) >= 500
+    o = SearchOracle(fx)
+    bad = []
+    for i in range(len(fx.seqs)):
+        loc, sc, rev = fx.want[i]
+        for bits in (16, int(fx.first_bits[i])):
+            g = o.search(fx.seqs[i], first_bits=bits, cap=1 << 16)
+            if not (g["n"] == len(loc) and np.array_equal(g["loc"], loc) and np.array_equal(g["score"], sc) and np.array_equal(g["rev"], rev)
+                    and g["max_hit"] == fx.max_hit[i] and g["thresh"] == fx.thresh[i] and g["rlist_len"] == fx.rlist_len[i]):
+                bad.append(i)
+        if g["kmer_misses"] != int(fx.kmer_misses[i]):
+            bad.append(i)
+    o.close()
+    assert bad == []
+
+
 def test_n_runs_and_the_retry_ladder(built):
     """Behaviour the recorded reads do not reach: windows holding 'N' are skipped (with the quirk that a run of N at the start of
     a restarted stretch ends the walk when 13 or fewer characters follow), and a read whose votes overflow the probe budget

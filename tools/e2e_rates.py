@@ -76,7 +76,7 @@ def write_sv_workload(path_fa, path_fq, n_reads, seed=2026, L=3_000_000):
     return bases
 
 
-def write_repeat_workload(path_fa, path_fq, n_reads, seed=2027, L=3_000_000):
+def write_repeat_workload(path_fa, path_fq, n_reads, seed=2027, L=3_000_000, dense=0):
     """A reference a k-mer vote has to work on: six repeat families (a 6-15 kb unit copied 8-20 times, every copy 1-4 % diverged from
     the unit), 150 microsatellite stretches of 200-800 bp and the rest random -- sub-reads then have several candidate regions, reads
     several scored locations with close scores (MAPQ < 60, the retry ladder of the vote tables, max-cmrs).  PacBio-like 10 kb reads,
@@ -89,6 +89,15 @@ def write_repeat_workload(path_fa, path_fq, n_reads, seed=2027, L=3_000_000):
         unit = synth.random_ref(rng, int(rng.integers(6000, 15000)))
         for c in range(int(rng.integers(8, 21))):
             v = synth.mutate(rng, unit, float(rng.uniform(0.01, 0.04)), (1, 1, 8))
+            a = int(rng.integers(20000, L - 40000))
+            ref[a:a + len(v)] = v
+            copies.append((a, len(v)))
+    if dense:
+        # one short unit in `dense` nearly identical copies: every k-mer of it has hundreds of locations (below the table's cutoff of
+        # 1 000), so a sub-read from a copy votes for more bins than the device kernel's LDS vote map holds (its HBM-table form runs)
+        unit = synth.random_ref(rng, 400)
+        for c in range(dense):
+            v = synth.mutate(rng, unit, 0.01, (1, 1, 8))
             a = int(rng.integers(20000, L - 40000))
             ref[a:a + len(v)] = v
             copies.append((a, len(v)))
@@ -107,7 +116,7 @@ def write_repeat_workload(path_fa, path_fq, n_reads, seed=2027, L=3_000_000):
         for i in range(n_reads):
             n = int(rng.integers(9000, 11000))
             if i % 3 == 0:
-                ca, cl = copies[int(rng.integers(0, len(copies)))]
+                ca, cl = copies[int(rng.integers(0, len(copies)))] if not (dense and i % 2 == 0) else copies[-1 - int(rng.integers(0, dense))]
                 a = max(0, min(L - n - 1, ca + int(rng.integers(-3000, max(cl - 3000, 1)))))
             else:
                 a = int(rng.integers(0, L - n - 1))

@@ -101,4 +101,18 @@ CVX_RECORD_CS="$WORK/test_3.cs" CVX_RECORD_TABLE="$WORK/test_3.table" "$BIN" --s
 echo "test_3: $(stat -c %s "$WORK/test_3.cs") bytes of sub-read records, $(stat -c %s "$WORK/test_3.table") bytes of table"
 mkdir -p "$REPO/oracle/_ref/golden_full"
 python3 "$HERE/pack_golden_cs.py" "$WORK/test_3.cs" "$WORK/test_3.table" "$REPO/tests/golden/cs_test_3.npz" "$REPO/oracle/_ref/golden_full/cs_test_3_full.npz"
+# round 5: the same recording on a repeat-rich reference (repeat families of diverged copies, microsatellites: tools/e2e_rates.py
+# write_repeat_workload at 1.2 Mbp, plus one 400-bp unit in 700 copies) -- sub-reads with 10^3..10^5 votes, lists with many close candidates, table sizes adapted UP by the
+# reference, reads that overflow the device kernel's LDS vote map and take its HBM-table form.  -> tests/golden/cs_rep.npz (every 2nd
+# recorded call; the table in compact form as above) and oracle/_ref/golden_full/cs_rep_full.npz (all of them)
+python3 - "$REPO" "$WORK/rep.fa" "$WORK/rep.fq" <<'PY'
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tools")
+import e2e_rates
+e2e_rates.write_repeat_workload(sys.argv[2], sys.argv[3], 64, seed=4711, L=1_200_000, dense=700)
+PY
+CVX_RECORD_CS="$WORK/rep.cs" CVX_RECORD_TABLE="$WORK/rep.table" "$BIN" --skip-write -x pacbio -t 1 -R 0.01 --no-progress \
+	-r "$WORK/rep.fa" -q "$WORK/rep.fq" > "$WORK/rep.sam" 2> "$WORK/rep.log" || true
+echo "repeat-rich: $(stat -c %s "$WORK/rep.cs") bytes of sub-read records, $(stat -c %s "$WORK/rep.table") bytes of table"
+python3 "$HERE/pack_golden_cs.py" "$WORK/rep.cs" "$WORK/rep.table" "$REPO/tests/golden/cs_rep.npz" "$REPO/oracle/_ref/golden_full/cs_rep_full.npz" 2
 rm -rf "$WORK"

@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOM = "void cvx::fill_ring_kernel<3, false, 0, true>(cvx::FillArgs)"      # the two-phase float-score instantiation with the LDS penalty table
+DOM = "void cvx::fill_ring_kernel<3, false, 0, true, 1>(cvx::FillArgs)"      # the two-phase float-score instantiation with the LDS penalty table
 
 
 def counters(path, kernel=DOM):
@@ -54,17 +54,20 @@ def class_report(stats_txt, sq_txt, ab_log):
     st = all_kernels(stats_txt, "void cvx::fill_ring_kernel")
     out = {}
     for name, c in sq.items():
-        m = re.search(r"<(\d), (true|false), (\d)(?:, (true|false))?>", name)
+        m = re.search(r"<(\d), (true|false), (\d)(?:, (true|false))?(?:, (\d))?>", name)
         if not m or "SQ_WAVE_CYCLES" not in c:
             continue
         M, mode = int(m.group(1)), int(m.group(3))
-        key = "M=%d %s%s" % (M, {0: "two-phase", 1: "exact", 2: "chained row blocks"}[mode], " (int16 runs)" if m.group(2) == "true" else "")
+        G = int(m.group(5)) if m.group(5) else 1
+        key = "M=%d %s%s%s%s" % (M, {0: "two-phase", 1: "exact", 2: "chained row blocks"}[mode], " (int16 runs)" if m.group(2) == "true" else "",
+                               " with the penalty table" if m.group(4) == "true" else "", (" x %d waves" % G) if G > 1 else "")
         e = {"kernel": name, "kernel_ms_alone_in_the_trace": st.get(name, {}).get("ms"),
              "valu_wave_insts": c.get("SQ_INSTS_VALU"), "salu_wave_insts": c.get("SQ_INSTS_SALU"),
              "valu_per_salu": (c["SQ_INSTS_VALU"] / c["SQ_INSTS_SALU"]) if c.get("SQ_INSTS_SALU") else None,
              "wave_state_share": {k: c[k] / c["SQ_WAVE_CYCLES"] for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if k in c},
              "valu_insts_per_wave_quad_cycle": c.get("SQ_INSTS_VALU", 0.0) / c["SQ_WAVE_CYCLES"]}
-        e.update(cells.get((M, mode == 2), {}))
+        if mode != 1:
+            e.update(cells.get((M, mode == 2), {}))
         if e.get("tiles") and "G_cells_per_s_in_the_batch" in e:
             cells_total = e["G_cells_per_s_in_the_batch"] * 1e9 * e["ms_in_the_batch"] * 1e-3
             # wave-instructions per 64 corridor cells (one per cell and lane if every slot-step were a real cell)

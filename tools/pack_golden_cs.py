@@ -1,6 +1,6 @@
-"""tools/pack_golden_cs.py CS_DUMP TABLE_DUMP SAMPLE.npz FULL.npz -- the recorder dumps of tools/make_golden_cs.sh as fixtures:
+"""tools/pack_golden_cs.py CS_DUMP TABLE_DUMP SAMPLE.npz FULL.npz [STRIDE] -- the recorder dumps of tools/make_golden_cs.sh as fixtures:
 the k-mer table in compact form (used prefixes, slot counts, RefTable, unit offset) and the recorded candidate-search calls
-(sub-read -> LocationScore list in the reference's order, maxHitNumber, threshold, kCount, table size of the first attempt).  SAMPLE keeps every `stride`-th sub-read."""
+(sub-read -> LocationScore list in the reference's order, maxHitNumber, threshold, kCount, table size of the first attempt).  SAMPLE keeps every STRIDE-th sub-read (default 6)."""
 import struct
 import sys
 
@@ -52,4 +52,4 @@ if __name__ == '__main__':
     print("table: k=%d, %d used prefixes, %d locations; %d recorded sub-reads, %d candidates" % (
         table['k'], len(table['prefix']), len(table['locs']), len(calls), sum(len(c[4]) for c in calls)))
     pack(table, calls, sys.argv[4])
-    pack(table, calls[::6], sys.argv[3])
+    pack(table, calls[::int(sys.argv[5]) if len(sys.argv) > 5 else 6], sys.argv[3])

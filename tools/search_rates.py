@@ -34,12 +34,12 @@ def big_index_rates(al, mbp=512, n_reads=100000, parity_n=2000, n_contigs=8, pmc
     try:
         ix.search(reads[:512])
         best = None
-        for _ in range(2):
+        for _ in range(3):                                  # (the first full-size call also grows the handle's arenas)
             c0 = time.perf_counter()
             got, max_hit, misses = ix.search(reads, extras=True)
             dt = time.perf_counter() - c0
             kms = al.stage_kernel_ms(capi.STAGE_SEARCH)
-            if best is None or kms < best[1]:
+            if best is None or dt < best[0]:
                 best = (dt, kms)
         dt, kms = best
     finally:
