@@ -61,13 +61,14 @@ namespace Convex {
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
 		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0),
 		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), stop(false), launches(0), requests(0), maxInFlight(0),
-		target(0), holdUs(20000), feedActive(true), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000) {
+		target(0), holdUs(20000), feedActive(true), textLaunches(0), textNs(0), deviceText(false), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000) {
 	if (const char * e = getenv("CVX_BATCH_TARGET")) target = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_HOLD_US")) holdUs = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_LEAD_US")) leadUs = atoi(e);      /* < 0: the plain timeout rule while a launch runs */
 	/* launches in flight: the upload and corridor analysis of the second run under the kernels of the first.  More (tried
 	 * with 4, and with the runtime's two stream sets) only makes the launches smaller: 20 000 reads 25.1 s against 21.2 s */
 	if (const char * e = getenv("CVX_BATCH_INFLIGHT")) maxFlight = atoi(e) > 0 ? atoi(e) : 1;
+	if (const char * e = getenv("CVX_DEVICE_TEXT")) deviceText = atoi(e) != 0;
 	dispatcher = std::thread([this] { dispatchLoop(); });
 }
 
@@ -152,6 +153,7 @@ void BatchingAligner::dispatchLoop() {
 			retired.pop_back();
 			lk.unlock();
 			if (l->job) backend->Release(l->job);
+			delete l->text;
 			delete l;
 			lk.lock();
 		}
@@ -159,7 +161,7 @@ void BatchingAligner::dispatchLoop() {
 		bool const canSubmit = (int) inFlight.size() < maxFlight;
 		if (canSubmit && shouldCut(inFlight.empty())) {
 			Launch * l = new Launch();
-			l->job = 0; l->results = 0; l->ops = 0; l->failed = false;
+			l->job = 0; l->results = 0; l->ops = 0; l->failed = false; l->text = 0;
 			size_t const take = std::min(queue.size(), (size_t) maxBatch);
 			l->reqs.assign(queue.begin(), queue.begin() + (long) take);
 			queue.erase(queue.begin(), queue.begin() + (long) take);
@@ -202,6 +204,15 @@ void BatchingAligner::dispatchLoop() {
 			if (!l->failed) {
 				try {
 					backend->Wait(l->job, &l->results, &l->ops);
+					if (deviceText) {
+						std::vector<ConvexAlignHip::Tile const *> tiles(l->reqs.size());
+						for (size_t i = 0; i < tiles.size(); ++i) tiles[i] = &l->reqs[i]->tile;
+						l->text = new ConvexAlignHip::JobText();
+						std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
+						backend->Text(l->job, tiles.data(), (int) tiles.size(), *l->text);
+						textNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();      /* (dispatcher only) */
+						textLaunches += 1;
+					}
 				} catch (...) {
 					l->failed = true;
 				}
@@ -263,7 +274,8 @@ int BatchingAligner::SingleAlign(int const mode, CorridorLine * corridor, int co
 	bool threw = failed;
 	if (!failed) {
 		try {
-			backend->Finish(req.tile, *r, ops);
+			if (l->text) backend->FinishText(req.tile, *r, *l->text, (int) (r - l->results));
+			else backend->Finish(req.tile, *r, ops);
 		} catch (...) {
 			threw = true;
 		}
@@ -293,7 +305,8 @@ int g_deviceUsers[kMaxDevices] = {0};
 int g_users = 0;
 long g_joined = 0;
 long g_lastLaunches = 0, g_lastRequests = 0;
-double g_lastParked = 0.0, g_lastFinish = 0.0, g_lastBusy = 0.0;
+double g_lastParked = 0.0, g_lastFinish = 0.0, g_lastBusy = 0.0, g_lastTextSeconds = 0.0;
+long g_lastTextLaunches = 0;
 std::chrono::steady_clock::time_point g_firstJoin;
 std::chrono::steady_clock::time_point const g_loaded = std::chrono::steady_clock::now();      /* ~ process start */
 bool g_poolAccounting = false;                       /* under g_sharedMtx */
@@ -359,6 +372,8 @@ SharedAligner::~SharedAligner() {
 		g_lastParked += g_shared[device]->ParkedSeconds();
 		g_lastFinish += g_shared[device]->FinishSeconds();
 		g_lastBusy += g_shared[device]->BusySeconds();
+		g_lastTextLaunches += g_shared[device]->TextLaunches();
+		g_lastTextSeconds += g_shared[device]->TextSeconds();
 		delete g_shared[device]; g_shared[device] = 0;
 		delete g_backend[device]; g_backend[device] = 0;
 	}
@@ -370,6 +385,7 @@ SharedAligner::~SharedAligner() {
 				"%.1f %% in their text stage; a launch was in flight %.1f %% of the time\n", g_joined, wall,
 				100.0 * g_lastParked / (wall * (double) g_joined), g_lastRequests ? 1e3 * g_lastParked / (double) g_lastRequests : 0.0,
 				100.0 * g_lastFinish / (wall * (double) g_joined), 100.0 * g_lastBusy / wall);
+		if (g_lastTextLaunches > 0) fprintf(stderr, "SharedAligner: text stage on the device for %ld launches (cvx_job_text + cvx_job_nm_profile), %.3f s of the dispatchers' time\n", g_lastTextLaunches, g_lastTextSeconds);
 		fprintf(stderr, "SharedAligner: library loaded at 0, first worker joined at %.2f s, last one left at %.2f s\n",
 				std::chrono::duration<double>(g_firstJoin - g_loaded).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - g_loaded).count());
 	}

@@ -90,6 +90,8 @@ public:
 	double ParkedSeconds() const { return parkedNs * 1e-9; }
 	double FinishSeconds() const { return finishNs * 1e-9; }
 	double BusySeconds() const { return busyNs * 1e-9; }
+	long TextLaunches() const { return textLaunches; }        /* launches whose text stage ran on the device (CVX_DEVICE_TEXT=1) */
+	double TextSeconds() const { return textNs * 1e-9; }      /* the dispatcher's time in those calls */
 
 private:
 	struct Launch;
@@ -109,6 +111,7 @@ private:
 		uint32_t const * ops;
 		int unfinished;                    /* workers still writing their text out of this launch's buffers */
 		bool failed;
+		ConvexAlignHip::JobText * text;    /* CVX_DEVICE_TEXT=1: the launch's text stage ran on the device (else 0) */
 	};
 	ConvexAlignHip * backend;
 	std::mutex mtx;
@@ -124,6 +127,9 @@ private:
 	int target;                                 /* batch target (CVX_BATCH_TARGET, 0 = none) and how long the oldest request may */
 	int holdUs;                                 /* wait for it (CVX_BATCH_HOLD_US) */
 	bool feedActive;                            /* see SetFeedActive (true until told otherwise) */
+	long textLaunches; long long textNs;
+	bool deviceText;                            /* CVX_DEVICE_TEXT=1: cvx_job_text + cvx_job_nm_profile per launch instead of one
+	                                             * host text stage per request on the workers (measured: DESIGN.md 6) */
 	bool stop;
 	long launches, requests, maxInFlight;
 	long long parkedNs, finishNs, busyNs;       /* under mtx */

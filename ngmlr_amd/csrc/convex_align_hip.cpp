@@ -166,22 +166,7 @@ void ConvexAlignHip::AlignTiles(Tile * tiles, int n) {
 void ConvexAlignHip::Finish(Tile & t, cvx_result const & r, uint32_t const * ops) const {
 	Align & a = *t.result;
 	int const refLen = t.refLen, qryLen = t.qryLen;
-	if (r.status == CVX_TILE_UNSUPPORTED) {
-		fprintf(stderr, "ConvexAlignHip: corridor shape not covered by any device kernel\n");
-		throw 1;
-	}
-	if (r.status != CVX_TILE_OK) {
-		if (r.status == CVX_TILE_TOO_LARGE) {
-			/* the reference's message (src/AlignmentMatrixFast.cpp:56), same float arithmetic for the size */
-			fprintf(stderr, "Warning: Couldn't allocate alignment matrix. Required memory (%llu) > max matrix size (%lu)\n\n",
-					(long long) ((float) r.cells / 1000.0f / 1000.0f), maxMatrixMB);
-		} else if (a.pBuffer2 != 0) {
-			a.pBuffer2[0] = '\0';
-		}
-		a.Score = -1.0f;
-		t.ret = -1;
-		return;
-	}
+	if (noAlignment(t, r)) return;
 	cvx_alignment_text txt;
 	for (;;) {
 		int rc = cvx_format_alignment(&r, ops, t.refSeq, refLen, qryLen, t.externalQStart,
@@ -212,6 +197,11 @@ void ConvexAlignHip::Finish(Tile & t, cvx_result const & r, uint32_t const * ops
 				txt.cigar_len, txt.md_len, a.maxBufferLength, a.maxMdBufferLength);
 		throw 1;
 	}
+	fillAlign(t, txt);
+}
+
+void ConvexAlignHip::fillAlign(Tile & t, cvx_alignment_text const & txt) const {
+	Align & a = *t.result;
 	a.QStart = txt.qstart;
 	a.QEnd = txt.qend;
 	a.firstPosition.refPosition = txt.first_ref;
@@ -226,6 +216,85 @@ void ConvexAlignHip::Finish(Tile & t, cvx_result const & r, uint32_t const * ops
 	a.Score = txt.score;
 	a.svType = txt.sv_type;
 	t.ret = txt.ret;
+}
+
+/* true: the tile has no alignment and the Align says so already (the cases Finish handles before it formats anything) */
+bool ConvexAlignHip::noAlignment(Tile & t, cvx_result const & r) const {
+	Align & a = *t.result;
+	if (r.status == CVX_TILE_UNSUPPORTED) {
+		fprintf(stderr, "ConvexAlignHip: corridor shape not covered by any device kernel\n");
+		throw 1;
+	}
+	if (r.status == CVX_TILE_OK) return false;
+	if (r.status == CVX_TILE_TOO_LARGE) {
+		/* the reference's message (src/AlignmentMatrixFast.cpp:56), same float arithmetic for the size */
+		fprintf(stderr, "Warning: Couldn't allocate alignment matrix. Required memory (%llu) > max matrix size (%lu)\n\n",
+				(long long) ((float) r.cells / 1000.0f / 1000.0f), maxMatrixMB);
+	} else if (a.pBuffer2 != 0) {
+		a.pBuffer2[0] = '\0';
+	}
+	a.Score = -1.0f;
+	t.ret = -1;
+	return true;
+}
+
+void ConvexAlignHip::Text(cvx_job job, Tile const * const * tiles, int n, JobText & jt) {
+	size_t const n1 = (size_t) (n > 0 ? n : 0);
+	jt.out.resize(n1 + 1);
+	jt.textOff.resize(n1 + 1);
+	jt.nmOff.assign(n1 + 1, 0);
+	jt.text = "";
+	if (n <= 0) return;
+	std::vector<int32_t> ext(2 * n1);
+	for (size_t i = 0; i < n1; ++i) { ext[i] = tiles[i]->externalQStart; ext[n1 + i] = tiles[i]->externalQEnd; }
+	uint64_t bytes = 0;
+	int rc = cvx_job_text(handle, job, ext.data(), ext.data() + n1, jt.out.data(), jt.textOff.data(), &jt.text, &bytes);
+	if (rc == CVX_OK) rc = cvx_job_nm_sizes(handle, job, 0, n, jt.nmOff.data());
+	if (rc == CVX_OK) {
+		jt.nm.resize((size_t) (3 * jt.nmOff[n1] + 3));
+		rc = cvx_job_nm_profile(handle, job, 0, n, jt.nmOff.data(), jt.nm.data(), jt.nmOff[n1] + 1, 0);
+	}
+	if (rc != CVX_OK) {
+		fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
+		throw 1;
+	}
+}
+
+/* what Finish leaves in the caller's Align, copied out of the job's device-made text (same growth rules for pBuffer2 and
+ * nmPerPosition, same hard error for a CIGAR beyond the caller's buffer) */
+void ConvexAlignHip::FinishText(Tile & t, cvx_result const & r, JobText const & jt, int index) const {
+	if (noAlignment(t, r)) return;
+	Align & a = *t.result;
+	cvx_alignment_text const & txt = jt.out[(size_t) index];
+	if (txt.md_len >= a.maxMdBufferLength) {       /* checkMdBufferLength: grow with new[] */
+		int cap = a.maxMdBufferLength > 0 ? a.maxMdBufferLength : 64;
+		while (cap <= txt.md_len) cap *= 2;
+		delete[] a.pBuffer2;
+		a.pBuffer2 = new char[cap];
+		a.maxMdBufferLength = cap;
+	}
+	if (txt.nm_count > a.nmPerPostionLength) {      /* addPosition: grow with new[] */
+		int cap = a.nmPerPostionLength > 0 ? a.nmPerPostionLength : 64;
+		while (cap < txt.nm_count) cap *= 2;
+		delete[] a.nmPerPosition;
+		a.nmPerPosition = new PositionNM[cap];
+		a.nmPerPostionLength = cap;
+	}
+	if (txt.cigar_len > a.maxBufferLength) {
+		fprintf(stderr, "CIGAR/MD buffer not long enough (%d %d > %d %d). Please report this!\n",
+				txt.cigar_len, txt.md_len, a.maxBufferLength, a.maxMdBufferLength);
+		throw 1;
+	}
+	char const * src = jt.text + jt.textOff[(size_t) index];
+	memcpy(a.pBuffer1, src, (size_t) (txt.cigar_len + 1 <= a.maxBufferLength ? txt.cigar_len + 1 : a.maxBufferLength));
+	memcpy(a.pBuffer2, src + txt.cigar_len + 1, (size_t) txt.md_len + 1);
+	uint64_t const e0 = jt.nmOff[(size_t) index], e1 = jt.nmOff[(size_t) index + 1];
+	if ((uint64_t) txt.nm_count != e1 - e0) {
+		fprintf(stderr, "ConvexAlignHip: nmPerPosition count of the device (%llu) differs from the text stage's (%d)\n", (unsigned long long) (e1 - e0), txt.nm_count);
+		throw 1;
+	}
+	if (e1 > e0) memcpy((void *) a.nmPerPosition, jt.nm.data() + 3 * e0, (size_t) (e1 - e0) * 3 * sizeof(int32_t));
+	fillAlign(t, txt);
 }
 
 }  // namespace Convex

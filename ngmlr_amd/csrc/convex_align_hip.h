@@ -81,7 +81,22 @@ public:
 	void Finish(Tile & t, cvx_result const & r, uint32_t const * ops) const;
 	void Release(cvx_job job);
 
+	/* The text stage of a whole finished job on the device instead of one Finish per tile on the workers' cores
+	 * (cvx_job_text + cvx_job_nm_profile: CIGAR, MD, the scalar fields and nmPerPosition from the ops and sequences
+	 * still resident in HBM).  Text belongs to the device thread, after Wait and before Release; FinishText may run
+	 * on any thread and only copies: the same Align, byte for byte, as Finish (tests/test_gpu_e2e.py, CVX_DEVICE_TEXT=1). */
+	struct JobText {
+		std::vector<cvx_alignment_text> out;
+		std::vector<uint64_t> textOff, nmOff;
+		std::vector<int32_t> nm;           /* (refPosition, readPosition, nm) triples of all tiles */
+		char const * text;                 /* the job's page-locked text buffer */
+	};
+	void Text(cvx_job job, Tile const * const * tiles, int n, JobText & jt);
+	void FinishText(Tile & t, cvx_result const & r, JobText const & jt, int index) const;
+
 private:
+	void fillAlign(Tile & t, cvx_alignment_text const & txt) const;
+	bool noAlignment(Tile & t, cvx_result const & r) const;
 	cvx_handle handle;
 	unsigned long maxMatrixMB;
 	std::vector<cvx_tile> packed;

@@ -165,6 +165,33 @@ def test_split_reads_with_structural_variants(built, tmp_path, extra):
     assert "CandidateSearchHip:" in err and "AlignPool: 160 reads" in err, err[-1500:]
 
 
+def test_text_stage_on_the_device_in_the_pipeline(built, tmp_path):
+    """CVX_DEVICE_TEXT=1: the dispatcher runs cvx_job_text + cvx_job_nm_profile once per launch (CIGAR, MD, the scalar fields and
+    nmPerPosition from the ops and sequences still in HBM) and the workers only copy (ConvexAlignHip::FinishText) instead of
+    formatting their own tile on a host core (Finish).  test_3 and the split-read workload (whose small-inversion detection reads
+    nmPerPosition, reference src/AlignmentBuffer.cpp:1267-1341): every SAM record identical to the unmodified reference's."""
+    import re
+    import sys
+    env = {"CVX_POOL_CONTEXTS": "256", "CVX_DEVICE_TEXT": "1"}
+    got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_ALL, env=env)
+    assert sorted(got) == _test_3_want()
+    m = re.search(r"text stage on the device for (\d+) launches", err)
+    k = re.search(r"SharedAligner: 985 alignments in (\d+) device launches", err)
+    assert m and k and int(m.group(1)) == int(k.group(1)), err[-1500:]
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ngmlr_ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/ngmlr_ref not built")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_rates
+    fa, fq = str(tmp_path / "sv_ref.fa"), str(tmp_path / "sv_reads.fq")
+    e2e_rates.write_sv_workload(fa, fq, 120, seed=78)
+    args = ["-x", "ont", "-R", "0.01", "--no-progress", "-r", fa, "-q", fq]
+    want, _ = _run(["-t", "16"] + args, tmp_path, binary=ref_bin)
+    got, err = _run(["-t", "8"] + args, tmp_path, binary=BIN_ALL, env=dict(env, CVX_POOL_CONTEXTS="128"))
+    assert sorted(got) == sorted(want)
+    assert re.search(r"text stage on the device for [1-9]\d* launches", err), err[-1500:]
+
+
 def test_repeat_rich_reference(built, tmp_path):
     """What a k-mer vote sees on a real genome: repeat families of 8-20 diverged copies and microsatellites, so that sub-reads cast
     10^4..10^5 votes, overflow the wave kernel's LDS map (the HBM-table form runs) and reads get several close candidates (MAPQ
