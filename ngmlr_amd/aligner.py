@@ -506,7 +506,13 @@ def format_alignment(lib, res: capi.CvxResult, ops: np.ndarray, tile, want_nm: b
     # What the reference's consumer reads: detectMisalignment walks nmPerPosition[i] for
     # i < alignmentLength (src/AlignmentBuffer.cpp:1320-1321), although only txt.nm_count triples were
     # written (positions > 16, none for insertion columns); the rest of the caller's buffer is zero here.
-    n = min(txt.alignment_length, nm_cap) if (txt.ret >= 0 and want_nm) else 0
+    # The buffer it walks is the caller's: (read length + 1) * 2 entries (src/AlignmentBuffer.cpp:277), doubled by addPosition
+    # while the written triples do not fit (src/ConvexAlignFast.cpp:79-92; ConvexAlignHip::Finish grows it the same way) -- an
+    # alignment with more columns than that (long deletions under a scoring with cheap gaps) is read up to the buffer's end.
+    align_cap = 2 * (H + 1)
+    while align_cap < txt.nm_count:
+        align_cap *= 2
+    n = min(txt.alignment_length, align_cap, nm_cap) if (txt.ret >= 0 and want_nm) else 0
     d["nm_per_position"] = nm[:n].copy()
     d["nm_count"] = txt.nm_count      # triples actually written
     d["status"] = res.status

@@ -139,3 +139,27 @@ def test_n_clip_flags_fire_like_the_reference(port_oracle, ref_oracle):
         assert got["sv_type"] == flag
         n_pos += flag
     assert n_pos >= 4
+
+
+def test_profile_of_an_alignment_longer_than_the_callers_buffer(built):
+    """Cheap gaps (match 3, mismatch -3, gaps -1 ... -0.5) turn a short read into an alignment with more columns than the
+    (read length + 1) * 2 entries the reference's caller allocates for nmPerPosition (src/AlignmentBuffer.cpp:277): the consumer
+    walks alignmentLength entries of that buffer (:1320), addPosition doubles it only when the written triples do not fit
+    (src/ConvexAlignFast.cpp:79-92).  The text stage and the checker must agree on exactly that view -- found by
+    tools/fuzz_parity.py's scoring sweep, where the harness compared buffers of different capacity."""
+    from oracle.pyoracle import Oracle, have_ref
+    from ngmlr_amd import synth
+    params = (3.0, -3.0, -1.0, -1.0, -0.5, 0.15)
+    port = Oracle("port", params)
+    ref = Oracle("reference", params) if have_ref() else None
+    tiles = synth.workload_short(100, seed=9000)
+    longer = 0
+    for t in tiles:
+        want, got = _format_from_oracle(port, t)
+        if got is None:
+            continue
+        assert same_alignment(want, got) is None, (t.tag, t.H, same_alignment(want, got))
+        if ref is not None:
+            assert same_alignment(ref.align(t), got) is None, (t.tag, t.H)
+        longer += got["alignment_length"] > 2 * (t.H + 1)
+    assert longer >= 3

@@ -1,6 +1,6 @@
 """Dev tool (GPU box): a randomised parity sweep of the HIP path against the oracle, far beyond the seeds the test suite pins.
 
-    fuzz_parity.py SECONDS [seed0]
+    fuzz_parity.py SECONDS [seed0] [scoring]
 
 Round r (seed = seed0 + r) draws tiles from every generator the tests use -- the corridor zoo (all constructors, error models, odd
 symbols), edge-hugging tiles (anchors corridors shifted by about their half-width, mult 1-3), the ONT mix with retries, short reads,
@@ -8,7 +8,10 @@ engineered long gaps, early-best tiles -- runs them through cvx_align under one 
 most of the time; chained row blocks of every height, no penalty table, gangs, no chaining, the int16-run kernels, the catch-all kernel, other walk widths) and compares every
 tile with oracle/convex_oracle.c on 16 host threads: status, score bits, CIGAR, MD, NM, clips, offsets, the per-position profile and
 the best cell.  Stops at the first round with a mismatch (exit code 1) and prints the tiles' tags and shapes; otherwise runs until
-SECONDS are over and prints the totals.  Results of a run: profiles/r05_fuzz_parity.txt."""
+SECONDS are over and prints the totals.  With a third argument `scoring` every round also draws its scoring parameters (the
+scorings of tests/test_gpu_parity.py's EXOTIC_SCORING -- the regime where the reference's SSE path and the scalar recurrence
+disagree --, decays 0 / 0.01 / 0.07 / 0.5 around the penalty table's switch, ...) and the checker is the reference itself
+(oracle/_ref) when it is there.  Results of two runs: profiles/r05_fuzz_parity.txt, r05_fuzz_parity_scoring.txt."""
 import os
 import sys
 import threading
@@ -22,7 +25,14 @@ from ngmlr_amd import synth                      # noqa: E402
 from ngmlr_amd.aligner import ConvexAlignHip     # noqa: E402
 from oracle.pyoracle import Oracle, same_alignment  # noqa: E402
 from tests import util                           # noqa: E402
-from tests.test_gpu_parity import _edge_hugging_tiles, _sv_tile, _early_best_tiles  # noqa: E402
+from tests.test_gpu_parity import _edge_hugging_tiles, _sv_tile, _early_best_tiles, EXOTIC_SCORING  # noqa: E402
+
+SCORINGS = EXOTIC_SCORING + [
+    dict(match=2.0, mismatch=-5.0, gap_open=-5.0, gap_extend=-5.0, gap_extend_min=-1.0, gap_decay=d) for d in (0.0, 0.01, 0.07, 0.5)] + [
+    dict(match=2.0, mismatch=-5.0, gap_open=-5.0, gap_extend=-2.0, gap_extend_min=-2.0, gap_decay=0.0),
+    dict(match=1.0, mismatch=-1.0, gap_open=-1.0, gap_extend=-1.0, gap_extend_min=-0.5, gap_decay=0.15),      # the ont preset's commented-out values (src/ArgParser.cpp:261-265)
+    dict(match=3.0, mismatch=-3.0, gap_open=-1.0, gap_extend=-1.0, gap_extend_min=-0.5, gap_decay=0.15),
+    dict(match=5.0, mismatch=-4.0, gap_open=-8.0, gap_extend=-6.0, gap_extend_min=-0.25, gap_decay=0.2)]
 
 KNOBS = [{}, {}, {}, {"CVX_TUNE_MAX_M": "1"}, {"CVX_TUNE_MAX_M": "1", "CVX_TUNE_CHAIN_M": "2"}, {"CVX_TUNE_MAX_M": "2", "CVX_TUNE_CHAIN_M": "4"},
          {"CVX_TUNE_FORCE_WRAP16": "1"}, {"CVX_TUNE_SSE_VARIANT": "1"}, {"CVX_TUNE_PEN_TABLE": "0"}, {"CVX_TUNE_GANGS": "1"}, {"CVX_TUNE_SMALL_BATCH": "1"},
@@ -51,7 +61,7 @@ def oracle_all(oracles, tiles):
         o = oracles[k]
         for i in range(k, len(tiles), len(oracles)):
             w = o.align(tiles[i])
-            f = o.last_fwd() if w["ret"] >= 0 else None
+            f = o.last_fwd() if (w["ret"] >= 0 and o.kind == "port") else None
             want[i] = (w, (f["best_x"], f["best_y"]) if f else None)
     ths = [threading.Thread(target=work, args=(k,)) for k in range(len(oracles))]
     for t in ths: t.start()
@@ -62,6 +72,8 @@ def oracle_all(oracles, tiles):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    vary = len(sys.argv) > 3 and sys.argv[3] == "scoring"
+    from oracle.pyoracle import have_ref
     oracles = [Oracle("port") for _ in range(THREADS)]
     t_start = time.time()
     totals = {"rounds": 0, "tiles": 0, "valid": 0, "cells": 0}
@@ -70,8 +82,14 @@ def main():
         seed = seed0 + r
         knobs = KNOBS[int(np.random.default_rng(seed ^ 0x5bd1).integers(0, len(KNOBS)))]
         tiles = draw(seed)
+        sc = {}
+        if vary:
+            sc = SCORINGS[int(np.random.default_rng(seed ^ 0x77).integers(0, len(SCORINGS)))]
+            params = (sc["match"], sc["mismatch"], sc["gap_open"], sc["gap_extend"], sc["gap_extend_min"], sc["gap_decay"])
+            for o in oracles: o.close()
+            oracles = [Oracle("reference" if have_ref() else "port", params) for _ in range(THREADS)]
         for k, v in knobs.items(): os.environ[k] = v
-        al = ConvexAlignHip(device=0)
+        al = ConvexAlignHip(device=0, **sc)
         for k in knobs: os.environ.pop(k)
         t0 = time.time()
         got = al.batch_align(tiles)
@@ -91,8 +109,8 @@ def main():
         nv = sum(1 for w, _ in want if w["ret"] >= 0)
         cells = int(sum(int(np.asarray(t.row_length, dtype=np.int64).sum()) for t in tiles))
         totals["rounds"] += 1; totals["tiles"] += len(tiles); totals["valid"] += nv; totals["cells"] += cells
-        print("seed %d knobs %s: %d tiles (%d with an alignment, %.2f G corridor cells), device %.2f s, oracle %.2f s: %d mismatches" % (
-            seed, knobs or "default", len(tiles), nv, cells / 1e9, t1 - t0, t2 - t1, len(bad)), flush=True)
+        print("seed %d knobs %s%s: %d tiles (%d with an alignment, %.2f G corridor cells), device %.2f s, oracle %.2f s: %d mismatches" % (
+            seed, knobs or "default", (" scoring %s vs %s" % (tuple(sc.values()), oracles[0].kind)) if sc else "", len(tiles), nv, cells / 1e9, t1 - t0, t2 - t1, len(bad)), flush=True)
         if bad:
             for b in bad[:20]: print("    ", b)
             print("FAILED after %d rounds" % totals["rounds"])
