@@ -357,8 +357,9 @@ struct cvx_context {
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
 	int tune_pen_table = 1;   /* tuning knob (env CVX_TUNE_PEN_TABLE = 0 / 1): convex penalty from the LDS table in the two-phase float-score fills */
 	int test_fail_compute = 0; /* test knob (env CVX_TUNE_FAIL_COMPUTE = k): the k-th compute stage of this handle fails (error-path tests) */
-	int bt_group = 0;          /* lanes per tile in the backtrack: 0 = auto (8 for the bulk, 32 for the much-longer-than-average
-	                            * reads), 8 / 16 / 32 = that many for all, 64 = the one-wave-per-tile walk (env CVX_TUNE_BT_GROUP) */
+	int bt_group = 0;          /* lanes per tile in the backtrack: 0 = auto (by the number of tiles walked together: 64 / 32 / 16 / 8, and 32 for
+	                            * the much-longer-than-average reads of a bulk walked at 8 or 16), 8 / 16 / 32 = that many for all, 64 = the
+	                            * one-wave-per-tile walk, -1 = round 4's rule (64 below 4 096 tiles, else 8 + 32) (env CVX_TUNE_BT_GROUP) */
 	bool overlap_post = false; /* tuning knob (env CVX_TUNE_OVERLAP_POST): backtrack/finalize/compaction of batch k on their own stream, beside the fills of batch k+1 */
 	bool sse_variant = false; /* scoring outside the regime where the reference's SSE path equals the scalar recurrence:
 	                           * every tile goes to the catch-all kernel's SSE-variant instantiation */
@@ -891,11 +892,23 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	 * batch), in front of it on the same stream otherwise (measured: PacBio 5.4 -> 4.9 ms with 8 lanes, ONT mix 8.2 -> 6.6 with 32) */
 	auto walk_list = [&](size_t at, int count, hipStream_t ws, hipStream_t side, bool fork) -> int {
 		if (count <= 0) return CVX_OK;
-		if (n_walk < 4096) {
+		/* Lanes per tile by the number of tiles walked together (round 5): a walk is a serial chain of probes per tile, and
+		 * what hides a probe's latency is other waves -- so few tiles get many lanes each (a probe then covers 64 / 32 / 16
+		 * path columns of a diagonal run instead of 8) until the walk has about six waves per SIMD, and only beyond that
+		 * is it issue-bound and eight lanes per tile the cheapest.  Measured against round 4's rule (one wave per tile below
+		 * 4 096 tiles, eight lanes from there on): C5 mix, 4 096 tiles of 100 kb, walk 39.5 ms at 8 lanes = 512 waves on 1 024
+		 * SIMDs, 25.9 at 16, 21.6 at 32, 19.4 at 64; ONT mix at 49 152 tiles in one walk 7.6 ms at 8, 6.0 at 16; the PacBio
+		 * bench (49 152 tiles): the walk alone 7.7 ms at 8 and 8.4 at 16, the pipelined step 114.4-114.9 against 113.9-114.1 ms
+		 * (profiles/r05_ab_bt_group.txt). */
+		const int auto_group = count <= 6144 ? 64 : count <= 12288 ? 32 : count <= 49152 ? 16 : 8;
+		if (h->bt_group < 0 ? n_walk < 4096 : (h->bt_group == 0 && auto_group == 64)) {
 			HIP_TRY(launch_backtrack(ba, b->d_lists.p + at, count, 64, ws));
-		} else if (h->bt_group != 0) {
+		} else if (h->bt_group > 0) {
 			HIP_TRY(launch_backtrack(ba, b->d_lists.p + at, count, h->bt_group, ws));
+		} else if (h->bt_group == 0 && auto_group >= 32) {
+			HIP_TRY(launch_backtrack(ba, b->d_lists.p + at, count, auto_group, ws));
 		} else {
+			const int bulk = h->bt_group < 0 ? 8 : auto_group;      /* 8 or 16; the much-longer-than-average reads at 32 */
 			const TileIn *tin = b->tin();
 			const uint64_t mean_h = b->n_rows / (uint64_t) std::max(n, 1);
 			int n_long = 0;
@@ -908,7 +921,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 			} else if (n_long > 0) {
 				HIP_TRY(launch_backtrack(ba, b->d_lists.p + at, n_long, 32, ws));
 			}
-			HIP_TRY(launch_backtrack(ba, b->d_lists.p + at + n_long, count - n_long, 8, ws));
+			HIP_TRY(launch_backtrack(ba, b->d_lists.p + at + n_long, count - n_long, bulk, ws));
 			if (n_long > 0 && fork) HIP_TRY(hipStreamWaitEvent(ws, b->ev_bt1, 0));
 		}
 		return CVX_OK;

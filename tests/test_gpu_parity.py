@@ -419,9 +419,9 @@ def test_two_phase_tracking_redo_path(built, port_oracle, monkeypatch, late_min)
 
 
 @pytest.mark.parametrize("env", [{"CVX_TUNE_BT_GROUP": "4"}, {"CVX_TUNE_BT_GROUP": "8"}, {"CVX_TUNE_BT_GROUP": "16"}, {"CVX_TUNE_BT_GROUP": "32"},
-                                 {"CVX_TUNE_BT_GROUP": "64"}, {"CVX_TUNE_OVERLAP_POST": "1"}, {"CVX_TUNE_BT_PER_CLASS": "0"}])
+                                 {"CVX_TUNE_BT_GROUP": "64"}, {"CVX_TUNE_BT_GROUP": "-1"}, {"CVX_TUNE_OVERLAP_POST": "1"}, {"CVX_TUNE_BT_PER_CLASS": "0"}])
 def test_runtime_knobs_do_not_change_results(built, port_oracle, monkeypatch, env):
-    """Every lanes-per-tile setting of the backtrack (the default picks 8 / 32 / 64 by batch shape), the
+    """Every lanes-per-tile setting of the backtrack (the default picks 8 / 16 / 32 / 64 by the number of tiles walked together; -1: round 4's rule), the
     post-fill overlap, and one walk behind all fills instead of one per fill class (the default for a batch of several
     classes, as this one is): same alignments.  A batch of > 4096 tiles so that the grouped kernels really run,
     chained and whole tiles mixed, a few reads much longer than the rest."""
