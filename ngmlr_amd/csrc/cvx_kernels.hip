@@ -640,6 +640,9 @@ fill_ring_kernel(const FillArgs a) {
 		chain_t0 = __builtin_amdgcn_s_memtime();
 	} else {
 		t = a.list[blockIdx.x];
+		/* the widest ring class of a batch of several (FillArgs::chain_prio, set by the host): its waves pay the most per step, its
+		 * tiles are the launch's long pole beside the narrower classes' -- one notch above those */
+		if (!GANG && a.chain_prio) { if (a.chain_prio >= 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #if CVX_FILL_PRIO
 		/* The list is longest-first and a tile is a serial chain of steps: in a batch of uneven tiles (ONT mix: median
 		 * 1.3 kb, up to 20 kb) the launch lasts as long as its longest tiles take at a sixth of a SIMD.  The first

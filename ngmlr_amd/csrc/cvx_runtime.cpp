@@ -352,6 +352,7 @@ struct cvx_context {
 	                           * Measured with the batching dispatcher at four launches in flight: no gain -- 20 000 reads 25.1 s against
 	                           * 21.2 s, launches get smaller and each still lasts as long as its slowest tile -- so it stays off. */
 	int tune_exact_steps = kExactDirectSteps;   /* tuning knob (env CVX_TUNE_EXACT_STEPS, 0 = off): tiles of this many steps go straight to the exact fill */
+	int tune_wide_prio = 1;   /* tuning knob (env CVX_TUNE_WIDE_PRIO = 0 / 1 / 2: off, priority 1, priority 2): the widest ring class of a batch of several one priority notch up */
 	int tune_chain_prio = -1; /* tuning knob (env CVX_TUNE_CHAIN_PRIO = 0 / 1): wave priority of chained blocks; -1 = the default (raised) */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
@@ -997,21 +998,26 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 2], ls));
 		RC_TRY(end_launch(ls));
 	}
+	int ring_classes = 0;
+	for (size_t c = 0; c < cls.size(); ++c) ring_classes += cls[c].empty() ? 0 : 1;
+	bool widest = true;
 	for (int cc = (int) cls.size() - 1; cc >= 0; --cc) {
 		const size_t c = (size_t) cc;
 		if (cls[c].empty()) continue;
 		const KernelClass &kc = kClasses[c / 2];
+		const int wide_prio = (h->tune_wide_prio && widest && ring_classes > 1) ? h->tune_wide_prio : 0;
+		widest = false;
 		launch_stats(cls[c], kc.m, kc.gang, (int) (c & 1));      /* `waves` = waves per tile (a gang's size) */
 		hipStream_t ls = fill_streams[launches % n_fill_streams];
 		RC_TRY(begin_launch(ls));
 		if (n_direct[c] > 0) {
 			/* the very long tiles of the class, exact from the first step (flagged above), before everything else */
 			FillArgs ad = fill_args(b->d_lists.p + seg_begin[c], n_direct[c]);
-			if (kc.gang > 1) ad.chain_prio = h->tune_gang_prio;
+			ad.chain_prio = kc.gang > 1 ? h->tune_gang_prio : wide_prio;
 			HIP_TRY(launch_fill(kc.m, kc.gang, (c & 1) != 0, 1, ad, 0, ls));
 		}
 		FillArgs a = fill_args(b->d_lists.p + seg_begin[c] + n_direct[c], (int) cls[c].size() - n_direct[c]);
-		if (kc.gang > 1) a.chain_prio = h->tune_gang_prio;
+		a.chain_prio = kc.gang > 1 ? h->tune_gang_prio : wide_prio;
 		if (a.list_n > 0) HIP_TRY(launch_fill(kc.m, kc.gang, (c & 1) != 0, 0, a, 0, ls));
 		HIP_TRY(hipEventRecord(b->lev[(size_t) launches * 4 + 1], ls));
 		/* exact-tracking pass over the tiles the two-phase pass flagged (usually none) */
@@ -1276,6 +1282,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_M")) c->tune_chain_m = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_PRIO")) c->tune_chain_prio = atoi(e) != 0;
+	if (const char *e = getenv("CVX_TUNE_WIDE_PRIO")) c->tune_wide_prio = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_EXACT_STEPS")) c->tune_exact_steps = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_TWO_LANES")) c->single_lane = atoi(e) == 0;
 	if (const char *e = getenv("CVX_TUNE_LONG_STEPS")) c->tune_long_steps = atoi(e);
