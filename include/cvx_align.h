@@ -351,7 +351,9 @@ void cvx_index_free(cvx_handle h, cvx_index ix);
  * that to cvx_index_upload).  start_table[i] / seq_lengths[i]: first nibble and number of bases of the i-th kept sequence;
  * ref_skip = --kmer-skip (2), bin_shift = --bin-size (4).  ref_table_index: room for 4^kmer_len + 2 records of 5 bytes;
  * ref_table: room for ref_table_capacity locations -- CVX_ERR_CAPACITY with *n_locations = the need when that is too few
- * (the index records are complete by then).  Host only, one thread, ~20 ns per sampled position. */
+ * (the index records are complete by then).  Host only: the walks one thread per sequence, the passes over the 4^k records on
+ * min(hardware threads, 16) threads (CVX_INDEX_THREADS).  Bound inside ngmlr at CompactPrefixTable::CreateTable
+ * (ngmlr_amd/csrc/index_build_binding.inc): a 2 Mbp reference 2.4 -> 0.36 s, table file byte-identical. */
 int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table, const uint64_t *seq_lengths, int32_t n_seqs,
 		int32_t kmer_len, int32_t ref_skip, int32_t bin_shift, void *ref_table_index, uint32_t *ref_table, uint64_t ref_table_capacity,
 		uint64_t *n_locations);

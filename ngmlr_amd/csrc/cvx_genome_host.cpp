@@ -113,8 +113,9 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 	int n_threads = (int) std::thread::hardware_concurrency();
 	if (n_threads > 16) n_threads = 16;
 	if (const char *e = getenv("CVX_INDEX_THREADS")) n_threads = atoi(e);
-	if (n_threads > n_seqs) n_threads = n_seqs;
 	if (n_threads < 1) n_threads = 1;
+	const int n_range_threads = n_threads;                /* the passes over the 4^k records do not care how many sequences there are */
+	if (n_threads > n_seqs) n_threads = n_seqs;
 	bool oom = false;
 
 	/* DecodeRefSequence(buf, id, start, len): len - 2 characters, the rest NUL */
@@ -193,11 +194,11 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 		work();
 		for (std::thread &t : ths) t.join();
 	};
-	auto parallel_ranges = [&](uint64_t n, auto &&fn) {      /* fn(begin, end) over [0, n) in n_threads pieces */
+	auto parallel_ranges = [&](uint64_t n, auto &&fn) {      /* fn(begin, end, piece) over [0, n) in n_range_threads pieces */
 		std::vector<std::thread> ths;
-		const uint64_t per = (n + (uint64_t) n_threads - 1) / (uint64_t) n_threads;
-		for (int t = 1; t < n_threads; ++t) ths.emplace_back([&, t] { fn(std::min(n, per * (uint64_t) t), std::min(n, per * (uint64_t) (t + 1))); });
-		fn(0, std::min(n, per));
+		const uint64_t per = (n + (uint64_t) n_range_threads - 1) / (uint64_t) n_range_threads;
+		for (int t = 1; t < n_range_threads; ++t) ths.emplace_back([&, t] { fn(std::min(n, per * (uint64_t) t), std::min(n, per * (uint64_t) (t + 1)), t); });
+		fn(0, std::min(n, per), 0);
 		for (std::thread &t : ths) t.join();
 	};
 
@@ -228,7 +229,7 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 		const uint64_t n_t = 1ull << (2 * nt), n_m = 1ull << (2 * nm);
 		std::vector<uint32_t> rc_t((size_t) n_t);
 		for (uint64_t v = 0; v < n_t; ++v) rc_t[(size_t) v] = (uint32_t) rc_bits(v, nt);
-		parallel_ranges(n_m, [&](uint64_t m0, uint64_t m1) {
+		parallel_ranges(n_m, [&](uint64_t m0, uint64_t m1, int) {
 			for (uint64_t m = m0; m < m1; ++m) {
 				const uint64_t rm = rc_bits(m, nm);
 				for (uint64_t h = 0; h < n_t; ++h)
@@ -241,19 +242,34 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 		});
 	}
 	uint8_t *idx = static_cast<uint8_t *>(ref_table_index);
-	memset(idx, 0, (size_t) (length + 1) * 5);
-	uint64_t next = 0;
 	auto put_tab = [&](uint64_t i, uint64_t v) { const uint32_t t = (uint32_t) v; memcpy(idx + 5 * i, &t, 4); };
-	uint64_t i = 0;
-	for (; i < length - 1; ++i) {
-		const int f = freq[(size_t) i];
-		put_tab(i, next + 1);
-		if (f > 0 && total[(size_t) i] < kMaxFreq) {
-			idx[5 * i + 4] = (uint8_t) (char) ((float) (kMaxFreq - total[(size_t) i]) * 100.0f / (float) kMaxFreq);
-			next += (uint64_t) f;
+	/* the running sum `next` of the reference's loop (:283-309), as a prefix sum in pieces: every piece sums the frequencies of
+	 * the k-mers it keeps, then writes its records from the sum of the pieces before it */
+	std::vector<uint64_t> piece_sum((size_t) n_range_threads + 1, 0);
+	parallel_ranges(length - 1, [&](uint64_t b, uint64_t e, int piece) {
+		uint64_t sum = 0;
+		for (uint64_t i = b; i < e; ++i) {
+			const int f = freq[(size_t) i];
+			if (f > 0 && total[(size_t) i] < kMaxFreq) sum += (uint64_t) f;
 		}
-	}
-	put_tab(i, next + 1);
+		piece_sum[(size_t) piece + 1] = sum;
+	});
+	for (int t = 0; t < n_range_threads; ++t) piece_sum[(size_t) t + 1] += piece_sum[(size_t) t];
+	parallel_ranges(length - 1, [&](uint64_t b, uint64_t e, int piece) {
+		uint64_t next = piece_sum[(size_t) piece];
+		for (uint64_t i = b; i < e; ++i) {
+			const int f = freq[(size_t) i];
+			put_tab(i, next + 1);
+			idx[5 * i + 4] = 0;
+			if (f > 0 && total[(size_t) i] < kMaxFreq) {
+				idx[5 * i + 4] = (uint8_t) (char) ((float) (kMaxFreq - total[(size_t) i]) * 100.0f / (float) kMaxFreq);
+				next += (uint64_t) f;
+			}
+		}
+	});
+	const uint64_t next = piece_sum[(size_t) n_range_threads];
+	memset(idx + 5 * (length - 1), 0, 10);                 /* records length - 1 (the end marker) and length (never written by the reference: Index()) */
+	put_tab(length - 1, next + 1);
 	total = std::vector<int32_t>();
 	lap("index");
 	*n_locations = next;
@@ -263,7 +279,7 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 	/* pass 2: BuildPrefixTable (positions relative to the unit's offset 0).  SaveToRefTable takes the first unused slot of the
 	 * k-mer's run, i.e. the run fills in the order of the walk: ascending positions.  With several threads the slots are
 	 * handed out by an atomic cursor per k-mer (the counter array of pass 1, reused) and every run is sorted afterwards. */
-	std::fill(freq.begin(), freq.end(), 0);
+	parallel_ranges(length, [&](uint64_t b, uint64_t e, int) { memset(freq.data() + b, 0, (size_t) (e - b) * sizeof(int32_t)); });
 	for_kept_kmers([&](uint64_t prefix, uint64_t pos) {
 		if (idx[5 * prefix + 4] == 0) return;              /* RefTableIndex[prefix].used() */
 		uint32_t tab;
@@ -273,7 +289,7 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 	});
 	if (oom) return CVX_ERR_OOM;
 	if (n_threads > 1) {
-		parallel_ranges(n_prefix, [&](uint64_t p0, uint64_t p1) {
+		parallel_ranges(n_prefix, [&](uint64_t p0, uint64_t p1, int) {
 			for (uint64_t p = p0; p < p1; ++p) {
 				const int32_t n = freq[(size_t) p];
 				if (n < 2) continue;

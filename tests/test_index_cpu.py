@@ -41,13 +41,8 @@ def _reference(rng):
     return seqs
 
 
-@pytest.fixture(scope="module")
-def reference_table(tmp_path_factory):
-    """the sequences and the table unit the unmodified reference built from them (one run for the module)"""
-    if not os.path.exists(REF_BIN):
-        pytest.skip("oracle/_ref/ngmlr_ref not built (needs /root/reference)")
-    tmp_path = tmp_path_factory.mktemp("index")
-    seqs = _reference(np.random.default_rng(31))
+def _build_with(binary, tmp_path, seqs):
+    """-> (table file bytes, SAM records) of `binary` run on `seqs` in tmp_path"""
     fa = str(tmp_path / "ref.fa")
     with open(fa, "wb") as f:
         for name, s in seqs:
@@ -57,11 +52,29 @@ def reference_table(tmp_path_factory):
                 f.write(raw[i:i + 70] + b"\n")
     fq = str(tmp_path / "r.fq")
     open(fq, "w").write("@r\n%s\n+\n%s\n" % (seqs[0][1][1000:1600].tobytes().decode(), "I" * 600))
-    res = subprocess.run([REF_BIN, "-x", "pacbio", "-t", "1", "-r", fa, "-q", fq, "-o", str(tmp_path / "o.sam")], cwd=str(tmp_path),
+    res = subprocess.run([binary, "-x", "pacbio", "-t", "1", "-r", fa, "-q", fq, "-o", str(tmp_path / "o.sam")], cwd=str(tmp_path),
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     raw = np.fromfile(fa + "-ht-13-2.2.ngm", dtype=np.uint8)
     os.remove(fa + "-ht-13-2.2.ngm")
+    sam = [l for l in open(str(tmp_path / "o.sam")).read().splitlines() if not l.startswith("@PG")]
+    return raw, sam, res.stderr.decode(errors="replace")
+
+
+@pytest.fixture(scope="module")
+def reference_run(tmp_path_factory):
+    """the sequences, the table file and the SAM of the unmodified reference (one run for the module)"""
+    if not os.path.exists(REF_BIN):
+        pytest.skip("oracle/_ref/ngmlr_ref not built (needs /root/reference)")
+    seqs = _reference(np.random.default_rng(31))
+    raw, sam, _ = _build_with(REF_BIN, tmp_path_factory.mktemp("index"), seqs)
+    return seqs, raw, sam
+
+
+@pytest.fixture(scope="module")
+def reference_table(reference_run):
+    """the sequences and the table unit the unmodified reference built from them"""
+    seqs, raw, _ = reference_run
     cookie, k, skip, units, isz = [int(x) for x in raw[:20].view(np.uint32)]
     assert (k, skip, units, isz) == (13, 2, 1, 4 ** 13 + 1)
     tl = int(raw[20:24].view(np.uint32)[0])
@@ -106,3 +119,18 @@ def test_index_builder_equals_the_reference_table(built, reference_table, monkey
     used = want_idx.reshape(-1, 5)[:, 4] != 0
     assert int((np.diff(tab.astype(np.int64)) > 0).sum()) > int(used.sum()), "no k-mer beyond the frequency cutoff kept its slots"
     assert tl < int(kept.sum()) // 3
+
+
+def test_index_builder_bound_inside_ngmlr_writes_the_reference_table(reference_run, tmp_path):
+    """cvx_index_build where ngmlr builds its table (ngmlr_amd/csrc/index_build_binding.inc at the top of
+    CompactPrefixTable::CreateTable, reference src/PrefixTable.cpp:323; tools/build_ngmlr_hip.sh, variant ngmlr_index_cpu: the
+    reference's CPU code with only that change): the -ht-13-2.2.ngm file it writes -- header, 4^13 + 1 index records, locations,
+    unit offset -- is the unmodified binary's byte for byte, and so is the SAM of the read mapped with it."""
+    binary = os.path.join(ROOT, "oracle", "_ref", "ngmlr_index_cpu")
+    if not os.path.exists(binary):
+        pytest.skip("oracle/_ref/ngmlr_index_cpu not built")
+    seqs, want_raw, want_sam = reference_run
+    raw, sam, err = _build_with(binary, tmp_path, seqs)
+    assert "cvx_index_build" in err, err[-1500:]          # the bound builder ran (its log line), not the reference's
+    assert raw.shape == want_raw.shape and np.array_equal(raw, want_raw)
+    assert sam == want_sam and any(not l.startswith("@") for l in sam)

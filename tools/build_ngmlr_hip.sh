@@ -28,19 +28,34 @@ mkdir -p "$REPO/oracle/_ref"
 #   ngmlr_hip_all      ngmlr_hip_pool + the candidate search of every CS thread's batch on the device (Convex::CandidateSearchHip,
 #                      cs_search_binding.inc at the top of CS::RunBatch, src/CS.cpp:400): alignment, sub-read scoring, k-mer vote
 #                      and SAM records on the drop-ins (SURVEY 8 f1 + f2 + f3 + f4's search half)
+#                      -- and the k-mer table itself built by cvx_index_build (index_build_binding.inc in CompactPrefixTable::CreateTable)
+#   ngmlr_index_cpu    the reference's CPU code with only that table builder bound: the table file it writes against the unmodified
+#                      binary's, without a GPU (tests/test_index_cpu.py)
 #   ngmlr_pool_cpu     the reference's CPU aligners + the same pool: the pool's own correctness without a GPU (tests/test_pool_cpu.py)
 #   ngmlr_ref          (nothing changed)       the unmodified reference, for wall-clock comparison only
 build_variant() {
-local OUT_NAME=$1 CLASS=$2 SCORER=${3:-} SAM=${4:-} POOL=${5:-} SEARCH=${6:-}
+local OUT_NAME=$1 CLASS=$2 SCORER=${3:-} SAM=${4:-} POOL=${5:-} SEARCH=${6:-} INDEX=${7:-}
 local T="$WORK/$OUT_NAME"
 cp -r /root/reference "$T"
 if [ "$CLASS" != "unmodified" ]; then
-python3 - "$T" "$REPO" "$CLASS" "$SCORER" "$SAM" "$POOL" "$SEARCH" <<'PY'
+python3 - "$T" "$REPO" "$CLASS" "$SCORER" "$SAM" "$POOL" "$SEARCH" "$INDEX" <<'PY'
 import re, sys
-T, REPO, CLASS, SCORER, SAM, POOL, SEARCH = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6], sys.argv[7]
+T, REPO, CLASS, SCORER, SAM, POOL, SEARCH, INDEX = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6], sys.argv[7], sys.argv[8]
 def sub1(s, old, new, what):
     assert s.count(old) == 1, (what, s.count(old))
     return s.replace(old, new, 1)
+if INDEX:
+    # the k-mer table built by cvx_index_build (ngmlr_amd/csrc/index_build_binding.inc at the top of CompactPrefixTable::CreateTable)
+    p = T + '/src/SequenceProvider.h'
+    s = open(p).read()
+    s = sub1(s, '\tChromosome getChrStart(uloc const position);\n', '\tChromosome getChrStart(uloc const position);\n\t/* the 4-bit genome as Init built it (read access for cvx_index_build) */\n'
+             '\tchar const * cvxBinRef() const { return binRef; }\n', 'SequenceProvider.h accessor')
+    open(p, 'w').write(s)
+    p = T + '/src/PrefixTable.cpp'
+    s = open(p).read()
+    s = sub1(s, '#include "PrefixTable.h"', '#include "PrefixTable.h"\n#include <vector>\n#include <stdlib.h>\n#include <stdint.h>\n#include "cvx_align.h"', 'PrefixTable.cpp includes')
+    s = sub1(s, 'void CompactPrefixTable::CreateTable(uint const length) {\n', 'void CompactPrefixTable::CreateTable(uint const length) {\n#include "index_build_binding.inc"\n', 'CompactPrefixTable::CreateTable')
+    open(p, 'w').write(s)
 if SEARCH:
     # the k-mer vote of a CS thread's batch on the device (ngmlr_amd/csrc/candidate_search_hip.h, cs_search_binding.inc)
     p = T + '/src/PrefixTable.h'
@@ -126,9 +141,10 @@ build_variant ngmlr_hip_full Convex::SharedAligner StrippedSWHip sam &
 build_variant ngmlr_sam cpu "" sam &
 build_variant ngmlr_hip_pool Convex::SharedAligner StrippedSWHip sam pool &
 build_variant ngmlr_pool_cpu cpu "" "" pool &
-build_variant ngmlr_hip_all Convex::SharedAligner StrippedSWHip sam pool search &
+build_variant ngmlr_hip_all Convex::SharedAligner StrippedSWHip sam pool search index &
+build_variant ngmlr_index_cpu cpu "" "" "" "" index &
 build_variant ngmlr_ref unmodified &     # the reference as it is: wall-clock yardstick of tools/e2e_rates.py
 wait
-test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched" && test -x "$REPO/oracle/_ref/ngmlr_hip_full" && test -x "$REPO/oracle/_ref/ngmlr_sam" && test -x "$REPO/oracle/_ref/ngmlr_hip_pool" && test -x "$REPO/oracle/_ref/ngmlr_pool_cpu" && test -x "$REPO/oracle/_ref/ngmlr_hip_all"
+test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched" && test -x "$REPO/oracle/_ref/ngmlr_hip_full" && test -x "$REPO/oracle/_ref/ngmlr_sam" && test -x "$REPO/oracle/_ref/ngmlr_hip_pool" && test -x "$REPO/oracle/_ref/ngmlr_pool_cpu" && test -x "$REPO/oracle/_ref/ngmlr_hip_all" && test -x "$REPO/oracle/_ref/ngmlr_index_cpu"
 readelf -d "$REPO/oracle/_ref/ngmlr_hip" | grep -E "RPATH|RUNPATH|NEEDED" | head
 rm -rf "$WORK"
