@@ -205,7 +205,7 @@ int cvx_device_synchronize(int device_id);
  *   - the first cvx_create on a device puts that device into hipDeviceScheduleBlockingSync mode (host threads that wait for
  *     it sleep instead of spinning; this also governs the host application's own HIP waits on that device).  CVX_WAIT=spin
  *     leaves the runtime's default; a runtime that refuses the flag is reported on stderr.
- *   - loading the library sets GPU_MAX_HW_QUEUES=8 in the environment unless the variable is already set (the HIP runtime
+ *   - loading the library sets GPU_MAX_HW_QUEUES=16 in the environment unless the variable is already set (the HIP runtime
  *     reads it at its first call): the streams of several handles in one process must not share hardware queues. */
 int cvx_create(int device_id, const cvx_params *params, uint64_t max_matrix_mb, cvx_handle *out);
 void cvx_destroy(cvx_handle h);

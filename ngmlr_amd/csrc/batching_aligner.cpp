@@ -61,7 +61,7 @@ namespace Convex {
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
 		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0),
 		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), stop(false), launches(0), requests(0), maxInFlight(0),
-		target(0), holdUs(20000), feedActive(true), textLaunches(0), textNs(0), deviceText(false), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000) {
+		target(0), holdUs(20000), feedActive(true), textLaunches(0), textNs(0), launchTrace(false), deviceText(false), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000) {
 	if (const char * e = getenv("CVX_BATCH_TARGET")) target = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_HOLD_US")) holdUs = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_LEAD_US")) leadUs = atoi(e);      /* < 0: the plain timeout rule while a launch runs */
@@ -69,6 +69,7 @@ BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, in
 	 * with 4, and with the runtime's two stream sets) only makes the launches smaller: 20 000 reads 25.1 s against 21.2 s */
 	if (const char * e = getenv("CVX_BATCH_INFLIGHT")) maxFlight = atoi(e) > 0 ? atoi(e) : 1;
 	if (const char * e = getenv("CVX_DEVICE_TEXT")) deviceText = atoi(e) != 0;
+	if (const char * e = getenv("CVX_LAUNCH_TRACE")) launchTrace = atoi(e) != 0;
 	dispatcher = std::thread([this] { dispatchLoop(); });
 }
 
@@ -163,6 +164,8 @@ void BatchingAligner::dispatchLoop() {
 			Launch * l = new Launch();
 			l->job = 0; l->results = 0; l->ops = 0; l->failed = false; l->text = 0;
 			size_t const take = std::min(queue.size(), (size_t) maxBatch);
+			l->oldestAt = oldest;
+			l->cutAt = std::chrono::steady_clock::now();
 			l->reqs.assign(queue.begin(), queue.begin() + (long) take);
 			queue.erase(queue.begin(), queue.begin() + (long) take);
 			if (!queue.empty()) oldest = std::chrono::steady_clock::now();
@@ -204,6 +207,11 @@ void BatchingAligner::dispatchLoop() {
 			if (!l->failed) {
 				try {
 					backend->Wait(l->job, &l->results, &l->ops);
+					if (launchTrace) {
+						std::chrono::steady_clock::time_point const t = std::chrono::steady_clock::now();
+						backend->Trace(l->job, (int) l->reqs.size(), std::chrono::duration<double, std::milli>(t - l->cutAt).count(),
+								std::chrono::duration<double, std::milli>(l->cutAt - l->oldestAt).count());
+					}
 					if (deviceText) {
 						std::vector<ConvexAlignHip::Tile const *> tiles(l->reqs.size());
 						for (size_t i = 0; i < tiles.size(); ++i) tiles[i] = &l->reqs[i]->tile;

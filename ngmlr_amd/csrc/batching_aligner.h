@@ -109,6 +109,7 @@ private:
 		std::vector<Request *> reqs;
 		cvx_result const * results;
 		uint32_t const * ops;
+		std::chrono::steady_clock::time_point cutAt, oldestAt;      /* CVX_LAUNCH_TRACE: when the launch was cut, when its oldest request arrived */
 		int unfinished;                    /* workers still writing their text out of this launch's buffers */
 		bool failed;
 		ConvexAlignHip::JobText * text;    /* CVX_DEVICE_TEXT=1: the launch's text stage ran on the device (else 0) */
@@ -128,6 +129,7 @@ private:
 	int holdUs;                                 /* wait for it (CVX_BATCH_HOLD_US) */
 	bool feedActive;                            /* see SetFeedActive (true until told otherwise) */
 	long textLaunches; long long textNs;
+	bool launchTrace;                           /* CVX_LAUNCH_TRACE=1: one stderr line per finished launch */
 	bool deviceText;                            /* CVX_DEVICE_TEXT=1: cvx_job_text + cvx_job_nm_profile per launch instead of one
 	                                             * host text stage per request on the workers (measured: DESIGN.md 6) */
 	bool stop;

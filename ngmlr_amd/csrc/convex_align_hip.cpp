@@ -133,6 +133,21 @@ void ConvexAlignHip::Wait(cvx_job job, cvx_result const ** results, uint32_t con
 	}
 }
 
+void ConvexAlignHip::Trace(cvx_job job, int nTiles, double serviceMs, double waitedMs) const {
+	cvx_timing t;
+	if (cvx_job_timing(job, &t) != CVX_OK) return;
+	char cls[256];
+	int at = 0;
+	cls[0] = '\0';
+	for (int i = 0; i < t.n_fill_launches && at < 200; ++i) {
+		cvx_launch_info li;
+		if (cvx_job_launch_info(job, i, &li) != CVX_OK) break;
+		at += snprintf(cls + at, sizeof(cls) - (size_t) at, " M%d%s x%d %.2f ms", li.slots_per_lane, li.waves > 1 ? "c" : "", li.n_tiles, li.ms);
+	}
+	fprintf(stderr, "cvx launch: %d tiles, %.1f M cells, oldest request waited %.1f ms, in flight %.1f ms: plan %.2f fill %.2f walk %.2f device total %.2f ms;%s%s\n",
+			nTiles, (double) t.cells * 1e-6, waitedMs, serviceMs, t.plan_ms, t.fill_ms, t.backtrack_ms, t.total_ms, cls, t.n_tiles_redone ? " (redo)" : "");
+}
+
 void ConvexAlignHip::Release(cvx_job job) {
 	cvx_job_release(handle, job);
 }

@@ -80,6 +80,8 @@ public:
 	void Wait(cvx_job job, cvx_result const ** results, uint32_t const ** ops);
 	void Finish(Tile & t, cvx_result const & r, uint32_t const * ops) const;
 	void Release(cvx_job job);
+	/* one line on stderr about a finished job: tiles, device stages, fill classes (CVX_LAUNCH_TRACE=1 in the dispatcher) */
+	void Trace(cvx_job job, int nTiles, double serviceMs, double waitedMs) const;
 
 	/* The text stage of a whole finished job on the device instead of one Finish per tile on the workers' cores
 	 * (cvx_job_text + cvx_job_nm_profile: CIGAR, MD, the scalar fields and nmPerPosition from the ops and sequences

@@ -1159,14 +1159,20 @@ void pack_pool_run(int n_tasks, const std::function<void(int)> &fn) { PackPool::
 }
 
 /* Before the HIP runtime reads its settings (it does at the first HIP call of the process, which for ngmlr and for bench.py is
- * one of ours): eight hardware queues per device instead of the runtime's four.  A handle runs its fill classes side by side
+ * one of ours): sixteen hardware queues per device instead of the runtime's four.  A handle runs its fill classes side by side
  * on three streams beside the upload stream, and a process holds several handles (ngmlr: the aligner, sixteen search handles,
  * the scoring plugin's); with four hardware queues the streams of a later handle share queues, and two fill classes that
  * share a queue run one after the other -- measured (gpurun_out/r05b): the ONT mix 45 ms per batch on the first handle of a
- * process, 59 ms on every later one (C5 mix: 195 / 288 ms); with eight queues every handle gets the 45 / 195.  Not
- * overridden when the user has set GPU_MAX_HW_QUEUES. */
+ * process, 59 ms on every later one (C5 mix: 195 / 288 ms); with eight queues every handle gets the 45 / 195.  Sixteen, not
+ * eight, because of ngmlr: there the aligner's fill streams are created when fifty streams of the search and scoring handles
+ * exist, and with eight queues two of its classes still landed on one -- the launch trace of the pipeline
+ * (CVX_LAUNCH_TRACE=1, profiles/r05_e2e_launch_trace.txt) showed a launch's fill lasting the SUM of its classes (M = 4 10.1 ms +
+ * M = 3 7.7 ms = 19 ms of a 20.5 ms launch); with sixteen: 10.7 of 12.2 ms, mapping 3.0 -> 2.6 s for 20 000 reads
+ * (profiles/r05_e2e_hw_queues.txt).  The bench configurations do not care (8 against 16: C5 6 834 - 6 887 both, ONT 8 550 - 8 970
+ * both); thirty-two oversubscribe the hardware (launches 53 ms in flight).  Not overridden when the user has set
+ * GPU_MAX_HW_QUEUES. */
 __attribute__((constructor)) static void cvx_process_settings() {
-	setenv("GPU_MAX_HW_QUEUES", "8", 0);
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);
 }
 
 extern "C" {

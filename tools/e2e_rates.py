@@ -288,7 +288,7 @@ def line(name, t, r, same):
         print("    " + r["pool_stats"], flush=True)
     if os.environ.get("E2E_VERBOSE"):
         for l in r["full_err"].splitlines():
-            if "library loaded" in l or "time" in l.lower() or "Done" in l or l.startswith("cvx_search_batch:") or l.startswith("cvx timeline"):
+            if "library loaded" in l or "time" in l.lower() or "Done" in l or l.startswith("cvx_search_batch:") or l.startswith("cvx timeline") or l.startswith("cvx launch"):
                 print("      | " + l[:200], flush=True)
 
 
