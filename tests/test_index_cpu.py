@@ -84,7 +84,7 @@ def reference_table(reference_run):
     return seqs, isz, tl, want_idx, want_locs
 
 
-@pytest.mark.parametrize("threads", ["1", "4"])
+@pytest.mark.parametrize("threads", ["1", "4", "16"])      # 16: more threads than sequences -- the passes over the 4^13 records still use them all
 def test_index_builder_equals_the_reference_table(built, reference_table, monkeypatch, threads):
     from ngmlr_amd import capi
     lib = capi.load()
