@@ -12,9 +12,12 @@
 
 #include <pthread.h>
 
+#include <atomic>
+
 #include "AlignmentBuffer.h"
 #include "NGM.h"
 #include "batching_aligner.h"
+#include "cvx_fiber.h"
 
 namespace Convex {
 
@@ -138,13 +141,101 @@ struct Pool {
 	}
 };
 
+/* The same pool on user-level contexts (cvx_fiber.h; the default, CVX_POOL_FIBERS=0 selects the pthread form above): a
+ * context is a fiber with its own AlignmentBuffer, min(16, cores) carrier threads run whichever of them hold a read that is
+ * not waiting for the device.  4 096 reads in flight by default (CVX_POOL_CONTEXTS), created on demand. */
+struct FiberContexts {
+	FiberPool * pool;
+	std::atomic<long> failed;
+	int maxContexts, carriers, queueLimit;
+	std::chrono::steady_clock::time_point born;
+
+	static void run(void * user, void ** slot, void * itemPtr) {
+		FiberContexts * const self = (FiberContexts *) user;
+		Item * const it = (Item *) itemPtr;
+		if (*slot == 0) {
+			/* what CS::DoRun does for its own thread (reference src/CS.cpp:414-419): the constructor writes the SAM
+			 * prolog once, under NGM's output lock */
+			NGM.AquireOutputLock();
+			*slot = new AlignmentBuffer(Config.getOutputFile());
+			NGM.ReleaseOutputLock();
+		}
+		AlignmentBuffer * const buffer = (AlignmentBuffer *) *slot;
+		SharedAligner::ThreadBegin();      /* counts as a worker of its dispatcher only while it holds a read */
+		try {
+			if (it->group != 0) buffer->processLongReadLIS(it->group);
+			else buffer->processShortRead(it->read);
+		} catch (...) {
+			fprintf(stderr, "AlignPool: exception while processing a read\n");
+			self->failed += 1;
+		}
+		SharedAligner::ThreadEnd();
+		delete it;
+	}
+	static void destroySlot(void *, void * slot) { delete (AlignmentBuffer *) slot; }      /* ~SAMWriter flushes this context's records */
+	static void carrierStart(void *, int) { pthread_setname_np(pthread_self(), "cvx-context"); }
+	static void lastItemTaken(void *) { SharedAligner::SetFeedActive(false); }
+
+	FiberContexts() : pool(0), failed(0), maxContexts(4096), carriers(16), queueLimit(0), born(std::chrono::steady_clock::now()) {
+		if (const char * e = getenv("CVX_POOL_CONTEXTS")) maxContexts = atoi(e) > 0 ? atoi(e) : 1;
+		unsigned const hw = std::thread::hardware_concurrency();
+		if (hw > 0 && (int) hw < carriers) carriers = (int) hw;
+		if (const char * e = getenv("CVX_POOL_CARRIERS")) carriers = atoi(e) > 0 ? atoi(e) : 1;
+		if (carriers > maxContexts) carriers = maxContexts;
+		queueLimit = maxContexts / 2 > 512 ? maxContexts / 2 : 512;
+		if (const char * e = getenv("CVX_POOL_QUEUE")) queueLimit = atoi(e) > 0 ? atoi(e) : 1;
+		size_t stackKb = 512;
+		if (const char * e = getenv("CVX_POOL_STACK_KB")) stackKb = atoi(e) >= 64 ? (size_t) atoi(e) : 64;
+		FiberPool::Callbacks cb;
+		cb.user = this;
+		cb.run = &FiberContexts::run;
+		cb.destroySlot = &FiberContexts::destroySlot;
+		cb.carrierStart = &FiberContexts::carrierStart;
+		cb.lastItemTaken = &FiberContexts::lastItemTaken;
+		pool = new FiberPool(carriers, maxContexts, stackKb * 1024, queueLimit, cb);
+	}
+	void submit(Item const it) { pool->Submit(new Item(it)); }
+	long drainAndStop() {
+		pool->CloseFeed();
+		pool->DrainAndStop();
+		FiberPool::Stats const s = pool->GetStats();
+		double const wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - born).count();
+		fprintf(stderr, "AlignPool: %ld reads on %ld user-level contexts (limit %d) over %d carrier threads in %.2f s: at most %ld reads in flight, %ld queued; "
+				"%ld parks; a context held a read %.2f ms on average, the carriers ran read code %.1f %% of their time (%.2f CPU-s), CS threads waited %.2f s for room in the queue\n",
+				s.items, s.fibers, maxContexts, s.carriers, wall, s.maxInFlight, s.maxQueued, s.parks,
+				s.items ? 1e3 * s.holdingSeconds / (double) s.items : 0.0, 100.0 * s.runningSeconds / (wall * (double) s.carriers), s.runningSeconds,
+				s.producerBlockedSeconds);
+		delete pool;
+		pool = 0;
+		return failed.load();
+	}
+};
+
+struct AnyPool {
+	Pool * threads;
+	FiberContexts * fibers;
+	AnyPool() : threads(0), fibers(0) {
+		const char * e = getenv("CVX_POOL_FIBERS");
+		if (e && atoi(e) == 0) threads = new Pool();
+		else fibers = new FiberContexts();
+	}
+	~AnyPool() { delete threads; delete fibers; }
+	void submit(Item const it) { if (fibers) fibers->submit(it); else threads->submit(it); }
+	long drainAndStop() { return fibers ? fibers->drainAndStop() : threads->drainAndStop(); }
+};
+
 std::mutex g_poolMtx;
-Pool * g_pool = 0;
+AnyPool * g_pool = 0;
 int g_producers = 0;
 
-Pool * poolForSubmit() {
+bool fibersWanted() {
+	const char * e = getenv("CVX_POOL_FIBERS");
+	return !(e && atoi(e) == 0);
+}
+
+AnyPool * poolForSubmit() {
 	std::lock_guard<std::mutex> g(g_poolMtx);
-	if (g_pool == 0) g_pool = new Pool();      /* a producer that never attached (not a reference call path) still works */
+	if (g_pool == 0) g_pool = new AnyPool();      /* a producer that never attached (not a reference call path) still works */
 	return g_pool;
 }
 
@@ -155,14 +246,16 @@ void AlignPool::Attach() {
 	std::lock_guard<std::mutex> g(g_poolMtx);
 	/* the aligner fronts built from now on (the CS threads' own, the contexts') register with their dispatcher per
 	 * read (ThreadBegin / ThreadEnd), not for their lifetime */
-	SharedAligner::UsePoolAccounting(true);
-	if (g_pool == 0) g_pool = new Pool();
+	/* thousands of user-level contexts: a launch waits for 2 048 tiles, 10 ms at most; 512 threads: 256 tiles, 30 ms */
+	if (fibersWanted()) SharedAligner::UsePoolAccounting(true, 2048, 10000);
+	else SharedAligner::UsePoolAccounting(true);
+	if (g_pool == 0) g_pool = new AnyPool();
 	g_producers += 1;
 	SharedAligner::SetFeedActive(true);
 }
 
 void AlignPool::Detach() {
-	Pool * last = 0;
+	AnyPool * last = 0;
 	{
 		std::lock_guard<std::mutex> g(g_poolMtx);
 		g_producers -= 1;

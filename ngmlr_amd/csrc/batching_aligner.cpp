@@ -239,7 +239,9 @@ void BatchingAligner::dispatchLoop() {
 				r->failed = l->failed;
 				r->result = l->failed ? 0 : &l->results[i];
 				r->done = true;
-				r->cv.notify_one();      /* under the lock: the request lives on its worker's stack until that worker has seen `done` */
+				/* under the lock: the request lives on its worker's stack until that worker has seen `done` */
+				if (r->fiber) FiberApi::Wake(r->fiber);      /* a read on a user-level context: runnable on its carrier (cvx_fiber.h) */
+				else r->cv.notify_one();
 			}
 			continue;
 		}
@@ -259,6 +261,7 @@ int BatchingAligner::SingleAlign(int const mode, CorridorLine * corridor, int co
 	req.tile.refSeq = refSeq; req.tile.qrySeq = qrySeq; req.tile.result = &result;
 	req.tile.externalQStart = externalQStart; req.tile.externalQEnd = externalQEnd; req.tile.ret = -1; req.tile.failed = false;
 	req.launch = 0; req.result = 0; req.done = false; req.failed = false;
+	req.fiber = FiberApi::Current();
 	ConvexAlignHip::Prepare(req.tile);       /* in the caller's thread; throws like the reference for a malformed call */
 
 	std::unique_lock<std::mutex> lk(mtx);
@@ -268,7 +271,16 @@ int BatchingAligner::SingleAlign(int const mode, CorridorLine * corridor, int co
 	parked += 1;
 	cvDispatch.notify_one();
 	std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
-	while (!req.done) req.cv.wait(lk);
+	if (req.fiber) {
+		/* the read gives its carrier thread back while its tile is in flight; the dispatcher's Wake makes it runnable there */
+		while (!req.done) {
+			lk.unlock();
+			FiberApi::Park();
+			lk.lock();
+		}
+	} else {
+		while (!req.done) req.cv.wait(lk);
+	}
 	std::chrono::steady_clock::time_point const t1 = std::chrono::steady_clock::now();
 	parkedNs += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
 	parked -= 1;
@@ -318,21 +330,29 @@ long g_lastTextLaunches = 0;
 std::chrono::steady_clock::time_point g_firstJoin;
 std::chrono::steady_clock::time_point const g_loaded = std::chrono::steady_clock::now();      /* ~ process start */
 bool g_poolAccounting = false;                       /* under g_sharedMtx */
+int g_poolTarget = 256, g_poolHoldUs = 30000;        /* the batch target a dispatcher gets under the pool (align_pool.cpp sets it with the accounting) */
 bool g_feedActive = true;                            /* under g_sharedMtx: handed to dispatchers created later */
 thread_local BatchingAligner * tl_dispatcher = 0;    /* the dispatcher of the SharedAligner this thread constructed (pool accounting) */
+/* ... or this user-level context: a fiber's aligner front travels with the fiber, not with its carrier thread */
+BatchingAligner * & currentDispatcher() {
+	Fiber * const f = FiberApi::Current();
+	return f ? reinterpret_cast<BatchingAligner * &>(FiberApi::Local(f, 0)) : tl_dispatcher;
+}
 }
 
-void SharedAligner::UsePoolAccounting(bool on) {
+void SharedAligner::UsePoolAccounting(bool on, int batchTarget, int holdMicroseconds) {
 	std::lock_guard<std::mutex> g(g_sharedMtx);
 	g_poolAccounting = on;
+	g_poolTarget = batchTarget;
+	g_poolHoldUs = holdMicroseconds;
 }
 void SharedAligner::SetFeedActive(bool active) {
 	std::lock_guard<std::mutex> g(g_sharedMtx);
 	g_feedActive = active;
 	for (int d = 0; d < kMaxDevices; ++d) if (g_shared[d]) g_shared[d]->SetFeedActive(active);
 }
-void SharedAligner::ThreadBegin() { if (tl_dispatcher) tl_dispatcher->WorkerJoined(); }
-void SharedAligner::ThreadEnd() { if (tl_dispatcher) tl_dispatcher->WorkerDone(); }
+void SharedAligner::ThreadBegin() { if (BatchingAligner * d = currentDispatcher()) d->WorkerJoined(); }
+void SharedAligner::ThreadEnd() { if (BatchingAligner * d = currentDispatcher()) d->WorkerDone(); }
 
 SharedAligner::SharedAligner(int const stdOutMode, float const match, float const mismatch, float const gapOpen,
 		float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId) : shared(0), device(0), perRead(false) {
@@ -359,9 +379,9 @@ SharedAligner::SharedAligner(int const stdOutMode, float const match, float cons
 		 * contexts hide that wait, and the device sees a few large launches instead of many small ones (CVX_BATCH_TARGET /
 		 * CVX_BATCH_HOLD_US override) */
 		g_shared[device]->SetFeedActive(g_feedActive);
-		if (perRead && !getenv("CVX_BATCH_TARGET")) g_shared[device]->SetBatchTarget(256, getenv("CVX_BATCH_HOLD_US") ? atoi(getenv("CVX_BATCH_HOLD_US")) : 30000);
+		if (perRead && !getenv("CVX_BATCH_TARGET")) g_shared[device]->SetBatchTarget(g_poolTarget, getenv("CVX_BATCH_HOLD_US") ? atoi(getenv("CVX_BATCH_HOLD_US")) : g_poolHoldUs);
 	}
-	if (perRead) tl_dispatcher = g_shared[device];
+	if (perRead) currentDispatcher() = g_shared[device];
 	else g_shared[device]->WorkerJoined();
 	g_deviceUsers[device] += 1;
 	g_users += 1;
@@ -369,7 +389,7 @@ SharedAligner::SharedAligner(int const stdOutMode, float const match, float cons
 }
 
 SharedAligner::~SharedAligner() {
-	if (perRead) { if (tl_dispatcher == shared) tl_dispatcher = 0; }
+	if (perRead) { if (currentDispatcher() == shared) currentDispatcher() = 0; }
 	else shared->WorkerDone();   /* (outside the process-wide lock: it only touches this device's aligner) */
 	std::lock_guard<std::mutex> g(g_sharedMtx);
 	g_deviceUsers[device] -= 1;

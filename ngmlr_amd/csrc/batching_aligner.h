@@ -45,6 +45,7 @@
 #include <vector>
 
 #include "convex_align_hip.h"
+#include "cvx_fiber.h"
 
 namespace Convex {
 
@@ -101,6 +102,7 @@ private:
 		cvx_result const * result;         /* set when the launch is done */
 		bool done;
 		bool failed;                       /* the whole launch failed */
+		Fiber * fiber;                     /* the caller runs on a user-level context (cvx_fiber.h): woken with FiberApi::Wake, not through cv */
 		std::condition_variable cv;        /* its own worker sleeps here: a finished launch wakes its own workers only (with
 		                                    * hundreds of contexts parked, one shared condition woke them all per launch) */
 	};
@@ -186,7 +188,7 @@ public:
 	 * no read, and "every registered worker is parked" must count only those that do.  After UsePoolAccounting(true) a
 	 * SharedAligner no longer registers for its lifetime; the thread that constructed it registers between ThreadBegin()
 	 * and ThreadEnd() (no-ops for a thread without such an aligner). */
-	static void UsePoolAccounting(bool on);
+	static void UsePoolAccounting(bool on, int batchTarget = 256, int holdMicroseconds = 30000);      /* + the dispatchers' batch target under the pool */
 	static void ThreadBegin();
 	static void ThreadEnd();
 	/* the pool's producers are gone and its queue is empty (false) / a producer attached (true): passed on to every dispatcher */

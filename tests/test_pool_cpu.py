@@ -19,30 +19,56 @@ def _records(text):
     return [l.rstrip("\n") for l in text.splitlines() if l.strip() and not l.startswith("@")]
 
 
-def _run(tmp_path, args, contexts):
-    env = dict(os.environ, CVX_POOL_CONTEXTS=str(contexts))
-    res = subprocess.run([BINARY, "--skip-write"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+PARKED = os.path.join(ROOT, "oracle", "_ref", "ngmlr_pool_parked")
+
+
+def _run(tmp_path, args, contexts, binary=BINARY, fibers=True, carriers=None):
+    env = dict(os.environ, CVX_POOL_CONTEXTS=str(contexts), CVX_POOL_FIBERS="1" if fibers else "0")
+    if carriers:
+        env["CVX_POOL_CARRIERS"] = str(carriers)
+    res = subprocess.run([binary, "--skip-write"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                          timeout=900, cwd=str(tmp_path), env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     return _records(res.stdout), res.stderr
 
 
 @pytest.mark.skipif(not os.path.exists(BINARY), reason="oracle/_ref/ngmlr_pool_cpu not built (tools/build_ngmlr_hip.sh needs /root/reference)")
-@pytest.mark.parametrize("threads,contexts", [(1, 1), (2, 48), (8, 256)])
-def test_pool_keeps_the_reference_sam(tmp_path, threads, contexts):
+@pytest.mark.parametrize("threads,contexts,fibers", [(1, 1, True), (2, 48, False), (8, 256, False), (8, 4096, True)])
+def test_pool_keeps_the_reference_sam(tmp_path, threads, contexts, fibers):
+    """Contexts as pthreads (CVX_POOL_FIBERS=0, round 4's form) and as user-level contexts on carrier threads (the default)."""
     # short reads (<= 256 bp: processShortRead) and long ones (processLongReadLIS) of test_2, one CS thread
-    got, _ = _run(tmp_path, ["-t", "1", "-r", os.path.join(E2E, "ref_chr21_20kb.fa"), "-q", os.path.join(E2E, "reads_100_2200bp.fa")], contexts)
+    got, _ = _run(tmp_path, ["-t", "1", "-r", os.path.join(E2E, "ref_chr21_20kb.fa"), "-q", os.path.join(E2E, "reads_100_2200bp.fa")], contexts, fibers=fibers)
     assert sorted(got) == sorted(_records(open(os.path.join(GOLDEN, "test_2.sam")).read())) and len(got) == 12
     # test_3: 142 PacBio reads, 985 convex alignments, split reads, both strands, unmapped reads
     fq = os.path.join(str(tmp_path), "test_3.fq")
     with gzip.open(os.path.join(E2E, "test_3_reads.fq.gz"), "rb") as f, open(fq, "wb") as o:
         o.write(f.read())
     got, err = _run(tmp_path, ["-x", "pacbio", "-t", str(threads), "-R", "0.01", "--no-progress",
-                               "-r", os.path.join(E2E, "test_3_reference.fasta.gz"), "-q", fq], contexts)
+                               "-r", os.path.join(E2E, "test_3_reference.fasta.gz"), "-q", fq], contexts, fibers=fibers)
     with gzip.open(os.path.join(GOLDEN, "test_3.sorted.sam.gz"), "rt") as f:
         want = [l.rstrip("\n") for l in f if l.strip() and not l.startswith("@")]
     assert sorted(got) == want and len(want) > 200
     assert "AlignPool: 142 reads on" in err, err[-600:]
+    assert ("user-level contexts" in err) == fibers
+
+
+@pytest.mark.skipif(not os.path.exists(PARKED), reason="oracle/_ref/ngmlr_pool_parked not built (tools/build_ngmlr_hip.sh needs /root/reference)")
+@pytest.mark.parametrize("contexts,carriers", [(4096, 8), (3, 2), (64, 1)])
+def test_reads_park_and_resume_inside_the_long_read_stage(tmp_path, contexts, carriers):
+    """VERDICT r5 item 1 without a GPU: every SingleAlign of ngmlr's own processLongReadLIS gives the read's user-level context back
+    to its carrier thread and is resumed later (tests/cpp/parking_cpu_aligner.h: the reference's CPU aligner behind the control
+    flow of SharedAligner::SingleAlign) -- 985 park / resume cycles on test_3, in the middle of the interval loop
+    (reference src/AlignmentBuffer.cpp:3361-3406) and of the retry loop (:291-425); the SAM must not change."""
+    fq = os.path.join(str(tmp_path), "test_3.fq")
+    with gzip.open(os.path.join(E2E, "test_3_reads.fq.gz"), "rb") as f, open(fq, "wb") as o:
+        o.write(f.read())
+    got, err = _run(tmp_path, ["-x", "pacbio", "-t", "4", "-R", "0.01", "--no-progress",
+                               "-r", os.path.join(E2E, "test_3_reference.fasta.gz"), "-q", fq], contexts, binary=PARKED, carriers=carriers)
+    with gzip.open(os.path.join(GOLDEN, "test_3.sorted.sam.gz"), "rt") as f:
+        want = [l.rstrip("\n") for l in f if l.strip() and not l.startswith("@")]
+    assert sorted(got) == want
+    assert "ParkingCpuAligner: 985 parks, 985 wakes" in err, err[-800:]
+    assert "985 parks;" in err and "over %d carrier threads" % carriers in err, err[-800:]
 
 
 @pytest.mark.skipif(not os.path.exists(BINARY) or not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ngmlr_ref")),
@@ -63,4 +89,8 @@ def test_pool_keeps_the_sam_of_split_reads(tmp_path):
     want = _records(res.stdout)
     got, err = _run(tmp_path, args, 96)
     assert sorted(got) == sorted(want) and len(want) >= 60
+    if os.path.exists(PARKED):      # the same reads with a park / resume in front of every alignment of the split-read path
+        got, err = _run(tmp_path, args, 2048, binary=PARKED)
+        assert sorted(got) == sorted(want)
+        assert "ParkingCpuAligner:" in err and " 0 parks" not in err
     assert any(int(l.split("\t")[1]) & 2048 for l in want)          # split reads among them

@@ -32,6 +32,8 @@ mkdir -p "$REPO/oracle/_ref"
 #   ngmlr_index_cpu    the reference's CPU code with only that table builder bound: the table file it writes against the unmodified
 #                      binary's, without a GPU (tests/test_index_cpu.py)
 #   ngmlr_pool_cpu     the reference's CPU aligners + the same pool: the pool's own correctness without a GPU (tests/test_pool_cpu.py)
+#   ngmlr_pool_parked  the same with a park / wake of the read's user-level context in front of every SingleAlign
+#                      (tests/cpp/parking_cpu_aligner.h): the fiber runtime under ngmlr's own long-read stage, no GPU
 #   ngmlr_ref          (nothing changed)       the unmodified reference, for wall-clock comparison only
 build_variant() {
 local OUT_NAME=$1 CLASS=$2 SCORER=${3:-} SAM=${4:-} POOL=${5:-} SEARCH=${6:-} INDEX=${7:-}
@@ -116,35 +118,41 @@ if SCORER:
 if CLASS != 'cpu':
     p = T + '/src/AlignmentBuffer.h'
     s = open(p).read()
-    s = s.replace('#include "ConvexAlignFast.h"', '#include "ConvexAlignFast.h"\n#include "convex_align_hip.h"\n#include "batching_aligner.h"', 1)
+    s = s.replace('#include "ConvexAlignFast.h"', '#include "ConvexAlignFast.h"\n#include "convex_align_hip.h"\n#include "batching_aligner.h"' + ('\n#include "parking_cpu_aligner.h"' if 'Parking' in CLASS else ''), 1)
     pat = re.compile(r'aligner = new Convex::ConvexAlignFast\(', re.S)
     assert len(pat.findall(s)) == 1
     s = pat.sub('aligner = new %s(' % CLASS, s)
     open(p, 'w').write(s)
 p = T + '/src/CMakeLists.txt'
 c = open(p).read()
-c = c.replace('add_executable(ngmlr', 'add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp\n%s/ngmlr_amd/csrc/batching_aligner.cpp\n%s/ngmlr_amd/csrc/stripped_sw_hip.cpp\n%s/ngmlr_amd/csrc/candidate_search_hip.cpp%s' % (REPO, REPO, REPO, REPO, REPO, REPO, ('\n%s/ngmlr_amd/csrc/align_pool.cpp' % REPO) if POOL else ''), 1)
+c = c.replace('add_executable(ngmlr', ('add_definitions(-DCVX_IN_NGMLR_TREE)\ninclude_directories(${CMAKE_CURRENT_SOURCE_DIR} %s/include %s/ngmlr_amd/csrc REPO_TESTS_CPP)\nadd_executable(ngmlr\n%s/ngmlr_amd/csrc/convex_align_hip.cpp\n%s/ngmlr_amd/csrc/batching_aligner.cpp\n%s/ngmlr_amd/csrc/stripped_sw_hip.cpp\n%s/ngmlr_amd/csrc/candidate_search_hip.cpp\n%s/ngmlr_amd/csrc/cvx_fiber.cpp%s' % (REPO, REPO, REPO, REPO, REPO, REPO, REPO, ('\n%s/ngmlr_amd/csrc/align_pool.cpp' % REPO) if POOL else '')).replace('REPO_TESTS_CPP', REPO + '/tests/cpp'), 1)
 c = c.replace('TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})', 'TARGET_LINK_LIBRARIES(ngmlr ${ZLIB_LIBRARIES})\nTARGET_LINK_LIBRARIES(ngmlr %s/ngmlr_amd/libcvxalign.so)\nset_target_properties(ngmlr PROPERTIES BUILD_RPATH "\\$ORIGIN/../../ngmlr_amd;/opt/rocm/lib" SKIP_BUILD_RPATH FALSE)' % REPO, 1)
 open(p, 'w').write(c)
 PY
 fi
 mkdir -p "$T/build" && cd "$T/build"
 cmake .. -DCMAKE_POLICY_VERSION_MINIMUM=3.5 -DCMAKE_BUILD_TYPE=RELWITHDEBINFO > "$WORK/$OUT_NAME.cmake.log" 2>&1
-make -j16 > "$WORK/$OUT_NAME.make.log" 2>&1 || { tail -30 "$WORK/$OUT_NAME.make.log"; exit 1; }
+make -j16 > "$WORK/$OUT_NAME.make.log" 2>&1 || { grep -m5 -B2 -A6 "error" "$WORK/$OUT_NAME.make.log"; exit 1; }
 local BIN=$(ls "$T"/bin/ngmlr-*/ngmlr)
 cp "$BIN" "$REPO/oracle/_ref/$OUT_NAME"
 echo "built $REPO/oracle/_ref/$OUT_NAME"
 }
-build_variant ngmlr_hip Convex::ConvexAlignHip &
-build_variant ngmlr_hip_batched Convex::SharedAligner &
-build_variant ngmlr_hip_full Convex::SharedAligner StrippedSWHip sam &
-build_variant ngmlr_sam cpu "" sam &
-build_variant ngmlr_hip_pool Convex::SharedAligner StrippedSWHip sam pool &
-build_variant ngmlr_pool_cpu cpu "" "" pool &
-build_variant ngmlr_hip_all Convex::SharedAligner StrippedSWHip sam pool search index &
-build_variant ngmlr_index_cpu cpu "" "" "" "" index &
-build_variant ngmlr_ref unmodified &     # the reference as it is: wall-clock yardstick of tools/e2e_rates.py
+# NGMLR_VARIANTS="ngmlr_pool_cpu ngmlr_hip_all" rebuilds only those (default: all nine)
+want() { [ -z "${NGMLR_VARIANTS:-}" ] || [[ " $NGMLR_VARIANTS " == *" $1 "* ]]; }
+bv() { if want "$1"; then build_variant "$@" & fi; }
+bv ngmlr_hip Convex::ConvexAlignHip
+bv ngmlr_hip_batched Convex::SharedAligner
+bv ngmlr_hip_full Convex::SharedAligner StrippedSWHip sam
+bv ngmlr_sam cpu "" sam
+bv ngmlr_hip_pool Convex::SharedAligner StrippedSWHip sam pool
+bv ngmlr_pool_cpu cpu "" "" pool
+bv ngmlr_pool_parked Convex::ParkingCpuAligner "" "" pool      # CPU aligner behind a park / wake per SingleAlign (tests/cpp/parking_cpu_aligner.h)
+bv ngmlr_hip_all Convex::SharedAligner StrippedSWHip sam pool search index
+bv ngmlr_index_cpu cpu "" "" "" "" index
+bv ngmlr_ref unmodified      # the reference as it is: wall-clock yardstick of tools/e2e_rates.py
 wait
-test -x "$REPO/oracle/_ref/ngmlr_hip" && test -x "$REPO/oracle/_ref/ngmlr_hip_batched" && test -x "$REPO/oracle/_ref/ngmlr_hip_full" && test -x "$REPO/oracle/_ref/ngmlr_sam" && test -x "$REPO/oracle/_ref/ngmlr_hip_pool" && test -x "$REPO/oracle/_ref/ngmlr_pool_cpu" && test -x "$REPO/oracle/_ref/ngmlr_hip_all" && test -x "$REPO/oracle/_ref/ngmlr_index_cpu"
+for v in ngmlr_hip ngmlr_hip_batched ngmlr_hip_full ngmlr_sam ngmlr_hip_pool ngmlr_pool_cpu ngmlr_pool_parked ngmlr_hip_all ngmlr_index_cpu ngmlr_ref; do
+	test -x "$REPO/oracle/_ref/$v" || { echo "missing oracle/_ref/$v"; exit 1; }
+done
 readelf -d "$REPO/oracle/_ref/ngmlr_hip" | grep -E "RPATH|RUNPATH|NEEDED" | head
 rm -rf "$WORK"
