@@ -599,7 +599,7 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs (ONT mix, ultra-long + SV, short reads) reported beside the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the e2e_pipeline extra (the reference's ngmlr with every drop-in bound against the unmodified build)")
-    ap.add_argument("--e2e-reads", type=int, default=4000, help="synthetic 10 kb reads of the e2e_pipeline extra")
+    ap.add_argument("--e2e-reads", type=int, default=20000, help="synthetic 10 kb reads of the e2e_pipeline extra")
     ap.add_argument("--alias-device", type=int, default=-1, metavar="D",
                     help="run the --gpus N code path (N handles, N host threads, one shared pack pool; --strong too) with every handle on physical "
                          "device D: exercises the N-device path on a one-GPU box -- NOT a scaling measurement (N batches' arenas share one HBM: "

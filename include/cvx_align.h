@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define CVX_ABI_VERSION 6
+#define CVX_ABI_VERSION 7
 
 /* return codes */
 enum {
@@ -138,6 +138,17 @@ typedef struct {
 	int32_t corridor_width;
 	int32_t reserved;
 } cvx_tile;
+
+/* ABI 7: the closed form behind a caller's rows (host only, no device call; any thread).  ngmlr's binding receives the
+ * CorridorLine[] its builders wrote (src/AlignmentBuffer.cpp:68-197) and cannot know which builder made them; this
+ * recovers (corridor_kind, k, d, right, offset, width) from the rows and the two sequence lengths -- k = qry_len * 1.0f /
+ * ref_len as at :117 / :141, d = width / 2.0f (endpoints), d = 0 and a fitted `right` (anchors), k = 1 (linear), a constant
+ * (full) -- and writes them into *form, whose other fields it leaves alone.  A form is returned only after every one of the
+ * n_rows rows has been compared with the expression the device evaluates; rows no form reproduces (or rows of different
+ * lengths) leave corridor_kind = CVX_CORRIDOR_ROWS.  row_offset / row_length are read with row_stride_bytes like
+ * cvx_tile's.  Returns CVX_OK (whatever the kind) or CVX_ERR_ARG. */
+int cvx_corridor_fit(const int32_t *row_offset, const int32_t *row_length, int32_t row_stride_bytes, int32_t n_rows,
+		int32_t ref_len, int32_t qry_len, cvx_tile *form);
 
 /* What the forward fill + backtrack leave behind (FwdResults, src/ConvexAlignFast.h:69-77). */
 typedef struct {

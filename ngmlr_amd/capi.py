@@ -28,7 +28,8 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_genome_decode", "cvx_submit_windows", "cvx_job_text",
            "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id", "cvx_job_poll", "cvx_score_kernel_ms",
            "cvx_index_upload", "cvx_index_free", "cvx_search_batch", "cvx_search_batch_ex", "cvx_job_nm_profile", "cvx_job_nm_sizes", "cvx_nm_profile_ops",
-           "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch", "cvx_stage_kernel_ms", "cvx_search_last_attempts", "cvx_index_build")
+           "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch", "cvx_stage_kernel_ms", "cvx_search_last_attempts", "cvx_index_build",
+           "cvx_corridor_fit")
 
 
 class CvxParams(C.Structure):
@@ -189,6 +190,7 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_search_last_attempts.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.cvx_index_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.cvx_corridor_fit.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CvxTile)]
     lib.cvx_score_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p]
     lib.cvx_format_alignment.argtypes = [C.POINTER(CvxResult), C.c_void_p, C.c_char_p, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
@@ -201,3 +203,18 @@ def load(path: str = None) -> C.CDLL:
 def check(rc: int) -> None:
     if rc != CVX_OK:
         raise CvxError(rc, load().cvx_last_error().decode(errors="replace"))
+
+
+def corridor_fit(row_offset, row_length, ref_len, qry_len, stride_bytes=4):
+    """cvx_corridor_fit on int32 arrays (packed, or the offset / length columns of a CorridorLine[] with stride 16) ->
+    (kind, k, d, right, offset, width)."""
+    import numpy as np
+    lib = load()
+    off = np.ascontiguousarray(row_offset, dtype=np.int32) if stride_bytes == 4 else row_offset
+    ln = np.ascontiguousarray(row_length, dtype=np.int32) if stride_bytes == 4 else row_length
+    n = len(off) if stride_bytes == 4 else qry_len
+    form = CvxTile()
+    rc = lib.cvx_corridor_fit(off.ctypes.data, ln.ctypes.data, stride_bytes, n, ref_len, qry_len, C.byref(form))
+    if rc != CVX_OK:
+        raise RuntimeError("cvx_corridor_fit: %s" % ERR_NAMES.get(rc, rc))
+    return (form.corridor_kind, form.corridor_k, form.corridor_d, form.corridor_right, form.corridor_offset, form.corridor_width)

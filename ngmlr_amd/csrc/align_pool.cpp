@@ -224,6 +224,9 @@ struct AnyPool {
 	long drainAndStop() { return fibers ? fibers->drainAndStop() : threads->drainAndStop(); }
 };
 
+std::atomic<long long> g_inputWaitNs(0), g_inputHeldNs(0);
+std::atomic<long> g_inputBatches(0), g_inputReads(0);
+
 std::mutex g_poolMtx;
 AnyPool * g_pool = 0;
 int g_producers = 0;
@@ -268,11 +271,25 @@ void AlignPool::Detach() {
 	if (last != 0) {
 		long const failed = last->drainAndStop();
 		delete last;
+		if (g_inputBatches.load() > 0) fprintf(stderr, "AlignPool: ngmlr's input lock (parse + split of the reads, one thread at a time): held %.2f s for %ld reads in %ld batches (%.1f us per read), "
+				"CS threads waited %.2f s for it\n", (double) g_inputHeldNs.load() * 1e-9, g_inputReads.load(), g_inputBatches.load(),
+				g_inputReads.load() ? (double) g_inputHeldNs.load() * 1e-3 / (double) g_inputReads.load() : 0.0, (double) g_inputWaitNs.load() * 1e-9);
 		if (failed > 0) {
 			fprintf(stderr, "AlignPool: %ld read(s) failed in their long-read stage: the run is incomplete\n", failed);
 			throw "AlignPool: reads failed";      /* into NGMTask::Run of the last CS thread: logged and rethrown, as for a CS thread's own exception */
 		}
 	}
+}
+
+long long AlignPool::ProbeNow() {
+	return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void AlignPool::InputLockTimes(long long beforeLock, long long locked, long long beforeUnlock, int reads) {
+	g_inputWaitNs += locked - beforeLock;
+	g_inputHeldNs += beforeUnlock - locked;
+	g_inputBatches += 1;
+	g_inputReads += reads;
 }
 
 void AlignPool::Submit(ReadGroup * group) {

@@ -44,6 +44,11 @@ public:
 	 * the queue is full (CVX_POOL_QUEUE, default 2 x contexts) */
 	static void Submit(ReadGroup * group);
 	static void SubmitShort(MappedRead * read);
+	/* Measurement only: how long ngmlr's CS threads wait for and hold the ONE lock under which reads are parsed and split into
+	 * sub-reads (_NGM::GetNextReadBatch, reference src/NGM.cpp:190-244: kseq_read, the per-base copy, ~40 sub-read objects per
+	 * 10 kb read) -- the serial stage of the pipeline that is not the device's.  Printed with the pool's statistics. */
+	static long long ProbeNow();
+	static void InputLockTimes(long long beforeLock, long long locked, long long beforeUnlock, int reads);
 };
 
 }  // namespace Convex

@@ -413,6 +413,11 @@ SharedAligner::~SharedAligner() {
 				"%.1f %% in their text stage; a launch was in flight %.1f %% of the time\n", g_joined, wall,
 				100.0 * g_lastParked / (wall * (double) g_joined), g_lastRequests ? 1e3 * g_lastParked / (double) g_lastRequests : 0.0,
 				100.0 * g_lastFinish / (wall * (double) g_joined), 100.0 * g_lastBusy / wall);
+		{
+			long prepared = 0, closedForm = 0;
+			ConvexAlignHip::CorridorStats(prepared, closedForm);
+			fprintf(stderr, "SharedAligner: %ld of %ld corridors travelled as closed forms (cvx_corridor_fit), the rest as row arrays\n", closedForm, prepared);
+		}
 		if (g_lastTextLaunches > 0) fprintf(stderr, "SharedAligner: text stage on the device for %ld launches (cvx_job_text + cvx_job_nm_profile), %.3f s of the dispatchers' time\n", g_lastTextLaunches, g_lastTextSeconds);
 		fprintf(stderr, "SharedAligner: library loaded at 0, first worker joined at %.2f s, last one left at %.2f s\n",
 				std::chrono::duration<double>(g_firstJoin - g_loaded).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - g_loaded).count());

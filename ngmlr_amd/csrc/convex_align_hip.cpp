@@ -5,7 +5,9 @@
  */
 #include "convex_align_hip.h"
 
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #ifdef CVX_IN_NGMLR_TREE
@@ -13,6 +15,16 @@
 #endif
 
 namespace Convex {
+
+namespace {
+std::atomic<long> g_prepared(0), g_closedForm(0);
+bool const g_fitCorridors = [] { const char * e = getenv("CVX_CORRIDOR_FIT"); return !(e && atoi(e) == 0); }();
+}
+
+void ConvexAlignHip::CorridorStats(long & prepared, long & closedForm) {
+	prepared = g_prepared.load();
+	closedForm = g_closedForm.load();
+}
 
 ConvexAlignHip::ConvexAlignHip(int const stdOutMode, float const match, float const mismatch,
 		float const gapOpen, float const gapExtend, float const gapExtendMin, float const gapDecay,
@@ -90,6 +102,23 @@ void ConvexAlignHip::Prepare(Tile & t) {
 		t.corridor[y].offsetInMatrix = acc;
 		acc += (unsigned long) (long) t.corridor[y].length;
 	}
+	/* The rows came out of one of ngmlr's corridor builders (src/AlignmentBuffer.cpp:68-197): recover its closed form -- in
+	 * the caller's thread, every row verified against the expression the device evaluates -- so that the launch carries
+	 * 32 bytes for this tile instead of 8 per read row through the pack threads, PCIe and the rows arena */
+	t.corridorKind = CVX_CORRIDOR_ROWS;
+	t.corridorK = t.corridorD = t.corridorRight = 0.0f;
+	t.corridorOffset = t.corridorWidth = 0;
+	g_prepared.fetch_add(1, std::memory_order_relaxed);
+	if (g_fitCorridors && t.corridorHeight > 0) {
+		cvx_tile form;
+		if (cvx_corridor_fit(&t.corridor[0].offset, &t.corridor[0].length, (int32_t) sizeof(CorridorLine), t.corridorHeight, t.refLen, t.qryLen, &form) == CVX_OK
+				&& form.corridor_kind != CVX_CORRIDOR_ROWS) {
+			t.corridorKind = form.corridor_kind;
+			t.corridorK = form.corridor_k; t.corridorD = form.corridor_d; t.corridorRight = form.corridor_right;
+			t.corridorOffset = form.corridor_offset; t.corridorWidth = form.corridor_width;
+			g_closedForm.fetch_add(1, std::memory_order_relaxed);
+		}
+	}
 }
 
 cvx_job ConvexAlignHip::Submit(Tile const * tiles, int n) {
@@ -104,11 +133,11 @@ cvx_job ConvexAlignHip::Submit(Tile const * tiles, int n) {
 		c.row_offset = &t.corridor[0].offset;
 		c.row_length = &t.corridor[0].length;
 		c.row_stride_bytes = (int32_t) sizeof(CorridorLine);
-		/* ngmlr hands over the rows its corridor builders produced (src/AlignmentBuffer.cpp:68-197); a caller that
-		 * knows which builder made them can pass its closed form instead (cvx_tile.corridor_kind) and skip the arrays */
-		c.corridor_kind = CVX_CORRIDOR_ROWS;
-		c.corridor_k = c.corridor_d = c.corridor_right = 0.0f;
-		c.corridor_offset = c.corridor_width = 0;
+		/* ngmlr hands over the rows its corridor builders produced (src/AlignmentBuffer.cpp:68-197); Prepare() has recovered
+		 * the builder's closed form where there is one (the arrays are then ignored by the library) */
+		c.corridor_kind = t.corridorKind;
+		c.corridor_k = t.corridorK; c.corridor_d = t.corridorD; c.corridor_right = t.corridorRight;
+		c.corridor_offset = t.corridorOffset; c.corridor_width = t.corridorWidth;
 		c.reserved = 0;
 	}
 	cvx_job job = 0;

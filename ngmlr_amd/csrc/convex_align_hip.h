@@ -59,6 +59,11 @@ public:
 		int ret;               /* out: what SingleAlign would have returned */
 		bool failed;           /* out (AlignTiles): this tile hit a hard error -- the reference would have thrown for it alone */
 		int refLen, qryLen;    /* filled by Prepare() */
+		/* filled by Prepare(): the closed form behind `corridor` when cvx_corridor_fit finds one (every row verified), else
+		 * CVX_CORRIDOR_ROWS -- Submit then sends 32 bytes instead of the tile's row arrays */
+		int32_t corridorKind;
+		float corridorK, corridorD, corridorRight;
+		int32_t corridorOffset, corridorWidth;
 	};
 	/* n independent corridor alignments in one device launch.  A hard error that belongs to one tile (a corridor no
 	 * kernel covers, a CIGAR that does not fit the caller's buffer) marks that tile `failed` and leaves the others
@@ -69,7 +74,8 @@ public:
 	/* The same in stages, for a driver that keeps launches in flight.  Prepare / Finish may run on any thread (they
 	 * touch only the tile and the caller's Align); Submit / Wait / Release belong to the ONE thread that owns this
 	 * aligner's device handle.
-	 *   Prepare  strlen + height check + the caller-visible offsetInMatrix side effect (throws like SingleAlign)
+	 *   Prepare  strlen + height check + the caller-visible offsetInMatrix side effect (throws like SingleAlign) + the
+	 *            corridor's closed form (cvx_corridor_fit; CVX_CORRIDOR_FIT=0 sends the rows as round 5 did)
 	 *   Submit   queues a launch for n prepared tiles, returns its job (throws on a hard error of the launch)
 	 *   Poll     non-blocking "is it done"; Wait  blocks until the job is done: result records and run-length ops, valid until Release
 	 *   Finish   convertCigar + flags of ONE tile into its Align (throws 1 for that tile's hard errors)
@@ -94,6 +100,8 @@ public:
 		char const * text;                 /* the job's page-locked text buffer */
 	};
 	void Text(cvx_job job, Tile const * const * tiles, int n, JobText & jt);
+	/* tiles Prepare() has seen in this process, and how many of them travelled as a closed form */
+	static void CorridorStats(long & prepared, long & closedForm);
 	void FinishText(Tile & t, cvx_result const & r, JobText const & jt, int index) const;
 
 private:

@@ -155,6 +155,12 @@ int main(int argc, char ** argv) {
 		if (scorer->SingleScore(0, 0, refs[0], qrys[0], one, 0) != 1 || one != 40.0f) bad++;
 	}
 	printf("shim_test: %zu tiles, %d valid, %d mismatches (%s)\n", recs.size(), valid, bad, batch ? "AlignTiles" : "SingleAlign");
+	{
+		/* how many of the CorridorLine[] arrays Prepare() recognised as one of the reference builders' closed forms */
+		long prepared = 0, closedForm = 0;
+		Convex::ConvexAlignHip::CorridorStats(prepared, closedForm);
+		printf("shim_test: %ld of %ld corridors travelled as closed forms\n", closedForm, prepared);
+	}
 	delete aligner;
 	return bad ? 1 : 0;
 }

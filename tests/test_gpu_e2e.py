@@ -100,22 +100,27 @@ def test_test_3_both_plugins_on_the_device(built, tmp_path):
     assert "StrippedSWHip::BatchScore" in syms
 
 
-@pytest.mark.parametrize("target", [0, 64])
-def test_test_3_alignment_contexts_off_the_cs_threads(built, tmp_path, target):
+@pytest.mark.parametrize("target,fibers", [(0, "1"), (64, "1"), (64, "0")])
+def test_test_3_alignment_contexts_off_the_cs_threads(built, tmp_path, target, fibers):
     """SURVEY 8 f1, second half (Convex::AlignPool, ngmlr_amd/csrc/align_pool.h): `-t 16` CS threads, 256 alignment
     contexts -- processLongReadLIS runs on a pool context instead of on the CS thread that scored the read's last
     sub-read (reference src/ScoreBuffer.cpp:152-159), so reads in flight are no longer bounded by -t.  Alignment,
     scoring and SAM records on the drop-ins; with and without a batch target for the dispatcher.  SAM records
     identical to the unmodified reference (sorted)."""
     import re
-    env = {"CVX_POOL_CONTEXTS": "256", "CVX_BATCH_TARGET": str(target), "CVX_BATCH_HOLD_US": "20000"}      # (target 0 = none; the pool's default is 256)
+    # contexts as user-level contexts on carrier threads (round 6, cvx_fiber.h: the read parks inside SharedAligner::SingleAlign by
+    # switching back to its carrier) and as pthreads (round 4's form, CVX_POOL_FIBERS=0)
+    env = {"CVX_POOL_CONTEXTS": "256", "CVX_BATCH_TARGET": str(target), "CVX_BATCH_HOLD_US": "20000", "CVX_POOL_FIBERS": fibers}      # (target 0 = none)
     got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_POOL, env=env)
     assert sorted(got) == _test_3_want()
     m = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", err)
     assert m and int(m.group(1)) == 985, err[-2000:]
-    p = re.search(r"AlignPool: (\d+) reads on (\d+) contexts \(limit 256\).*at most (\d+) reads in flight", err)
+    p = re.search(r"AlignPool: (\d+) reads on (\d+) (?:user-level )?contexts \(limit 256\).*at most (\d+) reads in flight", err)
     assert p and int(p.group(1)) == 142, err[-2000:]
     assert int(p.group(3)) > 16          # more reads in flight than CS threads: the point of the pool
+    assert ("user-level contexts" in err) == (fibers == "1")
+    if fibers == "1":
+        assert re.search(r"; 985 parks;", err), err[-2000:]      # every alignment gave its carrier thread back once
     print("test_3 -t 16, pool of 256 (target %d): %s alignments in %s launches, %s reads in flight at most" % (target, m.group(1), m.group(2), p.group(3)))
 
 

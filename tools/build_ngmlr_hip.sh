@@ -93,6 +93,10 @@ if POOL:
     p = T + '/src/NGM.cpp'
     s = open(p).read()
     s = sub1(s, 'Sleep(2000);', 'for (int cvxPoll = 0; cvxPoll < 100 && Running(); ++cvxPoll) Sleep(20);', 'NGM::MainLoop')
+    # measurement only: how long the CS threads wait for / hold the lock under which reads are parsed and split (align_pool.h)
+    s = sub1(s, 'std::vector<MappedRead*> _NGM::GetNextReadBatch(int desBatchSize) {\n\tNGMLock(&m_Mutex);', 'std::vector<MappedRead*> _NGM::GetNextReadBatch(int desBatchSize) {\n\tlong long const cvxT0 = Convex::AlignPool::ProbeNow();\n\tNGMLock(&m_Mutex);\n\tlong long const cvxT1 = Convex::AlignPool::ProbeNow();', 'GetNextReadBatch lock')
+    s = sub1(s, '\tm_CurCount -= desBatchSize;\n\n\tNGMUnlock(&m_Mutex);', '\tm_CurCount -= desBatchSize;\n\n\tConvex::AlignPool::InputLockTimes(cvxT0, cvxT1, Convex::AlignPool::ProbeNow(), count);\n\tNGMUnlock(&m_Mutex);', 'GetNextReadBatch unlock')
+    s = sub1(s, '#include "NGM.h"', '#include "NGM.h"\n#include "align_pool.h"', 'NGM.cpp include')
     open(p, 'w').write(s)
     p = T + '/src/GenericReadWriter.h'
     s = open(p).read()

@@ -161,7 +161,36 @@ def write_plain_workload(fa, fq, n_reads, rng, L):
     return bases
 
 
-def pipeline_summary(n_reads=4000, t_ref=32, spec=(32, 512, 256, 30000), extra_env=None):
+def _pool_numbers(line_):
+    """the AlignPool statistics line of a run -> dict (None for a binary without the pool)"""
+    if not line_:
+        return None
+    m = re.search(r"(\d+) reads on (\d+) (user-level )?contexts \(limit (\d+)\)(?: over (\d+) carrier threads)?.*?at most (\d+) reads in flight", line_)
+    if not m:
+        return None
+    out = {"kind": "user-level contexts (fibers) on carrier threads" if m.group(3) else "pthreads", "created": int(m.group(2)), "limit": int(m.group(4)),
+           "carrier_threads": int(m.group(5)) if m.group(5) else None, "max_reads_in_flight": int(m.group(6))}
+    m = re.search(r"in ([0-9.]+) s:", line_) or re.search(r"over ([0-9.]+) s:", line_)
+    if m:
+        out["pool_lifetime_s"] = float(m.group(1))
+    m = re.search(r"carriers ran read code ([0-9.]+) % of their time \(([0-9.]+) CPU-s\)", line_)
+    if m:
+        out["carrier_busy_share"], out["read_code_cpu_s"] = float(m.group(1)) / 100.0, float(m.group(2))
+    return out
+
+
+def _lock_numbers(line_):
+    """ngmlr's serial input stage (parse + split under one lock, reference src/NGM.cpp:190-244) as the pool's probe saw it"""
+    if not line_:
+        return None
+    m = re.search(r"held ([0-9.]+) s for (\d+) reads in (\d+) batches \(([0-9.]+) us per read\), CS threads waited ([0-9.]+) s", line_)
+    if not m:
+        return None
+    return {"held_s": float(m.group(1)), "reads": int(m.group(2)), "us_per_read": float(m.group(4)), "cs_threads_waited_s": float(m.group(5)),
+            "what": "_NGM::GetNextReadBatch: reads are parsed and split into sub-reads by one thread at a time; a lower bound of the mapping wall clock that is not the device path's"}
+
+
+def pipeline_summary(n_reads=20000, t_ref=32, spec=(32, 4096, 2048, 10000), extra_env=None):
     """What bench.py puts beside its line as `e2e_pipeline`: the reference's own ngmlr, unmodified (ngmlr_ref, CPU) against the
     build with every drop-in bound (ngmlr_hip_all: alignment, sub-read scoring, candidate search, SAM records on the device
     path, alignment contexts off the CS threads), same synthetic reads, SAM compared record by record.  -> dict (or a dict
@@ -188,7 +217,9 @@ def pipeline_summary(n_reads=4000, t_ref=32, spec=(32, 512, 256, 30000), extra_e
                 "tiles_per_launch": (r["launch"][0] / max(r["launch"][1], 1)) if r["launch"] else None,
                 "launch_in_flight_share": float(infl.group(1)) / 100.0 if infl else None,
                 "ms_parked_per_alignment": float(parked.group(1)) if parked else None,
-                "cpu_seconds": r["cpu_total_s"], "cpu_seconds_by_thread_class": r["cpu_by_class"], "peak_rss_mb": r["peak_rss_mb"]}
+                "cpu_seconds": r["cpu_total_s"], "cpu_seconds_by_thread_class": r["cpu_by_class"], "peak_rss_mb": r["peak_rss_mb"],
+                "alignment_contexts": _pool_numbers(r.get("pool_stats")), "input_lock": _lock_numbers(r.get("input_lock")),
+                "corridors_as_closed_forms": list(r["closed_forms"]) if r.get("closed_forms") else None}
     out = {"reads": n_reads, "read_bases": bases, "reference_bases": L, "host": effective_cores(),
            "ngmlr_ref": side(r0, t_ref), "ngmlr_hip_all": side(r1, t),
            "sam_identical": bool(r0["rc"] == 0 and r1["rc"] == 0 and r0["recs"] == r1["recs"]),
@@ -266,8 +297,11 @@ def run(name, t, ref, fq, extra_env=None):
     sc = re.search(r"StrippedSWHip: \d+ scoring calls.*", res.stderr)
     se = re.search(r"CandidateSearchHip: \d+ search calls.*", res.stderr)
     po = re.search(r"AlignPool: \d+ reads on.*", res.stderr)
+    il = re.search(r"AlignPool: ngmlr's input lock.*", res.stderr)
+    cf = re.search(r"SharedAligner: (\d+) of (\d+) corridors travelled as closed forms", res.stderr)
     cpu_by_class = {k: round(c, 2) for k, (c, n) in by.items()}
-    return {"peak_rss_mb": peak_rss_kb / 1024.0, "cpu_by_class": cpu_by_class, "cpu_total_s": sum(c for c, _ in by.values()), "wall": dt, "search_stats": se.group(0) if se else None, "cpu_note": cpu_note, "pool_stats": po.group(0) if po else None, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
+    return {"peak_rss_mb": peak_rss_kb / 1024.0, "cpu_by_class": cpu_by_class, "cpu_total_s": sum(c for c, _ in by.values()), "wall": dt, "search_stats": se.group(0) if se else None, "cpu_note": cpu_note, "pool_stats": po.group(0) if po else None, "input_lock": il.group(0) if il else None,
+            "closed_forms": (int(cf.group(1)), int(cf.group(2))) if cf else None, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
             "map_s": dt - float(mp.group(1)) if mp else None, "err": res.stderr[-400:], "full_err": res.stderr}
 
 
@@ -286,6 +320,10 @@ def line(name, t, r, same):
         print("    " + r["search_stats"], flush=True)
     if r.get("pool_stats"):
         print("    " + r["pool_stats"], flush=True)
+    if r.get("input_lock"):
+        print("    " + r["input_lock"], flush=True)
+    if r.get("closed_forms"):
+        print("    corridors sent as closed forms: %d of %d" % r["closed_forms"], flush=True)
     if os.environ.get("E2E_VERBOSE"):
         for l in r["full_err"].splitlines():
             if "library loaded" in l or "time" in l.lower() or "Done" in l or l.startswith("cvx_search_batch:") or l.startswith("cvx timeline") or l.startswith("cvx launch"):
