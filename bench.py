@@ -578,6 +578,74 @@ class Worker:
             retire(j, keep_last and not jobs)
 
 
+class BindingView:
+    """The step's tiles in the form ngmlr's binding holds them: corridors as the row arrays its builders
+    wrote (reference src/AlignmentBuffer.cpp:68-197), sequences in ordinary pageable memory.  fit=True: what
+    Convex::ConvexAlignHip::Prepare does per SingleAlign since round 6 -- cvx_corridor_fit recovers the builder's closed form from
+    the rows, every row verified, here for the whole table on the host's threads (cvx_corridor_fit_batch) EVERY step, inside the
+    timed region; fit=False: round 5's binding, the rows travel (packed by the pack threads, expanded on the device)."""
+
+    def __init__(self, ts, lib, fit, threads):
+        self.ts, self.lib, self.fit, self.threads = ts, lib, fit, threads
+        self.fitted = 0
+        self.fit_s = 0.0
+        self.read_bases = ts.read_bases
+
+    def __len__(self):
+        return len(self.ts)
+
+    def table(self):
+        tab = self.ts.table()
+        if self.fit:
+            import ctypes as C
+            tab = tab.copy()
+            n = C.c_int32(0)
+            c0 = time.perf_counter()
+            rc = self.lib.cvx_corridor_fit_batch(len(tab), tab.ctypes.data, self.threads, C.byref(n))
+            self.fit_s += time.perf_counter() - c0
+            if rc != 0:
+                raise RuntimeError("cvx_corridor_fit_batch: %d" % rc)
+            self.fitted = int(n.value)
+        return tab
+
+
+def binding_form_rates(lib, ts, dev, steps=5, warm=2, depth=2):
+    """`binding_input_form` of the line: the same tiles, the same whole-path steps (host buffers in -> results out), in the two
+    input forms a binding can hand over -- neither is `value`, which is measured on closed forms in a page-locked arena."""
+    out = {}
+    cores = min(os.cpu_count() or 1, 16)
+    ts.use_closed_form(False)                       # the table now points at the row arrays; the sequences are pageable (unpinned)
+    for key, fit in (("rows_fitted_to_closed_forms", True), ("row_arrays", False)):
+        view = BindingView(ts, lib, fit, cores)
+        w = Worker(dev, view, depth)
+        try:
+            w.steps(depth + 1, record=False)        # arenas of every slot
+            w.steps(warm, record=False)
+            lib.cvx_device_synchronize(dev)
+            view.fit_s = 0.0
+            c0 = time.perf_counter()
+            w.steps(steps, keep_last=True)
+            lib.cvx_device_synchronize(dev)
+            dt = time.perf_counter() - c0
+            valid = w.valid
+            w.last.release()
+            out[key] = {"Gbp_per_h": float(ts.read_bases) * steps / dt * 3600.0 / 1e9, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warm,
+                        "batches_in_flight": depth, "valid_alignments": "%d/%d" % (valid, len(ts)),
+                        "host_ms_per_step": {"cvx_submit": float(w.host_s[0]) / steps * 1e3, "cvx_wait": float(w.host_s[1]) / steps * 1e3}}
+            if fit:
+                out[key]["corridors_recognised"] = "%d/%d" % (view.fitted, len(ts))
+                out[key]["fit_ms_per_step"] = view.fit_s / steps * 1e3
+                out[key]["fit_threads"] = cores
+        except Exception as e:
+            out[key] = {"error": str(e)}
+        finally:
+            w.al.close()
+    out["what"] = ("sequences in pageable memory, corridors as row arrays (int32 offset / length per read row, 8 B per row): "
+                   "`rows_fitted_to_closed_forms` = cvx_corridor_fit_batch on %d host threads inside every step, then cvx_submit (what "
+                   "ConvexAlignHip::Prepare + Submit do since round 6); `row_arrays` = the rows travel (round 5's binding).  Not `value`." % cores)
+    return out
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1033,6 +1101,11 @@ def main() -> int:
         w.al.close()
     for ts in tilesets:
         ts.unpin()
+    if out is not None and args.gpus == 1 and not (args.no_extras or args.no_cpu_baseline):
+        try:
+            out["binding_input_form"] = binding_form_rates(lib, tilesets[0], devs[0])
+        except Exception as e:        # never let the extra measurement break the contract line
+            out["binding_input_form"] = {"error": str(e)}
     if out is not None and args.gpus == 1 and not (args.no_e2e or args.no_extras or args.no_cpu_baseline):
         # ngmlr's own pipeline (the reference's only published metric is end to end, README.md:25), outside the timed region and
         # after this process has given its device memory back: the reference's binary built with every drop-in (oracle/_ref/ngmlr_hip_all)

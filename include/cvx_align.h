@@ -149,6 +149,9 @@ typedef struct {
  * cvx_tile's.  Returns CVX_OK (whatever the kind) or CVX_ERR_ARG. */
 int cvx_corridor_fit(const int32_t *row_offset, const int32_t *row_length, int32_t row_stride_bytes, int32_t n_rows,
 		int32_t ref_len, int32_t qry_len, cvx_tile *form);
+/* The same for a tile table, in place, on n_threads host threads (0 = all): every tile with corridor_kind == CVX_CORRIDOR_ROWS
+ * gets its closed form when it has one; *n_fitted (may be NULL) = how many did. */
+int cvx_corridor_fit_batch(int32_t n_tiles, cvx_tile *tiles, int32_t n_threads, int32_t *n_fitted);
 
 /* What the forward fill + backtrack leave behind (FwdResults, src/ConvexAlignFast.h:69-77). */
 typedef struct {

@@ -245,6 +245,18 @@ typedef unsigned long long u64;
 
 /* per-lane predicate <-> wave-uniform 64-bit lane mask (SGPR pair) */
 CVX_DEV u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+/* A wave-uniform value that is needed in a rare path of a long loop (row staging, the direction flush): handed through an
+ * "s" constraint at its use, so that it lives in a scalar register across the loop instead of in a vector register the
+ * allocator then spills to scratch and reloads inside the loop (round 5: 26 spilled dwords, +16 GB of HBM traffic per launch) */
+CVX_DEV int in_sgpr(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
+CVX_DEV float in_sgpr(float v) { return __int_as_float(in_sgpr(__float_as_int(v))); }
+CVX_DEV unsigned in_sgpr(unsigned v) { return (unsigned) in_sgpr((int) v); }
+CVX_DEV u64 in_sgpr(u64 u) { return ((u64) in_sgpr((unsigned) (u >> 32)) << 32) | (u64) in_sgpr((unsigned) u); }
+template <typename T> CVX_DEV T *in_sgpr(T *p) {
+	const u64 u = (u64) p;
+	const unsigned lo = (unsigned) in_sgpr((int) (unsigned) u), hi = (unsigned) in_sgpr((int) (unsigned) (u >> 32));
+	return (T *) (((u64) hi << 32) | (u64) lo);
+}
 CVX_DEV bool lanes(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 /* mask of lane i <- mask of lane (i-1) mod 64 : the SALU twin of wave_ror:1 */
 CVX_DEV u64 rot1_m(u64 m) { return (m << 1) | (m >> 63); }
@@ -659,15 +671,24 @@ fill_ring_kernel(const FillArgs a) {
 			if (tid == 0) atomicAdd(a.redo_count, 1);
 		}
 	}
-	const TileIn ti = a.tin[t];
-	const TileRun tr = a.trun[t];
-	const RowView rv = row_view(a.rsrc[t], a.rows, ti.row_off, y0);      /* wave-uniform: closed forms are evaluated in make_rec */
+	/* The tile's constants are wave-uniform, but the records they come from are fetched with vector loads (nothing tells the
+	 * compiler the tables are not written meanwhile), and what is derived from them -- 64-bit addresses above all -- then sits in
+	 * vector registers for the whole step loop, to be spilled and reloaded in its rare paths (round 5: 26 dwords, +16 GB of
+	 * scratch traffic per launch).  Through readfirstlane once, here, they are scalar for good. */
+	TileIn ti = a.tin[t];
+	ti.ref_off = in_sgpr(ti.ref_off); ti.qry_off = in_sgpr(ti.qry_off); ti.W = in_sgpr(ti.W); ti.H = in_sgpr(ti.H);
+	ti.row_off = in_sgpr((u64) ti.row_off);
+	TileRun tr = a.trun[t];
+	tr.dir_off = in_sgpr((u64) tr.dir_off); tr.r0 = in_sgpr(tr.r0); tr.nsteps = in_sgpr(tr.nsteps);
+	RowView rv = row_view(a.rsrc[t], a.rows, ti.row_off, y0);      /* wave-uniform: closed forms are evaluated in make_rec */
+	rv.rows = in_sgpr(rv.rows); rv.fmt = in_sgpr(rv.fmt); rv.width = in_sgpr(rv.width);
+	rv.k = in_sgpr(rv.k); rv.d = in_sgpr(rv.d); rv.right = in_sgpr(rv.right);
 	const uint8_t *seq = a.seq;
 	const int H = CHAIN ? ct.rows : ti.H, W = ti.W;     /* rows of this task */
 	const unsigned qry_off = ti.qry_off + (unsigned) y0;
 	const int r0 = CHAIN ? ct.r0 : tr.r0;
 	const int nsteps = CHAIN ? ct.nsteps : tr.nsteps;
-	uint32_t *dirs = a.dirs + (CHAIN ? ct.dir_off : tr.dir_off);
+	uint32_t *dirs = in_sgpr(a.dirs + (CHAIN ? ct.dir_off : tr.dir_off));
 	/* per-slot state in VGPRs (static indexing only).  A slot that is not inside its
 	 * row's range holds the reference's empty element (score 0, run 0, STOP:
 	 * src/AlignmentMatrixFast.h:49-53), i.e. S = 0, runs = 0, V = Hc = gap_open;
@@ -705,9 +726,10 @@ fill_ring_kernel(const FillArgs a) {
 		rec.w = (int) (ref_base - (unsigned) yy);
 		if (yy < H) {
 			const RowDesc2 ol = row_at(rv, yy);
+			const long long Ws = (long long) W;
 			long long lo = ol.x > 0 ? ol.x : 0;
 			long long hi = (long long) ol.x + (long long) ol.y;
-			if (hi > W) hi = W;
+			if (hi > Ws) hi = Ws;
 			if (hi < lo) hi = lo;
 			rec.x = yy + y0 + (int) lo;
 			rec.y = (int) (hi - lo);
@@ -861,9 +883,11 @@ fill_ring_kernel(const FillArgs a) {
 		 * wait for this group's characters: gfx9 counts loads and stores in one vmcnt,
 		 * so a store issued just before that wait would be waited for in full */
 		if (g != 0 && (g & 7) == 0) {
-			uint32_t *d = dirs + ((size_t) ((g >> 3) - 1) * N + (size_t) tid * M) * 2;
+			/* scalar base of the block + a 32-bit lane offset (a per-lane 64-bit pointer kept across the loop was spilled) */
+			uint32_t *d = dirs + (size_t) ((g >> 3) - 1) * (N * 2);
+			const unsigned dl = (unsigned) tid * (M * 2);
 #pragma unroll
-			for (int j = 0; j < M; ++j) { d[2 * j] = accA[j]; d[2 * j + 1] = accB[j]; }
+			for (int j = 0; j < M; ++j) { d[dl + 2 * j] = accA[j]; d[dl + 2 * j + 1] = accB[j]; }
 		}
 
 #pragma unroll

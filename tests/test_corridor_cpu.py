@@ -104,6 +104,34 @@ def test_library_fit_on_generated_and_irregular_corridors():
     assert capi.corridor_fit(np.zeros(0, np.int32), np.zeros(0, np.int32), 10, 0)[0] == capi.CORRIDOR_ROWS
 
 
+def test_library_fit_scalar_and_avx2_forms_agree(tmp_path):
+    """cvx_corridor_fit picks an AVX2 form of its two passes where the host has it; the scalar form (CVX_CORRIDOR_NO_AVX2=1, read when
+    the library is loaded) must return the same closed forms."""
+    code = (
+        "import numpy as np, json, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from ngmlr_amd import capi, synth\n"
+        "rng = np.random.default_rng(3)\n"
+        "out = []\n"
+        "for _ in range(120):\n"
+        "    H = int(rng.integers(2, 30000)); W = max(1, int(H * rng.uniform(0.8, 1.3)))\n"
+        "    k = np.float32(H) * np.float32(1.0) / np.float32(W)\n"
+        "    off, ln = synth.affine_rows(H, k, np.float32(0.0), np.float32(rng.uniform(128.0, 3000.0)), int(rng.integers(200, 5000)))\n"
+        "    if rng.random() < 0.15: off[int(rng.integers(0, H))] += 1\n"
+        "    d = capi.corridor_fit(off, ln, W, H)\n"
+        "    o2 = synth.affine_rows(H, np.float32(d[1]), np.float32(d[2]), np.float32(d[3]), d[5])[0] if d[0] == 1 else None\n"
+        "    out.append([d[0], bool(o2 is None or np.array_equal(o2, off))])\n"
+        "print(json.dumps(out))\n") % ROOT
+    import json
+    res = {}
+    for name, env in (("avx2", {}), ("scalar", {"CVX_CORRIDOR_NO_AVX2": "1"})):
+        r = subprocess.run(["python", "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[name] = json.loads(r.stdout)
+    assert res["avx2"] == res["scalar"]
+    assert all(ok for _, ok in res["scalar"]) and sum(1 for k_, _ in res["scalar"] if k_ == 1) >= 90 and any(k_ == 0 for k_, _ in res["scalar"])
+
+
 def test_generators_carry_their_closed_form():
     for t in util.tile_zoo(n=48) + synth.workload_short(20) + synth.workload_ultralong_sv(4, read_len=3000):
         assert t.desc is not None

@@ -78,6 +78,16 @@ def test_register_budgets(device_asm):
         assert vgprs(body) <= 80, name                   # six waves per SIMD
     tab = dict(_kernels(device_asm, "_ZN3cvx16fill_ring_kernelILi3ELb0ELi0ELb1ELi1E"))
     assert len(tab) == 1 and vgprs(next(iter(tab.values()))) <= 72      # the PacBio launch: seven waves per SIMD
+    # round 6: no fill kernel touches scratch.  Round 5's builds spilled 6-26 dwords per lane and reloaded them in the step loop's rare
+    # paths (row staging, the direction flush): the tile's wave-uniform constants came out of vector loads and what was derived from
+    # them -- 64-bit addresses -- lived in vector registers; they go through readfirstlane once now (in_sgpr, cvx_kernels.hip)
+    meta = re.findall(r"\.name:\s+(_ZN3cvx16fill_ring_kernel\S+)\n\s+\.private_segment_fixed_size: (\d+)\n(?:.*\n){1,6}?\s+\.vgpr_spill_count: (\d+)", device_asm)
+    assert len(meta) == 32
+    for name, scratch, spilled in meta:
+        gang_or_wide = re.search(r"ELi[23]EEEvNS_8FillArgsE$", name) or "ILi4E" in name
+        assert (int(scratch), int(spilled)) == (0, 0) or gang_or_wide, (name, scratch, spilled)
+    one_wave_m3 = [m_ for m_ in meta if "ILi3E" in m_[0] and m_[0].endswith("ELi1EEEvNS_8FillArgsE")]
+    assert len(one_wave_m3) == 5 and all((int(sc_), int(sp_)) == (0, 0) for _, sc_, sp_ in one_wave_m3)
     walk = dict(_kernels(device_asm, "_ZN3cvx16backtrack_kernel"))
     assert len(walk) == 1
     assert vgprs(next(iter(walk.values()))) <= 32
