@@ -94,3 +94,46 @@ def test_pool_keeps_the_sam_of_split_reads(tmp_path):
         assert sorted(got) == sorted(want)
         assert "ParkingCpuAligner:" in err and " 0 parks" not in err
     assert any(int(l.split("\t")[1]) & 2048 for l in want)          # split reads among them
+
+
+@pytest.mark.skipif(not os.path.exists(BINARY) or not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ngmlr_ref")),
+                    reason="oracle/_ref/ngmlr_pool_cpu / ngmlr_ref not built (tools/build_ngmlr_hip.sh needs /root/reference)")
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_input_records_read_under_the_lock_objects_built_outside(tmp_path, split):
+    """ngmlr_amd/csrc/input_batch_binding.inc: _NGM::GetNextReadBatch (reference src/NGM.cpp:190-244) reads only the raw record
+    under NGM's input lock and runs the reference's own NextRead (copyToRead, splitRead) after the unlock.  Same reads, ids and
+    SAM as the unmodified reference on FASTQ input with long and short reads -- and on an input whose fourth record is malformed
+    (quality string shorter than the sequence): the reference reports the record and terminates the run (Log.Error), and so does the
+    binding, from the thread that finishes the record."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_rates
+    from ngmlr_amd import synth
+    rng = np.random.default_rng(41)
+    fa, fq = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq")
+    e2e_rates.write_plain_workload(fa, fq, 40, rng, 300_000)
+    ref = synth.random_ref(np.random.default_rng(2025), 10)       # (write_plain_workload drew the reference first from its own rng)
+    with open(fq, "a") as f:                                       # short reads (processShortRead) behind the long ones
+        for i in range(10):
+            f.write("@short%d\n%s\n+\n%s\n" % (i, "ACGTTGCATG" * 15, "I" * 150))
+    bad = str(tmp_path / "bad.fq")
+    recs = open(fq).read().split("\n")
+    recs[4 * 3 + 3] = recs[4 * 3 + 3][:-7]                         # fourth record: quality shorter than the sequence
+    open(bad, "w").write("\n".join(recs))
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ngmlr_ref")
+    for q in (fq, bad):
+        args = ["-x", "pacbio", "-t", "4", "-R", "0.01", "--no-progress", "-r", fa, "-q", q]
+        res = subprocess.run([ref_bin, "--skip-write"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(tmp_path))
+        env = dict(os.environ, CVX_POOL_CONTEXTS="64", CVX_INPUT_SPLIT=split)
+        got = subprocess.run([BINARY, "--skip-write"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(tmp_path), env=env)
+        if q == bad:
+            msg = "Read r3_%s: Length of read not equal length of quality values." % recs[12].split("_")[1]
+            assert res.returncode != 0 and msg in res.stderr and "Terminating" in res.stderr, res.stderr[-1500:]
+            assert got.returncode != 0 and msg in got.stderr and "Terminating" in got.stderr, got.stderr[-1500:]
+            continue
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert got.returncode == 0, got.stderr[-2000:]
+        want = _records(res.stdout)
+        assert sorted(_records(got.stdout)) == sorted(want) and len(want) == 50
+        assert "ngmlr's input lock" in got.stderr

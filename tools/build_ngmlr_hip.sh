@@ -24,7 +24,7 @@ mkdir -p "$REPO/oracle/_ref"
 #                      (runs without a GPU: tests/test_sam_cpu.py)
 #   ngmlr_hip_pool     ngmlr_hip_full + Convex::AlignPool: processLongReadLIS / processShortRead run on K >> t alignment
 #                      contexts instead of on the CS thread (align_pool.h; SURVEY 8 f1's second half), the main loop polls
-#                      for the end of the run every 20 ms instead of every 2 s, SAM buffers flush at 1 MB instead of 10 MB
+#                      for the end of the run every 20 ms instead of every 2 s, SAM buffers flush at 256 kB instead of 10 MB (thousands of contexts each own one)
 #   ngmlr_hip_all      ngmlr_hip_pool + the candidate search of every CS thread's batch on the device (Convex::CandidateSearchHip,
 #                      cs_search_binding.inc at the top of CS::RunBatch, src/CS.cpp:400): alignment, sub-read scoring, k-mer vote
 #                      and SAM records on the drop-ins (SURVEY 8 f1 + f2 + f3 + f4's search half)
@@ -96,11 +96,42 @@ if POOL:
     # measurement only: how long the CS threads wait for / hold the lock under which reads are parsed and split (align_pool.h)
     s = sub1(s, 'std::vector<MappedRead*> _NGM::GetNextReadBatch(int desBatchSize) {\n\tNGMLock(&m_Mutex);', 'std::vector<MappedRead*> _NGM::GetNextReadBatch(int desBatchSize) {\n\tlong long const cvxT0 = Convex::AlignPool::ProbeNow();\n\tNGMLock(&m_Mutex);\n\tlong long const cvxT1 = Convex::AlignPool::ProbeNow();', 'GetNextReadBatch lock')
     s = sub1(s, '\tm_CurCount -= desBatchSize;\n\n\tNGMUnlock(&m_Mutex);', '\tm_CurCount -= desBatchSize;\n\n\tConvex::AlignPool::InputLockTimes(cvxT0, cvxT1, Convex::AlignPool::ProbeNow(), count);\n\tNGMUnlock(&m_Mutex);', 'GetNextReadBatch unlock')
-    s = sub1(s, '#include "NGM.h"', '#include "NGM.h"\n#include "align_pool.h"', 'NGM.cpp include')
+    s = sub1(s, '#include "NGM.h"', '#include "NGM.h"\n#include "align_pool.h"\n#include <vector>\n#include <stdlib.h>\n#include <string.h>', 'NGM.cpp include')
+    # the read loop in two halves: the record under the input lock, the MappedRead objects outside it (input_batch_binding.inc)
+    s = sub1(s, '\tint i = 0;\n\twhile (count < desBatchSize && !eof) {', '\tint i = 0;\n#include "input_batch_binding.inc"\n\twhile (count < desBatchSize && !eof) {', 'GetNextReadBatch loop')
+    open(p, 'w').write(s)
+    p = T + '/src/IParser.h'
+    s = open(p).read()
+    s = sub1(s, '\tint parseRead(MappedRead * pRead) {', '\t/* cvx (input_batch_binding.inc): parseRead in two halves -- the raw record (kseq state: under the caller\'s lock), and the MappedRead from it */\n'
+             '\tvirtual int cvxReadRecord(kseq_t * rec) { (void) rec; return -3; }\n'
+             '\tint cvxFinishRead(MappedRead * pRead, kseq_t * rec, int const l) { return copyToRead(pRead, rec, l); }\n\n\tint parseRead(MappedRead * pRead) {', 'IParser accessors')
+    open(p, 'w').write(s)
+    p = T + '/src/FastxParser.h'
+    s = open(p).read()
+    s = sub1(s, '\tvirtual int doParseRead(MappedRead * read) {', '\t/* cvx: the next record, its strings swapped out of the parser (which goes on with the caller\'s previous buffers) */\n'
+             '\tvirtual int cvxReadRecord(kseq_t * rec) {\n\t\tint l = kseq_read(tmp);\n\t\t{      /* (also for l < 0: copyToRead reads the name of a record whose quality string has the wrong length) */\n'
+             '\t\t\tkstring_t t;\n\t\t\tt = rec->name; rec->name = tmp->name; tmp->name = t;\n\t\t\tt = rec->comment; rec->comment = tmp->comment; tmp->comment = t;\n'
+             '\t\t\tt = rec->seq; rec->seq = tmp->seq; tmp->seq = t;\n\t\t\tt = rec->qual; rec->qual = tmp->qual; tmp->qual = t;\n\t\t}\n\t\treturn l;\n\t}\n\n'
+             '\tvirtual int doParseRead(MappedRead * read) {', 'FastXParser::cvxReadRecord')
+    open(p, 'w').write(s)
+    p = T + '/src/ReadProvider.h'
+    s = open(p).read()
+    s = sub1(s, '\tvirtual MappedRead * NextRead(IParser * parser, int const id);', '\tvirtual MappedRead * NextRead(IParser * parser, int const id, kseq_t * cvxRec = 0, int const cvxL = 0);\npublic:\n'
+             '\t/* cvx (input_batch_binding.inc): the raw record under the input lock, NextRead on it outside */\n'
+             '\tint cvxReadRecord(kseq_t * rec) { return parser1->cvxReadRecord(rec); }\n'
+             '\tMappedRead * cvxGenerateRead(int const readid, kseq_t * rec, int const l) { return NextRead(parser1, readid, rec, l); }\nprivate:', 'ReadProvider accessors')
+    open(p, 'w').write(s)
+    p = T + '/src/ReadProvider.cpp'
+    s = open(p).read()
+    s = sub1(s, 'MappedRead * ReadProvider::NextRead(IParser * parser, int const id) {', 'MappedRead * ReadProvider::NextRead(IParser * parser, int const id, kseq_t * cvxRec, int const cvxL) {', 'NextRead signature')
+    s = sub1(s, '\t\tl = parser->parseRead(read);', '\t\tl = cvxRec ? parser->cvxFinishRead(read, cvxRec, cvxL) : parser->parseRead(read);', 'NextRead parse')
+    open(p, 'w').write(s)
+    p = T + '/src/NGM.cpp'
+    s = open(p).read()
     open(p, 'w').write(s)
     p = T + '/src/GenericReadWriter.h'
     s = open(p).read()
-    s = sub1(s, 'BUFFER_LIMIT =  10000000;', 'BUFFER_LIMIT =  1000000;', 'BUFFER_LIMIT')
+    s = sub1(s, 'BUFFER_LIMIT =  10000000;', 'BUFFER_LIMIT =  262144;', 'BUFFER_LIMIT')
     open(p, 'w').write(s)
 if SAM:
     p = T + '/src/SAMWriter.cpp'
