@@ -222,6 +222,12 @@ int cvx_device_synchronize(int device_id);
  *   - loading the library sets GPU_MAX_HW_QUEUES=16 in the environment unless the variable is already set (the HIP runtime
  *     reads it at its first call): the streams of several handles in one process must not share hardware queues. */
 int cvx_create(int device_id, const cvx_params *params, uint64_t max_matrix_mb, cvx_handle *out);
+/* ABI 7: the same with flags.  CVX_CREATE_SERVICE: the handle will only make the short calls (cvx_score_batch, cvx_search_batch*,
+ * cvx_genome_decode) from a thread that blocks in them -- its stream gets the device's highest priority, so that a 0.3 ms scoring
+ * kernel does not queue behind a 10 ms fill of an aligning handle in the same process.  MEASURED AND OFF: inside ngmlr the run got
+ * slower with it (profiles/r06_e2e_service_prio.txt); the flag is recorded in the handle, the priority applies only with CVX_SERVICE_PRIO=1. */
+enum { CVX_CREATE_SERVICE = 1 };
+int cvx_create_ex(int device_id, const cvx_params *params, uint64_t max_matrix_mb, uint32_t flags, cvx_handle *out);
 void cvx_destroy(cvx_handle h);
 
 /* Synchronous convenience form: upload, run, download.  ops_arena receives the

@@ -29,7 +29,7 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id", "cvx_job_poll", "cvx_score_kernel_ms",
            "cvx_index_upload", "cvx_index_free", "cvx_search_batch", "cvx_search_batch_ex", "cvx_job_nm_profile", "cvx_job_nm_sizes", "cvx_nm_profile_ops",
            "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch", "cvx_stage_kernel_ms", "cvx_search_last_attempts", "cvx_index_build",
-           "cvx_corridor_fit", "cvx_corridor_fit_batch")
+           "cvx_corridor_fit", "cvx_corridor_fit_batch", "cvx_create_ex")
 
 
 class CvxParams(C.Structure):

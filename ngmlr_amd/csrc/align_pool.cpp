@@ -12,7 +12,9 @@
 
 #include <pthread.h>
 
+#include <algorithm>
 #include <atomic>
+#include <cstring>
 
 #include "AlignmentBuffer.h"
 #include "NGM.h"
@@ -180,6 +182,28 @@ struct FiberContexts {
 		if (const char * e = getenv("CVX_POOL_CONTEXTS")) maxContexts = atoi(e) > 0 ? atoi(e) : 1;
 		unsigned const hw = std::thread::hardware_concurrency();
 		if (hw > 0 && (int) hw < carriers) carriers = (int) hw;
+		/* A container's CPU quota stalls EVERY thread of the process once a period's budget is spent: 16 carriers + 32 CS threads on
+		 * a 16-core quota were throttled for 15 s of thread time in a 1.7 s run, and the dispatcher's cvx_submit with them
+		 * (profiles/r06_e2e_thread_matrix.txt).  The carriers take half of what the cgroup allows; the CS threads (-t) are ngmlr's. */
+		{
+			double cores = 0.0;
+			if (FILE * f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+				char q[64];
+				double period = 0.0;
+				if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) cores = atof(q) / period;
+				fclose(f);
+			} else if (FILE * g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+				double quota = -1.0, period = 0.0;
+				if (fscanf(g, "%lf", &quota) != 1) quota = -1.0;
+				fclose(g);
+				if (FILE * p2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(p2, "%lf", &period) != 1) period = 0.0; fclose(p2); }
+				if (quota > 0.0 && period > 0.0) cores = quota / period;
+			}
+			if (cores >= 1.0) {
+				int const half = (int) (cores / 2.0 + 0.5);
+				carriers = std::min(carriers, std::max(2, half));
+			}
+		}
 		if (const char * e = getenv("CVX_POOL_CARRIERS")) carriers = atoi(e) > 0 ? atoi(e) : 1;
 		if (carriers > maxContexts) carriers = maxContexts;
 		queueLimit = maxContexts / 2 > 512 ? maxContexts / 2 : 512;

@@ -162,7 +162,7 @@ void BatchingAligner::dispatchLoop() {
 		bool const canSubmit = (int) inFlight.size() < maxFlight;
 		if (canSubmit && shouldCut(inFlight.empty())) {
 			Launch * l = new Launch();
-			l->job = 0; l->results = 0; l->ops = 0; l->failed = false; l->text = 0;
+			l->job = 0; l->results = 0; l->ops = 0; l->failed = false; l->text = 0; l->submitMs = l->waitMs = 0.0;
 			size_t const take = std::min(queue.size(), (size_t) maxBatch);
 			l->oldestAt = oldest;
 			l->cutAt = std::chrono::steady_clock::now();
@@ -180,6 +180,7 @@ void BatchingAligner::dispatchLoop() {
 			} catch (...) {
 				l->failed = true;
 			}
+			l->submitMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - l->cutAt).count();
 			lk.lock();
 			if (inFlight.empty()) { busySince = std::chrono::steady_clock::now(); frontSince = busySince; }
 			inFlight.push_back(l);
@@ -206,9 +207,12 @@ void BatchingAligner::dispatchLoop() {
 			lk.unlock();
 			if (!l->failed) {
 				try {
+					std::chrono::steady_clock::time_point const tw = std::chrono::steady_clock::now();
 					backend->Wait(l->job, &l->results, &l->ops);
 					if (launchTrace) {
 						std::chrono::steady_clock::time_point const t = std::chrono::steady_clock::now();
+						l->waitMs = std::chrono::duration<double, std::milli>(t - tw).count();
+						fprintf(stderr, "cvx dispatcher: submit %.2f ms, wait entered %.2f ms after the cut, blocked in it %.2f ms; ", l->submitMs, std::chrono::duration<double, std::milli>(tw - l->cutAt).count(), l->waitMs);
 						backend->Trace(l->job, (int) l->reqs.size(), std::chrono::duration<double, std::milli>(t - l->cutAt).count(),
 								std::chrono::duration<double, std::milli>(l->cutAt - l->oldestAt).count());
 					}

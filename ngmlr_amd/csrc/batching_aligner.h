@@ -112,6 +112,7 @@ private:
 		cvx_result const * results;
 		uint32_t const * ops;
 		std::chrono::steady_clock::time_point cutAt, oldestAt;      /* CVX_LAUNCH_TRACE: when the launch was cut, when its oldest request arrived */
+		double submitMs, waitMs;            /* CVX_LAUNCH_TRACE: the dispatcher's time inside Submit (tile table + cvx_submit) and blocked in Wait */
 		int unfinished;                    /* workers still writing their text out of this launch's buffers */
 		bool failed;
 		ConvexAlignHip::JobText * text;    /* CVX_DEVICE_TEXT=1: the launch's text stage ran on the device (else 0) */

@@ -30,7 +30,7 @@ CandidateSearchHip * CandidateSearchHip::Get(int kmerLength, void const * refTab
 	if (g_instance != 0) return g_instance;
 	cvx_params p = { 2.0f, -5.0f, -5.0f, -5.0f, -1.0f, 0.15f };      /* the search has no scoring; a handle needs a valid set */
 	for (int l = 0; l < kLanes; ++l) {
-		if (cvx_create(deviceId, &p, 0, &g_handle[l]) != CVX_OK) {
+		if (cvx_create_ex(deviceId, &p, 0, CVX_CREATE_SERVICE, &g_handle[l]) != CVX_OK) {
 			/* no silent host path: a binary built with the device search fails loudly without its device */
 			fprintf(stderr, "CandidateSearchHip: %s\n", cvx_last_error());
 			for (int q = 0; q < l; ++q) { cvx_destroy(g_handle[q]); g_handle[q] = 0; }

@@ -82,21 +82,66 @@ void set_err(const char *fmt, ...) {
 		return CVX_ERR_HIP;                                                        \
 	}
 
+/* Buffers that grow while a handle streams jobs of changing size (ngmlr's pipeline: launches of 50 to 4 000 tiles on five job
+ * slots).  Two things made cvx_submit take 15-50 ms per call there (profiles/r06_e2e_submit_trace.txt, `upload stage`):
+ *   - hipFree / hipHostFree wait for everything in flight on the device.  An outgrown block is therefore not freed on the spot
+ *     but parked (defer_release) and given back when its handle has nothing in flight, or at cvx_destroy;
+ *   - every slot climbed to the size of the largest launch by itself.  Slots of one handle share a high-water mark per buffer
+ *     (bind): the first growth of a slot goes straight to the largest capacity any of them has had. */
+struct DeferredFrees {
+	std::mutex mtx;
+	std::vector<void *> dev, host;
+	void drain() {
+		std::vector<void *> d, h;
+		{
+			std::lock_guard<std::mutex> lk(mtx);
+			d.swap(dev);
+			h.swap(host);
+		}
+		for (void *p : d) (void) hipFree(p);
+		for (void *p : h) (void) hipHostFree(p);
+	}
+	bool empty() { std::lock_guard<std::mutex> lk(mtx); return dev.empty() && host.empty(); }
+};
+DeferredFrees g_deferred;
+
+/* the streams the service handles of a process share, per device (cvx_create_ex; never destroyed: they die with the process) */
+static const int kServiceStreamsMax = 16, kMaxServiceDevices = 64;
+struct ServiceStreams { hipStream_t st[kServiceStreamsMax] = {nullptr}; unsigned next = 0; };
+ServiceStreams g_service_streams[kMaxServiceDevices];
+std::mutex g_service_mtx;
+
 template <typename T>
 struct DevBuf {
 	T *p = nullptr;
 	size_t cap = 0; /* elements */
+	size_t *hwm = nullptr;      /* shared by the same buffer of every job slot of the handle (bytes) */
 	int ensure(size_t n) {
 		if (n <= cap) return CVX_OK;
-		if (p) { (void) hipFree(p); p = nullptr; cap = 0; }
-		size_t want = n + n / 8 + 64;
+		const size_t old = cap;
+		if (p) {
+			std::lock_guard<std::mutex> lk(g_deferred.mtx);
+			g_deferred.dev.push_back(p);
+			p = nullptr; cap = 0;
+		}
+		const size_t asked = n + n / 8 + 64;
+		size_t want = asked;
+		if (want < 2 * old) want = 2 * old;      /* a buffer that has to grow at least doubles; the first allocation stays close to what was asked for */
+		if (hwm && want * sizeof(T) < *hwm && *hwm / 16 <= asked * sizeof(T)) want = (*hwm + sizeof(T) - 1) / sizeof(T);      /* (never more than 16 x what was asked for) */
 		hipError_t e = hipMalloc((void **) &p, want * sizeof(T));
+		if (e != hipSuccess && want > asked) {      /* the generous size does not fit: give back what is parked, then what was asked for may */
+			(void) hipGetLastError();
+			g_deferred.drain();
+			want = asked;
+			e = hipMalloc((void **) &p, want * sizeof(T));
+		}
 		if (e != hipSuccess) {
 			set_err("hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
 			p = nullptr;
 			return CVX_ERR_OOM;
 		}
 		cap = want;
+		if (hwm && cap * sizeof(T) > *hwm) *hwm = cap * sizeof(T);
 		return CVX_OK;
 	}
 	void release() {
@@ -110,11 +155,26 @@ struct DevBuf {
 struct PinBuf {
 	void *p = nullptr;
 	size_t cap = 0; /* bytes */
+	size_t *hwm = nullptr;
 	int ensure(size_t bytes) {
 		if (bytes <= cap) return CVX_OK;
-		if (p) { (void) hipHostFree(p); p = nullptr; cap = 0; }
-		const size_t want = bytes + bytes / 8 + 4096;
+		const size_t old = cap;
+		if (p) {
+			std::lock_guard<std::mutex> lk(g_deferred.mtx);
+			g_deferred.host.push_back(p);
+			p = nullptr; cap = 0;
+		}
+		const size_t asked = bytes + bytes / 8 + 4096;
+		size_t want = asked;
+		if (want < 2 * old) want = 2 * old;                     /* (see DevBuf::ensure) */
+		if (hwm && want < *hwm && *hwm / 16 <= asked) want = *hwm;
 		hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+		if (e != hipSuccess && want > asked) {
+			(void) hipGetLastError();
+			g_deferred.drain();
+			want = asked;
+			e = hipHostMalloc(&p, want, hipHostMallocDefault);
+		}
 		if (e != hipSuccess) {
 			(void) hipGetLastError();
 			set_err("hipHostMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
@@ -122,6 +182,7 @@ struct PinBuf {
 			return CVX_ERR_OOM;
 		}
 		cap = want;
+		if (hwm && cap > *hwm) *hwm = cap;
 		return CVX_OK;
 	}
 	void release() {
@@ -231,6 +292,18 @@ struct cvx_batch_s {
 	const ResultRec *res() const { return h_res.as<ResultRec>(); }
 	const BatchSummary *summary() const { return reinterpret_cast<const BatchSummary *>(h_res.as<uint8_t>() + (size_t) n * sizeof(ResultRec)); }
 
+	/* the buffers whose size follows the job's tile count or cells: the same buffer of every slot of a handle shares one mark */
+	static const int kSharedMarks = 32;
+	void bind(size_t *marks) {
+		int k = 0;
+		PinBuf *pins[] = { &h_seq, &h_delta, &h_rsrc, &h_tin, &h_plan, &h_trun, &h_tout, &h_lists, &h_res, &h_ops, &h_chain };
+		for (PinBuf *b_ : pins) b_->hwm = &marks[k++];
+		d_seq.hwm = &marks[k++]; d_rows.hwm = &marks[k++]; d_delta.hwm = &marks[k++]; d_rsrc.hwm = &marks[k++]; d_tin.hwm = &marks[k++];
+		d_plan.hwm = &marks[k++]; d_trun.hwm = &marks[k++]; d_tout.hwm = &marks[k++]; d_dirs.hwm = &marks[k++]; d_regions.hwm = &marks[k++];
+		d_lists.hwm = &marks[k++]; d_dstoff.hwm = &marks[k++]; d_dense.hwm = &marks[k++]; d_res.hwm = &marks[k++];
+		d_chain.hwm = &marks[k++]; d_bnd.hwm = &marks[k++]; d_chain_out.hwm = &marks[k++];
+		static_assert(11 + 17 <= kSharedMarks, "marks");
+	}
 	int make_events() {
 		if (!ev_in) HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
 		if (!ev_res) HIP_TRY(hipEventCreateWithFlags(&ev_res, hipEventDisableTiming));
@@ -327,6 +400,8 @@ struct cvx_context {
 	                                  * fills of the batches that follow */
 	hipStream_t s_post = nullptr;    /* backtrack, finalize, compaction, result download: runs beside the NEXT batch's fill */
 	hipStream_t aux[kAuxStreams] = {nullptr};  /* concurrent fill classes */
+	bool service = false;                      /* cvx_create_ex(CVX_CREATE_SERVICE): short search / scoring / decode calls only */
+	bool owns_main = true;                     /* false: s_main is one of the process's shared service streams */
 	/* a second set (main, post, aux) for small streaming jobs (experiment, off by default: see single_lane): the jobs of a
 	 * batching driver (tens of tiles each) are latency-bound chains of small kernels on an otherwise empty device;
 	 * consecutive ones can alternate between the two sets */
@@ -354,6 +429,8 @@ struct cvx_context {
 	int tune_exact_steps = kExactDirectSteps;   /* tuning knob (env CVX_TUNE_EXACT_STEPS, 0 = off): tiles of this many steps go straight to the exact fill */
 	int tune_wide_prio = 1;   /* tuning knob (env CVX_TUNE_WIDE_PRIO = 0 / 1 / 2: off, priority 1, priority 2): the widest ring class of a batch of several one priority notch up */
 	int tune_chain_prio = -1; /* tuning knob (env CVX_TUNE_CHAIN_PRIO = 0 / 1): wave priority of chained blocks; -1 = the default (raised) */
+	int tune_chain_lds_kb = 48; /* tuning knob (env CVX_TUNE_CHAIN_LDS_KB): LDS per CU the residency cap of a chained class may hold while ring classes
+	                           * of the same batch run beside it (0 = no limit: round 5's rule) */
 	int tune_chain_m = 0;     /* test knob (env CVX_TUNE_CHAIN_M): row-block height class (1, 2, 4) of chained tiles */
 	int tune_force_wrap = 0;  /* test knob (env CVX_TUNE_FORCE_WRAP16): route every tile to the int16-run kernels */
 	int tune_pen_table = 1;   /* tuning knob (env CVX_TUNE_PEN_TABLE = 0 / 1): convex penalty from the LDS table in the two-phase float-score fills */
@@ -367,6 +444,7 @@ struct cvx_context {
 	/* freed batches keep their device arenas and pinned staging and wait here for the next upload
 	 * (at most kPoolBatches): hipMalloc / hipFree of multi-GB arenas per call are slow, and hipFree
 	 * synchronises the whole device, which would serialise handles that work side by side */
+	size_t marks[cvx_batch_s::kSharedMarks] = {0};   /* high-water marks of the streaming slots' buffers (cvx_batch_s::bind) */
 	std::vector<cvx_batch_s *> pool;
 	std::vector<cvx_batch_s *> pending;      /* streaming jobs whose compute stage is not queued yet */
 	std::vector<cvx_batch_s *> live;         /* every streaming job the caller has not released yet (cvx_destroy frees what is left) */
@@ -991,6 +1069,18 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		const size_t per_cu = (size_t) ((resident + (uint64_t) h->num_cus - 1) / (uint64_t) h->num_cus);
 		size_t pad_lds = per_cu >= 32 ? 0 : (size_t) (160 * 1024) / per_cu - 4096;
 		pad_lds = std::min<size_t>(pad_lds, 60 * 1024) / 256 * 256;
+		/* The padding is LDS the ring classes of the same batch cannot use: a handful of chained retries among a thousand whole
+		 * tiles (ngmlr's own launches: 10-40 chained tiles, resident = 768 tasks = 3 per CU at 50 KB each) held 150 of a CU's
+		 * 160 KB for their 7 ms, and the M = 3 / M = 4 classes -- 4-5 KB per wave -- crawled until they were gone: a launch's
+		 * fill was the SUM of the chained class and the widest ring class (18.6 = 7.0 + 11.7 ms, profiles/r06_e2e_launch_trace.txt).
+		 * Beside ring classes the cap may hold tune_chain_lds_kb per CU; more tasks than can run then sit in their back-off sleep. */
+		bool rings_beside = false;
+		for (size_t rc_ = 0; rc_ < cls.size(); ++rc_) rings_beside = rings_beside || !cls[rc_].empty();
+		if (rings_beside && h->tune_chain_lds_kb > 0 && per_cu > 0 && per_cu < 32) {
+			const size_t budget = (size_t) h->tune_chain_lds_kb * 1024 / per_cu;
+			const size_t capped = budget > 4096 ? (budget - 4096) / 256 * 256 : 0;
+			pad_lds = std::min(pad_lds, capped);
+		}
 		HIP_TRY(launch_fill(m, 1, (c & 1) != 0, 2, a, pad_lds, ls));
 		HIP_TRY(launch_chain_reduce(reinterpret_cast<const int32_t *>(b->d_chain.p + chain_tile_off[c]), (int) hp.chain_tiles[c].size(),
 				b->d_trun.p, b->d_chain_out.p, b->d_tout.p, ls));
@@ -1199,6 +1289,10 @@ int cvx_device_synchronize(int device_id) {
 }
 
 int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_handle *out) {
+	return cvx_create_ex(device_id, p, max_matrix_mb, 0u, out);
+}
+
+int cvx_create_ex(int device_id, const cvx_params *p, uint64_t max_matrix_mb, uint32_t flags, cvx_handle *out) {
 	ABI_GUARD_BEGIN
 	if (!p || !out) { set_err("cvx_create: NULL argument"); return CVX_ERR_ARG; }
 	*out = nullptr;
@@ -1288,6 +1382,7 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	if (const char *e = getenv("CVX_TUNE_MAX_M")) c->tune_max_slots = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_M")) c->tune_chain_m = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_CHAIN_PRIO")) c->tune_chain_prio = atoi(e) != 0;
+	if (const char *e = getenv("CVX_TUNE_CHAIN_LDS_KB")) c->tune_chain_lds_kb = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char *e = getenv("CVX_TUNE_WIDE_PRIO")) c->tune_wide_prio = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_EXACT_STEPS")) c->tune_exact_steps = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_TWO_LANES")) c->single_lane = atoi(e) == 0;
@@ -1302,7 +1397,34 @@ int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_h
 	 * set for small jobs) are created by its first alignment call (ensure_streams).  ngmlr holds 32 handles that only ever
 	 * score or search on `main`: 224 streams that were created at start-up and destroyed at exit for nothing
 	 * (0.8 s between the last alignment and the process's exit, profiles/r04_timeline_e2e.txt). */
-	hipError_t e = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
+	/* A SERVICE handle (CVX_CREATE_SERVICE: ngmlr's 16 searching and 32 scoring handles) makes short, latency-bound calls from a
+	 * thread that blocks in them: its stream is created at the device's highest priority, which on this runtime also means a
+	 * hardware queue out of another pool than the aligning handle's fill streams' -- 50 normal streams on 16 hardware queues put
+	 * fill classes behind each other and scoring kernels behind 10 ms fills (profiles/r06_e2e_launch_trace.txt). */
+	hipError_t e = hipSuccess;
+	c->service = (flags & CVX_CREATE_SERVICE) != 0;
+	const char *sp = getenv("CVX_SERVICE_PRIO");
+	int shared = 4;      /* CVX_SERVICE_STREAMS: streams per device the service handles of a process share (0 = one of its own per handle) */
+	if (const char *e2 = getenv("CVX_SERVICE_STREAMS")) shared = atoi(e2) > 0 ? std::min(atoi(e2), kServiceStreamsMax) : 0;
+	if (c->service && shared > 0) {
+		/* ngmlr holds 32 service handles beside the aligner's ten streams, and the runtime spreads a process's streams over
+		 * sixteen hardware queues: two fill classes that land on one queue run one after the other (a launch's fill was the SUM
+		 * of its classes again with -t 32, profiles/r06_e2e_launch_trace.txt), a 0.3 ms scoring kernel waits behind a 10 ms fill.
+		 * The service handles therefore take turns on a few shared streams -- their calls are short, every call waits on its own
+		 * event -- and the process stays below sixteen streams: one hardware queue each. */
+		std::lock_guard<std::mutex> lk(g_service_mtx);
+		ServiceStreams &ss = g_service_streams[device_id % kMaxServiceDevices];
+		const int k = ss.next++ % shared;
+		if (ss.st[k] == nullptr) e = hipStreamCreateWithFlags(&ss.st[k], hipStreamNonBlocking);
+		c->s_main = ss.st[k];
+		c->owns_main = false;
+	} else if (c->service && sp && atoi(sp) != 0) {      /* (measured: 20 000 reads map in 3.07 s with it against 2.33 s without, search calls 7.0 against 3.4 ms -- off unless asked for) */
+		int prio_lo = 0, prio_hi = 0;
+		(void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     /* numerically lower = higher priority */
+		e = hipStreamCreateWithPriority(&c->s_main, hipStreamNonBlocking, prio_hi);
+	} else {
+		e = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
+	}
 	if (e != hipSuccess) {
 		set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
 		cvx_destroy(c);
@@ -1317,7 +1439,8 @@ void cvx_destroy(cvx_handle h) {
 	if (!h) return;
 	(void) hipSetDevice(h->device);
 	(void) hipDeviceSynchronize();
-	if (h->s_main) (void) hipStreamDestroy(h->s_main);
+	g_deferred.drain();
+	if (h->s_main && h->owns_main) (void) hipStreamDestroy(h->s_main);      /* (a service handle's stream belongs to the process) */
 	if (h->s_post) (void) hipStreamDestroy(h->s_post);
 	if (h->s_text) (void) hipStreamDestroy(h->s_text);
 	if (h->s_io) (void) hipStreamDestroy(h->s_io);
@@ -1456,16 +1579,29 @@ static int submit_common(cvx_handle h, int32_t n, const cvx_tile *tiles, const c
 	HIP_TRY(hipSetDevice(h->device));
 	/* first hand the device whatever is ready to run, then spend host time on packing (a job that fails there keeps
 	 * its own error; this call reports only what happens to the batch being submitted) */
+	static const bool trace = getenv("CVX_SUBMIT_TRACE") != nullptr;      /* where a slow cvx_submit spends its time (stderr, calls over 5 ms) */
+	const auto t0 = std::chrono::steady_clock::now();
+	if (h->live.empty() && !g_deferred.empty()) g_deferred.drain();      /* nothing of this handle is in flight: outgrown blocks go back now */
 	(void) pump(h, false, nullptr);
+	const auto t1 = std::chrono::steady_clock::now();
 	cvx_batch_s *b = acquire_batch(h);
 	if (!b) return CVX_ERR_OOM;
+	b->bind(h->marks);
+	const auto t2 = std::chrono::steady_clock::now();
 	int rc = stage_upload(h, b, n, tiles, genome, ref_position);
+	const auto t3 = std::chrono::steady_clock::now();
 	if (rc == CVX_OK) rc = stage_plan(h, b, h->s_io);
 	if (rc != CVX_OK) { discard_batch(h, b); return rc; }
 	b->in_flight = true;
 	h->pending.push_back(b);
 	h->live.push_back(b);
+	const auto t4 = std::chrono::steady_clock::now();
 	(void) pump(h, false, nullptr);
+	if (trace) {
+		const auto t5 = std::chrono::steady_clock::now();
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+		if (ms(t0, t5) > 5.0) fprintf(stderr, "cvx_submit: %d tiles in %.2f ms: pump %.2f, batch slot %.2f, upload stage %.2f, plan stage %.2f, pump %.2f\n", n, ms(t0, t5), ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5));
+	}
 	*out = b;
 	return CVX_OK;
 	ABI_GUARD_END

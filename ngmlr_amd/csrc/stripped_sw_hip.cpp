@@ -35,7 +35,7 @@ StrippedSWHip::StrippedSWHip(int const deviceId) : device(deviceId >= 0 && devic
 	if (g_handle[device][lane] == 0) {
 		/* the scoring kernel has fixed weights; the handle only needs a valid scoring triple */
 		cvx_params p = { 2.0f, -5.0f, -5.0f, -5.0f, -1.0f, 0.15f };
-		if (cvx_create(device, &p, 0, &g_handle[device][lane]) != CVX_OK) {
+		if (cvx_create_ex(device, &p, 0, CVX_CREATE_SERVICE, &g_handle[device][lane]) != CVX_OK) {
 			fprintf(stderr, "StrippedSWHip: %s\n", cvx_last_error());
 			g_handle[device][lane] = 0;
 			throw "StrippedSWHip: no usable MI355X";

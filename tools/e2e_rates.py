@@ -190,7 +190,7 @@ def _lock_numbers(line_):
             "what": "_NGM::GetNextReadBatch: reads are parsed and split into sub-reads by one thread at a time; a lower bound of the mapping wall clock that is not the device path's"}
 
 
-def pipeline_summary(n_reads=20000, t_ref=32, spec=(32, 4096, 2048, 10000), extra_env=None):
+def pipeline_summary(n_reads=20000, t_ref=32, spec=(20, 4096, 2048, 10000), extra_env=None):
     """What bench.py puts beside its line as `e2e_pipeline`: the reference's own ngmlr, unmodified (ngmlr_ref, CPU) against the
     build with every drop-in bound (ngmlr_hip_all: alignment, sub-read scoring, candidate search, SAM records on the device
     path, alignment contexts off the CS threads), same synthetic reads, SAM compared record by record.  -> dict (or a dict
@@ -203,7 +203,9 @@ def pipeline_summary(n_reads=20000, t_ref=32, spec=(32, 4096, 2048, 10000), extr
     fa, fq = os.path.join(tmp, "ps_ref.fa"), os.path.join(tmp, "ps_reads.fq")
     bases = write_plain_workload(fa, fq, n_reads, rng, L)
     t, ctx, target, hold = spec
-    env = {"CVX_POOL_CONTEXTS": str(ctx), "CVX_BATCH_TARGET": str(target), "CVX_BATCH_HOLD_US": str(hold)}
+    # CVX_CS_BATCH: reads per CS batch = per device search / scoring call (the reference's cBatchSize is 10); 20 CS threads + the pool's
+    # carriers (half of the container's CPU quota) stay below a 16-core quota -- more threads get the whole process throttled
+    env = {"CVX_POOL_CONTEXTS": str(ctx), "CVX_BATCH_TARGET": str(target), "CVX_BATCH_HOLD_US": str(hold), "CVX_CS_BATCH": "20"}
     env.update(extra_env or {})
     r0 = run("ngmlr_ref", t_ref, fa, fq)
     r1 = run("ngmlr_hip_all", t, fa, fq, env)
@@ -225,7 +227,7 @@ def pipeline_summary(n_reads=20000, t_ref=32, spec=(32, 4096, 2048, 10000), extr
            "sam_identical": bool(r0["rc"] == 0 and r1["rc"] == 0 and r0["recs"] == r1["recs"]),
            "wall_ratio": r1["wall"] / max(r0["wall"], 1e-9),
            "map_ratio": (r1["map_s"] / r0["map_s"]) if (r0["map_s"] and r1["map_s"]) else None,
-           "settings": "ngmlr_hip_all -t %d, %d alignment contexts, batch target %d tiles / %d us; ngmlr_ref -t %d" % (t, ctx, target, hold, t_ref),
+           "settings": "ngmlr_hip_all -t %d, %d alignment contexts, batch target %d tiles / %d us, %s reads per CS batch; ngmlr_ref -t %d" % (t, ctx, target, hold, env["CVX_CS_BATCH"], t_ref),
            "what": "the reference's ngmlr binary built from /root/reference with the drop-ins (tools/build_ngmlr_hip.sh) against the unmodified build, "
                    "-x pacbio, synthetic 10 kb reads on a 2 Mbp random reference; wall includes ngmlr's index construction, map = wall - index time; "
                    "CPU seconds sampled from /proc/<pid>/task by thread name; peak RSS = VmHWM"}
@@ -271,7 +273,7 @@ def run(name, t, ref, fq, extra_env=None):
                     ticks[tid] = (comm, int(f[11]) + int(f[12]))
             except OSError:
                 pass
-            time.sleep(0.1)
+            time.sleep(0.02)
     dt = time.perf_counter() - t0
     cg1 = cgroup_cpu_stat()
 
@@ -326,8 +328,8 @@ def line(name, t, r, same):
         print("    corridors sent as closed forms: %d of %d" % r["closed_forms"], flush=True)
     if os.environ.get("E2E_VERBOSE"):
         for l in r["full_err"].splitlines():
-            if "library loaded" in l or "time" in l.lower() or "Done" in l or l.startswith("cvx_search_batch:") or l.startswith("cvx timeline") or l.startswith("cvx launch"):
-                print("      | " + l[:200], flush=True)
+            if "library loaded" in l or "time" in l.lower() or "Done" in l or l.startswith("cvx_search_batch:") or l.startswith("cvx timeline") or l.startswith("cvx launch") or l.startswith("cvx dispatcher") or l.startswith("cvx_submit:"):
+                print("      | " + l[:460], flush=True)
 
 
 def cgroup_cpu_stat():
