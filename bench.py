@@ -288,7 +288,7 @@ def other_config(al, tiles, what, parity_n, parity_max_cells=3.0e8):
             tm = batch.run()
             if best is None or tm.total_ms < best.total_ms:
                 best = tm
-        classes = [{"M": li["slots_per_lane"], "tasks_or_waves": li["waves"], "int16_runs": li["wrap16"], "tiles": li["n_tiles"],
+        classes = [{"M": li["slots_per_lane"], "tasks_or_waves": li["waves"], "kind": ("whole", "gang", "chained", "catch-all")[li.get("kind", 0) & 3], "int16_runs": li["wrap16"], "tiles": li["n_tiles"],
                     "ms": li["ms"], "G_cells_per_s": li["cells"] / max(li["ms"], 1e-6) * 1e-6} for li in batch.launches()]
         res, ops = batch.download()
         n_valid = sum(1 for i in range(len(tiles)) if res[i].status == 0)
@@ -1069,7 +1069,9 @@ def main() -> int:
                 "launch_tiles": meta["n_tiles"],
                 "alg_bytes_per_launch": meta["alg_bytes"],
                 "gcups": meta["cells"] / (dms * 1e-3) / 1e9,
-                "all_fill_launches": {"M%d_NW%d_wrap%d" % k_: {"ms": float(np.mean(v)), "tiles": launch_meta[k_]["n_tiles"]} for k_, v in launch_ms.items()},
+                "all_fill_launches": {"M%d_NW%d_wrap%d" % k_: {"ms": float(np.mean(v)), "tiles": launch_meta[k_]["n_tiles"],
+                                                             "kind": ("whole tiles", "gang of waves per tile", "chained row blocks", "catch-all kernel")[launch_meta[k_].get("kind", 0) & 3]}
+                                      for k_, v in launch_ms.items()},
             },
             # every device of the run: its own dominant fill launch against the roofline and its own timed wall, so that a scaling run
             # explains itself (one straggling device shows as skew, a slower launch on every device as a lower `frac`)

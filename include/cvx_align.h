@@ -190,6 +190,7 @@ typedef struct {
 	uint64_t chain_task_ticks, chain_poll_ticks;
 } cvx_timing;
 
+enum { CVX_LAUNCH_WHOLE = 0, CVX_LAUNCH_GANG = 1, CVX_LAUNCH_CHAINED = 2, CVX_LAUNCH_CATCH_ALL = 3 };
 /* One forward-fill launch of the last cvx_batch_run (HIP-event timed on the stream). */
 typedef struct {
 	int32_t slots_per_lane;  /* M */
@@ -197,6 +198,8 @@ typedef struct {
 	int32_t wrap16;          /* int16 gap-run wrap emulation compiled in */
 	int32_t n_tiles;
 	float ms;                /* kernel duration */
+	int32_t kind;            /* ABI 7 (in what was padding): CVX_LAUNCH_WHOLE one wave per tile, CVX_LAUNCH_GANG `waves` waves on one ring per
+	                          * tile, CVX_LAUNCH_CHAINED `waves` row-block tasks in the launch, CVX_LAUNCH_CATCH_ALL the catch-all kernel */
 	uint64_t cells;          /* sum of row_length over the launch's tiles */
 	uint64_t active_cells;   /* cells inside [0,W) */
 	uint64_t alg_bytes;      /* algorithmic bytes: sum over tiles of C + 6H + 2W */
@@ -227,6 +230,23 @@ int cvx_create(int device_id, const cvx_params *params, uint64_t max_matrix_mb, 
  * kernel does not queue behind a 10 ms fill of an aligning handle in the same process.  MEASURED AND OFF: inside ngmlr the run got
  * slower with it (profiles/r06_e2e_service_prio.txt); the flag is recorded in the handle, the priority applies only with CVX_SERVICE_PRIO=1. */
 enum { CVX_CREATE_SERVICE = 1 };
+/* ABI 7: which of the process-wide settings above this process really got (a host that initialised HIP before
+ * the library was loaded gets neither, and its mixed launches run their fill classes one after the other).
+ *   hw_queues_env             GPU_MAX_HW_QUEUES as the process's environment has it now (0: unset)
+ *   hw_queues_set_by_library  1: the library exported it when it was loaded; 0: the user's value was left alone.  (The runtime
+ *                             reads the variable at ITS first call: a value exported after that -- HIP initialised before this
+ *                             library was loaded -- has no effect, which no runtime call can report: compare launch traces.)
+ *   blocking_sync             1: hipDeviceScheduleBlockingSync applied to the device by the first cvx_create; 0: not in effect
+ *                             (blocking_sync_why: 2 the runtime refused -- a context was already active --, 3 CVX_WAIT=spin);
+ *                             -1: no handle has been created on the device yet
+ *   service_streams           streams the CVX_CREATE_SERVICE handles of the process share per device (0: one each) */
+typedef struct {
+	int32_t hw_queues_env, hw_queues_set_by_library;
+	int32_t blocking_sync, blocking_sync_why;
+	int32_t service_streams;
+	int32_t reserved[3];
+} cvx_regime;
+int cvx_runtime_regime(int device_id, cvx_regime *out);
 int cvx_create_ex(int device_id, const cvx_params *params, uint64_t max_matrix_mb, uint32_t flags, cvx_handle *out);
 void cvx_destroy(cvx_handle h);
 

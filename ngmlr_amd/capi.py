@@ -29,7 +29,7 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id", "cvx_job_poll", "cvx_score_kernel_ms",
            "cvx_index_upload", "cvx_index_free", "cvx_search_batch", "cvx_search_batch_ex", "cvx_job_nm_profile", "cvx_job_nm_sizes", "cvx_nm_profile_ops",
            "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch", "cvx_stage_kernel_ms", "cvx_search_last_attempts", "cvx_index_build",
-           "cvx_corridor_fit", "cvx_corridor_fit_batch", "cvx_create_ex")
+           "cvx_corridor_fit", "cvx_corridor_fit_batch", "cvx_create_ex", "cvx_runtime_regime")
 
 
 class CvxParams(C.Structure):
@@ -43,6 +43,11 @@ class CvxTile(C.Structure):
                 ("row_stride_bytes", C.c_int32), ("corridor_kind", C.c_int32),
                 ("corridor_k", C.c_float), ("corridor_d", C.c_float), ("corridor_right", C.c_float),
                 ("corridor_offset", C.c_int32), ("corridor_width", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CvxRegime(C.Structure):
+    _fields_ = [("hw_queues_env", C.c_int32), ("hw_queues_set_by_library", C.c_int32), ("blocking_sync", C.c_int32),
+                ("blocking_sync_why", C.c_int32), ("service_streams", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 CORRIDOR_ROWS, CORRIDOR_AFFINE, CORRIDOR_CONST = 0, 1, 2
@@ -66,7 +71,7 @@ class CvxTiming(C.Structure):
 
 class CvxLaunchInfo(C.Structure):
     _fields_ = [("slots_per_lane", C.c_int32), ("waves", C.c_int32), ("wrap16", C.c_int32),
-                ("n_tiles", C.c_int32), ("ms", C.c_float), ("cells", C.c_uint64),
+                ("n_tiles", C.c_int32), ("ms", C.c_float), ("kind", C.c_int32), ("cells", C.c_uint64),
                 ("active_cells", C.c_uint64), ("alg_bytes", C.c_uint64), ("read_bases", C.c_uint64)]
 
 
@@ -190,6 +195,8 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_search_last_attempts.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.cvx_index_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.cvx_runtime_regime.argtypes = [C.c_int, C.POINTER(CvxRegime)]
+    lib.cvx_create_ex.argtypes = [C.c_int, C.POINTER(CvxParams), C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p)]
     lib.cvx_corridor_fit_batch.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     lib.cvx_corridor_fit.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CvxTile)]
     lib.cvx_score_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p]

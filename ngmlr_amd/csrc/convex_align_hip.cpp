@@ -171,7 +171,7 @@ void ConvexAlignHip::Trace(cvx_job job, int nTiles, double serviceMs, double wai
 	for (int i = 0; i < t.n_fill_launches && at < 200; ++i) {
 		cvx_launch_info li;
 		if (cvx_job_launch_info(job, i, &li) != CVX_OK) break;
-		at += snprintf(cls + at, sizeof(cls) - (size_t) at, " M%d%s x%d %.2f ms", li.slots_per_lane, li.waves > 1 ? "c" : "", li.n_tiles, li.ms);
+		at += snprintf(cls + at, sizeof(cls) - (size_t) at, " M%d%s x%d %.2f ms", li.slots_per_lane, li.kind == CVX_LAUNCH_CHAINED ? "c" : (li.kind == CVX_LAUNCH_GANG ? "g" : (li.kind == CVX_LAUNCH_CATCH_ALL ? "x" : "")), li.n_tiles, li.ms);
 	}
 	fprintf(stderr, "cvx launch: %d tiles, %.1f M cells, oldest request waited %.1f ms, in flight %.1f ms: plan %.2f fill %.2f walk %.2f device total %.2f ms;%s%s\n",
 			nTiles, (double) t.cells * 1e-6, waitedMs, serviceMs, t.plan_ms, t.fill_ms, t.backtrack_ms, t.total_ms, cls, t.n_tiles_redone ? " (redo)" : "");

@@ -25,6 +25,15 @@ static inline int cvxHostVoteTableLen(IRefProvider const * rp, int referenceLen)
 	return cvxSearchableUnit(rp) != 0 ? 1 : referenceLen;
 }
 
+/* The smallest size DoRun's per-batch adaptation (src/CS.cpp:482-489) may take the thread's vote table down to.  The reference
+ * goes down to 2^8 while few first attempts overflow; with the device search bound the first attempt never runs below 2^16
+ * (cs_search_binding.inc), so the thread's own value stops there as well: the overflows it counts and the size they were
+ * counted at then agree, and the upward adaptation does not have to climb from 8 to 16 on overflows measured at 2^16 before
+ * the binding follows it. */
+static inline int cvxMinTableBits(IRefProvider const * rp, int referenceValue) {
+	return cvxSearchableUnit(rp) != 0 ? 16 : referenceValue;
+}
+
 /* reads per CS batch (src/CS.cpp:34: 10, "reduced batch size for low read number PacBio samples") -- with the vote on the device
  * it is also the size of a search call.  The reference's value unless CVX_CS_BATCH is set (measurements: a call of 100 reads
  * amortises the host round trips of the ladder ten times over; DoRun's per-batch adaptation thresholds scale with it) */

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -92,7 +93,7 @@ int cvx_genome_encode(int32_t n, const char *const *seqs, const uint64_t *length
  */
 int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table, const uint64_t *seq_lengths, int32_t n_seqs,
 		int32_t kmer_len, int32_t ref_skip, int32_t bin_shift, void *ref_table_index, uint32_t *ref_table, uint64_t ref_table_capacity,
-		uint64_t *n_locations) {
+		uint64_t *n_locations) try {
 	if (!bin_ref || !start_table || !seq_lengths || n_seqs <= 0 || kmer_len < 4 || kmer_len > 15 || ref_skip < 0 || bin_shift < 0 || bin_shift > 30 ||
 			!ref_table_index || !n_locations) return CVX_ERR_ARG;
 	const uint64_t n_prefix = 1ull << (2 * kmer_len);
@@ -114,9 +115,10 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 	if (n_threads > 16) n_threads = 16;
 	if (const char *e = getenv("CVX_INDEX_THREADS")) n_threads = atoi(e);
 	if (n_threads < 1) n_threads = 1;
+	if (n_threads > 64) n_threads = 64;                   /* (an unbounded value spawned that many threads per pass: ADVICE r5) */
 	const int n_range_threads = n_threads;                /* the passes over the 4^k records do not care how many sequences there are */
 	if (n_threads > n_seqs) n_threads = n_seqs;
-	bool oom = false;
+	std::atomic<bool> oom(false);                         /* written by the workers */
 
 	/* DecodeRefSequence(buf, id, start, len): len - 2 characters, the rest NUL */
 	auto decode = [&](int32_t s, std::vector<char> &buf) {
@@ -190,15 +192,21 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 			}
 		};
 		std::vector<std::thread> ths;
-		for (int t = 1; t < n_threads; ++t) ths.emplace_back(work);
+		/* (a thread that cannot be created is work the others pick up: the sequences come off a shared counter) */
+		for (int t = 1; t < n_threads; ++t) { try { ths.emplace_back(work); } catch (const std::system_error &) { break; } }
 		work();
 		for (std::thread &t : ths) t.join();
 	};
 	auto parallel_ranges = [&](uint64_t n, auto &&fn) {      /* fn(begin, end, piece) over [0, n) in n_range_threads pieces */
 		std::vector<std::thread> ths;
 		const uint64_t per = (n + (uint64_t) n_range_threads - 1) / (uint64_t) n_range_threads;
-		for (int t = 1; t < n_range_threads; ++t) ths.emplace_back([&, t] { fn(std::min(n, per * (uint64_t) t), std::min(n, per * (uint64_t) (t + 1)), t); });
+		int started = 1;
+		for (int t = 1; t < n_range_threads; ++t) {
+			try { ths.emplace_back([&, t] { fn(std::min(n, per * (uint64_t) t), std::min(n, per * (uint64_t) (t + 1)), t); }); started = t + 1; }
+			catch (const std::system_error &) { break; }
+		}
 		fn(0, std::min(n, per), 0);
+		for (int t = started; t < n_range_threads; ++t) fn(std::min(n, per * (uint64_t) t), std::min(n, per * (uint64_t) (t + 1)), t);      /* pieces whose thread could not be created */
 		for (std::thread &t : ths) t.join();
 	};
 
@@ -301,6 +309,10 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
 	}
 	lap("fill");
 	return CVX_OK;
+} catch (const std::bad_alloc &) {      /* nothing leaves an extern "C" function as an exception (a worker's own failures are flagged, see oom) */
+	return CVX_ERR_OOM;
+} catch (...) {
+	return CVX_ERR_OOM;
 }
 
 }  /* extern "C" */

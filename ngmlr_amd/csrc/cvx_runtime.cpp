@@ -402,6 +402,7 @@ struct cvx_context {
 	hipStream_t aux[kAuxStreams] = {nullptr};  /* concurrent fill classes */
 	bool service = false;                      /* cvx_create_ex(CVX_CREATE_SERVICE): short search / scoring / decode calls only */
 	bool owns_main = true;                     /* false: s_main is one of the process's shared service streams */
+	std::mutex streams_mtx;                    /* ensure_streams */
 	/* a second set (main, post, aux) for small streaming jobs (experiment, off by default: see single_lane): the jobs of a
 	 * batching driver (tens of tiles each) are latency-bound chains of small kernels on an otherwise empty device;
 	 * consecutive ones can alternate between the two sets */
@@ -532,14 +533,21 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
 /* the streams of an aligning handle beside `main` (cvx_create makes only that one) */
 int ensure_streams(cvx_context *c) {
 	if (c->s_io) return CVX_OK;
+	/* (a handle is not re-entrant, but two threads making a handle's first alignment-side calls at once -- stage_upload and
+	 * cvx_nm_profile_ops both come here -- must not create the set twice; and a creation that fails half-way leaves what exists in
+	 * place: the next call creates only what is missing -- ADVICE r5) */
+	std::lock_guard<std::mutex> lk(c->streams_mtx);
+	if (c->s_io) return CVX_OK;
 	int prio_lo = 0, prio_hi = 0;
 	(void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     /* numerically lower = higher priority */
-	hipError_t e = hipStreamCreateWithFlags(&c->s_post, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_text, hipStreamNonBlocking);
-	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_main2, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_post2, hipStreamNonBlocking);
-	for (int i = 0; i < kAuxStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->aux2[i], hipStreamNonBlocking);
+	hipError_t e = hipSuccess;
+	auto make = [&](hipStream_t *st) { if (e == hipSuccess && *st == nullptr) e = hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+	make(&c->s_post);
+	make(&c->s_text);
+	for (int i = 0; i < kAuxStreams; ++i) make(&c->aux[i]);
+	make(&c->s_main2);
+	make(&c->s_post2);
+	for (int i = 0; i < kAuxStreams; ++i) make(&c->aux2[i]);
 	if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->s_io, hipStreamNonBlocking, prio_hi);      /* last: its existence says "all of them" */
 	if (e != hipSuccess) { set_err("hipStreamCreate failed: %s", hipGetErrorString(e)); return CVX_ERR_HIP; }
 	return CVX_OK;
@@ -939,10 +947,10 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		a.sp = h->sp;
 		return a;
 	};
-	auto launch_stats = [&](const std::vector<int32_t> &v, int m, int nw, int wrap) {
+	auto launch_stats = [&](const std::vector<int32_t> &v, int m, int nw, int wrap, int kind) {
 		cvx_launch_info li;
 		memset(&li, 0, sizeof(li));
-		li.slots_per_lane = m; li.waves = nw; li.wrap16 = wrap; li.n_tiles = (int) v.size();
+		li.slots_per_lane = m; li.waves = nw; li.wrap16 = wrap; li.n_tiles = (int) v.size(); li.kind = kind;
 		for (int32_t ti : v) {
 			const TilePlan &p = b->plan()[(size_t) ti];
 			const TileIn &in = b->tin()[(size_t) ti];
@@ -1050,7 +1058,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	for (size_t c = 0; c < hp.chain_tasks.size(); ++c) {
 		if (hp.chain_tasks[c].empty()) continue;
 		const int m = kChainClasses[c / 2];
-		launch_stats(hp.chain_tiles[c], m, (int) hp.chain_tasks[c].size(), (int) (c & 1));     /* `waves` = row-block tasks */
+		launch_stats(hp.chain_tiles[c], m, (int) hp.chain_tasks[c].size(), (int) (c & 1), CVX_LAUNCH_CHAINED);     /* `waves` = row-block tasks */
 		hipStream_t ls = fill_streams[launches % n_fill_streams];
 		RC_TRY(begin_launch(ls));
 		FillArgs a = fill_args(nullptr, (int) hp.chain_tasks[c].size());
@@ -1097,7 +1105,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		const KernelClass &kc = kClasses[c / 2];
 		const int wide_prio = (h->tune_wide_prio && widest && ring_classes > 1) ? h->tune_wide_prio : 0;
 		widest = false;
-		launch_stats(cls[c], kc.m, kc.gang, (int) (c & 1));      /* `waves` = waves per tile (a gang's size) */
+		launch_stats(cls[c], kc.m, kc.gang, (int) (c & 1), kc.gang > 1 ? CVX_LAUNCH_GANG : CVX_LAUNCH_WHOLE);      /* `waves` = waves per tile (a gang's size) */
 		hipStream_t ls = fill_streams[launches % n_fill_streams];
 		RC_TRY(begin_launch(ls));
 		if (n_direct[c] > 0) {
@@ -1116,7 +1124,7 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 		RC_TRY(end_launch(ls));
 	}
 	if (!generic.empty()) {
-		launch_stats(generic, 0, 16, 1);
+		launch_stats(generic, 0, 16, 1, CVX_LAUNCH_CATCH_ALL);
 		hipStream_t ls = fill_streams[launches % n_fill_streams];
 		RC_TRY(begin_launch(ls));
 		const FillArgs a = fill_args(b->d_lists.p + generic_begin, (int) generic.size());
@@ -1261,7 +1269,10 @@ void pack_pool_run(int n_tasks, const std::function<void(int)> &fn) { PackPool::
  * (profiles/r05_e2e_hw_queues.txt).  The bench configurations do not care (8 against 16: C5 6 834 - 6 887 both, ONT 8 550 - 8 970
  * both); thirty-two oversubscribe the hardware (launches 53 ms in flight).  Not overridden when the user has set
  * GPU_MAX_HW_QUEUES. */
+static int g_hwq_set_by_library = 0;            /* 1: the constructor exported GPU_MAX_HW_QUEUES itself (the user had not) */
+static std::atomic<int> g_blocking_sync[64];    /* per device: 0 not decided, 1 applied, 2 refused by the runtime, 3 CVX_WAIT=spin */
 __attribute__((constructor)) static void cvx_process_settings() {
+	g_hwq_set_by_library = getenv("GPU_MAX_HW_QUEUES") == nullptr;
 	setenv("GPU_MAX_HW_QUEUES", "16", 0);
 }
 
@@ -1290,6 +1301,21 @@ int cvx_device_synchronize(int device_id) {
 
 int cvx_create(int device_id, const cvx_params *p, uint64_t max_matrix_mb, cvx_handle *out) {
 	return cvx_create_ex(device_id, p, max_matrix_mb, 0u, out);
+}
+
+int cvx_runtime_regime(int device_id, cvx_regime *out) {
+	if (!out || device_id < 0) { set_err("cvx_runtime_regime: bad argument"); return CVX_ERR_ARG; }
+	memset(out, 0, sizeof(*out));
+	const char *q = getenv("GPU_MAX_HW_QUEUES");
+	out->hw_queues_env = q ? atoi(q) : 0;
+	out->hw_queues_set_by_library = g_hwq_set_by_library;
+	const int b = g_blocking_sync[device_id & 63].load();
+	out->blocking_sync = b == 1 ? 1 : (b == 0 ? -1 : 0);
+	out->blocking_sync_why = b;
+	int shared = 4;
+	if (const char *e2 = getenv("CVX_SERVICE_STREAMS")) shared = atoi(e2) > 0 ? std::min(atoi(e2), kServiceStreamsMax) : 0;
+	out->service_streams = shared;
+	return CVX_OK;
 }
 
 int cvx_create_ex(int device_id, const cvx_params *p, uint64_t max_matrix_mb, uint32_t flags, cvx_handle *out) {
@@ -1338,8 +1364,9 @@ int cvx_create_ex(int device_id, const cvx_params *p, uint64_t max_matrix_mb, ui
 		static std::once_flag once[64];
 		std::call_once(once[device_id & 63], [&] {
 			const char *w = getenv("CVX_WAIT");
-			if (w && strcmp(w, "spin") == 0) return;
+			if (w && strcmp(w, "spin") == 0) { g_blocking_sync[device_id & 63] = 3; return; }
 			const hipError_t fe = hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+			g_blocking_sync[device_id & 63] = fe == hipSuccess ? 1 : 2;
 			if (fe != hipSuccess) {
 				(void) hipGetLastError();
 				fprintf(stderr, "cvx_create: device %d stays in its current scheduling mode (%s): host threads that wait for it will spin\n", device_id, hipGetErrorString(fe));

@@ -86,6 +86,11 @@ class Oracle:
         self.lib.oracle_port_last_fwd(a)
         return dict(best_x=a[0], best_y=a[1], ref_position=a[2], qstart=a[3], qend=a[4])
 
+    def last_fill_score_bits(self) -> int:
+        """bits of the forward fill's curr_max of the last align() (port only) -- also for tiles validPath rejects"""
+        self.lib.oracle_port_last_fill_score.restype = C.c_float
+        return int(np.float32(self.lib.oracle_port_last_fill_score()).view(np.uint32))
+
     def last_ops(self) -> np.ndarray:
         n = self.lib.oracle_port_last_ops(None, 0)
         a = np.zeros(max(n, 1), dtype=np.int32)

@@ -98,3 +98,14 @@ def test_bench_fails_loudly_when_devices_are_missing(built):
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert res.returncode == 2
     assert "needs 2 visible MI355X device(s)" in res.stderr and res.stdout.strip() == ""
+
+
+def test_runtime_regime_without_a_device(built):
+    """cvx_runtime_regime answers without a device: what the library did to the process's environment when it was loaded."""
+    from ngmlr_amd import capi
+    lib = capi.load()
+    r = capi.CvxRegime()
+    assert lib.cvx_runtime_regime(0, C.byref(r)) == 0
+    assert r.hw_queues_env >= 1 and r.blocking_sync == -1 and r.service_streams == 4
+    assert r.hw_queues_set_by_library == (0 if os.environ.get("CVX_TEST_HWQ_PRESET") else 1) or r.hw_queues_env != 16
+    assert lib.cvx_runtime_regime(0, None) != 0

@@ -20,10 +20,17 @@ def _check(hip_aligner, port_oracle, tiles, need_valid=True):
     for t, g in zip(tiles, got):
         want = port_oracle.align(t)
         d = same_alignment(want, g)
-        if d is None and want["ret"] >= 0 and port_oracle.kind == "port":     # (the reference does not expose its best cell)
+        if d is None and port_oracle.kind == "port":     # (the reference does not expose its best cell)
+            # the RAW fill result of EVERY tile, valid or not (a wrong fill score on tiles validPath rejects went
+            # unnoticed for three rounds because only alignments were compared).  A tile without any positive score keeps the
+            # reference's start value -1 and takes its first cell in the backtrack: nothing to compare there.
             f = port_oracle.last_fwd()
-            if (f["best_x"], f["best_y"]) != (g["best_x"], g["best_y"]):
-                d = "argmax cell"
+            fs = port_oracle.last_fill_score_bits()
+            if fs != 0xBF800000 and g["status"] not in (4, 5):      # (too large / empty: never filled)
+                if fs != g["fwd_score_bits"]:
+                    d = "raw fill score %08x vs %08x" % (g["fwd_score_bits"], fs)
+                elif (f["best_x"], f["best_y"]) != (g["best_x"], g["best_y"]):
+                    d = "argmax cell"
         assert g["status"] != -1, "tile %s fell outside every device kernel" % t.tag
         n_valid += want["ret"] >= 0
         if d:

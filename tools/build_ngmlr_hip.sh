@@ -73,6 +73,8 @@ if SEARCH:
     s = sub1(s, 'void CS::Cleanup() {', 'void CS::Cleanup() {\n\tConvex::CandidateSearchHip::Shutdown();', 'CS::Cleanup')
     # reads per CS batch = reads per device search / scoring call: the reference's 10 unless CVX_CS_BATCH says otherwise (a measurement knob)
     s = sub1(s, 'int const cBatchSize = 10;', 'int const cBatchSize = cvxCsBatchSize(10);', 'cBatchSize')
+    # DoRun's downward adaptation of the vote-table size stops where the device's first attempt does (cs_search_binding.h)
+    s = sub1(s, 'if (m_Overflows <= 5 && !up && c_SrchTableBitLen > 8) {', 'if (m_Overflows <= 5 && !up && c_SrchTableBitLen > cvxMinTableBits(m_RefProvider, 8)) {', 'DoRun adaptation floor')
     open(p, 'w').write(s)
 if POOL:
     # reads in flight decoupled from the CS threads (ngmlr_amd/csrc/align_pool.h)

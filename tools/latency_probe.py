@@ -23,5 +23,5 @@ for n in ns:
         job.release()
     print("n=%4d  submit+wait wall %7.2f ms (best %7.2f)   device: plan %.2f fill %.2f bt %.2f total %.2f ms   classes %s" % (
         n, 1e3 * float(np.median(walls)), 1e3 * min(walls), tm.plan_ms, tm.fill_ms, tm.backtrack_ms, tm.total_ms,
-        ["M%d x%d %s %.2fms" % (l["slots_per_lane"], l["n_tiles"], "chain" if l["waves"] > 1 else "ring", l["ms"]) for l in li]), flush=True)
+        ["M%d x%d %s %.2fms" % (l["slots_per_lane"], l["n_tiles"], "chain" if l.get("kind") == 2 else "gang" if l.get("kind") == 1 else "ring", l["ms"]) for l in li]), flush=True)
 al.close()
