@@ -1,5 +1,6 @@
 /* batching_aligner.cpp -- see batching_aligner.h */
 #include "batching_aligner.h"
+#include "service_device.h"
 
 #include <algorithm>
 #include <chrono>
@@ -362,13 +363,12 @@ SharedAligner::SharedAligner(int const stdOutMode, float const match, float cons
 		float const gapExtend, float const gapExtendMin, float const gapDecay, int const deviceId) : shared(0), device(0), perRead(false) {
 	std::lock_guard<std::mutex> g(g_sharedMtx);
 	perRead = g_poolAccounting;
-	int nDev = cvx_device_count();
-	if (const char * e = getenv("CVX_DEVICES")) nDev = atoi(e) < nDev ? atoi(e) : nDev;      /* use only the first k devices */
+	/* CVX_DEVICES=k: only the first k devices.  CVX_ALIAS_DEVICES=k: deal the workers over k LOGICAL devices (own backend, own
+	 * dispatcher each) that all live on the physical devices present -- the multi-device path of this class on a one-GPU box
+	 * (tests; not a scaling measurement).  One rule for the whole pipeline: service_device.h */
+	int nDev = 0, nPhysical = 0;
+	DeviceLayout(nDev, nPhysical);
 	if (nDev > kMaxDevices) nDev = kMaxDevices;
-	/* CVX_ALIAS_DEVICES=k: deal the workers over k LOGICAL devices (own backend, own dispatcher each) that all live on the
-	 * physical devices present -- the multi-device path of this class on a one-GPU box (tests; not a scaling measurement) */
-	int const nPhysical = nDev;
-	if (const char * e = getenv("CVX_ALIAS_DEVICES")) { if (atoi(e) > 0 && nPhysical > 0) nDev = atoi(e) < kMaxDevices ? atoi(e) : kMaxDevices; }
 	/* deviceId >= 0 pins the worker; the default spreads them */
 	device = (deviceId >= 0 && nDev > 0) ? deviceId % nDev : (nDev > 0 ? (int) (g_joined % nDev) : 0);
 	if (g_joined == 0) g_firstJoin = std::chrono::steady_clock::now();

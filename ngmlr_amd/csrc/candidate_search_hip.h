@@ -11,8 +11,10 @@
  * the kCount rule for the mapping quality, AllocScores with the LocationScore list in the reference's order, SendToBuffer
  * (the binding is ngmlr_amd/csrc/cs_search_binding.inc, inserted by tools/build_ngmlr_hip.sh and shown in INTEGRATION.md).
  *
- * One instance per process: the table unit is uploaded once; searching threads are dealt round-robin over sixteen device
- * handles (own streams, own persistent staging), calls on different handles overlap, a call sleeps while the device works.
+ * One instance per process.  Per DEVICE (round 6, service_device.h: CS thread number k searches and scores on logical device
+ * k mod n, as SharedAligner deals the alignment contexts): the table unit is uploaded when a thread of that device first
+ * searches, and the device's threads are dealt round-robin over its sixteen handles (own persistent staging; the streams are
+ * the process's shared service streams), calls on different handles overlap, a call sleeps while the device works.
  * No CPU path: a device error throws (the CS thread ends, as it would on any other hard error).
  */
 #ifndef CANDIDATE_SEARCH_HIP_H
@@ -31,7 +33,7 @@ public:
 	 * TableUnit::RefTable, cRefTableLen, Offset: reference src/PrefixTable.h:15-75), created on first use.  Throws when the
 	 * device or its memory is not there: no silent host path. */
 	static CandidateSearchHip * Get(int kmerLength, void const * refTableIndex, uint32_t const * refTable, uint32_t nLocations,
-			uint64_t unitOffset, int deviceId = 0);
+			uint64_t unitOffset);
 	/* frees the handles and the table (end of the run) and prints the statistics line */
 	static void Shutdown();
 
@@ -50,9 +52,9 @@ public:
 	void Search(Batch & b, float sensitivity, float minKmerHits, int binShift, int firstTableBits = 16);
 
 private:
-	CandidateSearchHip() : index(0), device(0) { }
-	cvx_index index;
-	int device;
+	CandidateSearchHip() { }
+	/* what Get() was given: a device's copy of the table is uploaded on that device's first search */
+	int kmerLength; void const * refTableIndex; uint32_t const * refTable; uint32_t nLocations; uint64_t unitOffset;
 };
 
 }  // namespace Convex

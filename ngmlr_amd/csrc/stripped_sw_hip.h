@@ -20,7 +20,9 @@
 
 class StrippedSWHip: public IAlignment {
 public:
-	explicit StrippedSWHip(int const deviceId = 0);
+	/* deviceId < 0 (the default): the logical device of the constructing thread (service_device.h: CS thread k of the process
+	 * scores and searches on device k mod n) */
+	explicit StrippedSWHip(int const deviceId = -1);
 	virtual ~StrippedSWHip();
 
 	virtual int GetScoreBatchSize() const { return 1024; }   /* src/StrippedSW.h:53-55 */

@@ -144,6 +144,22 @@ def test_candidate_search_bound_in_the_pipeline(built, tmp_path):
     assert re.search(r"SharedAligner: 985 alignments", err), err[-1500:]
 
 
+def test_every_stage_on_two_logical_devices(built, tmp_path):
+    """with CVX_ALIAS_DEVICES=2 (two logical devices on the one GPU of a test box -- the N-device code path, not
+    a scaling measurement) the whole pipeline binary deals EVERY stage over the devices: alignment contexts (SharedAligner: two
+    backends, two dispatchers), and each CS thread's candidate search and sub-read scoring on its own logical device (the k-mer
+    table resident on both, service_device.h).  SAM identical on test_3; the statistics lines say what ran where."""
+    import re
+    got, err = _run(_test_3_args(tmp_path, 8), tmp_path, binary=BIN_ALL, env={"CVX_POOL_CONTEXTS": "256", "CVX_ALIAS_DEVICES": "2"})
+    assert sorted(got) == _test_3_want()
+    dev = re.findall(r"CandidateSearchHip: device (\d) \(physical 0\): (\d+) search calls, (\d+) reads", err)
+    assert sorted(d for d, _, _ in dev) == ["0", "1"], err[-2500:]
+    assert all(int(c) > 0 for _, c, _ in dev) and sum(int(r) for _, _, r in dev) >= 5663
+    sc = re.findall(r"StrippedSWHip: (\d+) scoring calls on device (\d) \(physical 0\)", err)
+    assert sorted(d for _, d in sc) == ["0", "1"] and all(int(c) > 0 for c, _ in sc), err[-2500:]
+    assert re.search(r"SharedAligner: 985 alignments", err), err[-1500:]
+
+
 @pytest.mark.parametrize("extra", [[], ["--subread-corridor", "80"]])
 def test_split_reads_with_structural_variants(built, tmp_path, extra):
     """BASELINE.json configs[4]'s shape end to end: ONT-like reads of 8-30 kb (20 % error) on a random reference, a third of them
