@@ -404,6 +404,15 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 		float sensitivity, float min_kmer_hits, int32_t bin_shift, int32_t first_bits,
 		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used,
 		float *max_hit, int32_t *kmer_misses);
+/* ABI 7: the same for reads that already lie back to back in one block: read i = arena[offsets[i] .. offsets[i + 1] - 1), with its
+ * terminating NUL at offsets[i + 1] - 1 (offsets has n + 1 entries).  No per-read pointer chasing on the host, one copy of the block
+ * -- and none at all when the block lies in memory from cvx_host_alloc: the device pulls it as it is (a caller that keeps its
+ * reads resident: 100 000 sub-reads per call at genome scale spent 4.6 x the kernels' time marshalling strings).
+ * Outputs as for cvx_search_batch_ex; `cands` in memory from cvx_host_alloc comes back without a staging copy. */
+int cvx_search_batch_arena(cvx_handle h, cvx_index ix, int32_t n, const uint8_t *arena, const uint64_t *offsets,
+		float sensitivity, float min_kmer_hits, int32_t bin_shift, int32_t first_bits,
+		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used,
+		float *max_hit, int32_t *kmer_misses);
 
 /* attempts[i] = vote-table sizes tried for read i in the handle's last cvx_search_batch(_ex) call (ABI 6): 1 = the first attempt
  * produced the list; more = the first attempt ran out of its probe budget -- the event CS::RunRead counts in m_Overflows

@@ -369,6 +369,51 @@ class KmerIndex:
         lists = [None if ncand[i] < 0 else cands[int(begin[i]):int(begin[i]) + int(ncand[i])].copy() for i in range(n)]
         return (lists, max_hit[:n], misses[:n]) if extras else lists
 
+    @staticmethod
+    def make_arena(reads: Sequence[bytes], lib=None):
+        """The reads back to back with a NUL behind each (cvx_search_batch_arena's input form) -> (arena uint8[], offsets uint64[n + 1],
+        pinned handle or None).  lib: put the block into page-locked memory from cvx_host_alloc (the device then pulls it as it is)."""
+        lens = np.fromiter((len(r) for r in reads), dtype=np.int64, count=len(reads))
+        offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+        np.cumsum(lens + 1, out=offsets[1:])
+        total = int(offsets[-1])
+        blob = b"\0".join(reads) + b"\0" if len(reads) else b""
+        pinned = None
+        if lib is not None and total:
+            p = C.c_void_p()
+            if lib.cvx_host_alloc(total + 64, C.byref(p)) == 0:
+                arena = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(total + 64,))
+                arena[:total] = np.frombuffer(blob, dtype=np.uint8)
+                arena[total:] = 0
+                pinned = (lib, p)
+                return arena, offsets, pinned
+        arena = np.frombuffer(blob + b"\0" * 64, dtype=np.uint8).copy()
+        return arena, offsets, pinned
+
+    def search_arena(self, arena: np.ndarray, offsets: np.ndarray, sensitivity: float = 0.8, min_kmer_hits: float = 0.0, bin_shift: int = 4,
+                     first_bits: int = 0, cands: Optional[np.ndarray] = None):
+        """cvx_search_batch_arena: reads that lie back to back -> flat outputs (n_cand int32[n], begin uint64[n], cands CANDIDATE_DTYPE[used],
+        max_hit float32[n], kmer_misses int32[n]); read i's list = cands[begin[i] : begin[i] + n_cand[i]] (n_cand < 0: the reference gives up)."""
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        max_hit = np.zeros(max(n, 1), dtype=np.float32)
+        misses = np.zeros(max(n, 1), dtype=np.int32)
+        ncand = np.zeros(max(n, 1), dtype=np.int32)
+        begin = np.zeros(max(n, 1), dtype=np.uint64)
+        used = C.c_uint64()
+        if cands is None:
+            cands = np.zeros(1 << 16, dtype=CANDIDATE_DTYPE)
+        while True:
+            rc = self.al.lib.cvx_search_batch_arena(self.al.h, self.ix, n, arena.ctypes.data, offsets.ctypes.data, sensitivity, min_kmer_hits, bin_shift, first_bits,
+                                                   ncand.ctypes.data, begin.ctypes.data, cands.ctypes.data, len(cands), C.byref(used),
+                                                   max_hit.ctypes.data, misses.ctypes.data)
+            if rc == -6 and used.value > len(cands):
+                cands = np.zeros(int(used.value) + int(used.value) // 8 + 64, dtype=CANDIDATE_DTYPE)
+                continue
+            capi.check(rc)
+            break
+        return ncand[:n], begin[:n], cands[:int(used.value)], max_hit[:n], misses[:n]
+
     def free(self) -> None:
         if self.ix:
             self.al.lib.cvx_index_free(self.al.h, self.ix)

@@ -29,7 +29,7 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id", "cvx_job_poll", "cvx_score_kernel_ms",
            "cvx_index_upload", "cvx_index_free", "cvx_search_batch", "cvx_search_batch_ex", "cvx_job_nm_profile", "cvx_job_nm_sizes", "cvx_nm_profile_ops",
            "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch", "cvx_stage_kernel_ms", "cvx_search_last_attempts", "cvx_index_build",
-           "cvx_corridor_fit", "cvx_corridor_fit_batch", "cvx_create_ex", "cvx_runtime_regime")
+           "cvx_corridor_fit", "cvx_corridor_fit_batch", "cvx_create_ex", "cvx_runtime_regime", "cvx_search_batch_arena")
 
 
 class CvxParams(C.Structure):
@@ -190,6 +190,8 @@ def load(path: str = None) -> C.CDLL:
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.cvx_search_batch_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]
+    lib.cvx_search_batch_arena.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]
     lib.cvx_score_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.cvx_stage_kernel_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
     lib.cvx_search_last_attempts.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]

@@ -33,9 +33,10 @@ struct SearchCandidate {         /* same layout as cvx_candidate (include/cvx_al
 	int32_t reverse;
 };
 struct SearchArgs {
-	/* the table: m_TabIndex per prefix (4^k + 2 entries), used flags, RefTable */
-	const uint32_t *tab;
-	const uint8_t *used;
+	/* the table: ONE 8-byte record per prefix (round 6) -- x = where its row starts in RefTable (m_TabIndex - 1), y = the row's length
+	 * with Index::used() in bit 31 -- instead of m_TabIndex[p], m_TabIndex[p + 1] and a byte of flags in two arrays: a k-mer's look-up
+	 * is one sector of HBM, not two (the look-ups were half of the search's traffic at genome scale); then RefTable */
+	const uint2 *rows;
 	const uint32_t *locs;
 	unsigned long long unit_offset;
 	int32_t k;

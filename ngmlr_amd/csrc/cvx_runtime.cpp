@@ -2094,8 +2094,7 @@ struct cvx_index_s {             /* one unit of ngmlr's CompactPrefixTable, resi
 	uint64_t n_index = 0;        /* 4^k + 2 */
 	uint64_t unit_offset = 0;
 	uint32_t n_locs = 0;
-	DevBuf<uint32_t> d_tab;
-	DevBuf<uint8_t> d_used;
+	DevBuf<uint2> d_rows;            /* (row start, row length | used << 31) per prefix: SearchArgs::rows */
 	DevBuf<uint32_t> d_locs;
 };
 
@@ -2105,36 +2104,35 @@ int cvx_index_upload(cvx_handle h, int32_t k, const void *index, const uint32_t 
 	*out = nullptr;
 	HIP_TRY(hipSetDevice(h->device));
 	const uint64_t n_index = (1ull << (2 * k)) + 2ull;
-	/* unpack the 5-byte Index records (uint m_TabIndex; char m_RevCompIndex, #pragma pack(1): src/PrefixTable.h:15-31) */
-	std::vector<uint32_t> tab((size_t) n_index);
-	std::vector<uint8_t> used((size_t) n_index);
+	/* the 5-byte Index records (uint m_TabIndex; char m_RevCompIndex, #pragma pack(1): src/PrefixTable.h:15-31) as one 8-byte
+	 * record per prefix: where GetRefEntry's row starts (m_TabIndex - 1), how long it is (the next record's m_TabIndex - this
+	 * one's, PrefixTable.cpp:476-532) and Index::used() */
 	const uint8_t *p = static_cast<const uint8_t *>(index);
-	for (uint64_t i = 0; i < n_index; ++i) {
-		uint32_t t;
-		memcpy(&t, p + 5 * i, 4);
-		tab[(size_t) i] = t;
-		used[(size_t) i] = p[5 * i + 4] != 0;                 /* Index::used() */
-	}
-	for (uint64_t i = 0; i + 1 < n_index; ++i)
-		if (used[(size_t) i] && (tab[(size_t) i] == 0 || tab[(size_t) i + 1] < tab[(size_t) i] || (uint64_t) tab[(size_t) i + 1] - 1 > n_locs)) {
+	auto tab_at = [&](uint64_t i) { uint32_t t; memcpy(&t, p + 5 * i, 4); return t; };
+	std::vector<uint2> rows;
+	try { rows.resize((size_t) n_index - 1); } catch (const std::bad_alloc &) { set_err("cvx_index_upload: out of host memory"); return CVX_ERR_OOM; }
+	for (uint64_t i = 0; i + 1 < n_index; ++i) {
+		const uint32_t t0 = tab_at(i), t1 = tab_at(i + 1);
+		const bool used = p[5 * i + 4] != 0;                  /* Index::used() */
+		if (used && (t0 == 0 || t1 < t0 || (uint64_t) t1 - 1 > n_locs || t1 - t0 > 0x7FFFFFFFu)) {
 			set_err("cvx_index_upload: index entry %llu points outside the %u locations", (unsigned long long) i, n_locs);
 			return CVX_ERR_ARG;
 		}
+		rows[(size_t) i] = make_uint2(used ? t0 - 1u : 0u, used ? ((t1 - t0) | 0x80000000u) : 0u);
+	}
 	cvx_index_s *ix = new (std::nothrow) cvx_index_s();
 	if (!ix) return CVX_ERR_OOM;
 	ix->device = h->device; ix->k = k; ix->n_index = n_index; ix->unit_offset = unit_offset; ix->n_locs = n_locs;
-	int rc = ix->d_tab.ensure((size_t) n_index);
-	if (rc == CVX_OK) rc = ix->d_used.ensure((size_t) n_index);
+	int rc = ix->d_rows.ensure(rows.size());
 	if (rc == CVX_OK) rc = ix->d_locs.ensure((size_t) n_locs + 1);
 	hipError_t e = hipSuccess;
 	if (rc == CVX_OK) {
-		e = hipMemcpy(ix->d_tab.p, tab.data(), (size_t) n_index * 4, hipMemcpyHostToDevice);
-		if (e == hipSuccess) e = hipMemcpy(ix->d_used.p, used.data(), (size_t) n_index, hipMemcpyHostToDevice);
+		e = hipMemcpy(ix->d_rows.p, rows.data(), rows.size() * sizeof(uint2), hipMemcpyHostToDevice);
 		if (e == hipSuccess && n_locs) e = hipMemcpy(ix->d_locs.p, locs, (size_t) n_locs * 4, hipMemcpyHostToDevice);
 	}
 	if (rc != CVX_OK || e != hipSuccess) {
 		if (e != hipSuccess) { set_err("cvx_index_upload: %s", hipGetErrorString(e)); rc = CVX_ERR_HIP; }
-		ix->d_tab.release(); ix->d_used.release(); ix->d_locs.release(); delete ix;
+		ix->d_rows.release(); ix->d_locs.release(); delete ix;
 		return rc;
 	}
 	*out = ix;
@@ -2145,11 +2143,15 @@ int cvx_index_upload(cvx_handle h, int32_t k, const void *index, const uint32_t 
 void cvx_index_free(cvx_handle h, cvx_index ix) {
 	if (!ix) return;
 	if (h) { (void) hipSetDevice(h->device); (void) hipDeviceSynchronize(); }
-	ix->d_tab.release(); ix->d_used.release(); ix->d_locs.release();
+	ix->d_rows.release(); ix->d_locs.release();
 	delete ix;
 }
 
-int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
+} /* extern "C" */
+
+/* the reads either as n NUL-terminated strings (seqs / lens) or back to back in one block (arena / offsets: read i =
+ * arena[offsets[i] .. offsets[i + 1] - 1) with a NUL at offsets[i + 1] - 1) */
+static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens, const uint8_t *arena, const uint64_t *offsets,
 		float sensitivity, float min_hits, int32_t bin_shift, int32_t first_bits,
 		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used,
 		float *max_hit, int32_t *kmer_misses) {
@@ -2157,7 +2159,7 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	static_assert(sizeof(SearchCandidate) == sizeof(cvx_candidate), "SearchCandidate mirrors cvx_candidate");
 	/* bin_shift >= 1: the "bin is listed" flag lives in bit 63 of the vote table's key, and with a shift of 0 a vote near the
 	 * start of the genome (location - offset in the read < 0) would set that bit itself; ngmlr's bin size is 4 */
-	if (!h || !ix || n < 0 || (n > 0 && (!seqs || !lens || !n_candidates || !cand_begin)) || bin_shift < 1 || bin_shift > 30 ||
+	if (!h || !ix || n < 0 || (n > 0 && ((!arena && (!seqs || !lens)) || (arena && !offsets) || !n_candidates || !cand_begin)) || bin_shift < 1 || bin_shift > 30 ||
 			(first_bits != 0 && (first_bits < 8 || first_bits > 20))) {
 		set_err("cvx_search_batch: bad argument (bin_shift 1..30, first_bits 0 or 8..20)"); return CVX_ERR_ARG;
 	}
@@ -2170,23 +2172,39 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	hipStream_t st = h->s_main;
 	/* the reads, a NUL behind each (the N-run scan of PrefixIteration relies on the terminator), in page-locked staging */
 	uint64_t bytes = 0;
-	for (int i = 0; i < n; ++i) {
-		if (!seqs[i] || lens[i] < 0) { set_err("cvx_search_batch: bad read %d", i); return CVX_ERR_ARG; }
-		bytes += (uint64_t) lens[i] + 1;
+	if (arena) {
+		for (int i = 0; i < n; ++i) {
+			if (offsets[i + 1] <= offsets[i] || offsets[i + 1] - offsets[i] > 0x7FFFFFFFull || arena[offsets[i + 1] - 1] != 0) {
+				set_err("cvx_search_batch_arena: read %d is not [offsets[i], offsets[i + 1] - 1) followed by a NUL", i); return CVX_ERR_ARG;
+			}
+		}
+		bytes = offsets[n] - offsets[0];
+	} else {
+		for (int i = 0; i < n; ++i) {
+			if (!seqs[i] || lens[i] < 0) { set_err("cvx_search_batch: bad read %d", i); return CVX_ERR_ARG; }
+			bytes += (uint64_t) lens[i] + 1;
+		}
 	}
 	const size_t n1 = (size_t) n;
-	RC_TRY(ss->h_seq.ensure((size_t) bytes + 64));
+	/* a block that lies in memory from cvx_host_alloc travels as it is: the host touches no base (the 64 bytes behind the last read
+	 * that the kernels may read are cleared on the device) */
+	const uint8_t *src = arena ? arena + offsets[0] : nullptr;
+	const bool zero_copy = arena && in_pinned_block(reinterpret_cast<const char *>(src), bytes + 4);
+	if (!zero_copy) RC_TRY(ss->h_seq.ensure((size_t) bytes + 64));
 	/* meta: [off u64 n][list_off u64 n][begin u64 n][len i32 n][work i32 n] */
 	RC_TRY(ss->h_meta.ensure(n1 * (8 + 8 + 8 + 4 + 4) + 64));
 	/* out: [events u64 n][ncand i32 n][miss i32 n][maxhit f32 n] (the dense candidates get their own buffer below) */
 	RC_TRY(ss->h_out.ensure(n1 * (8 + 4 + 4 + 4) + 64));
-	uint8_t *hseq = ss->h_seq.as<uint8_t>();
+	uint8_t *hseq = zero_copy ? nullptr : ss->h_seq.as<uint8_t>();
 	uint64_t *h_off = ss->h_meta.as<uint64_t>(), *h_listoff = h_off + n1, *h_begin = h_listoff + n1;
 	int32_t *h_len = reinterpret_cast<int32_t *>(h_begin + n1), *h_work = h_len + n1;
 	unsigned long long *h_events = ss->h_out.as<unsigned long long>();
 	int32_t *h_ncand = reinterpret_cast<int32_t *>(h_events + n1), *h_miss = h_ncand + n1;
 	float *h_maxhit = reinterpret_cast<float *>(h_miss + n1);
-	{
+	if (arena) {
+		for (int i = 0; i < n; ++i) { h_off[i] = offsets[i] - offsets[0]; h_len[i] = (int32_t) (offsets[i + 1] - offsets[i] - 1); }
+		if (!zero_copy) { memcpy(hseq, src, (size_t) bytes); memset(hseq + bytes, 0, 64); }
+	} else {
 		uint64_t at = 0;
 		for (int i = 0; i < n; ++i) {
 			h_off[i] = at;
@@ -2203,11 +2221,16 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	RC_TRY(ss->d_events.ensure(n1)); RC_TRY(ss->d_maxhit.ensure(n1));
 	SearchArgs a;
 	memset(&a, 0, sizeof(a));
-	a.tab = ix->d_tab.p; a.used = ix->d_used.p; a.locs = ix->d_locs.p; a.unit_offset = ix->unit_offset; a.k = ix->k;
+	a.rows = ix->d_rows.p; a.locs = ix->d_locs.p; a.unit_offset = ix->unit_offset; a.k = ix->k;
 	a.seq = ss->d_seq.p; a.seq_off = ss->d_off.p; a.seq_len = ss->d_len.p; a.n = n;
 	a.events = ss->d_events.p; a.list_off = ss->d_listoff.p; a.n_cand = ss->d_ncand.p; a.max_hit = ss->d_maxhit.p; a.kmer_misses = ss->d_miss.p;
 	a.sensitivity = sensitivity; a.min_hits = min_hits; a.bin_shift = bin_shift;
-	HIP_TRY(hipMemcpyAsync(ss->d_seq.p, hseq, (size_t) ((bytes + 63) / 4 * 4), hipMemcpyHostToDevice, st));
+	if (zero_copy) {
+		HIP_TRY(hipMemsetAsync(ss->d_seq.p + bytes / 4 * 4, 0, 68, st));      /* what lies behind the block, first: the copy below is rounded up to whole dwords */
+		HIP_TRY(hipMemcpyAsync(ss->d_seq.p, src, (size_t) ((bytes + 3) / 4 * 4), hipMemcpyHostToDevice, st));
+	} else {
+		HIP_TRY(hipMemcpyAsync(ss->d_seq.p, hseq, (size_t) ((bytes + 63) / 4 * 4), hipMemcpyHostToDevice, st));
+	}
 	HIP_TRY(hipMemcpyAsync(ss->d_off.p, h_off, n1 * 8, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(ss->d_len.p, h_len, n1 * 4, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(ss->d_miss.p, 0, n1 * 4, st));
@@ -2369,6 +2392,23 @@ int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const
 	if (kmer_misses) memcpy(kmer_misses, h_miss, n1 * 4);
 	return CVX_OK;
 	ABI_GUARD_END
+}
+
+extern "C" {
+
+int cvx_search_batch_ex(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
+		float sensitivity, float min_hits, int32_t bin_shift, int32_t first_bits,
+		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used,
+		float *max_hit, int32_t *kmer_misses) {
+	return search_common(h, ix, n, seqs, lens, nullptr, nullptr, sensitivity, min_hits, bin_shift, first_bits, n_candidates, cand_begin, cands, cand_capacity, cand_used, max_hit, kmer_misses);
+}
+
+int cvx_search_batch_arena(cvx_handle h, cvx_index ix, int32_t n, const uint8_t *arena, const uint64_t *offsets,
+		float sensitivity, float min_hits, int32_t bin_shift, int32_t first_bits,
+		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used,
+		float *max_hit, int32_t *kmer_misses) {
+	if (n > 0 && (!arena || !offsets)) { set_err("cvx_search_batch_arena: NULL arena"); return CVX_ERR_ARG; }
+	return search_common(h, ix, n, nullptr, nullptr, arena ? arena : reinterpret_cast<const uint8_t *>(""), offsets, sensitivity, min_hits, bin_shift, first_bits, n_candidates, cand_begin, cands, cand_capacity, cand_used, max_hit, kmer_misses);
 }
 
 int cvx_search_last_attempts(cvx_handle h, int32_t n, int32_t *attempts) {

@@ -73,8 +73,9 @@ search_count_kernel(const SearchArgs a) {
 			if (ch == 'N') { seq += q + 1; length -= q + 1; restart = true; break; }
 			prefix = ((prefix << 2) | (uint64_t) ((ch >> 1) & 3)) & mask;
 			const uint64_t rc = rev_comp13(prefix, K);
-			if (a.used[prefix]) events += a.tab[prefix + 1] - a.tab[prefix];
-			if (a.used[rc]) events += a.tab[rc + 1] - a.tab[rc];
+			const uint2 rf = a.rows[prefix], rr = a.rows[rc];
+			if (rf.y >> 31) events += rf.y & 0x7FFFFFFFu;
+			if (rr.y >> 31) events += rr.y & 0x7FFFFFFFu;
 		}
 		if (!restart) break;
 	}
@@ -154,12 +155,14 @@ search_kernel(const SearchArgs a) {
 			const unsigned long long pos = offset + (unsigned long long) p + 1ull - (unsigned long long) K;
 			/* CS.cpp:57-99 over GetRefEntry (PrefixTable.cpp:476-532): forward row, then the reverse complement's row */
 			const uint64_t rcp = rev_comp13(prefix, K);
-			const bool use_f = a.used[prefix] != 0, use_r = a.used[rcp] != 0;
+			const uint2 row_f = a.rows[prefix], row_r = a.rows[rcp];
+			const bool use_f = (row_f.y >> 31) != 0u, use_r = (row_r.y >> 31) != 0u;
 			if (!use_f && !use_r) misses += 1;       /* entries[0].refTotal == 0 (PrefixTable.cpp:489-525), counted before the votes */
 			for (int rev = 0; rev < 2 && !overflow; ++rev) {
 				const uint64_t pr = rev ? rcp : prefix;
 				if (!(rev ? use_r : use_f)) continue;
-				const uint32_t start = a.tab[pr] - 1u, nloc = a.tab[pr + 1] - 1u - start;
+				const uint32_t start = rev ? row_r.x : row_f.x, nloc = (rev ? row_r.y : row_f.y) & 0x7FFFFFFFu;
+				(void) pr;
 				const unsigned long long corr = rev ? (unsigned long long) read_len - (pos + (unsigned long long) K) : pos;
 				for (uint32_t j = 0; j < nloc && !overflow; ++j) {
 					const unsigned long long loc = (unsigned long long) a.locs[start + j] + a.unit_offset;
@@ -491,10 +494,11 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 			/* table rows of all its k-mers, both orientations: one round trip for the wave */
 			const uint64_t pr = ((uint64_t) C.c_prefix_hi[lane] << 32) | C.c_prefix_lo[lane];
 			const uint64_t rc = rev_comp13(pr, K);
-			const bool uf = a.used[pr] != 0, ur = a.used[rc] != 0;
+			const uint2 rf = a.rows[pr], rr = a.rows[rc];      /* one 8-byte record each: start, length | used << 31 */
+			const bool uf = (rf.y >> 31) != 0u, ur = (rr.y >> 31) != 0u;
 			uint32_t sf = 0, sr = 0;
-			if (uf) { sf = a.tab[pr] - 1u; n0 = a.tab[pr + 1] - 1u - sf; }
-			if (ur) { sr = a.tab[rc] - 1u; n1 = a.tab[rc + 1] - 1u - sr; }
+			if (uf) { sf = rf.x; n0 = rf.y & 0x7FFFFFFFu; }
+			if (ur) { sr = rr.x; n1 = rr.y & 0x7FFFFFFFu; }
 			C.c_start[0][lane] = sf; C.c_start[1][lane] = sr;
 			miss = !uf && !ur;                  /* entries[0].refTotal == 0 (PrefixTable.cpp:489-525): kCount, CS.cpp:67-69 */
 		}

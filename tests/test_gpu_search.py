@@ -139,3 +139,42 @@ def test_device_search_corners_against_the_checker(hip_aligner, search_kernel):
         w = o.search(r, sensitivity=0.5, min_hits=2.0, bin_shift=2, cap=1 << 20)
         assert (w["n"] < 0 and got2[i] is None) or _same(got2[i], w["loc"], w["score"], w["rev"]), i
     o.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_arena_form_returns_the_recorded_lists(hip_aligner, pinned, search_kernel):
+    """cvx_search_batch_arena (ABI 7): the reads back to back in ONE block -- pageable, or page-locked memory from cvx_host_alloc that
+    the device pulls as it is -- against the recorded reference calls of test_3 and of the repeat-rich recording, all three kernel
+    forms: lists, order, maxHitNumber, kCount as through the string form."""
+    for name in ("cs_test_3.npz", "cs_rep.npz"):
+        fx = SearchFixture(os.path.join(util.GOLDEN, name))
+        idx, locs = fx.index_arrays()
+        ix = KmerIndex(hip_aligner, fx.k, idx, locs, fx.unit_offset)
+        arena, offsets, pin = KmerIndex.make_arena(fx.seqs, hip_aligner.lib if pinned else None)
+        assert (pin is not None) == pinned
+        try:
+            want_lists, want_mh, want_ms = ix.search(fx.seqs, extras=True)
+            ncand, begin, cands, mh, ms = ix.search_arena(arena, offsets)
+        finally:
+            ix.free()
+            if pin:
+                pin[0].cvx_host_free(pin[1])
+        bad = [i for i in range(len(fx.seqs))
+               if not _same(cands[int(begin[i]):int(begin[i]) + max(int(ncand[i]), 0)] if ncand[i] >= 0 else None, *fx.want[i])]
+        assert not bad, (name, len(bad), bad[:5])
+        assert np.array_equal(mh, want_mh) and np.array_equal(ms, want_ms)
+        assert sum(len(g) for g in want_lists if g is not None) == int(ncand[ncand > 0].sum())
+    # a block that does not end its reads with a NUL is refused
+    arena, offsets, _ = KmerIndex.make_arena([b"ACGT" * 40, b"TTGA" * 50])
+    arena2 = arena.copy()
+    arena2[int(offsets[1]) - 1] = ord("A")
+    fx = SearchFixture(os.path.join(util.GOLDEN, "cs_test_3.npz"))
+    idx, locs = fx.index_arrays()
+    ix = KmerIndex(hip_aligner, fx.k, idx, locs, fx.unit_offset)
+    try:
+        with pytest.raises(Exception):
+            ix.search_arena(arena2, offsets)
+        n, _, _, _, _ = ix.search_arena(arena, offsets)
+        assert len(n) == 2
+    finally:
+        ix.free()

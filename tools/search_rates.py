@@ -31,25 +31,41 @@ def big_index_rates(al, mbp=512, n_reads=100000, parity_n=2000, n_contigs=8, pmc
     t0 = time.perf_counter()
     ix = KmerIndex(al, k, idx5.view(np.dtype([("tab", "<u4"), ("rc", "i1")])), locs, 0)
     t_up = time.perf_counter() - t0
+    arena, offsets, pinned = KmerIndex.make_arena(reads, al.lib)
     try:
         ix.search(reads[:512])
+        # (a) the string form, through Python's marshalling of 100 000 strings and 100 000 result arrays (round 5's figure)
+        c0 = time.perf_counter()
+        got, max_hit, misses = ix.search(reads, extras=True)
+        dt_strings = time.perf_counter() - c0
+        # (b) the arena form: reads back to back in page-locked memory, flat outputs (cvx_search_batch_arena) -- what a caller that keeps
+        # its reads resident pays; the candidate buffer is sized by the first call
+        ncand, begin, cands, mh2, ms2 = ix.search_arena(arena, offsets)
+        cbuf = np.zeros(len(cands) + len(cands) // 8 + 64, dtype=cands.dtype)
         best = None
-        for _ in range(3):                                  # (the first full-size call also grows the handle's arenas)
+        for _ in range(3):
             c0 = time.perf_counter()
-            got, max_hit, misses = ix.search(reads, extras=True)
+            ncand, begin, cands, mh2, ms2 = ix.search_arena(arena, offsets, cands=cbuf)
             dt = time.perf_counter() - c0
             kms = al.stage_kernel_ms(capi.STAGE_SEARCH)
             if best is None or dt < best[0]:
                 best = (dt, kms)
         dt, kms = best
+        # the two forms return the same lists
+        same_forms = bool(np.array_equal(mh2, max_hit) and np.array_equal(ms2, misses) and
+                          all((g is None and ncand[i] < 0) or (g is not None and ncand[i] == len(g) and np.array_equal(cands[int(begin[i]):int(begin[i]) + int(ncand[i])], g))
+                              for i, g in enumerate(got)))
     finally:
         ix.free()
+        if pinned:
+            pinned[0].cvx_host_free(pinned[1])
     # votes of the batch: every location of every k-mer the table knows, both orientations (what CS::PrefixSearch walks)
     tab = idx5.reshape(-1, 5)[:, :4].copy().view(np.uint32).ravel()
     used = idx5.reshape(-1, 5)[:, 4] != 0
     row_len = np.zeros(len(tab), dtype=np.int64)
     row_len[:-1] = np.where(used[:-1], np.diff(tab.astype(np.int64)), 0)
     votes = 0
+    sectors = 0      # 64-byte sectors the look-ups of a sub-read need at the least: one index record per k-mer and orientation, its row of locations
     n_v = min(len(reads), 4000)
     code = np.zeros(256, dtype=np.int64)
     for ch, v in ((65, 0), (67, 1), (84, 2), (71, 3)):
@@ -63,7 +79,9 @@ def big_index_rates(al, mbp=512, n_reads=100000, parity_n=2000, n_contigs=8, pmc
         wc = (w ^ 2)[:, ::-1]
         prc = (wc * (4 ** np.arange(k - 1, -1, -1))).sum(axis=1)
         votes += int(row_len[p].sum() + row_len[prc].sum())
+        sectors += 2 * len(p) + int(((row_len[p] * 4 + 63) // 64).sum() + ((row_len[prc] * 4 + 63) // 64).sum())
     votes_per_read = votes / max(n_v, 1)
+    sectors_per_read = sectors / max(n_v, 1)
     # parity of a sample against the CPU restatement over the same table
     from oracle.pyoracle import SearchOracle
     orc = SearchOracle(raw=(k, 0, idx5, locs))
@@ -87,18 +105,42 @@ def big_index_rates(al, mbp=512, n_reads=100000, parity_n=2000, n_contigs=8, pmc
     out = {
         "reference_bases": int(sum(len(c) for c in contigs)), "contigs": len(contigs), "kmer_len": k, "locations": int(len(locs)),
         "table_bytes": int(len(idx5) + 4 * len(locs)), "sub_reads": len(reads), "sub_read_bases": int(bases),
-        "seconds": dt, "sub_reads_per_s": len(reads) / dt, "kernel_ms": kms, "kernel_sub_reads_per_s": len(reads) / max(kms * 1e-3, 1e-9),
+        "seconds": dt, "sub_reads_per_s": len(reads) / dt, "kernel_ms": kms, "whole_call_over_kernels": dt * 1e3 / max(kms, 1e-9),
+        "string_form": {"seconds": dt_strings, "sub_reads_per_s": len(reads) / dt_strings, "equal_to_the_arena_form": same_forms,
+                        "what": "cvx_search_batch_ex through this tool's Python marshalling of 100 000 strings in and 100 000 arrays out (round 5's `whole call`)"}, "kernel_sub_reads_per_s": len(reads) / max(kms * 1e-3, 1e-9),
         "votes_per_sub_read": votes_per_read, "kernel_votes_per_s": votes_per_read * len(reads) / max(kms * 1e-3, 1e-9),
         "lists": n_lists, "candidates": n_cand,
         "parity": "%d/%d lists equal to the CPU restatement of CS::RunRead over the same table (entries, order, maxHitNumber, kCount)" % (len(sample) - bad, len(sample)),
         "parity_detail": first, "cpu_checker_sub_reads_per_s_one_thread": len(sample) / max(dt_cpu, 1e-9),
         "setup_seconds": {"reference": t_ref, "cvx_index_build": t_tab, "cvx_index_upload": t_up},
         "bytes_per_vote": pmc_bytes_per_vote,
+        "random_sector_peak": None, "sectors_per_sub_read": sectors_per_read,
+        "kernel_sector_reads_per_s": sectors_per_read * len(reads) / max(kms * 1e-3, 1e-9),
         "bound": "HBM random access: the 5-byte index records (4^13 of them, 335 MB) and the location table exceed L2 + MALL, so every k-mer costs two "
                  "random index sectors (itself and its reverse complement) and every vote a location from a row of ~2-3 entries; the vote itself is LDS work",
-        "what": "cvx_search_batch_ex over a %d Mbp synthetic reference with repeat families and microsatellites; table by cvx_index_build (byte-identical "
+        "what": "cvx_search_batch_arena (reads back to back in page-locked memory, flat outputs) over a %d Mbp synthetic reference with repeat families and microsatellites; table by cvx_index_build (byte-identical "
                 "to ngmlr's own: tests/test_index_cpu.py), resident in HBM; kernel_ms = every kernel of the call from HIP events (cvx_stage_kernel_ms)" % mbp}
+    peak = random_sector_peak()
+    out["random_sector_peak"] = peak
+    if peak and "G_accesses_per_s" in peak:
+        out["kernel_frac_of_random_peak"] = out["kernel_sector_reads_per_s"] / (peak["G_accesses_per_s"] * 1e9)
     return out
+
+
+def random_sector_peak():
+    """tools/ubench_gather.hip (built into tools/bin by __graft_entry__.build()): G random 64-byte-sector reads / s of this device,
+    the ceiling "HBM random access" is measured against -> dict or None"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "ubench_gather")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120).stdout
+        last = [l for l in out.splitlines() if l.startswith("RANDOM_SECTOR_PEAK")][-1].split()
+        return {"G_accesses_per_s": float(last[1]), "GB_per_s_of_64B_sectors": float(last[2]),
+                "what": "tools/ubench_gather.hip: best of 8 / 16 / 64 bytes per access, 1-16 loads in flight per lane, 1-8 waves per SIMD, over 4 GiB"}
+    except Exception as e:
+        return {"error": str(e)}
 
 
 def main():
