@@ -61,15 +61,53 @@ decode_windows_kernel(const uint8_t *bin, const unsigned long long *starts, int 
 		if (go) n_dec = (dstart & 1ull) + 2ull * ((dend - dstart + 1ull) / 2ull);
 	}
 	uint8_t *out = dst + w.dst_off;
-	for (long long i = threadIdx.x; i < n_chars; i += blockDim.x) {
-		uint8_t c = 'x';
+	/* Sixteen characters per lane and trip (round 6; a byte per lane -- 64-byte stores per wave instruction -- reached 1.6 TB/s of the
+	 * 1.5 B per character this kernel moves): the lane owns one 16-byte-ALIGNED piece of the destination, reads the
+	 * 8-9 genome bytes behind it with one unaligned 8-byte load (+ one byte when the piece starts on a low nibble), expands them
+	 * through a table packed into a 64-bit constant, and stores the piece with one dwordx4; the window's ragged head and tail (its
+	 * address in the arena is whatever the tile layout gave it) go byte by byte. */
+	const unsigned long long kLut = 0x3F3F3F4E43475441ull;      /* 'A' 'T' 'G' 'C' 'N' '?' '?' '?' : dec4, src/SequenceProvider.cpp:90-104 */
+	const long long head = (long long) ((16u - (unsigned) ((uintptr_t) out & 15u)) & 15u);      /* characters in front of the first aligned piece */
+	const long long n_pieces = n_chars > head ? (n_chars - head + 15) / 16 : 0;
+	auto char_at = [&](const long long i) -> uint8_t {      /* the kernel's definition of character i (used for the ragged ends) */
 		const long long k = i - off;
-		if (go && k >= 0 && (unsigned long long) k < n_dec) {
-			const unsigned long long p = dstart + (unsigned long long) k;
-			const unsigned b = bin[p >> 1];
-			c = dec4_char((p & 1ull) ? (b & 0xFu) : (b >> 4));
+		if (!(go && k >= 0 && (unsigned long long) k < n_dec)) return (uint8_t) 'x';
+		const unsigned long long p = dstart + (unsigned long long) k;
+		const unsigned b = bin[p >> 1];
+		return dec4_char((p & 1ull) ? (b & 0xFu) : (b >> 4));
+	};
+	for (long long i = threadIdx.x; i < (head < n_chars ? head : n_chars); i += blockDim.x) out[i] = char_at(i);
+	for (long long pc = threadIdx.x; pc < n_pieces; pc += blockDim.x) {
+		const long long i0 = head + 16 * pc;
+		const long long k0 = i0 - off;
+		const bool whole = i0 + 16 <= n_chars;
+		const bool inside = go && k0 >= 0 && (unsigned long long) (k0 + 16) <= n_dec;      /* all sixteen are decoded characters */
+		if (whole && inside) {
+			const unsigned long long p0 = dstart + (unsigned long long) k0;
+			const uint8_t *src = bin + (p0 >> 1);
+			unsigned long long lo8;
+			__builtin_memcpy(&lo8, src, 8);                  /* nibbles p0 & ~1 .. + 15, high nibble of a byte first */
+			unsigned extra = 0;
+			if (p0 & 1ull) extra = src[8];
+			uint32_t wv[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				uint32_t word = 0;
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const unsigned t = (unsigned) (4 * q + c) + (unsigned) (p0 & 1ull);      /* nibble index from the first loaded byte */
+					const unsigned byte = t < 16u ? (unsigned) ((lo8 >> (8u * (t >> 1))) & 0xFFull) : extra;
+					unsigned nib = (t & 1u) ? (byte & 0xFu) : (byte >> 4);
+					nib = nib < 5u ? nib : 5u;
+					word |= (uint32_t) ((kLut >> (8u * nib)) & 0xFFull) << (8 * c);
+				}
+				wv[q] = word;
+			}
+			*reinterpret_cast<uint4 *>(out + i0) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+		} else {
+			const long long i1 = i0 + 16 < n_chars ? i0 + 16 : n_chars;
+			for (long long i = i0; i < i1; ++i) out[i] = char_at(i);
 		}
-		out[i] = c;
 	}
 }
 

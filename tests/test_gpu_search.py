@@ -178,3 +178,27 @@ def test_arena_form_returns_the_recorded_lists(hip_aligner, pinned, search_kerne
         assert len(n) == 2
     finally:
         ix.free()
+
+
+def test_device_search_on_recorded_calls_at_genome_scale(hip_aligner, search_kernel):
+    """The device against the unmodified reference where the table is a gigabyte in HBM (tests/golden/cs_big.npz, 840 recorded RunRead
+    calls on a 512 Mbp reference; the table rebuilt by cvx_index_build and checked against the recording's hashes): every list,
+    its order, maxHitNumber and kCount, in all three kernel forms, through the string form and the arena form."""
+    fx, idx5, locs = util.big_search_case()
+    ix = KmerIndex(hip_aligner, fx.k, idx5.view(np.dtype([("tab", "<u4"), ("rc", "i1")])), locs, fx.unit_offset)
+    try:
+        got, max_hit, _ = ix.search(fx.seqs, extras=True)
+        arena, offsets, _pin = KmerIndex.make_arena(fx.seqs)
+        ncand, begin, cands, mh2, _ = ix.search_arena(arena, offsets)
+        miss = np.zeros(len(fx.seqs), dtype=np.int32)
+        for b in sorted(set(int(x) for x in fx.first_bits)):      # kCount is summed over the ladder: at the table size the reference's first attempt had
+            sel = [i for i in range(len(fx.seqs)) if int(fx.first_bits[i]) == b]
+            _, _, ms = ix.search([fx.seqs[i] for i in sel], first_bits=b, extras=True)
+            miss[sel] = ms
+    finally:
+        ix.free()
+    bad = [i for i in range(len(fx.seqs)) if not _same(got[i], *fx.want[i])]
+    assert not bad, (len(bad), bad[:5])
+    assert all(_same(cands[int(begin[i]):int(begin[i]) + int(ncand[i])] if ncand[i] >= 0 else None, *fx.want[i]) for i in range(len(fx.seqs)))
+    assert np.array_equal(max_hit, fx.max_hit.astype(np.float32)) and np.array_equal(mh2, max_hit)
+    assert np.array_equal(miss, fx.kmer_misses.astype(np.int32))

@@ -70,6 +70,26 @@ def test_oracle_reproduces_recorded_searches_on_a_repeat_rich_reference(built):
     assert bad == []
 
 
+def test_oracle_reproduces_recorded_searches_at_genome_scale(built):
+    """VERDICT r5 item 5d / missing #6: RunRead calls recorded from the unmodified reference where the k-mer table leaves every cache
+    (512 Mbp, 62 M used prefixes, 179 M locations; tools/make_golden_cs.sh --big).  cvx_index_build rebuilds the table the
+    reference searched (SHA-256 of index and locations as the packer verified them against the reference's dump), and the CPU
+    restatement reproduces all 840 recorded calls over it: lists, order, maxHitNumber, threshold, rList length, kCount."""
+    fx, idx5, locs = util.big_search_case()
+    assert len(fx.seqs) >= 500 and sum(len(w[0]) for w in fx.want) >= 1000
+    o = SearchOracle(raw=(fx.k, fx.unit_offset, idx5, locs))
+    bad = []
+    for i in range(len(fx.seqs)):
+        loc, sc, rev = fx.want[i]
+        g = o.search(fx.seqs[i], first_bits=int(fx.first_bits[i]), cap=1 << 16)
+        if not (g["n"] == len(loc) and np.array_equal(g["loc"], loc) and np.array_equal(g["score"], sc) and np.array_equal(g["rev"], rev)
+                and g["max_hit"] == fx.max_hit[i] and g["thresh"] == fx.thresh[i] and g["rlist_len"] == fx.rlist_len[i]
+                and g["kmer_misses"] == int(fx.kmer_misses[i])):
+            bad.append(i)
+    o.close()
+    assert bad == []
+
+
 def test_n_runs_and_the_retry_ladder(built):
     """Behaviour the recorded reads do not reach: windows holding 'N' are skipped (with the quirk that a run of N at the start of
     a restarted stretch ends the walk when 13 or fewer characters follow), and a read whose votes overflow the probe budget

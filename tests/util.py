@@ -310,3 +310,39 @@ def synthetic_search_case(seed=41):
     reads = [base, with_n, tail2, tail1, lead, short, allN, heavy, bytes(b[:40]), b"", bytes(b[:13]),
              foreign, bytes(b[:150]) + foreign[:106], foreign[:56] + heavy[:200]]
     return fx, reads
+
+
+# --------------------------------------------------------------------------- candidate search at genome scale
+
+_BIG = {}
+
+
+def big_search_case():
+    """tests/golden/cs_big.npz (tools/make_golden_cs.sh --big): 840 candidate-search calls recorded from the unmodified reference on
+    ngmlr_amd.synth.big_reference(512 Mbp) -- a k-mer table that leaves every cache.  The 1 GB table is not stored: it is rebuilt here
+    with cvx_index_build from the same generator and must hash to what the packer saw equal to the reference's own table.
+    -> (fixture-like object with seqs / want / max_hit / thresh / rlist_len / kmer_misses / first_bits, k, index bytes, locations)"""
+    if "case" in _BIG:
+        return _BIG["case"]
+    import hashlib
+    from ngmlr_amd import capi
+    z = np.load(os.path.join(GOLDEN, "cs_big.npz"))
+    contigs = synth.big_reference(512 << 20, n_contigs=8)
+    idx5, locs, _ = synth.kmer_table(capi.load(), contigs, k=int(z["k"]), skip=int(z["ref_skip"]))
+    del contigs
+    assert hashlib.sha256(idx5.tobytes()).hexdigest() == str(z["index_sha256"]), "the rebuilt index is not the recorded reference table"
+    assert hashlib.sha256(locs.tobytes()).hexdigest() == str(z["locs_sha256"]) and len(locs) == int(z["n_locations"])
+
+    class Case:
+        pass
+    fx = Case()
+    off = np.concatenate([[0], np.cumsum(z["seq_len"].astype(np.int64))])
+    raw = z["seqs"].tobytes()
+    fx.seqs = [raw[int(off[i]):int(off[i + 1])] for i in range(len(z["seq_len"]))]
+    so = np.concatenate([[0], np.cumsum(z["n_scores"].astype(np.int64))])
+    fx.want = [(z["loc"][int(so[i]):int(so[i + 1])], z["score"][int(so[i]):int(so[i + 1])], z["rev"][int(so[i]):int(so[i + 1])]) for i in range(len(fx.seqs))]
+    fx.max_hit, fx.thresh, fx.rlist_len = z["max_hit"], z["thresh"], z["rlist_len"]
+    fx.kmer_misses, fx.first_bits = z["kmer_misses"], z["first_bits"]
+    fx.k, fx.unit_offset = int(z["k"]), int(z["unit_offset"])
+    _BIG["case"] = (fx, idx5, locs)
+    return _BIG["case"]

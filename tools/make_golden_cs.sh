@@ -79,6 +79,40 @@ mkdir -p "$T/build" && cd "$T/build"
 cmake .. -DCMAKE_POLICY_VERSION_MINIMUM=3.5 -DCMAKE_BUILD_TYPE=RELWITHDEBINFO > "$WORK/cmake.log" 2>&1
 make -j16 > "$WORK/make.log" 2>&1 || { tail -30 "$WORK/make.log"; exit 1; }
 BIN=$(ls "$T"/bin/ngmlr-*/ngmlr)
+if [ "${1:-}" = "--big" ]; then
+# the one regime without a reference-made vector -- a k-mer table that leaves every cache.  The unmodified
+# reference maps 20 PacBio-like 10 kb reads (800 sub-reads) on ngmlr_amd.synth.big_reference (512 Mbp in 8 contigs, repeat families,
+# microsatellites: the reference of bench.py's candidate_search_big), recorder hooks on.  The 1 GB table is NOT stored: the packer
+# checks that cvx_index_build produces the very table the reference built (every used prefix, its slot count and weight byte, every
+# location) and keeps its SHA-256; the tests rebuild the table from the same generator, check the hash and search over it.
+# -> tests/golden/cs_big.npz (the recorded calls + the hashes; small enough to commit)
+python3 - "$REPO" "$WORK/big.fa" "$WORK/big.fq" <<'PY'
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from ngmlr_amd import synth
+contigs = synth.big_reference(512 << 20, n_contigs=8)
+with open(sys.argv[2], "wb") as f:
+    for i, c in enumerate(contigs):
+        f.write(b">big%d\n" % i)
+        b = c.tobytes()
+        for a in range(0, len(b), 1 << 20):
+            f.write(b[a:a + (1 << 20)] + b"\n")
+rng = np.random.default_rng(77)
+with open(sys.argv[3], "w") as f:
+    for i in range(20):
+        c = contigs[int(rng.integers(0, len(contigs)))]
+        a = int(rng.integers(0, len(c) - 12000))
+        q = synth.mutate(rng, c[a:a + 10400], 0.15, (6, 3, 1))
+        if rng.random() < 0.5:
+            q = synth.revcomp(q)
+        f.write("@big%d_%d\n%s\n+\n%s\n" % (i, a, q.tobytes().decode(), "I" * len(q)))
+PY
+CVX_RECORD_CS="$WORK/big.cs" CVX_RECORD_TABLE="$WORK/big.table" "$BIN" --skip-write -x pacbio -t 1 -R 0.01 --no-progress \
+	-r "$WORK/big.fa" -q "$WORK/big.fq" > "$WORK/big.sam" 2> "$WORK/big.log" || true
+echo "big: $(stat -c %s "$WORK/big.cs") bytes of sub-read records, $(stat -c %s "$WORK/big.table") bytes of table"
+python3 "$HERE/pack_golden_cs.py" --big "$WORK/big.cs" "$WORK/big.table" "$REPO/tests/golden/cs_big.npz"
+else
 D="$T/test/data"
 python3 - "$D/test_3/read.fa.gz" "$WORK/test_3.fq" <<'PY'
 import sys, gzip
@@ -115,4 +149,5 @@ CVX_RECORD_CS="$WORK/rep.cs" CVX_RECORD_TABLE="$WORK/rep.table" "$BIN" --skip-wr
 	-r "$WORK/rep.fa" -q "$WORK/rep.fq" > "$WORK/rep.sam" 2> "$WORK/rep.log" || true
 echo "repeat-rich: $(stat -c %s "$WORK/rep.cs") bytes of sub-read records, $(stat -c %s "$WORK/rep.table") bytes of table"
 python3 "$HERE/pack_golden_cs.py" "$WORK/rep.cs" "$WORK/rep.table" "$REPO/tests/golden/cs_rep.npz" "$REPO/oracle/_ref/golden_full/cs_rep_full.npz" 2
+fi
 rm -rf "$WORK"

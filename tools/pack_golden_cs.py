@@ -46,7 +46,44 @@ def pack(table, calls, out):
                         kmer_misses=np.array([c[5] for c in calls], dtype=np.int32), first_bits=np.array([c[6] for c in calls], dtype=np.int32))
 
 
+def pack_big(cs_path, table_path, out):
+    """--big: the recorded calls on ngmlr_amd.synth.big_reference + the SHA-256 of the table, after checking that cvx_index_build
+    (what the tests will rebuild it with) produces exactly the table the reference dumped"""
+    import hashlib
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ngmlr_amd import capi, synth
+    table = read_table(table_path)
+    calls = read_cs(cs_path)
+    contigs = synth.big_reference(512 << 20, n_contigs=8)
+    idx5, locs, starts = synth.kmer_table(capi.load(), contigs, k=int(table['k']), skip=int(table['skip']))
+    rec = idx5.reshape(-1, 5)
+    tab = rec[:, :4].copy().view('<u4').ravel()
+    used = rec[:, 4] != 0
+    pre = np.flatnonzero(used[:-2]).astype(np.uint32)
+    assert np.array_equal(pre, table['prefix']), "used prefixes differ from the reference's table"
+    assert np.array_equal(tab[pre], table['tab']) and np.array_equal(tab[pre + 1] - tab[pre], table['cnt']), "table rows differ"
+    assert np.array_equal(rec[pre, 4].view('i1'), table['rc']), "weight bytes differ"
+    assert np.array_equal(locs, table['locs']), "locations differ"
+    seqs = b''.join(c[0] for c in calls)
+    recs = np.concatenate([c[4] for c in calls])
+    np.savez_compressed(out, k=np.int32(table['k']), ref_skip=np.int32(table['skip']), unit_offset=np.uint64(table['offset']),
+                        reference=np.array("ngmlr_amd.synth.big_reference(512 << 20, n_contigs=8)"),
+                        index_sha256=np.array(hashlib.sha256(idx5.tobytes()).hexdigest()), locs_sha256=np.array(hashlib.sha256(locs.tobytes()).hexdigest()),
+                        n_locations=np.int64(len(locs)), n_used_prefixes=np.int64(len(pre)),
+                        seqs=np.frombuffer(seqs, dtype=np.uint8), seq_len=np.array([len(c[0]) for c in calls], dtype=np.int32),
+                        max_hit=np.array([c[1] for c in calls], dtype=np.float32), thresh=np.array([c[2] for c in calls], dtype=np.float32),
+                        rlist_len=np.array([c[3] for c in calls], dtype=np.int32), n_scores=np.array([len(c[4]) for c in calls], dtype=np.int32),
+                        loc=recs['loc'], score=recs['score'], rev=recs['rev'],
+                        kmer_misses=np.array([c[5] for c in calls], dtype=np.int32), first_bits=np.array([c[6] for c in calls], dtype=np.int32))
+    print("big: k=%d, %d used prefixes, %d locations = the table cvx_index_build makes; %d recorded sub-reads, %d candidates" % (
+        table['k'], len(pre), len(locs), len(calls), len(recs)))
+
+
 if __name__ == '__main__':
+    if sys.argv[1] == '--big':
+        pack_big(sys.argv[2], sys.argv[3], sys.argv[4])
+        sys.exit(0)
     table = read_table(sys.argv[2])
     calls = read_cs(sys.argv[1])
     print("table: k=%d, %d used prefixes, %d locations; %d recorded sub-reads, %d candidates" % (

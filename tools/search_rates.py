@@ -116,8 +116,10 @@ def big_index_rates(al, mbp=512, n_reads=100000, parity_n=2000, n_contigs=8, pmc
         "bytes_per_vote": pmc_bytes_per_vote,
         "random_sector_peak": None, "sectors_per_sub_read": sectors_per_read,
         "kernel_sector_reads_per_s": sectors_per_read * len(reads) / max(kms * 1e-3, 1e-9),
-        "bound": "HBM random access: the 5-byte index records (4^13 of them, 335 MB) and the location table exceed L2 + MALL, so every k-mer costs two "
-                 "random index sectors (itself and its reverse complement) and every vote a location from a row of ~2-3 entries; the vote itself is LDS work",
+        "bound": "NOT the random-access rate of HBM (round 6: tools/ubench_gather.hip puts that at ~51 G sectors/s on this device; the kernels "
+                 "read `kernel_sector_reads_per_s`, a few per cent of it): the latency of a wave's dependent round trips at under one wave per SIMD -- "
+                 "a read owns a wave whose vote map takes 47 KB of LDS (2 048 slots: a sub-read of a genome with repeats votes for ~10^3 bins), so "
+                 "three waves fit a CU and every LDS / HBM round trip of the ~20 vote batches of a sub-read is exposed",
         "what": "cvx_search_batch_arena (reads back to back in page-locked memory, flat outputs) over a %d Mbp synthetic reference with repeat families and microsatellites; table by cvx_index_build (byte-identical "
                 "to ngmlr's own: tests/test_index_cpu.py), resident in HBM; kernel_ms = every kernel of the call from HIP events (cvx_stage_kernel_ms)" % mbp}
     peak = random_sector_peak()
