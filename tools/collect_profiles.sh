@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 400 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+timeout -s KILL 700 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o p -- python $R/bench.py --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
 timeout -s KILL 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o p -- python $R/bench.py --steps 1 --warmup 0 --resident-steps 0 --no-cpu-baseline > $OUT/${TAG}_fetch.log 2>&1

@@ -8,6 +8,8 @@
                                            reference in a third of them, -x ont: ngmlr's split-read path (BASELINE.json configs[4]'s shape)
     e2e_rates.py --synthetic-rep N [threads] PacBio-like 10 kb reads on a reference with repeat families and microsatellites: several
                                            candidate regions per sub-read, close scores (what the candidate search and MAPQ see on a real genome)
+    e2e_rates.py --synthetic-big N [threads] the same reads on a 512 Mbp reference with repeats (the 1 GB k-mer table leaves every cache): the
+                                           reference's only published metric is a genome-sized run (README.md:25)
     e2e_rates.py --synthetic N [threads]   BASELINE.md section 2's workload: N synthetic PacBio-like 10 kb reads (15 % error,
                                            ins:del:sub 6:3:1, half of them reverse-complemented) on a 2 Mbp random reference;
                                            ngmlr_ref at -t nproc' (best of a few thread counts) against the batched drop-ins with
@@ -190,6 +192,33 @@ def _lock_numbers(line_):
             "what": "_NGM::GetNextReadBatch: reads are parsed and split into sub-reads by one thread at a time; a lower bound of the mapping wall clock that is not the device path's"}
 
 
+def write_big_workload(fa, fq, n_reads, seed=31):
+    """a reference whose k-mer table leaves every cache -- ngmlr_amd.synth.big_reference (512 Mbp in 8 contigs,
+    24 repeat families, 600 microsatellites; the reference of bench.py's candidate_search_big) -- and PacBio-like 10 kb reads drawn
+    uniformly from it (15 % error 6:3:1, half of them reverse-complemented).  -> read bases"""
+    from ngmlr_amd import synth
+    contigs = synth.big_reference(512 << 20, n_contigs=8)
+    with open(fa, "wb") as f:
+        for i, c in enumerate(contigs):
+            f.write(b">big%d\n" % i)
+            b = c.tobytes()
+            for a in range(0, len(b), 1 << 20):
+                f.write(b[a:a + (1 << 20)] + b"\n")
+    rng = np.random.default_rng(seed)
+    bases = 0
+    with open(fq, "w") as f:
+        for i in range(n_reads):
+            c = contigs[int(rng.integers(0, len(contigs)))]
+            n = int(rng.integers(9000, 11000))
+            a = int(rng.integers(0, len(c) - n - 1))
+            q = synth.mutate(rng, c[a:a + n], 0.15, (6, 3, 1))
+            if rng.random() < 0.5:
+                q = synth.revcomp(q)
+            bases += len(q)
+            f.write("@b%d_%d\n%s\n+\n%s\n" % (i, a, q.tobytes().decode(), "I" * len(q)))
+    return bases
+
+
 def pipeline_summary(n_reads=20000, t_ref=32, spec=(20, 4096, 2048, 10000), extra_env=None):
     """What bench.py puts beside its line as `e2e_pipeline`: the reference's own ngmlr, unmodified (ngmlr_ref, CPU) against the
     build with every drop-in bound (ngmlr_hip_all: alignment, sub-read scoring, candidate search, SAM records on the device
@@ -358,7 +387,7 @@ def effective_cores():
     return ", ".join(out)
 
 
-def synthetic(n_reads, threads, sv=False, rep=False):
+def synthetic(n_reads, threads, sv=False, rep=False, big=False):
     from ngmlr_amd import synth
     global PRESET
     rng = np.random.default_rng(2025)
@@ -370,6 +399,10 @@ def synthetic(n_reads, threads, sv=False, rep=False):
         L = 3_000_000
         bases = write_sv_workload(fa, fq, n_reads, L=L)
         print("SV workload (ONT-like 8-30 kb reads, 20 % error, a third with an inversion / deletion / insertion; -x ont):")
+    elif big:
+        L = 512 << 20
+        bases = write_big_workload(fa, fq, n_reads)
+        print("genome-sized reference (512 Mbp in 8 contigs, repeat families, microsatellites: the k-mer table is 1 GB and leaves every cache):")
     elif rep:
         L = 3_000_000
         bases = write_repeat_workload(fa, fq, n_reads, L=L)
@@ -440,8 +473,8 @@ def test_3(threads):
 
 if __name__ == "__main__":
     args = sys.argv[1:]
-    if args and args[0] in ("--synthetic", "--synthetic-sv", "--synthetic-rep"):
+    if args and args[0] in ("--synthetic", "--synthetic-sv", "--synthetic-rep", "--synthetic-big"):
         n = int(args[1]) if len(args) > 1 else 2000
-        synthetic(n, [int(x) for x in args[2:]] or [64, 256, 512], sv=args[0] == "--synthetic-sv", rep=args[0] == "--synthetic-rep")
+        synthetic(n, [int(x) for x in args[2:]] or [64, 256, 512], sv=args[0] == "--synthetic-sv", rep=args[0] == "--synthetic-rep", big=args[0] == "--synthetic-big")
     else:
         test_3([int(x) for x in args] or [1, 16, 64])
