@@ -32,7 +32,10 @@ __device__ __forceinline__ uint8_t dec4_char(unsigned v) {
 __global__ void __launch_bounds__(256)
 decode_windows_kernel(const uint8_t *bin, const unsigned long long *starts, int n_starts,
 		const WindowDesc *win, int n, uint8_t *dst) {
-	const int wi = blockIdx.x;
+	/* one WAVE per window, four windows per workgroup (round 6: a 4.5 kb window is 285 sixteen-character pieces -- a workgroup of 256
+	 * lanes did one piece per lane and spent its life starting up) */
+	const int wi = blockIdx.x * 4 + (int) (threadIdx.x >> 6);
+	const int lane = (int) (threadIdx.x & 63u);
 	if (wi >= n) return;
 	const WindowDesc w = win[wi];
 	const long long n_chars = w.n_chars;                 /* characters to produce (the caller's NUL is not stored) */
@@ -76,8 +79,8 @@ decode_windows_kernel(const uint8_t *bin, const unsigned long long *starts, int 
 		const unsigned b = bin[p >> 1];
 		return dec4_char((p & 1ull) ? (b & 0xFu) : (b >> 4));
 	};
-	for (long long i = threadIdx.x; i < (head < n_chars ? head : n_chars); i += blockDim.x) out[i] = char_at(i);
-	for (long long pc = threadIdx.x; pc < n_pieces; pc += blockDim.x) {
+	for (long long i = lane; i < (head < n_chars ? head : n_chars); i += 64) out[i] = char_at(i);
+	for (long long pc = lane; pc < n_pieces; pc += 64) {
 		const long long i0 = head + 16 * pc;
 		const long long k0 = i0 - off;
 		const bool whole = i0 + 16 <= n_chars;
@@ -114,7 +117,7 @@ decode_windows_kernel(const uint8_t *bin, const unsigned long long *starts, int 
 hipError_t launch_decode_windows(const uint8_t *bin, const uint64_t *starts, int n_starts,
 		const WindowDesc *win, int n, uint8_t *dst, hipStream_t st) {
 	if (n <= 0) return hipSuccess;
-	hipLaunchKernelGGL(decode_windows_kernel, dim3(n), dim3(256), 0, st, bin,
+	hipLaunchKernelGGL(decode_windows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, bin,
 			reinterpret_cast<const unsigned long long *>(starts), n_starts, win, n, dst);
 	return hipGetLastError();
 }
