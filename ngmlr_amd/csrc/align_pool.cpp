@@ -156,11 +156,22 @@ struct FiberContexts {
 		FiberContexts * const self = (FiberContexts *) user;
 		Item * const it = (Item *) itemPtr;
 		if (*slot == 0) {
-			/* what CS::DoRun does for its own thread (reference src/CS.cpp:414-419): the constructor writes the SAM
-			 * prolog once, under NGM's output lock */
-			NGM.AquireOutputLock();
-			*slot = new AlignmentBuffer(Config.getOutputFile());
-			NGM.ReleaseOutputLock();
+			/* What CS::DoRun does for its own thread (reference src/CS.cpp:414-419).  The output lock there protects ONE thing in
+			 * the constructor: the SAM prolog, written by whichever AlignmentBuffer is built first (`if (first) { WriteProlog();
+			 * first = false; }`, src/AlignmentBuffer.h:318-321).  The first context of the process is built under the lock like
+			 * every CS thread's own buffer; by the time it is done the prolog is out -- every producer built its buffer under
+			 * the lock before it submitted anything -- and the thousands that follow need not queue behind each other and behind
+			 * every SAM flush for a constructor that allocates (2 700 of them in a 1.2 s run, CVX_POOL_LOCKED_CTOR=1 restores it). */
+			static std::atomic<bool> prologOut(false);
+			static bool const lockedCtor = [] { const char * e = getenv("CVX_POOL_LOCKED_CTOR"); return e && atoi(e) != 0; }();
+			if (lockedCtor || !prologOut.load(std::memory_order_acquire)) {
+				NGM.AquireOutputLock();
+				*slot = new AlignmentBuffer(Config.getOutputFile());
+				NGM.ReleaseOutputLock();
+				prologOut.store(true, std::memory_order_release);
+			} else {
+				*slot = new AlignmentBuffer(Config.getOutputFile());
+			}
 		}
 		AlignmentBuffer * const buffer = (AlignmentBuffer *) *slot;
 		SharedAligner::ThreadBegin();      /* counts as a worker of its dispatcher only while it holds a read */
@@ -184,7 +195,9 @@ struct FiberContexts {
 		if (hw > 0 && (int) hw < carriers) carriers = (int) hw;
 		/* A container's CPU quota stalls EVERY thread of the process once a period's budget is spent: 16 carriers + 32 CS threads on
 		 * a 16-core quota were throttled for 15 s of thread time in a 1.7 s run, and the dispatcher's cvx_submit with them
-		 * (profiles/r06_e2e_thread_matrix.txt).  The carriers take half of what the cgroup allows; the CS threads (-t) are ngmlr's. */
+		 * (profiles/r06_e2e_thread_matrix.txt).  The carriers take five eighths of what the cgroup allows -- at steady state the
+		 * contexts need twice the CPU of the CS threads (80 000 reads: 22.4 against 11.4 CPU-s, ten carriers 28 500 reads/s against
+		 * eight's 22 500, profiles/r06_e2e_steady_state.txt); the CS threads (-t) are ngmlr's. */
 		{
 			double cores = 0.0;
 			if (FILE * f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -200,8 +213,8 @@ struct FiberContexts {
 				if (quota > 0.0 && period > 0.0) cores = quota / period;
 			}
 			if (cores >= 1.0) {
-				int const half = (int) (cores / 2.0 + 0.5);
-				carriers = std::min(carriers, std::max(2, half));
+				int const share = (int) (cores * 0.625 + 0.5);
+				carriers = std::min(carriers, std::max(2, share));
 			}
 		}
 		if (const char * e = getenv("CVX_POOL_CARRIERS")) carriers = atoi(e) > 0 ? atoi(e) : 1;
