@@ -414,9 +414,9 @@ SharedAligner::~SharedAligner() {
 				g_lastLaunches, g_lastLaunches ? (double) g_lastRequests / (double) g_lastLaunches : 0.0);
 		double const wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_firstJoin).count();
 		fprintf(stderr, "SharedAligner: %ld workers over %.2f s: %.1f %% of their time parked in SingleAlign (%.2f ms per alignment), "
-				"%.1f %% in their text stage; a launch was in flight %.1f %% of the time\n", g_joined, wall,
+				"%.1f %% in their text stage (%.2f CPU-s, %.0f us per alignment); a launch was in flight %.1f %% of the time\n", g_joined, wall,
 				100.0 * g_lastParked / (wall * (double) g_joined), g_lastRequests ? 1e3 * g_lastParked / (double) g_lastRequests : 0.0,
-				100.0 * g_lastFinish / (wall * (double) g_joined), 100.0 * g_lastBusy / wall);
+				100.0 * g_lastFinish / (wall * (double) g_joined), g_lastFinish, g_lastRequests ? 1e6 * g_lastFinish / (double) g_lastRequests : 0.0, 100.0 * g_lastBusy / wall);
 		{
 			long prepared = 0, closedForm = 0;
 			ConvexAlignHip::CorridorStats(prepared, closedForm);

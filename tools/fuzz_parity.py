@@ -37,7 +37,7 @@ SCORINGS = EXOTIC_SCORING + [
 KNOBS = [{}, {}, {}, {"CVX_TUNE_MAX_M": "1"}, {"CVX_TUNE_MAX_M": "1", "CVX_TUNE_CHAIN_M": "2"}, {"CVX_TUNE_MAX_M": "2", "CVX_TUNE_CHAIN_M": "4"},
          {"CVX_TUNE_FORCE_WRAP16": "1"}, {"CVX_TUNE_SSE_VARIANT": "1"}, {"CVX_TUNE_PEN_TABLE": "0"}, {"CVX_TUNE_GANGS": "1"}, {"CVX_TUNE_SMALL_BATCH": "1"},
          {"CVX_TUNE_BT_GROUP": "4"}, {"CVX_TUNE_BT_GROUP": "32"}, {"CVX_TUNE_BT_PER_CLASS": "0"}, {"CVX_TUNE_LATE_MIN": "1"},
-         {"CVX_TUNE_BT_GROUP": "-1"}, {"CVX_TUNE_BT_GROUP": "16"}, {"CVX_TUNE_WIDE_PRIO": "0"}]
+         {"CVX_TUNE_BT_GROUP": "-1"}, {"CVX_TUNE_BT_GROUP": "16"}, {"CVX_TUNE_WIDE_PRIO": "0"}, {"CVX_TUNE_CHAIN_LDS_KB": "0"}, {"CVX_TUNE_CHAIN_LDS_KB": "16"}]
 THREADS = 16
 
 
