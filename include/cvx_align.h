@@ -235,7 +235,8 @@ enum { CVX_CREATE_SERVICE = 1 };
  *   hw_queues_env             GPU_MAX_HW_QUEUES as the process's environment has it now (0: unset)
  *   hw_queues_set_by_library  1: the library exported it when it was loaded; 0: the user's value was left alone.  (The runtime
  *                             reads the variable at ITS first call: a value exported after that -- HIP initialised before this
- *                             library was loaded -- has no effect, which no runtime call can report: compare launch traces.)
+ *                             library was loaded -- has no effect; runtime_up_at_load says whether that was the case, and the first
+ *                             cvx_create then says so on stderr.)
  *   blocking_sync             1: hipDeviceScheduleBlockingSync applied to the device by the first cvx_create; 0: not in effect
  *                             (blocking_sync_why: 2 the runtime refused -- a context was already active --, 3 CVX_WAIT=spin);
  *                             -1: no handle has been created on the device yet
@@ -244,7 +245,8 @@ typedef struct {
 	int32_t hw_queues_env, hw_queues_set_by_library;
 	int32_t blocking_sync, blocking_sync_why;
 	int32_t service_streams;
-	int32_t reserved[3];
+	int32_t runtime_up_at_load;      /* 1: the process already had /dev/kfd open when the library was loaded (a runtime that cannot see the variable any more) */
+	int32_t reserved[2];
 } cvx_regime;
 int cvx_runtime_regime(int device_id, cvx_regime *out);
 int cvx_create_ex(int device_id, const cvx_params *params, uint64_t max_matrix_mb, uint32_t flags, cvx_handle *out);

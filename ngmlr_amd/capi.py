@@ -47,7 +47,7 @@ class CvxTile(C.Structure):
 
 class CvxRegime(C.Structure):
     _fields_ = [("hw_queues_env", C.c_int32), ("hw_queues_set_by_library", C.c_int32), ("blocking_sync", C.c_int32),
-                ("blocking_sync_why", C.c_int32), ("service_streams", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("blocking_sync_why", C.c_int32), ("service_streams", C.c_int32), ("runtime_up_at_load", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 CORRIDOR_ROWS, CORRIDOR_AFFINE, CORRIDOR_CONST = 0, 1, 2

@@ -26,6 +26,8 @@
  * CVX_ERR_NO_DEVICE.
  */
 #include <hip/hip_runtime_api.h>
+#include <dirent.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1271,8 +1273,19 @@ void pack_pool_run(int n_tasks, const std::function<void(int)> &fn) { PackPool::
  * GPU_MAX_HW_QUEUES. */
 static int g_hwq_set_by_library = 0;            /* 1: the constructor exported GPU_MAX_HW_QUEUES itself (the user had not) */
 static std::atomic<int> g_blocking_sync[64];    /* per device: 0 not decided, 1 applied, 2 refused by the runtime, 3 CVX_WAIT=spin */
+static int g_runtime_up_at_load = 0;             /* 1: the process had /dev/kfd open when this library was loaded -- a HIP / HSA runtime was already
+                                                  * initialised, so the variable exported below cannot reach it any more */
 __attribute__((constructor)) static void cvx_process_settings() {
 	g_hwq_set_by_library = getenv("GPU_MAX_HW_QUEUES") == nullptr;
+	if (DIR *d = opendir("/proc/self/fd")) {
+		while (struct dirent *e = readdir(d)) {
+			char path[64], target[64];
+			snprintf(path, sizeof(path), "/proc/self/fd/%s", e->d_name);
+			const ssize_t n = readlink(path, target, sizeof(target) - 1);
+			if (n > 0) { target[n] = 0; if (strcmp(target, "/dev/kfd") == 0) { g_runtime_up_at_load = 1; break; } }
+		}
+		closedir(d);
+	}
 	setenv("GPU_MAX_HW_QUEUES", "16", 0);
 }
 
@@ -1315,6 +1328,7 @@ int cvx_runtime_regime(int device_id, cvx_regime *out) {
 	int shared = 4;
 	if (const char *e2 = getenv("CVX_SERVICE_STREAMS")) shared = atoi(e2) > 0 ? std::min(atoi(e2), kServiceStreamsMax) : 0;
 	out->service_streams = shared;
+	out->runtime_up_at_load = g_runtime_up_at_load;
 	return CVX_OK;
 }
 
@@ -1363,6 +1377,9 @@ int cvx_create_ex(int device_id, const cvx_params *p, uint64_t max_matrix_mb, ui
 		 * already active with another policy) is reported, the waits then spin */
 		static std::once_flag once[64];
 		std::call_once(once[device_id & 63], [&] {
+			if (g_runtime_up_at_load && g_hwq_set_by_library)
+				fprintf(stderr, "cvx_create: a HIP runtime was already initialised when libcvxalign.so was loaded: GPU_MAX_HW_QUEUES=16 came too late for it -- "
+						"export it before the process starts, or mixed launches run their fill classes one after the other (cvx_runtime_regime)\n");
 			const char *w = getenv("CVX_WAIT");
 			if (w && strcmp(w, "spin") == 0) { g_blocking_sync[device_id & 63] = 3; return; }
 			const hipError_t fe = hipSetDeviceFlags(hipDeviceScheduleBlockingSync);

@@ -106,6 +106,6 @@ def test_runtime_regime_without_a_device(built):
     lib = capi.load()
     r = capi.CvxRegime()
     assert lib.cvx_runtime_regime(0, C.byref(r)) == 0
-    assert r.hw_queues_env >= 1 and r.blocking_sync == -1 and r.service_streams == 4
+    assert r.hw_queues_env >= 1 and r.blocking_sync == -1 and r.service_streams == 4 and r.runtime_up_at_load == 0
     assert r.hw_queues_set_by_library == (0 if os.environ.get("CVX_TEST_HWQ_PRESET") else 1) or r.hw_queues_env != 16
     assert lib.cvx_runtime_regime(0, None) != 0
