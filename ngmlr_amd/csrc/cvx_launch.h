@@ -62,16 +62,25 @@ struct SearchArgs {
 	float *scores;                   /* two floats per table entry: forward, reverse */
 	float sensitivity, min_hits;
 	int32_t bin_shift;
-	/* search_wave_kernel (one wave per read, vote table in LDS): candidates of read i at cand + cand_off[i] (a fixed
-	 * kSearchWaveCand entries per read); n_cand[i] = kSearchNeedsHbm when the read has more bins than the LDS table holds */
+	/* search_wave_kernel (one wave per read, vote table in LDS): candidates of read i at cand + cand_off[i] (room for two per
+	 * entry the read can have: search_wave_cand()); n_cand[i] = kSearchNeedsHbm when the read does not fit the LDS table */
 	const uint64_t *cand_off;
 };
-static const int kSearchWaveSlots = 2048;            /* LDS table slots per read (entries <= half of them) */
-static const int kSearchWaveCand = kSearchWaveSlots; /* at most two candidates per entry, entries <= slots / 2 */
+/* the LDS vote map of a read has 2^log2s slots and holds 3/4 of that many bins (cvx_search.hip, LdsVotes) */
+static const int kSearchWaveLog2Min = 9, kSearchWaveLog2Max = 12, kSearchWaveLog2Default = 11;
+static const int kSearchWaveSeq = 4096;              /* longest read (with its NUL) the LDS form takes */
+static inline int search_wave_entries(const int log2s) { return (3 << log2s) / 4; }
+/* the smallest map that certainly holds a read casting `votes` votes (a bin takes at least one); the largest for more than that */
+static inline int search_wave_log2(const unsigned long long votes) {
+	for (int l = kSearchWaveLog2Min; l < kSearchWaveLog2Max; ++l) if (votes <= (unsigned long long) search_wave_entries(l)) return l;
+	return kSearchWaveLog2Max;
+}
 static const int kSearchNeedsHbm = -2;
+size_t search_wave_lds_bytes(int log2s, int seq_cap);
 hipError_t launch_search_count(const SearchArgs &a, hipStream_t st);
 hipError_t launch_search(const SearchArgs &a, hipStream_t st);
-hipError_t launch_search_wave(const SearchArgs &a, hipStream_t st);
+/* seq_cap: bytes of LDS for the read, >= the launch's longest read + 65, a multiple of 4 */
+hipError_t launch_search_wave(const SearchArgs &a, int log2s, int seq_cap, hipStream_t st);
 hipError_t launch_search_wave_hbm(const SearchArgs &a, hipStream_t st);      /* a wave per read over the real table in HBM */
 /* dense[dst_begin[i] ...) = the n_cand[i] candidates of read i, which lie at sparse + src_off[i] */
 hipError_t launch_search_compact(const SearchCandidate *sparse, const uint64_t *src_off, const int32_t *n_cand, const uint64_t *dst_begin,

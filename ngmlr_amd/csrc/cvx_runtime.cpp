@@ -1279,7 +1279,7 @@ __attribute__((constructor)) static void cvx_process_settings() {
 	g_hwq_set_by_library = getenv("GPU_MAX_HW_QUEUES") == nullptr;
 	if (DIR *d = opendir("/proc/self/fd")) {
 		while (struct dirent *e = readdir(d)) {
-			char path[64], target[64];
+			char path[320], target[64];
 			snprintf(path, sizeof(path), "/proc/self/fd/%s", e->d_name);
 			const ssize_t n = readlink(path, target, sizeof(target) - 1);
 			if (n > 0) { target[n] = 0; if (strcmp(target, "/dev/kfd") == 0) { g_runtime_up_at_load = 1; break; } }
@@ -2252,29 +2252,31 @@ static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *cons
 	HIP_TRY(hipMemcpyAsync(ss->d_len.p, h_len, n1 * 4, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(ss->d_miss.p, 0, n1 * 4, st));
 	HIP_TRY(hipMemsetAsync(ss->d_maxhit.p, 0, n1 * 4, st));
-	/* Every read starts on the wave-per-read kernel with its vote table in LDS (cvx_search.hip); a read with more bins than that
-	 * table holds, or longer than its sequence buffer, is redone -- the same attempt, then the rest of the ladder -- by the same
-	 * kernel over the real table in HBM, which needs the vote count of the reads to size its lists.  Candidates of read i
-	 * lie at d_cand + src_off[i]: a fixed kSearchWaveCand entries for an LDS-table read, the sparse region behind all of those
-	 * (two slots per vote) for the others.  CVX_TUNE_SEARCH_WAVE=2 sends every read to the HBM-table form, =0 to the
-	 * lane-per-read kernel (one serial chain of votes per read; an independent implementation: tests, A/B). */
+	/* A read starts on the wave-per-read kernel with its vote map in LDS (cvx_search.hip), in the smallest map that certainly holds
+	 * it: a call of CVX_TUNE_SEARCH_CLASSIFY (2 048) reads or more counts every read's votes first (one cheap kernel and one round
+	 * trip) and sorts the reads into launches by map size -- 6 KB of LDS for a read of <= 384 votes, 24 KB for <= 1 536, 48 KB
+	 * above -- so that as many reads as possible share a CU; a smaller call takes the 2^11-slot map for every read without
+	 * counting (its reads do not fill the device anyway).  A read that does not fit its map after all (more than 3 072 bins; a bin
+	 * beyond 32 bits; longer than the sequence buffer) is redone -- the same attempt, then the rest of the ladder -- by the same
+	 * kernel over the real table in HBM, which needs the vote count to size its lists.  Candidates of read i lie at d_cand +
+	 * src_off[i]: two per bin its map can hold (or per vote, when that is fewer) for an LDS-map read, the sparse region behind all
+	 * of those (two slots per vote) for the others.  CVX_TUNE_SEARCH_WAVE=2 sends every read to the HBM-table form, =0 to the
+	 * lane-per-read kernel (one serial chain of votes per read; an independent implementation: tests, A/B);
+	 * CVX_TUNE_SEARCH_LOG2=9..12 forces one map size (tests: a small one sends most reads through the fall-back). */
 	const char *wave_env = getenv("CVX_TUNE_SEARCH_WAVE");      /* (read per call: the parity tests switch it inside one process) */
 	const int wave_mode = wave_env ? atoi(wave_env) : 1;
 	const bool use_wave = wave_mode == 1;
 	const bool lane_serial = wave_mode == 0;
-	const uint64_t fixed_total = (uint64_t) n * (uint64_t) kSearchWaveCand;
-	RC_TRY(ss->d_cand.ensure((size_t) fixed_total + 64));
-	RC_TRY(ss->d_srcoff.ensure(n1));
-	RC_TRY(ss->h_srcoff.ensure(n1 * 8));
-	uint64_t *h_srcoff = ss->h_srcoff.as<uint64_t>();
-	for (int i = 0; i < n; ++i) h_srcoff[i] = (uint64_t) i * (uint64_t) kSearchWaveCand;
-	HIP_TRY(hipMemcpyAsync(ss->d_srcoff.p, h_srcoff, n1 * 8, hipMemcpyHostToDevice, st));
+	const char *cls_env = getenv("CVX_TUNE_SEARCH_CLASSIFY"), *log2_env = getenv("CVX_TUNE_SEARCH_LOG2");
+	const int classify_min = cls_env ? atoi(cls_env) : 2048;
+	const int forced_log2 = log2_env ? std::min(kSearchWaveLog2Max, std::max(kSearchWaveLog2Min, atoi(log2_env))) : 0;
+	const bool classify = use_wave && !forced_log2 && n >= classify_min;
 	bool counted = false;
 	uint64_t total = 0;             /* votes of the reads that took the HBM-table form so far: their rList / candidate regions */
 	std::vector<uint8_t> has_region(n1, 0);
 	ss->kev_used = 0;
 	ss->kernel_ms = 0.0f;
-	auto count_votes = [&]() -> int {      /* votes per read (all reads: the pass is cheap): sizes of the HBM kernel's lists */
+	auto count_votes = [&]() -> int {      /* votes per read (all reads: the pass is cheap): map sizes, sizes of the HBM kernel's lists */
 		RC_TRY(ss->kmark(st));
 		HIP_TRY(launch_search_count(a, st));
 		RC_TRY(ss->kmark(st));
@@ -2283,6 +2285,23 @@ static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *cons
 		counted = true;
 		return CVX_OK;
 	};
+	if (classify) RC_TRY(count_votes());
+	std::vector<uint8_t> map_log2(n1, 0);      /* 0: not an LDS-map read */
+	RC_TRY(ss->d_srcoff.ensure(n1));
+	RC_TRY(ss->h_srcoff.ensure(n1 * 8));
+	uint64_t *h_srcoff = ss->h_srcoff.as<uint64_t>();
+	uint64_t fixed_total = 0;
+	for (int i = 0; i < n; ++i) {
+		h_srcoff[i] = fixed_total;
+		if (!use_wave || h_len[i] + 1 > kSearchWaveSeq) continue;
+		const int l = forced_log2 ? forced_log2 : classify ? search_wave_log2(h_events[i]) : kSearchWaveLog2Default;
+		map_log2[(size_t) i] = (uint8_t) l;
+		uint64_t bins = (uint64_t) search_wave_entries(l);
+		if (classify && h_events[i] < bins) bins = h_events[i];
+		fixed_total += 2 * bins;
+	}
+	RC_TRY(ss->d_cand.ensure((size_t) fixed_total + 64));
+	HIP_TRY(hipMemcpyAsync(ss->d_srcoff.p, h_srcoff, n1 * 8, hipMemcpyHostToDevice, st));
 	/* Regions only for the reads that really go to the HBM-table form, handed out when a read first gets there and kept for its
 	 * retries (sizing them by the votes of all n reads cost a repeat-rich call gigabytes per handle).  The
 	 * candidate arena grows without losing the lists already in it. */
@@ -2321,7 +2340,7 @@ static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *cons
 	std::string tr;
 	auto tr_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
 	std::vector<int32_t> work_wave, work_hbm;
-	for (int i = 0; i < n; ++i) (use_wave ? work_wave : work_hbm).push_back(i);
+	for (int i = 0; i < n; ++i) (map_log2[(size_t) i] ? work_wave : work_hbm).push_back(i);
 	ss->attempts.assign(n1, 0);
 	for (int attempt = 0; !work_wave.empty() || !work_hbm.empty(); ++attempt) {
 		const int bits = attempt == 0 ? bits0 : bits0 + 1 + attempt;
@@ -2330,16 +2349,25 @@ static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *cons
 		for (int32_t i : work_hbm) ss->attempts[(size_t) i] += 1;
 		a.bits = bits;
 		a.hpoc_factor = attempt == 0 ? 0.333f : 0.777f;
-		a.work = ss->d_work.p;
 		std::vector<int32_t> next_wave, next_hbm, hbm_now(work_hbm);
 		if (!work_wave.empty()) {
-			memcpy(h_work, work_wave.data(), work_wave.size() * 4);
-			HIP_TRY(hipMemcpyAsync(ss->d_work.p, h_work, work_wave.size() * 4, hipMemcpyHostToDevice, st));
-			a.n_work = (int32_t) work_wave.size();
+			/* one launch per map size, back to back (the work list holds the sizes' reads one after the other) */
+			size_t at = 0;
 			a.cand = ss->d_cand.p; a.cand_off = ss->d_srcoff.p;
-			RC_TRY(ss->kmark(st));
-			HIP_TRY(launch_search_wave(a, st));
-			RC_TRY(ss->kmark(st));
+			for (int l = kSearchWaveLog2Min; l <= kSearchWaveLog2Max; ++l) {
+				const size_t first = at;
+				int longest = 0;
+				for (int32_t i : work_wave) if (map_log2[(size_t) i] == l) { h_work[at++] = i; longest = std::max(longest, h_len[i]); }
+				if (at == first) continue;
+				HIP_TRY(hipMemcpyAsync(ss->d_work.p + first, h_work + first, (at - first) * 4, hipMemcpyHostToDevice, st));
+				a.work = ss->d_work.p + first;
+				a.n_work = (int32_t) (at - first);
+				RC_TRY(ss->kmark(st));
+				HIP_TRY(launch_search_wave(a, l, (longest + 65 + 63) / 64 * 64, st));
+				RC_TRY(ss->kmark(st));
+				if (trace) { char b[96]; snprintf(b, sizeof(b), " [2^%d-slot maps: %zu reads]", l, at - first); tr += b; }
+			}
+			a.work = ss->d_work.p;
 			HIP_TRY(hipMemcpyAsync(h_ncand, ss->d_ncand.p, n1 * 4, hipMemcpyDeviceToHost, st));
 			RC_TRY(search_wait(ss, st));
 			for (int32_t i : work_wave) {
@@ -2349,6 +2377,7 @@ static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *cons
 			if (trace) { char b[160]; snprintf(b, sizeof(b), " [bits %d wave %zu -> %zu to hbm, %zu retry, at %.2f ms]", bits, work_wave.size(), hbm_now.size() - work_hbm.size(), next_wave.size(), tr_ms()); tr += b; }
 		}
 		if (!hbm_now.empty()) {
+			a.work = ss->d_work.p;
 			if (!counted) RC_TRY(count_votes());
 			RC_TRY(give_regions(hbm_now));
 			for (int32_t i : hbm_now) h_srcoff[i] = fixed_total + 2 * h_listoff[i];

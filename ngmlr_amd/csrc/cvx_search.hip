@@ -223,13 +223,13 @@ search_kernel(const SearchArgs a) {
  * Two tables behind the same code (template parameter):
  *   LdsVotes  the reference's table of 2^bits entries is needed only for its COLLISION BEHAVIOUR (which probe step opens
  *             which entry, when the budget runs out): it stays virtual, and the slots a sub-read really occupies live in an
- *             LDS map  virtual slot -> (bin, forward score, reverse score, listed).  A read with more bins than the map
- *             holds (kSearchWaveSlots / 2), or longer than its sequence buffer, is flagged kSearchNeedsHbm and redone with
+ *             LDS map  virtual slot -> (bin, forward score, reverse score, listed) of 2^9 .. 2^12 slots, sized per read by
+ *             the host from the read's vote count.  A read with more bins than its map holds (3/4 of the slots), a bin
+ *             beyond 32 bits, a score beyond 16, or longer than kSearchWaveSeq, is flagged kSearchNeedsHbm and redone with
  *   HbmVotes  the real table in HBM (keys / scores of search_kernel's layout), any number of bins, any read length.
  * Same outputs as search_kernel: candidates at cand + cand_off[i] (LdsVotes) or cand + 2 * list_off[i] (HbmVotes).
  */
 namespace {
-const int kSearchWaveSeq = 4096;        /* longest read (with its NUL) the LDS form takes */
 const uint32_t kFreeSlot = 0xFFFFFFFFu;
 enum { kProbeFree = 0, kProbeMatch = 1, kProbeOther = 2 };
 
@@ -259,53 +259,74 @@ __device__ __forceinline__ uint64_t shfl_u64(const uint64_t v, const int src) {
 
 struct LdsVotes {
 	static const bool kLds = true;
-	struct Store {
-		uint32_t slot[kSearchWaveSlots];      /* virtual slot of the entry | listed << 31; kFreeSlot: free */
-		uint32_t bin_lo[kSearchWaveSlots], bin_hi[kSearchWaveSlots];
-		float f[kSearchWaveSlots], r[kSearchWaveSlots];
-		uint16_t rlist[kSearchWaveSlots / 2];
-		uint8_t seq[kSearchWaveSeq + 64];     /* the read and its NUL: the serial walk reads LDS, not HBM */
-	};
-	Store *T;
+	/* The map of one read, carved out of the workgroup's dynamic LDS (round 6): `slots` = 2^log2s entries of 12 bytes --
+	 *   slot[h]  virtual slot of the entry | listed << 31 (kFreeSlot: free)
+	 *   bin[h]   the bin, 32 bits: a vote whose bin does not fit sends the read to the table in HBM (a location before the start of
+	 *            the unit, i.e. a negative difference; no genome has 2^36 bases per unit)
+	 *   fr[h]    forward score in the low half, reverse score in the high half, as integers: votes are +1.0f, so a score IS a count; a
+	 *            count that would pass 65535 sends the read to HBM as well
+	 * -- at most 3/4 full, behind them rList (16-bit map positions) and the read.  Round 5's map was 2 048 slots of 20 bytes at most
+	 * half full, 47 KB whatever the read: three reads per CU, and a sub-read of a 512 Mbp genome (1 200-1 450 bins) never fitted.
+	 * The host picks log2s per read from its vote count (search_common): 6 KB for a read with <= 384 votes, 24 KB for one with
+	 * <= 1 536. */
+	uint32_t *slot, *bin, *fr;
+	uint16_t *rlist;
+	uint8_t *seq;
+	int log2s, cap;
+	uint32_t smask;
 	int entries;
+	static __host__ __device__ size_t bytes(const int log2s, const int seq_cap) {
+		const size_t S = (size_t) 1 << log2s;
+		return S * 12 + (S * 3 / 4) * 2 + (size_t) seq_cap;
+	}
+	__device__ void carve(uint32_t *base, const int log2s_) {
+		log2s = log2s_;
+		const uint32_t S = 1u << log2s;
+		smask = S - 1u; cap = (int) (S * 3u / 4u);
+		slot = base; bin = base + S; fr = base + 2u * S;
+		rlist = reinterpret_cast<uint16_t *>(base + 3u * S);
+		seq = reinterpret_cast<uint8_t *>(rlist + cap);
+		entries = 0;
+	}
 	__device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
-	__device__ int seq_at(const int p) { return T->seq[p]; }
+	__device__ int seq_at(const int p) { return seq[p]; }
+	__device__ static bool fits(const uint64_t b) { return (b >> 32) == 0ull; }
 	/* what the virtual table holds at slot e, as far as a vote for `bin` cares */
-	__device__ int find(const uint32_t e, const uint64_t bin, int &idx, bool &listed) const {
-		static_assert(kSearchWaveSlots == 2048, "the map's hash keeps 11 bits");
-		int h = (int) ((e * 2654435761u) >> (32 - 11));
+	__device__ int find(const uint32_t e, const uint64_t b, int &idx, bool &listed) const {
+		uint32_t h = (e * 2654435761u) >> (32 - log2s);
 		uint32_t sv;
 		for (;;) {
-			sv = T->slot[h];
+			sv = slot[h];
 			if (sv == kFreeSlot || (sv & 0x7FFFFFFFu) == e) break;
-			h = (h + 1) & (kSearchWaveSlots - 1);
+			h = (h + 1u) & smask;
 		}
 		if (sv == kFreeSlot) return kProbeFree;
-		if (T->bin_lo[h] == (uint32_t) bin && T->bin_hi[h] == (uint32_t) (bin >> 32)) { idx = h; listed = (sv >> 31) != 0u; return kProbeMatch; }
+		if (bin[h] == (uint32_t) b) { idx = (int) h; listed = (sv >> 31) != 0u; return kProbeMatch; }
 		return kProbeOther;
 	}
 	/* open (or join, when another lane of the batch just opened it) the entry of virtual slot e */
-	__device__ void claim(const uint32_t e, const uint64_t bin, int &idx, bool &creator, bool &hazard) {
-		int h = (int) ((e * 2654435761u) >> (32 - 11));
+	__device__ void claim(const uint32_t e, const uint64_t b, int &idx, bool &creator, bool &hazard) {
+		uint32_t h = (e * 2654435761u) >> (32 - log2s);
 		for (;;) {
-			const uint32_t old = atomicCAS(&T->slot[h], kFreeSlot, e);
-			if (old == kFreeSlot) { creator = true; T->bin_lo[h] = (uint32_t) bin; T->bin_hi[h] = (uint32_t) (bin >> 32); T->f[h] = 0.0f; T->r[h] = 0.0f; break; }
+			const uint32_t old = atomicCAS(&slot[h], kFreeSlot, e);
+			if (old == kFreeSlot) { creator = true; bin[h] = (uint32_t) b; fr[h] = 0u; break; }
 			if ((old & 0x7FFFFFFFu) == e) break;
-			h = (h + 1) & (kSearchWaveSlots - 1);
+			h = (h + 1u) & smask;
 		}
-		idx = h;
+		idx = (int) h;
 		hazard = false;         /* decided by verify() once the creators' bins are visible */
 	}
-	__device__ bool verify(const int idx, const uint64_t bin) const { return T->bin_lo[idx] == (uint32_t) bin && T->bin_hi[idx] == (uint32_t) (bin >> 32); }
-	__device__ void unclaim(const int idx, const uint32_t e) { (void) e; T->slot[idx] = kFreeSlot; }
-	__device__ float score(const int idx, const bool rev) const { return rev ? T->r[idx] : T->f[idx]; }
-	__device__ void set_score(const int idx, const bool rev, const float s) { if (rev) T->r[idx] = s; else T->f[idx] = s; }
-	__device__ void set_listed(const int idx, const uint32_t e) { T->slot[idx] = e | 0x80000000u; }
-	__device__ void list_put(const int pos, const int idx) { T->rlist[pos] = (uint16_t) idx; }
-	__device__ int list_at(const int pos) const { return T->rlist[pos]; }
-	__device__ uint64_t bin_of(const int idx) const { return ((uint64_t) T->bin_hi[idx] << 32) | T->bin_lo[idx]; }
-	__device__ float2 scores_of(const int idx) const { return make_float2(T->f[idx], T->r[idx]); }
-	__device__ bool room_for(const int n_new) const { return entries + n_new <= kSearchWaveSlots / 2; }
+	__device__ bool verify(const int idx, const uint64_t b) const { return bin[idx] == (uint32_t) b; }
+	__device__ void unclaim(const int idx, const uint32_t e) { (void) e; slot[idx] = kFreeSlot; }
+	__device__ float score(const int idx, const bool rev) const { return (float) reinterpret_cast<const uint16_t *>(fr)[2 * idx + (rev ? 1 : 0)]; }
+	__device__ static bool score_fits(const float s) { return s <= 65535.0f; }
+	__device__ void set_score(const int idx, const bool rev, const float s) { reinterpret_cast<uint16_t *>(fr)[2 * idx + (rev ? 1 : 0)] = (uint16_t) (uint32_t) s; }
+	__device__ void set_listed(const int idx, const uint32_t e) { slot[idx] = e | 0x80000000u; }
+	__device__ void list_put(const int pos, const int idx) { rlist[pos] = (uint16_t) idx; }
+	__device__ int list_at(const int pos) const { return rlist[pos]; }
+	__device__ uint64_t bin_of(const int idx) const { return (uint64_t) bin[idx]; }
+	__device__ float2 scores_of(const int idx) const { const uint32_t v = fr[idx]; return make_float2((float) (v & 0xFFFFu), (float) (v >> 16)); }
+	__device__ bool room_for(const int n_new) const { return entries + n_new <= cap; }
 };
 
 struct HbmVotes {
@@ -357,6 +378,8 @@ struct HbmVotes {
 	__device__ uint64_t bin_of(const int idx) const { return __hip_atomic_load(&keys[(uint32_t) idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~kListed; }
 	__device__ float2 scores_of(const int idx) const { return make_float2(score(idx, false), score(idx, true)); }
 	__device__ bool room_for(const int n_new) const { (void) n_new; return true; }
+	__device__ static bool fits(const uint64_t b) { (void) b; return true; }
+	__device__ static bool score_fits(const float s) { (void) s; return true; }
 };
 
 /* the running state of a read's vote (CS::RunRead's locals, CS.cpp:324-398) */
@@ -405,6 +428,7 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 			listed = false;
 		} else {
 			score = tb.score(idx, reverse) + 1.0f;
+			if (!TABLE::score_fits(score)) { S.too_many = true; return; }
 		}
 		if (lane == 0) tb.set_score(idx, reverse, score);
 		if (score > S.max_hit) { S.max_hit = score; S.thresh = S.max_hit * a.sensitivity; }
@@ -471,6 +495,7 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		}
 		float s = 0.0f;
 		if (active) s = tb.score(idx, rev) + (float) (__popcll(grp_hr & lt) + 1);
+		if (TABLE::kLds && __ballot(active && !TABLE::score_fits(s)) != 0ull) { S.too_many = true; return; }      /* (the attempt is discarded: what it already changed does not matter) */
 		const float pm = wave_incl_max(s, lane);
 		const float mh = pm > S.max_hit ? pm : S.max_hit;                 /* maxHitNumber right after this vote */
 		const bool qual = active && s >= mh * a.sensitivity;
@@ -524,6 +549,7 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 				const unsigned long long corr = rev ? (unsigned long long) read_len - (pos + (unsigned long long) K) : pos;
 				bin = (loc - corr) >> a.bin_shift;
 			}
+			if (TABLE::kLds && __ballot(active && !TABLE::fits(bin)) != 0ull) { S.too_many = true; break; }
 			cast_batch(active, bin, rev, c);
 		}
 		if (!S.overflow && !S.too_many) S.misses += C.miss_upto[63];
@@ -595,21 +621,21 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 }  // namespace
 
 __global__ void __launch_bounds__(64)
-search_wave_kernel(const SearchArgs a) {
-	__shared__ LdsVotes::Store T;
+search_wave_kernel(const SearchArgs a, const int log2s, const int seq_cap) {
+	extern __shared__ uint32_t map_lds[];
 	__shared__ ChunkRows C;
 	const int q = blockIdx.x;
 	if (q >= a.n_work) return;
 	const int lane = threadIdx.x;
 	const int i = a.work ? a.work[q] : q;
 	const int read_len = a.seq_len[i];
-	if (read_len + 1 > kSearchWaveSeq) { if (lane == 0) a.n_cand[i] = kSearchNeedsHbm; return; }
+	if (read_len + 65 > seq_cap) { if (lane == 0) a.n_cand[i] = kSearchNeedsHbm; return; }      /* (the host sized seq_cap for the launch's longest read: cannot happen) */
 	const uint8_t *gseq = a.seq + a.seq_off[i];
-	for (int s = lane; s < kSearchWaveSlots; s += 64) T.slot[s] = kFreeSlot;
-	for (int s = lane; s < read_len + 64; s += 64) T.seq[s] = s < read_len ? gseq[s] : (uint8_t) 0;      /* coalesced; NULs behind the read */
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	LdsVotes tb;
-	tb.T = &T; tb.entries = 0;
+	tb.carve(map_lds, log2s);
+	for (uint32_t s = (uint32_t) lane; s <= tb.smask; s += 64u) tb.slot[s] = kFreeSlot;
+	for (int s = lane; s < read_len + 64; s += 64) tb.seq[s] = s < read_len ? gseq[s] : (uint8_t) 0;      /* coalesced; NULs behind the read */
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	search_vote_read(a, tb, C, i, lane, a.cand + a.cand_off[i]);
 }
 
@@ -652,9 +678,12 @@ hipError_t launch_search_compact(const SearchCandidate *sparse, const uint64_t *
 	return hipGetLastError();
 }
 
-hipError_t launch_search_wave(const SearchArgs &a, hipStream_t st) {
+size_t search_wave_lds_bytes(const int log2s, const int seq_cap) { return LdsVotes::bytes(log2s, seq_cap); }
+
+hipError_t launch_search_wave(const SearchArgs &a, const int log2s, const int seq_cap, hipStream_t st) {
 	if (a.n_work <= 0) return hipSuccess;
-	hipLaunchKernelGGL(search_wave_kernel, dim3(a.n_work), dim3(64), 0, st, a);
+	if (log2s < kSearchWaveLog2Min || log2s > kSearchWaveLog2Max || seq_cap < 65 || seq_cap > kSearchWaveSeq + 64 || (seq_cap & 3)) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(search_wave_kernel, dim3(a.n_work), dim3(64), LdsVotes::bytes(log2s, seq_cap), st, a, log2s, seq_cap);
 	return hipGetLastError();
 }
 

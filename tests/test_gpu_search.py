@@ -19,11 +19,18 @@ def _same(got, loc, sc, rev):
         and np.array_equal(got["reverse"], rev)
 
 
-@pytest.fixture(params=["wave", "wave_hbm", "lane"])
+@pytest.fixture(params=["wave", "wave_sorted", "wave_small", "wave_hbm", "lane"])
 def search_kernel(request, monkeypatch):
-    """The device kernels of the vote: one wave per read casting 64 votes at a time, with the vote table in LDS (the default; reads
+    """The device kernels of the vote: one wave per read casting 64 votes at a time, with the vote map in LDS (the default; reads
     it cannot hold fall back per read) or with the real table in HBM (CVX_TUNE_SEARCH_WAVE=2 sends every read there), and one lane
-    per read casting its votes one by one over a table in HBM (=0: an independent implementation of the same contract)."""
+    per read casting its votes one by one over a table in HBM (=0: an independent implementation of the same contract).  The LDS
+    form three ways: as a small call takes it (one map size for every read), as a large call does (CVX_TUNE_SEARCH_CLASSIFY=0:
+    votes counted first, reads sorted into launches by map size, 2^9 .. 2^12 slots), and with the smallest map forced on every
+    read (CVX_TUNE_SEARCH_LOG2=9: most reads overflow it and are redone over the table in HBM)."""
+    if request.param == "wave_sorted":
+        monkeypatch.setenv("CVX_TUNE_SEARCH_CLASSIFY", "0")
+    if request.param == "wave_small":
+        monkeypatch.setenv("CVX_TUNE_SEARCH_LOG2", "9")
     if request.param == "wave_hbm":
         monkeypatch.setenv("CVX_TUNE_SEARCH_WAVE", "2")
     if request.param == "lane":
@@ -90,7 +97,10 @@ def test_device_search_on_a_repeat_rich_reference(hip_aligner, search_kernel, ca
     finally:
         ix.free()
     err = capfd.readouterr().err
-    if search_kernel == "wave":
+    if search_kernel == "wave_sorted":
+        sizes = set(int(x) for x in re.findall(r"2\^(\d+)-slot maps", err))
+        assert len(sizes) >= 3, "the reads of this recording should spread over the map sizes\n" + err[-600:]
+    if search_kernel == "wave_small":
         to_hbm = sum(int(x) for x in re.findall(r"wave \d+ -> (\d+) to hbm", err))
         assert to_hbm >= 10, "no sub-read overflowed the LDS vote map: the transition to the HBM-table form was not exercised\n" + err[-600:]
 

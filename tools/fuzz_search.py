@@ -6,8 +6,8 @@ Round r (seed = seed0 + r): a fresh reference of 1-6 Mbp in 1-5 sequences with r
 (synth.big_reference), ngmlr's k-mer table of it (cvx_genome_encode + cvx_index_build), 2 500 sub-reads of a length drawn for the
 round (64 ... 1 000; 15 % error, half reverse-complemented) plus odd ones -- random junk, reads with N, reads shorter than a k-mer,
 a microsatellite read, reads of one repeat unit --, CS::RunRead's parameters drawn for the round (sensitivity, minimum hits, bin
-shift, first table size 2^8 ... 2^18) and one of the three kernel forms (one wave per read with the vote map in LDS, the same over
-the table in HBM, one lane per read).  Every list is compared with the CPU restatement over the very same table on 16 host threads:
+shift, first table size 2^8 ... 2^18) and one of the kernel forms (one wave per read with the vote map in LDS -- one map size, sorted
+by map size, the smallest sizes forced --, the same over the table in HBM, one lane per read).  Every list is compared with the CPU restatement over the very same table on 16 host threads:
 entries, order, scores, strands, maxHitNumber, kCount.  Stops at the first round with a mismatch (exit code 1)."""
 import os
 import sys
@@ -23,7 +23,11 @@ from ngmlr_amd.aligner import ConvexAlignHip, KmerIndex   # noqa: E402
 from oracle.pyoracle import SearchOracle                  # noqa: E402
 
 THREADS = 16
-FORMS = [("wave", None), ("wave", None), ("wave_hbm", "2"), ("lane", "0")]
+# (name, environment of the search call): the runtime reads these per call
+FORMS = [("wave", {}), ("wave sorted by map size", {"CVX_TUNE_SEARCH_CLASSIFY": "0"}), ("wave sorted by map size", {"CVX_TUNE_SEARCH_CLASSIFY": "0"}),
+         ("wave 2^9 maps", {"CVX_TUNE_SEARCH_LOG2": "9"}), ("wave 2^10 maps", {"CVX_TUNE_SEARCH_LOG2": "10"}), ("wave 2^12 maps", {"CVX_TUNE_SEARCH_LOG2": "12"}),
+         ("wave_hbm", {"CVX_TUNE_SEARCH_WAVE": "2"}), ("lane", {"CVX_TUNE_SEARCH_WAVE": "0"})]
+KNOBS = ("CVX_TUNE_SEARCH_WAVE", "CVX_TUNE_SEARCH_CLASSIFY", "CVX_TUNE_SEARCH_LOG2")
 
 
 def main():
@@ -38,11 +42,8 @@ def main():
         mbp = float(rng.choice([1, 2, 4, 6]))
         n_ctg = int(rng.integers(1, 6))
         contigs = synth.big_reference(int(mbp * (1 << 20)), n_contigs=n_ctg, seed=seed, families=int(rng.integers(2, 12)), microsats=int(rng.integers(5, 60)))
-        form, wave_env = FORMS[int(rng.integers(0, len(FORMS)))]
-        if wave_env is None: os.environ.pop("CVX_TUNE_SEARCH_WAVE", None)
-        else: os.environ["CVX_TUNE_SEARCH_WAVE"] = wave_env
+        form, form_env = FORMS[int(rng.integers(0, len(FORMS)))]
         al = ConvexAlignHip(device=0)
-        os.environ.pop("CVX_TUNE_SEARCH_WAVE", None)
         idx5, locs, starts = synth.kmer_table(al.lib, contigs)
         length = int(rng.choice([64, 128, 256, 256, 400, 1000]))
         reads = synth.sample_subreads(contigs, 2500, length=length, err=float(rng.choice([0.05, 0.15, 0.25])), seed=seed)
@@ -59,10 +60,13 @@ def main():
                "bin_shift": int(rng.choice([2, 4, 4, 6])), "first_bits": int(rng.choice([8, 10, 12, 16, 16, 18]))}
         ix = KmerIndex(al, 13, idx5.view(np.dtype([("tab", "<u4"), ("rc", "i1")])), locs, 0)
         try:
+            for kn in KNOBS: os.environ.pop(kn, None)
+            os.environ.update(form_env)          # (round 6: until then the variable was cleared again before the call that reads it)
             t0 = time.time()
             got, max_hit, misses = ix.search(reads, extras=True, **par)
             t1 = time.time()
         finally:
+            for kn in KNOBS: os.environ.pop(kn, None)
             ix.free()
             al.close()
         orc = SearchOracle(raw=(13, 0, idx5, locs))
