@@ -242,18 +242,34 @@ struct ChunkRows {                      /* the chunk of <= 64 k-mers being cast 
 	uint8_t scr[256];                              /* duplicate detection inside a batch */
 };
 
+/* Inclusive scans over the wave on the DPP path (round 6; six ds_bpermute round trips each until then): row_shr 1 / 2 / 4 / 8 inside a
+ * row of 16 lanes -- a lane whose source lies outside its row takes the identity --, then lane 15 of a row into the next row
+ * (row_bcast:15, rows 1 and 3) and lane 31 into rows 2 and 3 (row_bcast:31).  Every lane of the wave has to be active. */
+/* A wave is its own workgroup here and its LDS instructions execute in order: what one lane wrote is there for the next LDS
+ * instruction of any lane.  Only the compiler has to be kept from moving accesses across; a workgroup-scope fence would also
+ * wait for every global load in flight (the next batch's locations). */
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+#define CVX_DPP(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rows), 0xf, false)
 __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, const int lane) {
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) { const uint32_t u = (uint32_t) __shfl_up((int) v, d, 64); if (lane >= d) v += u; }
+	(void) lane;
+	v += (uint32_t) CVX_DPP((int) v, 0x111, 0xf); v += (uint32_t) CVX_DPP((int) v, 0x112, 0xf);
+	v += (uint32_t) CVX_DPP((int) v, 0x114, 0xf); v += (uint32_t) CVX_DPP((int) v, 0x118, 0xf);
+	v += (uint32_t) CVX_DPP((int) v, 0x142, 0xa); v += (uint32_t) CVX_DPP((int) v, 0x143, 0xc);
 	return v;
 }
+/* (v >= 0: the identity is 0.0f) */
 __device__ __forceinline__ float wave_incl_max(float v, const int lane) {
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) { const float u = __shfl_up(v, d, 64); if (lane >= d) v = u > v ? u : v; }
+	(void) lane;
+#define CVX_DPP_FMAX(ctrl, rows) { const float u = __int_as_float(CVX_DPP(__float_as_int(v), ctrl, rows)); v = u > v ? u : v; }
+	CVX_DPP_FMAX(0x111, 0xf) CVX_DPP_FMAX(0x112, 0xf) CVX_DPP_FMAX(0x114, 0xf) CVX_DPP_FMAX(0x118, 0xf) CVX_DPP_FMAX(0x142, 0xa) CVX_DPP_FMAX(0x143, 0xc)
+#undef CVX_DPP_FMAX
 	return v;
 }
-__device__ __forceinline__ uint64_t shfl_u64(const uint64_t v, const int src) {
-	const uint32_t lo = (uint32_t) __shfl((int) (uint32_t) v, src, 64), hi = (uint32_t) __shfl((int) (uint32_t) (v >> 32), src, 64);
+/* lane `src` (the same for every lane) of a register: v_readlane, no LDS round trip */
+__device__ __forceinline__ int lane_of(const int v, const int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float lane_of(const float v, const int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ uint64_t lane_of(const uint64_t v, const int src) {
+	const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, src), hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), src);
 	return ((uint64_t) hi << 32) | lo;
 }
 
@@ -288,30 +304,37 @@ struct LdsVotes {
 		seq = reinterpret_cast<uint8_t *>(rlist + cap);
 		entries = 0;
 	}
-	__device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
-	__device__ int seq_at(const int p) { return seq[p]; }
+	__device__ void fence() const { lds_fence(); }
+	__device__ int char_at(const int p) const { return seq[p]; }
+	/* the map's own probe sequence of key e: double hashing (an odd step walks all 2^log2s slots) -- the lanes of a batch probe at
+	 * once and the wave waits for the longest chain, which under linear probing at 60 % load is several times the mean */
+	__device__ uint32_t first_slot(const uint32_t e) const { return (e * 2654435761u) >> (32 - log2s); }
+	__device__ uint32_t slot_step(const uint32_t e) const { return ((e * 0x85EBCA6Bu) >> (32 - log2s)) | 1u; }
 	__device__ static bool fits(const uint64_t b) { return (b >> 32) == 0ull; }
 	/* what the virtual table holds at slot e, as far as a vote for `bin` cares */
 	__device__ int find(const uint32_t e, const uint64_t b, int &idx, bool &listed) const {
-		uint32_t h = (e * 2654435761u) >> (32 - log2s);
+		uint32_t h = first_slot(e);
+		const uint32_t step = slot_step(e);
 		uint32_t sv;
 		for (;;) {
 			sv = slot[h];
 			if (sv == kFreeSlot || (sv & 0x7FFFFFFFu) == e) break;
-			h = (h + 1u) & smask;
+			h = (h + step) & smask;
 		}
-		if (sv == kFreeSlot) return kProbeFree;
+		if (sv == kFreeSlot) { idx = (int) h; return kProbeFree; }      /* (where claim() starts) */
 		if (bin[h] == (uint32_t) b) { idx = (int) h; listed = (sv >> 31) != 0u; return kProbeMatch; }
 		return kProbeOther;
 	}
-	/* open (or join, when another lane of the batch just opened it) the entry of virtual slot e */
+	/* open (or join, when another lane of the batch just opened it) the entry of virtual slot e; idx: the free map slot find()
+	 * ended at -- everything before it on e's probe sequence is taken by other keys and stays so */
 	__device__ void claim(const uint32_t e, const uint64_t b, int &idx, bool &creator, bool &hazard) {
-		uint32_t h = (e * 2654435761u) >> (32 - log2s);
+		uint32_t h = (uint32_t) idx;
+		const uint32_t step = slot_step(e);
 		for (;;) {
 			const uint32_t old = atomicCAS(&slot[h], kFreeSlot, e);
 			if (old == kFreeSlot) { creator = true; bin[h] = (uint32_t) b; fr[h] = 0u; break; }
 			if ((old & 0x7FFFFFFFu) == e) break;
-			h = (h + 1u) & smask;
+			h = (h + step) & smask;
 		}
 		idx = (int) h;
 		hazard = false;         /* decided by verify() once the creators' bins are visible */
@@ -336,24 +359,11 @@ struct HbmVotes {
 	uint32_t *rlist;
 	const uint8_t *gseq;     /* the read, seq_bytes of it readable (its NUL included) */
 	int seq_bytes;
-	uint8_t *win;            /* LDS: kSeqWindow bytes of the read around the walk's cursor */
-	int win_at;
-	int lane;
 	int entries;
-	static const int kSeqWindow = 512;
 	/* lanes of one wave share these through L2: every access is an agent-scope atomic (no stale L1 lines), so ordering them
 	 * needs no more than the wave's own memory operations completing -- a workgroup fence; an agent-scope one would write L2 back */
 	__device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
-	/* (called with the same p by every lane: the walk is uniform) */
-	__device__ int seq_at(const int p) {
-		if (p < win_at || p >= win_at + kSeqWindow) {
-			win_at = p & ~63;
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-			for (int s = lane; s < kSeqWindow; s += 64) win[s] = win_at + s < seq_bytes ? gseq[win_at + s] : (uint8_t) 0;
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-		}
-		return win[p - win_at];
-	}
+	__device__ int char_at(const int p) const { return p < seq_bytes ? gseq[p] : 0; }
 	__device__ int find(const uint32_t e, const uint64_t bin, int &idx, bool &listed) const {
 		const uint64_t key = __hip_atomic_load(&keys[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (key == kEmptyKey) return kProbeFree;
@@ -394,16 +404,12 @@ template <class TABLE>
 __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, const int i, const int lane, SearchCandidate *out) {
 	const int bits = a.bits;
 	const uint32_t size = 1u << bits;
-	long long length = a.seq_len[i];
 	const int read_len = a.seq_len[i];
 	const int K = a.k;
-	const uint64_t mask = (1ull << (2 * K)) - 1ull;
 	const uint64_t lt = (1ull << lane) - 1ull, gt = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
 	VoteState S;
 	S.hpoc = (long long) ((float) size * a.hpoc_factor);       /* CS.cpp:352 / :379 */
 	S.max_hit = 0.0f; S.thresh = 0.0f; S.rlen = 0; S.misses = 0; S.overflow = false; S.too_many = false;
-	unsigned long long offset = 0;
-	int sb = 0;       /* the walk's cursor into the read (the reference's moving `sequence` pointer) */
 
 	/* one vote, every lane with the same arguments (uniform control flow); lane 0 writes.  CS.cpp:101-149 */
 	auto vote_serial = [&](const uint64_t bin, const bool reverse) {
@@ -423,7 +429,7 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 			bool creator = false, hazard = false;
 			if (lane == 0) tb.claim(e, bin, idx, creator, hazard);
 			tb.fence();
-			idx = __shfl(idx, 0, 64);
+			idx = lane_of(idx, 0);
 			tb.entries += 1;
 			listed = false;
 		} else {
@@ -442,8 +448,8 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 	/* the batch's votes one by one (lane j holds vote j: bin, orientation, k-mer index in the chunk) */
 	auto cast_serial = [&](const int m, const uint64_t bin, const bool rev, const int c) {
 		for (int j = 0; j < m; ++j) {
-			vote_serial(shfl_u64(bin, j), __shfl((int) rev, j, 64) != 0);
-			if (S.overflow) { S.misses += C.miss_upto[__shfl(c, j, 64)]; return; }
+			vote_serial(lane_of(bin, j), lane_of((int) rev, j) != 0);
+			if (S.overflow) { S.misses += C.miss_upto[lane_of(c, j)]; return; }
 			if (S.too_many) return;
 		}
 	};
@@ -464,7 +470,7 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 				if ((long long) ++steps >= S.hpoc) break;               /* this vote alone exhausts the budget */
 			}
 		}
-		const uint32_t total_steps = (uint32_t) __shfl((int) wave_incl_sum(active ? steps : 0u, lane), 63, 64);
+		const uint32_t total_steps = (uint32_t) lane_of((int) wave_incl_sum(active ? steps : 0u, lane), 63);
 		const int n_free = __popcll(__ballot(active && st == kProbeFree));
 		if ((long long) total_steps >= S.hpoc || !tb.room_for(n_free)) { cast_serial(m, bin, rev, c); return; }
 		/* new entries; two votes of the batch that open the same slot for different bins cannot be ordered here */
@@ -483,11 +489,11 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		/* votes of the batch for the same entry: ranked in lane order per orientation, listed once */
 		uint64_t grp_h = 1ull << lane, grp_hr = 1ull << lane;
 		if (active) C.scr[(uint32_t) idx & 255u] = (uint8_t) lane;
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+		lds_fence();
 		uint64_t todo = __ballot(active && C.scr[(uint32_t) idx & 255u] != (uint8_t) lane);
 		while (todo != 0ull) {
 			const int l = __ffsll((unsigned long long) todo) - 1;
-			const int kh = __shfl(idx, l, 64);
+			const int kh = lane_of(idx, l);
 			const uint64_t same_h = __ballot(active && idx == kh);
 			const uint64_t same_f = __ballot(active && idx == kh && !rev);
 			if (active && idx == kh) { grp_h = same_h; grp_hr = rev ? (same_h & ~same_f) : same_f; }
@@ -505,14 +511,14 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		if (lister) { tb.list_put(S.rlen + __popcll(lb & lt), idx); tb.set_listed(idx, e); }
 		S.rlen += __popcll(lb);
 		if (active && (grp_hr & gt) == 0ull) tb.set_score(idx, rev, s);
-		const float last = __shfl(pm, 63, 64);
+		const float last = lane_of(pm, 63);
 		if (last > S.max_hit) { S.max_hit = last; S.thresh = S.max_hit * a.sensitivity; }
 		tb.fence();
 	};
 
 	/* the votes of the chunk's first `cn` k-mers, in order */
 	auto cast_chunk = [&](const int cn) {
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      /* lane 0's chunk entries -> every lane */
+		lds_fence();      /* the walk's chunk entries -> every lane */
 		uint32_t n0 = 0, n1 = 0;
 		bool miss = false;
 		if (lane < cn) {
@@ -532,63 +538,74 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		C.row_first[2 * lane + 1] = incl - n1;
 		if (lane == 63) C.row_first[128] = incl;
 		C.miss_upto[lane] = (uint16_t) wave_incl_sum(miss ? 1u : 0u, lane);
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+		lds_fence();
 		const uint32_t votes = C.row_first[128];
-		for (uint32_t v0 = 0; v0 < votes && !S.overflow && !S.too_many; v0 += 64) {
+		/* lane t of the batch that starts at vote v0: its table row (the last row that starts at or before vote v0 + t; empty rows
+		 * start where the next one does) and its location -- the load is issued here and waited for where the bin is computed, one
+		 * batch later: the round trip to HBM runs under the casting of the batch before */
+		struct Fetched { bool active, rev; int c; uint32_t loc; };
+		auto fetch = [&](const uint32_t v0) {
+			Fetched f;
 			const uint32_t v = v0 + (uint32_t) lane;
-			const bool active = v < votes;
-			uint64_t bin = 0;
-			bool rev = false;
-			int c = 0;
-			if (active) {
-				int lo = 0, hi = 128;             /* the last row that starts at or before vote v (empty rows start where the next one does) */
+			f.active = v < votes; f.rev = false; f.c = 0; f.loc = 0u;
+			if (f.active) {
+				int lo = 0, hi = 128;
 				while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (C.row_first[mid] <= v) lo = mid; else hi = mid; }
-				c = lo >> 1; rev = (lo & 1) != 0;
-				const unsigned long long loc = (unsigned long long) a.locs[C.c_start[lo & 1][c] + (v - C.row_first[lo])] + a.unit_offset;
-				const unsigned long long pos = C.c_pos[c];
-				const unsigned long long corr = rev ? (unsigned long long) read_len - (pos + (unsigned long long) K) : pos;
+				f.c = lo >> 1; f.rev = (lo & 1) != 0;
+				f.loc = a.locs[C.c_start[lo & 1][f.c] + (v - C.row_first[lo])];
+			}
+			return f;
+		};
+		Fetched cur = fetch(0u);
+		for (uint32_t v0 = 0; v0 < votes && !S.overflow && !S.too_many; v0 += 64) {
+			Fetched nxt = cur;
+			if (v0 + 64u < votes) nxt = fetch(v0 + 64u);
+			uint64_t bin = 0;
+			if (cur.active) {
+				const unsigned long long loc = (unsigned long long) cur.loc + a.unit_offset;
+				const unsigned long long pos = C.c_pos[cur.c];
+				const unsigned long long corr = cur.rev ? (unsigned long long) read_len - (pos + (unsigned long long) K) : pos;
 				bin = (loc - corr) >> a.bin_shift;
 			}
-			if (TABLE::kLds && __ballot(active && !TABLE::fits(bin)) != 0ull) { S.too_many = true; break; }
-			cast_batch(active, bin, rev, c);
+			if (TABLE::kLds && __ballot(cur.active && !TABLE::fits(bin)) != 0ull) { S.too_many = true; break; }
+			cast_batch(cur.active, bin, cur.rev, cur.c);
+			cur = nxt;
 		}
 		if (!S.overflow && !S.too_many) S.misses += C.miss_upto[63];
 	};
 
-	/* CSstatic.cpp:23-73: the walk, collecting k-mers 64 at a time */
-	int cn = 0;
-	auto push = [&](const uint64_t prefix, const unsigned long long pos) {
-		if (lane == 0) { C.c_prefix_lo[cn] = (uint32_t) prefix; C.c_prefix_hi[cn] = (uint32_t) (prefix >> 32); C.c_pos[cn] = (uint32_t) pos; }
-		cn += 1;
-		if (cn == 64) { cast_chunk(64); cn = 0; }
-	};
-	for (; !S.overflow && !S.too_many;) {
-		if (length < K) break;
-		if (tb.seq_at(sb) == 'N') {
-			int n_skip = 1;
-			while (tb.seq_at(sb + n_skip) == 'N') ++n_skip;
-			sb += n_skip;
-			if (n_skip >= length - K) break;
-			length -= n_skip;
-			offset += (unsigned long long) n_skip;
-		}
-		uint64_t prefix = 0;
-		bool restart = false;
-		for (int p = 0; p < K - 1; ++p) {
-			const int ch = tb.seq_at(sb + p);
-			if (ch == 'N') { sb += p + 1; length -= p + 1; offset += (unsigned long long) (p + 1); restart = true; break; }
-			prefix = (prefix << 2) | (uint64_t) ((ch >> 1) & 3);
-		}
-		if (restart) continue;
-		for (int p = K - 1; p < length && !S.overflow && !S.too_many; ++p) {
-			const int ch = tb.seq_at(sb + p);
-			if (ch == 'N') { sb += p + 1; length -= p + 1; offset += (unsigned long long) (p + 1); restart = true; break; }
-			prefix = ((prefix << 2) | (uint64_t) ((ch >> 1) & 3)) & mask;
-			push(prefix, offset + (unsigned long long) p + 1ull - (unsigned long long) K);
-		}
-		if (!restart) break;
+	/* CSstatic.cpp:23-73, the walk, 64 window positions at a time (round 6; until then one k-mer per trip of a serial loop: 30 % of a
+	 * read's time).  The reference pushes every window [q, q + K) that holds no 'N', in order of q: an 'N' restarts the scan behind
+	 * it, and restarting changes nothing about which windows follow.  One exception: at the top of its loop -- at the start of the
+	 * read, or after a restart that lands on another 'N' -- it skips the run of n_skip 'N's and STOPS when n_skip >= length - K,
+	 * where a plain scan would stop at n_skip > length - K: the read's last window is lost when exactly K bases follow a run of
+	 * 'N's that is two or more long or starts the read (a lone 'N' inside the read restarts without that test). */
+	const int n_win_all = read_len - K + 1;
+	int n_win = n_win_all;
+	if (n_win_all >= 2) {
+		const int q = n_win_all - 1;
+		if (tb.char_at(q - 1) == 'N' && (q == 1 || tb.char_at(q - 2) == 'N')) n_win -= 1;
 	}
-	if (cn > 0 && !S.overflow && !S.too_many) cast_chunk(cn);
+	for (int q0 = 0; q0 < n_win && !S.overflow && !S.too_many; q0 += 64) {
+		const int q = q0 + lane;
+		uint64_t prefix = 0;
+		bool ok = q < n_win;
+		if (ok) {
+			for (int j = 0; j < K; ++j) {
+				const int ch = tb.char_at(q + j);
+				ok = ok && ch != 'N';
+				prefix = (prefix << 2) | (uint64_t) ((ch >> 1) & 3);
+			}
+		}
+		const uint64_t okb = __ballot(ok);
+		const int cn = __popcll(okb);
+		if (cn == 0) continue;
+		if (ok) {
+			const int at = __popcll(okb & lt);
+			C.c_prefix_lo[at] = (uint32_t) prefix; C.c_prefix_hi[at] = (uint32_t) (prefix >> 32); C.c_pos[at] = (uint32_t) q;
+		}
+		cast_chunk(cn);
+	}
 
 	if (S.too_many) { if (lane == 0) a.n_cand[i] = kSearchNeedsHbm; return; }      /* redone over a table in HBM: nothing of this attempt counts */
 	/* kCount is reset per read, not per attempt (CS.cpp:338): the k-mers an overflowed attempt visited stay counted */
@@ -614,7 +631,7 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		int at = n + incl - cnt;
 		if (vf >= thr && r < S.rlen) { SearchCandidate cd; cd.location = (bin << a.bin_shift) + half; cd.score = vf; cd.reverse = 0; out[at++] = cd; }
 		if (vr >= thr && r < S.rlen) { SearchCandidate cd; cd.location = (bin << a.bin_shift) + half; cd.score = vr; cd.reverse = 1; out[at++] = cd; }
-		n += __shfl(incl, 63, 64);
+		n += lane_of(incl, 63);
 	}
 	if (lane == 0) { a.n_cand[i] = n; a.max_hit[i] = S.max_hit; }
 }
@@ -643,14 +660,13 @@ search_wave_kernel(const SearchArgs a, const int log2s, const int seq_cap) {
 __global__ void __launch_bounds__(64)
 search_wave_hbm_kernel(const SearchArgs a) {
 	__shared__ ChunkRows C;
-	__shared__ uint8_t window[HbmVotes::kSeqWindow];
 	const int q = blockIdx.x;
 	if (q >= a.n_work) return;
 	const int lane = threadIdx.x;
 	const int i = a.work ? a.work[q] : q;
 	const size_t size = (size_t) 1 << a.bits;
 	HbmVotes tb;
-	tb.win = window; tb.win_at = -(1 << 30); tb.lane = lane; tb.seq_bytes = a.seq_len[i] + 1;
+	tb.seq_bytes = a.seq_len[i] + 1;
 	tb.keys = a.keys + (size_t) q * size;
 	tb.fr = a.scores + 2 * (size_t) q * size;
 	tb.rlist = a.rlist + a.list_off[i];

@@ -151,6 +151,30 @@ def test_device_search_corners_against_the_checker(hip_aligner, search_kernel):
     o.close()
 
 
+def test_device_walk_over_reads_with_N(hip_aligner, search_kernel):
+    """The wave kernels enumerate a read's k-mers from a closed form of CS::PrefixIteration, 64 window positions at a time (round 6;
+    tests/test_search_cpu.py pins the form against the checker's serial walk): 1 500 variants of a read the table knows with 'N's
+    sprinkled in, the tail patterns the reference treats specially forced often -- lists, maxHitNumber and kCount against the
+    checker, in every kernel form."""
+    from tests.test_search_cpu import n_pattern_reads
+    fx, base_reads = util.synthetic_search_case()
+    rng = np.random.default_rng(9)
+    reads = n_pattern_reads(rng, base_reads[0], 1500)
+    o = SearchOracle(fx)
+    want = [o.search(r, cap=1 << 12) for r in reads]
+    o.close()
+    idx, locs = fx.index_arrays()
+    ix = KmerIndex(hip_aligner, fx.k, idx, locs, 0)
+    try:
+        got, max_hit, misses = ix.search(reads, extras=True)
+    finally:
+        ix.free()
+    bad = [i for i, (w, g) in enumerate(zip(want, got)) if not (_same(g, w["loc"], w["score"], w["rev"]) and int(misses[i]) == w["kmer_misses"]
+                                                                 and float(max_hit[i]) == float(np.float32(w["max_hit"])))]
+    assert not bad, (len(bad), [(reads[i], want[i]["n"], want[i]["kmer_misses"], int(misses[i])) for i in bad[:3]])
+    assert sum(1 for r in reads if b"N" in r) > 500 and sum(w["n"] for w in want) > 500
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 def test_arena_form_returns_the_recorded_lists(hip_aligner, pinned, search_kernel):
     """cvx_search_batch_arena (ABI 7): the reads back to back in ONE block -- pageable, or page-locked memory from cvx_host_alloc that

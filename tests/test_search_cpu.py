@@ -105,3 +105,60 @@ def test_n_runs_and_the_retry_ladder(built):
     # 13 characters behind a run of two N: nothing from that tail; behind a single N: one k-mer
     a, b = res[2], res[3]
     assert a["max_hit"] < b["max_hit"] or a["n"] <= b["n"]
+
+
+def n_pattern_reads(rng, base: bytes, n: int, K: int = 13):
+    """Variants of `base` with 'N's sprinkled in and the tail patterns PrefixIteration treats specially (a run of 'N's with exactly
+    K bases behind it) -- shared with tests/test_gpu_search.py."""
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(0, len(base) + 1)) if rng.random() < 0.5 else int(rng.integers(0, 4 * K))
+        a = int(rng.integers(0, len(base) - L + 1))
+        s = bytearray(base[a:a + L])
+        pn = float(rng.choice([0.0, 0.01, 0.05, 0.3]))
+        for p in range(L):
+            if rng.random() < pn:
+                s[p] = ord("N")
+        if L > K + 2 and rng.random() < 0.4:
+            r, q = int(rng.integers(1, 4)), L - K
+            for p in range(max(0, q - r), q):
+                s[p] = ord("N")
+            if rng.random() < 0.7:
+                for p in range(q, L):
+                    s[p] = base[a + p] if base[a + p] != ord("N") else ord("A")
+        out.append(bytes(s))
+    return out
+
+
+def walk_windows(s: bytes, K: int) -> int:
+    """How many k-mers CS::PrefixIteration (reference src/CSstatic.cpp:23-73) visits, in the closed form the wave kernels of
+    cvx_search.hip use: every window without an 'N', except that the read's last window is lost when it directly follows a run of
+    'N's that is two or more long or starts the read (`n_skip >= length - prefixBasecount` at :33 where `>` would keep it)."""
+    n_all = len(s) - K + 1
+    n = n_all
+    if n_all >= 2:
+        q = n_all - 1
+        if s[q - 1] == ord("N") and (q == 1 or s[q - 2] == ord("N")):
+            n -= 1
+    return sum(1 for q in range(max(n, 0)) if ord("N") not in s[q:q + K])
+
+
+@pytest.mark.parametrize("K", [13, 5])
+def test_closed_form_of_the_kmer_walk(built, K):
+    """The wave kernels enumerate a read's k-mers 64 window positions at a time from a closed form of PrefixIteration instead of
+    walking it serially (round 6).  Pinned here on the CPU: over an EMPTY table every visited k-mer counts as a miss (kCount,
+    src/CS.cpp:67-69), so the checker's kCount is the number of k-mers its serial walk -- the restatement of the reference's --
+    visits; 6 000 random 'N' patterns per k-mer length, the tail patterns forced often."""
+    idx5 = np.zeros(((1 << (2 * K)) + 2) * 5, dtype=np.uint8)
+    o = SearchOracle(raw=(K, 0, idx5, np.zeros(1, dtype=np.uint32)))
+    rng = np.random.default_rng(70 + K)
+    base = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=300).tobytes()
+    reads = n_pattern_reads(rng, base, 6000, K) + [b"", b"N", b"N" * K, b"N" + base[:K], b"NN" + base[:K], base[:3] + b"N" + base[:K],
+                                                    base[:3] + b"NN" + base[:K], base[:K] + b"N", base[:K + 1] + b"NN" + base[:K - 1]]
+    try:
+        bad = [(r, o.search(r, cap=64)["kmer_misses"], walk_windows(r, K)) for r in reads]
+        bad = [b for b in bad if b[1] != b[2]]
+    finally:
+        o.close()
+    assert not bad, (len(bad), bad[:3])
+    assert sum(walk_windows(r, K) for r in reads) > 30000
