@@ -233,13 +233,12 @@ namespace {
 const uint32_t kFreeSlot = 0xFFFFFFFFu;
 enum { kProbeFree = 0, kProbeMatch = 1, kProbeOther = 2 };
 
-struct ChunkRows {                      /* the chunk of <= 64 k-mers being cast (LDS, both table forms) */
-	uint32_t c_prefix_lo[64], c_prefix_hi[64];      /* k-mers in walk order */
-	uint32_t c_pos[64];
+struct ChunkRows {                      /* the chunk being cast: the k-mers at 64 consecutive window positions (LDS, both table forms) */
 	uint32_t c_start[2][64];                       /* where their table rows start, forward / reverse complement */
 	uint32_t row_first[129];                       /* votes before row 2 c + rev, in casting order; [128] = all of them */
 	uint16_t miss_upto[64];                        /* k-mers 0..c with neither row in the table (kCount) */
-	uint8_t scr[256];                              /* duplicate detection inside a batch */
+	uint8_t row_at[64];                            /* a batch's rows by the vote they start at */
+	uint8_t scr[1024];                             /* duplicate detection inside a batch */
 };
 
 /* Inclusive scans over the wave on the DPP path (round 6; six ds_bpermute round trips each until then): row_shr 1 / 2 / 4 / 8 inside a
@@ -263,6 +262,12 @@ __device__ __forceinline__ float wave_incl_max(float v, const int lane) {
 #define CVX_DPP_FMAX(ctrl, rows) { const float u = __int_as_float(CVX_DPP(__float_as_int(v), ctrl, rows)); v = u > v ? u : v; }
 	CVX_DPP_FMAX(0x111, 0xf) CVX_DPP_FMAX(0x112, 0xf) CVX_DPP_FMAX(0x114, 0xf) CVX_DPP_FMAX(0x118, 0xf) CVX_DPP_FMAX(0x142, 0xa) CVX_DPP_FMAX(0x143, 0xc)
 #undef CVX_DPP_FMAX
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_umax(uint32_t v) {
+#define CVX_DPP_UMAX(ctrl, rows) { const uint32_t u = (uint32_t) CVX_DPP((int) v, ctrl, rows); v = u > v ? u : v; }
+	CVX_DPP_UMAX(0x111, 0xf) CVX_DPP_UMAX(0x112, 0xf) CVX_DPP_UMAX(0x114, 0xf) CVX_DPP_UMAX(0x118, 0xf) CVX_DPP_UMAX(0x142, 0xa) CVX_DPP_UMAX(0x143, 0xc)
+#undef CVX_DPP_UMAX
 	return v;
 }
 /* lane `src` (the same for every lane) of a register: v_readlane, no LDS round trip */
@@ -316,10 +321,12 @@ struct LdsVotes {
 		uint32_t h = first_slot(e);
 		const uint32_t step = slot_step(e);
 		uint32_t sv;
-		for (;;) {
-			sv = slot[h];
-			if (sv == kFreeSlot || (sv & 0x7FFFFFFFu) == e) break;
-			h = (h + step) & smask;
+		for (;;) {      /* two slots of the sequence per round trip */
+			const uint32_t h1 = (h + step) & smask;
+			const uint32_t s0 = slot[h], s1 = slot[h1];
+			if (s0 == kFreeSlot || (s0 & 0x7FFFFFFFu) == e) { sv = s0; break; }
+			if (s1 == kFreeSlot || (s1 & 0x7FFFFFFFu) == e) { sv = s1; h = h1; break; }
+			h = (h1 + step) & smask;
 		}
 		if (sv == kFreeSlot) { idx = (int) h; return kProbeFree; }      /* (where claim() starts) */
 		if (bin[h] == (uint32_t) b) { idx = (int) h; listed = (sv >> 31) != 0u; return kProbeMatch; }
@@ -488,9 +495,9 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		tb.entries += __popcll(__ballot(creator));
 		/* votes of the batch for the same entry: ranked in lane order per orientation, listed once */
 		uint64_t grp_h = 1ull << lane, grp_hr = 1ull << lane;
-		if (active) C.scr[(uint32_t) idx & 255u] = (uint8_t) lane;
+		if (active) C.scr[(uint32_t) idx & 1023u] = (uint8_t) lane;      /* (1 024 buckets: 64 lanes over 256 met by chance eight times a batch, each a trip of the loop below) */
 		lds_fence();
-		uint64_t todo = __ballot(active && C.scr[(uint32_t) idx & 255u] != (uint8_t) lane);
+		uint64_t todo = __ballot(active && C.scr[(uint32_t) idx & 1023u] != (uint8_t) lane);
 		while (todo != 0ull) {
 			const int l = __ffsll((unsigned long long) todo) - 1;
 			const int kh = lane_of(idx, l);
@@ -516,54 +523,87 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		tb.fence();
 	};
 
-	/* the votes of the chunk's first `cn` k-mers, in order */
-	auto cast_chunk = [&](const int cn) {
-		lds_fence();      /* the walk's chunk entries -> every lane */
-		uint32_t n0 = 0, n1 = 0;
-		bool miss = false;
-		if (lane < cn) {
-			/* table rows of all its k-mers, both orientations: one round trip for the wave */
-			const uint64_t pr = ((uint64_t) C.c_prefix_hi[lane] << 32) | C.c_prefix_lo[lane];
-			const uint64_t rc = rev_comp13(pr, K);
-			const uint2 rf = a.rows[pr], rr = a.rows[rc];      /* one 8-byte record each: start, length | used << 31 */
-			const bool uf = (rf.y >> 31) != 0u, ur = (rr.y >> 31) != 0u;
-			uint32_t sf = 0, sr = 0;
-			if (uf) { sf = rf.x; n0 = rf.y & 0x7FFFFFFFu; }
-			if (ur) { sr = rr.x; n1 = rr.y & 0x7FFFFFFFu; }
-			C.c_start[0][lane] = sf; C.c_start[1][lane] = sr;
-			miss = !uf && !ur;                  /* entries[0].refTotal == 0 (PrefixTable.cpp:489-525): kCount, CS.cpp:67-69 */
+	/* CSstatic.cpp:23-73, the walk, 64 window positions at a time (round 6; until then one k-mer per trip of a serial loop: 30 % of a
+	 * read's time).  The reference pushes every window [q, q + K) that holds no 'N', in order of q: an 'N' restarts the scan behind
+	 * it, and restarting changes nothing about which windows follow.  One exception: at the top of its loop -- at the start of the
+	 * read, or after a restart that lands on another 'N' -- it skips the run of n_skip 'N's and STOPS when n_skip >= length - K,
+	 * where a plain scan would stop at n_skip > length - K: the read's last window is lost when exactly K bases follow a run of
+	 * 'N's that is two or more long or starts the read (a lone 'N' inside the read restarts without that test).
+	 * tests/test_search_cpu.py::test_closed_form_of_the_kmer_walk pins this form against the checker's serial walk. */
+	const int n_win_all = read_len - K + 1;
+	int n_win = n_win_all;
+	if (n_win_all >= 2) {
+		const int q = n_win_all - 1;
+		if (tb.char_at(q - 1) == 'N' && (q == 1 || tb.char_at(q - 2) == 'N')) n_win -= 1;
+	}
+	/* lane t of the chunk that starts at window q0: its k-mer and the table rows of the k-mer and of its reverse complement (one
+	 * 8-byte record each: start, length | used << 31).  The loads are issued here, a chunk ahead of their use. */
+	struct Kmers { bool ok; uint2 rf, rr; };
+	auto lookup = [&](const int q0) {
+		Kmers k;
+		const int q = q0 + lane;
+		k.ok = q < n_win; k.rf = make_uint2(0u, 0u); k.rr = make_uint2(0u, 0u);
+		uint64_t prefix = 0;
+		if (k.ok) {
+			for (int j = 0; j < K; ++j) {
+				const int ch = tb.char_at(q + j);
+				k.ok = k.ok && ch != 'N';
+				prefix = (prefix << 2) | (uint64_t) ((ch >> 1) & 3);
+			}
 		}
+		/* (unconditional loads -- a lane without a k-mer reads record 0 and drops it: a load inside a branch makes the compiler wait
+		 * for ALL loads in flight where the branches join, and these are meant to stay in flight for a whole chunk) */
+		if (!k.ok) prefix = 0;
+		const uint2 rf = a.rows[prefix], rr = a.rows[rev_comp13(prefix, K)];
+		k.rf = k.ok ? rf : make_uint2(0u, 0u); k.rr = k.ok ? rr : make_uint2(0u, 0u);
+		return k;
+	};
+
+	/* the votes of the chunk's k-mers, in order (lane c = the k-mer at window q0 + c; a window with an 'N' has no rows and is no miss) */
+	auto cast_chunk = [&](const Kmers &k, const int q0) {
+		const bool uf = (k.rf.y >> 31) != 0u, ur = (k.rr.y >> 31) != 0u;
+		const uint32_t n0 = uf ? k.rf.y & 0x7FFFFFFFu : 0u, n1 = ur ? k.rr.y & 0x7FFFFFFFu : 0u;
+		const bool miss = k.ok && !uf && !ur;                  /* entries[0].refTotal == 0 (PrefixTable.cpp:489-525): kCount, CS.cpp:67-69 */
+		C.c_start[0][lane] = uf ? k.rf.x : 0u; C.c_start[1][lane] = ur ? k.rr.x : 0u;
 		const uint32_t incl = wave_incl_sum(n0 + n1, lane);
-		C.row_first[2 * lane] = incl - n0 - n1;
-		C.row_first[2 * lane + 1] = incl - n1;
-		if (lane == 63) C.row_first[128] = incl;
+		const uint32_t first_f = incl - n0 - n1, first_r = incl - n1;      /* votes before this lane's forward / reverse row */
+		C.row_first[2 * lane] = first_f;
+		C.row_first[2 * lane + 1] = first_r;
 		C.miss_upto[lane] = (uint16_t) wave_incl_sum(miss ? 1u : 0u, lane);
 		lds_fence();
-		const uint32_t votes = C.row_first[128];
-		/* lane t of the batch that starts at vote v0: its table row (the last row that starts at or before vote v0 + t; empty rows
-		 * start where the next one does) and its location -- the load is issued here and waited for where the bin is computed, one
-		 * batch later: the round trip to HBM runs under the casting of the batch before */
+		const uint32_t votes = (uint32_t) lane_of((int) incl, 63);
+		/* lane t of the batch that starts at vote v0: its table row -- the last non-empty row that starts at or before vote v0 + t --
+		 * and its location.  The rows that start inside the batch drop their number at the vote they start with (non-empty rows
+		 * start at different votes), a running maximum carries it over the votes behind, `carry` (the row of the vote before the
+		 * batch) over the votes in front of the first: four LDS instructions and a DPP scan where a binary search over the 128 row
+		 * starts made seven dependent LDS round trips.  The location's load is issued here and waited for where the bin is
+		 * computed, one batch later: the round trip to HBM runs under the casting of the batch before. */
 		struct Fetched { bool active, rev; int c; uint32_t loc; };
+		uint32_t carry = 0u;
 		auto fetch = [&](const uint32_t v0) {
 			Fetched f;
 			const uint32_t v = v0 + (uint32_t) lane;
-			f.active = v < votes; f.rev = false; f.c = 0; f.loc = 0u;
-			if (f.active) {
-				int lo = 0, hi = 128;
-				while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (C.row_first[mid] <= v) lo = mid; else hi = mid; }
-				f.c = lo >> 1; f.rev = (lo & 1) != 0;
-				f.loc = a.locs[C.c_start[lo & 1][f.c] + (v - C.row_first[lo])];
-			}
+			C.row_at[lane] = 0;
+			lds_fence();
+			if (n0 != 0u && first_f - v0 < 64u) C.row_at[first_f - v0] = (uint8_t) (2 * lane);          /* (unsigned: a row from before v0 wraps far beyond 64) */
+			if (n1 != 0u && first_r - v0 < 64u) C.row_at[first_r - v0] = (uint8_t) (2 * lane + 1);
+			lds_fence();
+			uint32_t row = wave_incl_umax((uint32_t) C.row_at[lane]);
+			row = row > carry ? row : carry;
+			carry = (uint32_t) lane_of((int) row, 63);
+			f.active = v < votes; f.rev = (row & 1u) != 0u; f.c = (int) (row >> 1);
+			uint32_t at = C.c_start[row & 1u][f.c] + (v - C.row_first[row]);
+			if (!f.active) at = 0u;
+			f.loc = a.locs[at];      /* (unconditional, as in lookup()) */
 			return f;
 		};
 		Fetched cur = fetch(0u);
 		for (uint32_t v0 = 0; v0 < votes && !S.overflow && !S.too_many; v0 += 64) {
-			Fetched nxt = cur;
-			if (v0 + 64u < votes) nxt = fetch(v0 + 64u);
+			const Fetched nxt = fetch(v0 + 64u);      /* (behind the last batch: no lane active) */
 			uint64_t bin = 0;
 			if (cur.active) {
 				const unsigned long long loc = (unsigned long long) cur.loc + a.unit_offset;
-				const unsigned long long pos = C.c_pos[cur.c];
+				const unsigned long long pos = (unsigned long long) (q0 + cur.c);
 				const unsigned long long corr = cur.rev ? (unsigned long long) read_len - (pos + (unsigned long long) K) : pos;
 				bin = (loc - corr) >> a.bin_shift;
 			}
@@ -574,37 +614,11 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		if (!S.overflow && !S.too_many) S.misses += C.miss_upto[63];
 	};
 
-	/* CSstatic.cpp:23-73, the walk, 64 window positions at a time (round 6; until then one k-mer per trip of a serial loop: 30 % of a
-	 * read's time).  The reference pushes every window [q, q + K) that holds no 'N', in order of q: an 'N' restarts the scan behind
-	 * it, and restarting changes nothing about which windows follow.  One exception: at the top of its loop -- at the start of the
-	 * read, or after a restart that lands on another 'N' -- it skips the run of n_skip 'N's and STOPS when n_skip >= length - K,
-	 * where a plain scan would stop at n_skip > length - K: the read's last window is lost when exactly K bases follow a run of
-	 * 'N's that is two or more long or starts the read (a lone 'N' inside the read restarts without that test). */
-	const int n_win_all = read_len - K + 1;
-	int n_win = n_win_all;
-	if (n_win_all >= 2) {
-		const int q = n_win_all - 1;
-		if (tb.char_at(q - 1) == 'N' && (q == 1 || tb.char_at(q - 2) == 'N')) n_win -= 1;
-	}
+	Kmers kc = lookup(0);
 	for (int q0 = 0; q0 < n_win && !S.overflow && !S.too_many; q0 += 64) {
-		const int q = q0 + lane;
-		uint64_t prefix = 0;
-		bool ok = q < n_win;
-		if (ok) {
-			for (int j = 0; j < K; ++j) {
-				const int ch = tb.char_at(q + j);
-				ok = ok && ch != 'N';
-				prefix = (prefix << 2) | (uint64_t) ((ch >> 1) & 3);
-			}
-		}
-		const uint64_t okb = __ballot(ok);
-		const int cn = __popcll(okb);
-		if (cn == 0) continue;
-		if (ok) {
-			const int at = __popcll(okb & lt);
-			C.c_prefix_lo[at] = (uint32_t) prefix; C.c_prefix_hi[at] = (uint32_t) (prefix >> 32); C.c_pos[at] = (uint32_t) q;
-		}
-		cast_chunk(cn);
+		const Kmers kn = lookup(q0 + 64);      /* (behind the last chunk: no lane with a k-mer) */
+		cast_chunk(kc, q0);
+		kc = kn;
 	}
 
 	if (S.too_many) { if (lane == 0) a.n_cand[i] = kSearchNeedsHbm; return; }      /* redone over a table in HBM: nothing of this attempt counts */

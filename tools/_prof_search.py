@@ -9,11 +9,11 @@ reads = synth.sample_subreads(contigs, 100000)
 ix = KmerIndex(al, 13, idx5.view(np.dtype([("tab", "<u4"), ("rc", "i1")])), locs, 0)
 arena, offsets, pinned = KmerIndex.make_arena(reads, al.lib)
 ix.search_arena(arena, offsets)
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 al.lib.cvx_debug_search_prof(out)
+names = ["chunks", " lookup", " fetch(binsearch+issue)", " bin wait", " cast_batch", "  probe", "  claim+verify", "  dups", "  score+scan+writes", "batches", "total", "reads", "lookup-issue"]
 for rep in range(2):
     t0 = time.perf_counter(); ix.search_arena(arena, offsets); dt = time.perf_counter() - t0
     al.lib.cvx_debug_search_prof(out)
-    v = list(out); n = max(v[6], 1)
-    print("call %.2f ms kernels %.2f ms; per read (cycles of s_memtime @100MHz?): total %.0f  chunks %.0f (lookup %.0f, loc+binsearch %.0f, cast %.0f)  walk %.0f  collect %.0f  reads %d" % (
-        dt * 1e3, al.stage_kernel_ms(capi.STAGE_SEARCH), v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, (v[0] - v[1] - v[5]) / n, v[5] / n, v[6]))
+    v = list(out); n = max(v[11], 1)
+    print("call %.2f ms kernels %.2f ms; per read:" % (dt * 1e3, al.stage_kernel_ms(capi.STAGE_SEARCH)), ", ".join("%s %.0f" % (names[z], v[z] / n) for z in range(13)))
