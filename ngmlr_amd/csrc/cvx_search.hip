@@ -41,45 +41,62 @@ __device__ __forceinline__ uint64_t rev_comp13(uint64_t prefix, const int k) {
 	return r;
 }
 
-/* events (votes) of every read: the size of its rList / candidate regions */
-__global__ void __launch_bounds__(64)
+/* CSstatic.cpp:23-73 in closed form: the windows [q, q + K), q < kmer_windows(), that hold no 'N' are the k-mers the reference
+ * visits, in order of q.  (The reference restarts its scan behind every 'N', which changes nothing about the windows that follow,
+ * with one exception: at the top of its loop -- at the start of the read, or after a restart that lands on another 'N' -- it
+ * skips the run of n_skip 'N's and STOPS when n_skip >= length - K, where a plain scan would stop at n_skip > length - K: the
+ * read's last window is lost when exactly K bases follow a run of 'N's that is two or more long or starts the read; a lone 'N'
+ * inside the read restarts without that test.)  tests/test_search_cpu.py::test_closed_form_of_the_kmer_walk pins this form
+ * against the checker's serial walk; search_kernel below keeps the serial walk. */
+template <class CHAR_AT>
+__device__ __forceinline__ int kmer_windows(const int read_len, const int K, CHAR_AT char_at) {
+	const int n_all = read_len - K + 1;
+	if (n_all >= 2) {
+		const int q = n_all - 1;
+		if (char_at(q - 1) == 'N' && (q == 1 || char_at(q - 2) == 'N')) return n_all - 1;
+	}
+	return n_all;
+}
+/* the k-mer of window q (2 bits per base as (c >> 1) & 3); false when the window holds an 'N' */
+template <class CHAR_AT>
+__device__ __forceinline__ bool kmer_at(const int q, const int K, CHAR_AT char_at, uint64_t &prefix) {
+	bool ok = true;
+	prefix = 0;
+	for (int j = 0; j < K; ++j) {
+		const int ch = char_at(q + j);
+		ok = ok && ch != 'N';
+		prefix = (prefix << 2) | (uint64_t) ((ch >> 1) & 3);
+	}
+	return ok;
+}
+
+/* events (votes) of every read: which LDS map it gets, the size of its rList / candidate regions.  One wave per read, a lane per
+ * window (round 6: a lane per read walked its 256 bases as a chain of dependent loads, 1.15 ms per 100 000 sub-reads). */
+__global__ void __launch_bounds__(256)
 search_count_kernel(const SearchArgs a) {
-	const int i = blockIdx.x * 64 + threadIdx.x;
+	const int i = blockIdx.x * 4 + (int) (threadIdx.x >> 6);
+	const int lane = (int) (threadIdx.x & 63u);
 	if (i >= a.n) return;
 	const uint8_t *seq = a.seq + a.seq_off[i];
-	long long length = a.seq_len[i];
+	const int read_len = a.seq_len[i];
 	const int K = a.k;
-	const uint64_t mask = (1ull << (2 * K)) - 1ull;
+	auto char_at = [&](const int p) -> int { return p <= read_len ? seq[p] : 0; };      /* (the NUL behind the read is there) */
+	const int n_win = kmer_windows(read_len, K, char_at);
 	unsigned long long events = 0;
-	for (;;) {
-		if (length < K) break;
-		if (*seq == 'N') {
-			long long n_skip = 1;
-			while (seq[n_skip] == 'N') ++n_skip;
-			seq += n_skip;
-			if (n_skip >= length - K) break;
-			length -= n_skip;
-		}
+	for (int q0 = 0; q0 < n_win; q0 += 64) {
+		const int q = q0 + lane;
 		uint64_t prefix = 0;
-		bool restart = false;
-		for (long long q = 0; q < K - 1; ++q) {
-			const int ch = seq[q];
-			if (ch == 'N') { seq += q + 1; length -= q + 1; restart = true; break; }
-			prefix = (prefix << 2) | (uint64_t) ((ch >> 1) & 3);
-		}
-		if (restart) continue;
-		for (long long q = K - 1; q < length; ++q) {
-			const int ch = seq[q];
-			if (ch == 'N') { seq += q + 1; length -= q + 1; restart = true; break; }
-			prefix = ((prefix << 2) | (uint64_t) ((ch >> 1) & 3)) & mask;
-			const uint64_t rc = rev_comp13(prefix, K);
-			const uint2 rf = a.rows[prefix], rr = a.rows[rc];
+		if (q < n_win && kmer_at(q, K, char_at, prefix)) {
+			const uint2 rf = a.rows[prefix], rr = a.rows[rev_comp13(prefix, K)];
 			if (rf.y >> 31) events += rf.y & 0x7FFFFFFFu;
 			if (rr.y >> 31) events += rr.y & 0x7FFFFFFFu;
 		}
-		if (!restart) break;
 	}
-	a.events[i] = events;
+	for (int d = 32; d >= 1; d >>= 1) {
+		const uint32_t lo = (uint32_t) __shfl_down((int) (uint32_t) events, d, 64), hi = (uint32_t) __shfl_down((int) (uint32_t) (events >> 32), d, 64);
+		events += ((unsigned long long) hi << 32) | lo;
+	}
+	if (lane == 0) a.events[i] = events;
 }
 
 /* one lane = one CS::RunRead attempt with a table of 2^bits entries */
@@ -524,33 +541,17 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 	};
 
 	/* CSstatic.cpp:23-73, the walk, 64 window positions at a time (round 6; until then one k-mer per trip of a serial loop: 30 % of a
-	 * read's time).  The reference pushes every window [q, q + K) that holds no 'N', in order of q: an 'N' restarts the scan behind
-	 * it, and restarting changes nothing about which windows follow.  One exception: at the top of its loop -- at the start of the
-	 * read, or after a restart that lands on another 'N' -- it skips the run of n_skip 'N's and STOPS when n_skip >= length - K,
-	 * where a plain scan would stop at n_skip > length - K: the read's last window is lost when exactly K bases follow a run of
-	 * 'N's that is two or more long or starts the read (a lone 'N' inside the read restarts without that test).
-	 * tests/test_search_cpu.py::test_closed_form_of_the_kmer_walk pins this form against the checker's serial walk. */
-	const int n_win_all = read_len - K + 1;
-	int n_win = n_win_all;
-	if (n_win_all >= 2) {
-		const int q = n_win_all - 1;
-		if (tb.char_at(q - 1) == 'N' && (q == 1 || tb.char_at(q - 2) == 'N')) n_win -= 1;
-	}
+	 * read's time): kmer_windows() / kmer_at() above. */
+	auto char_at = [&](const int p) -> int { return tb.char_at(p); };
+	const int n_win = kmer_windows(read_len, K, char_at);
 	/* lane t of the chunk that starts at window q0: its k-mer and the table rows of the k-mer and of its reverse complement (one
 	 * 8-byte record each: start, length | used << 31).  The loads are issued here, a chunk ahead of their use. */
 	struct Kmers { bool ok; uint2 rf, rr; };
 	auto lookup = [&](const int q0) {
 		Kmers k;
 		const int q = q0 + lane;
-		k.ok = q < n_win; k.rf = make_uint2(0u, 0u); k.rr = make_uint2(0u, 0u);
 		uint64_t prefix = 0;
-		if (k.ok) {
-			for (int j = 0; j < K; ++j) {
-				const int ch = tb.char_at(q + j);
-				k.ok = k.ok && ch != 'N';
-				prefix = (prefix << 2) | (uint64_t) ((ch >> 1) & 3);
-			}
-		}
+		k.ok = q < n_win && kmer_at(q, K, char_at, prefix);
 		/* (unconditional loads -- a lane without a k-mer reads record 0 and drops it: a load inside a branch makes the compiler wait
 		 * for ALL loads in flight where the branches join, and these are meant to stay in flight for a whole chunk) */
 		if (!k.ok) prefix = 0;
@@ -725,7 +726,7 @@ hipError_t launch_search_wave_hbm(const SearchArgs &a, hipStream_t st) {
 
 hipError_t launch_search_count(const SearchArgs &a, hipStream_t st) {
 	if (a.n <= 0) return hipSuccess;
-	hipLaunchKernelGGL(search_count_kernel, dim3((a.n + 63) / 64), dim3(64), 0, st, a);
+	hipLaunchKernelGGL(search_count_kernel, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
 	return hipGetLastError();
 }
 
