@@ -215,7 +215,7 @@ def test_text_stage_on_the_device_in_the_pipeline(built, tmp_path):
 
 def test_repeat_rich_reference(built, tmp_path):
     """What a k-mer vote sees on a real genome: repeat families of 8-20 diverged copies and microsatellites, so that sub-reads cast
-    10^4..10^5 votes, overflow the wave kernel's LDS map (the HBM-table form runs) and reads get several close candidates (MAPQ
+    10^4..10^5 votes, overflow the wave kernel's LDS map (forced to its smallest size here: the HBM-table form runs) and reads get several close candidates (MAPQ
     spread over 10..60).  The unmodified reference against the binary with everything on the drop-ins: every SAM record identical."""
     import re
     import sys
@@ -228,7 +228,7 @@ def test_repeat_rich_reference(built, tmp_path):
     e2e_rates.write_repeat_workload(fa, fq, 240, seed=91)
     args = ["-x", "pacbio", "-R", "0.01", "--no-progress", "-r", fa, "-q", fq]
     want, _ = _run(["-t", "16"] + args, tmp_path, binary=ref_bin)
-    got, err = _run(["-t", "8"] + args, tmp_path, binary=BIN_ALL, env={"CVX_POOL_CONTEXTS": "128", "CVX_SEARCH_TRACE": "1"})
+    got, err = _run(["-t", "8"] + args, tmp_path, binary=BIN_ALL, env={"CVX_POOL_CONTEXTS": "128", "CVX_SEARCH_TRACE": "1", "CVX_TUNE_SEARCH_LOG2": "9"})      # (the smallest LDS map: since round 6 the default one holds these sub-reads)
     assert sorted(got) == sorted(want)
     mapq = [int(l.split("\t")[4]) for l in want]
     assert sum(1 for q in mapq if q < 40) >= 20 and sum(1 for q in mapq if q >= 40) >= 20, "the workload must produce ambiguous and unambiguous reads"

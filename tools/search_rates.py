@@ -116,10 +116,13 @@ def big_index_rates(al, mbp=512, n_reads=100000, parity_n=2000, n_contigs=8, pmc
         "bytes_per_vote": pmc_bytes_per_vote,
         "random_sector_peak": None, "sectors_per_sub_read": sectors_per_read,
         "kernel_sector_reads_per_s": sectors_per_read * len(reads) / max(kms * 1e-3, 1e-9),
-        "bound": "NOT the random-access rate of HBM (round 6: tools/ubench_gather.hip puts that at ~51 G sectors/s on this device; the kernels "
-                 "read `kernel_sector_reads_per_s`, a few per cent of it): the latency of a wave's dependent round trips at under one wave per SIMD -- "
-                 "a read owns a wave whose vote map takes 47 KB of LDS (2 048 slots: a sub-read of a genome with repeats votes for ~10^3 bins), so "
-                 "three waves fit a CU and every LDS / HBM round trip of the ~20 vote batches of a sub-read is exposed",
+        "bound": "NOT the random-access rate of HBM (tools/ubench_gather.hip puts that at ~51 G sectors/s on this device; the kernels read "
+                 "`kernel_sector_reads_per_s`): the latency of a wave's dependent LDS round trips at 1.25 waves per SIMD -- a read owns a wave "
+                 "whose vote map is sized from its vote count (2^9..2^12 slots of 12 bytes, at most 3/4 full; a sub-read of this genome votes for "
+                 "1 200-1 450 bins: 2^11 slots, 30 KB of LDS with rList and the read), five reads fit a CU, and each of a sub-read's ~21 vote "
+                 "batches is a chain of ~20 LDS round trips (row of the vote, probe, claim, duplicates, score); the loads from HBM run a batch "
+                 "/ a chunk ahead.  Round 5's fixed 1 024-bin map held none of these sub-reads: each was cast twice (LDS attempt discarded, "
+                 "then the 1 MB table in HBM)",
         "what": "cvx_search_batch_arena (reads back to back in page-locked memory, flat outputs) over a %d Mbp synthetic reference with repeat families and microsatellites; table by cvx_index_build (byte-identical "
                 "to ngmlr's own: tests/test_index_cpu.py), resident in HBM; kernel_ms = every kernel of the call from HIP events (cvx_stage_kernel_ms)" % mbp}
     peak = random_sector_peak()
