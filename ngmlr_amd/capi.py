@@ -28,7 +28,7 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_genome_decode", "cvx_submit_windows", "cvx_job_text",
            "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id", "cvx_job_poll", "cvx_score_kernel_ms",
            "cvx_index_upload", "cvx_index_free", "cvx_search_batch", "cvx_search_batch_ex", "cvx_job_nm_profile", "cvx_job_nm_sizes", "cvx_nm_profile_ops",
-           "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch", "cvx_stage_kernel_ms", "cvx_search_last_attempts", "cvx_index_build",
+           "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch", "cvx_stage_kernel_ms", "cvx_search_last_attempts", "cvx_index_build", "cvx_index_build_device",
            "cvx_corridor_fit", "cvx_corridor_fit_batch", "cvx_create_ex", "cvx_runtime_regime", "cvx_search_batch_arena")
 
 
@@ -195,6 +195,8 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_score_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.cvx_stage_kernel_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
     lib.cvx_search_last_attempts.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.cvx_index_build_device.argtypes = [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.cvx_index_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.cvx_runtime_regime.argtypes = [C.c_int, C.POINTER(CvxRegime)]

@@ -45,6 +45,7 @@
 
 #include "cvx_align.h"
 #include "cvx_host_logic.h"
+#include "cvx_index_build.h"
 #include "cvx_launch.h"
 #include "cvx_types.h"
 
@@ -2154,6 +2155,33 @@ int cvx_index_upload(cvx_handle h, int32_t k, const void *index, const uint32_t 
 	}
 	*out = ix;
 	return CVX_OK;
+	ABI_GUARD_END
+}
+
+int cvx_index_build_device(int32_t device_id, const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table, const uint64_t *seq_lengths, int32_t n_seqs,
+		int32_t kmer_len, int32_t ref_skip, int32_t bin_shift, void *ref_table_index, uint32_t *ref_table, uint64_t ref_table_capacity,
+		uint64_t *n_locations) {
+	ABI_GUARD_BEGIN
+	if (!bin_ref || !start_table || !seq_lengths || n_seqs <= 0 || kmer_len < 4 || kmer_len > 15 || ref_skip < 0 || bin_shift < 0 || bin_shift > 30 ||
+			!ref_table_index || !n_locations) { set_err("cvx_index_build_device: bad argument (kmer_len 4..15, bin_shift 0..30)"); return CVX_ERR_ARG; }
+	for (int32_t s = 0; s < n_seqs; ++s) {
+		if ((start_table[s] & 1ull) || start_table[s] + seq_lengths[s] > n_nibbles) { set_err("cvx_index_build_device: sequence %d does not start on a byte or leaves the genome", s); return CVX_ERR_ARG; }
+		if (s > 0 && start_table[s] < start_table[s - 1]) { set_err("cvx_index_build_device: sequences out of order (a row lists its locations in walk order)"); return CVX_ERR_ARG; }
+	}
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void) hipGetLastError(); set_err("cvx_index_build_device: no HIP device"); return CVX_ERR_NO_DEVICE; }
+	if (device_id < 0 || device_id >= ndev) { set_err("cvx_index_build_device: device %d of %d", device_id, ndev); return CVX_ERR_ARG; }
+	HIP_TRY(hipSetDevice(device_id));
+	hipStream_t st = nullptr;
+	HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	char err[320];
+	err[0] = 0;
+	const int rc = index_build_device(bin_ref, n_nibbles, start_table, seq_lengths, n_seqs, kmer_len, ref_skip, bin_shift, ref_table_index, ref_table,
+			ref_table_capacity, n_locations, st, err, sizeof(err));
+	(void) hipStreamSynchronize(st);
+	(void) hipStreamDestroy(st);
+	if (rc != CVX_OK) set_err("cvx_index_build_device: %s", err);
+	return rc;
 	ABI_GUARD_END
 }
 

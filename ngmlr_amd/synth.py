@@ -512,9 +512,10 @@ def big_reference(total_bases: int = 512 << 20, n_contigs: int = 8, seed: int = 
     return contigs
 
 
-def kmer_table(lib, contigs: Sequence[np.ndarray], k: int = 13, skip: int = 2, bin_shift: int = 4):
+def kmer_table(lib, contigs: Sequence[np.ndarray], k: int = 13, skip: int = 2, bin_shift: int = 4, device: int = None):
     """-> (index bytes [(4^k + 2) * 5], locations uint32[], start table uint64[]) for `contigs`: cvx_genome_encode + cvx_index_build,
-    i.e. what ngmlr's SequenceProvider and CompactPrefixTable build from the same sequences (host only)."""
+    i.e. what ngmlr's SequenceProvider and CompactPrefixTable build from the same sequences (host only); device = a device
+    number: the table by cvx_index_build_device instead (same bytes)."""
     import ctypes as C
     from . import capi
     n = len(contigs)
@@ -533,8 +534,12 @@ def kmer_table(lib, contigs: Sequence[np.ndarray], k: int = 13, skip: int = 2, b
     cap = int(kept.sum()) // (skip + 1) + 64
     locs = np.zeros(cap, dtype=np.uint32)
     nl = C.c_uint64()
-    capi.check(lib.cvx_index_build(binref.ctypes.data, nn.value, starts.ctypes.data, kept.ctypes.data, len(kept), k, skip, bin_shift,
-                                   idx.ctypes.data, locs.ctypes.data, cap, C.byref(nl)))
+    if device is None:
+        capi.check(lib.cvx_index_build(binref.ctypes.data, nn.value, starts.ctypes.data, kept.ctypes.data, len(kept), k, skip, bin_shift,
+                                       idx.ctypes.data, locs.ctypes.data, cap, C.byref(nl)))
+    else:
+        capi.check(lib.cvx_index_build_device(device, binref.ctypes.data, nn.value, starts.ctypes.data, kept.ctypes.data, len(kept), k, skip, bin_shift,
+                                              idx.ctypes.data, locs.ctypes.data, cap, C.byref(nl)))
     return idx, locs[:nl.value], starts[:ns.value]
 
 

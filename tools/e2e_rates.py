@@ -277,9 +277,19 @@ def run(name, t, ref, fq, extra_env=None):
     out_path, err_path = os.path.join(tmp, "run.out"), os.path.join(tmp, "run.err")
     cg0 = cgroup_cpu_stat()
     t0 = time.perf_counter()
+    stamp = os.environ.get("E2E_STDERR_TIMES") is not None      # every stderr line with the second it arrived at (where a run's wall clock goes outside the pool)
     with open(out_path, "wb") as fo, open(err_path, "wb") as fe:
         proc = subprocess.Popen([binary, "--skip-write", "-x", PRESET, "-t", str(t), "-R", "0.01", "--no-progress", "-r", ref_copy, "-q", fq],
-                                stdout=fo, stderr=fe, cwd=tmp, env=env)
+                                stdout=fo, stderr=subprocess.PIPE if stamp else fe, cwd=tmp, env=env)
+        if stamp:
+            import threading
+
+            def pump():
+                for raw in proc.stderr:
+                    fe.write(raw)
+                    sys.stderr.write("  [%7.3f s] %s\n" % (time.perf_counter() - t0, raw.decode("utf-8", "replace").rstrip()[:160]))
+            pump_thread = threading.Thread(target=pump, daemon=True)
+            pump_thread.start()
         ticks = {}
         peak_rss_kb = 0
         hz = os.sysconf("SC_CLK_TCK")
@@ -304,6 +314,8 @@ def run(name, t, ref, fq, extra_env=None):
                 pass
             time.sleep(0.02)
     dt = time.perf_counter() - t0
+    if stamp:
+        pump_thread.join(timeout=5)
     cg1 = cgroup_cpu_stat()
 
     class Res:
