@@ -403,8 +403,8 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
  * cvx_index_build.  The reference's serial walk is local -- which windows a sequence offers depends on the 'N's around them,
  * which of those it keeps on the two sampled k-mers before -- so it runs a window per thread: sampled windows compacted in
  * walk order, the drop rule against the neighbours in that list, a histogram, row starts by a scan, and the rows by a stable
- * radix sort of (k-mer, position) (scan and sort: rocPRIM).  512 Mbp: 4.05 s on eight host threads -> TBD s including the
- * copies; CVX_ERR_NO_DEVICE without a device (the host builder above is the alternative, not a silent substitute). */
+ * radix sort of (k-mer, position) (scan and sort: rocPRIM).  512 Mbp: 3.8-4.1 s on eight host threads -> 0.30-0.35 s including the
+ * copies in and out (1.3 GB); CVX_ERR_NO_DEVICE without a device (the host builder above is the alternative, not a silent substitute). */
 int cvx_index_build_device(int32_t device_id, const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table, const uint64_t *seq_lengths,
 		int32_t n_seqs, int32_t kmer_len, int32_t ref_skip, int32_t bin_shift, void *ref_table_index, uint32_t *ref_table,
 		uint64_t ref_table_capacity, uint64_t *n_locations);

@@ -55,7 +55,7 @@ if INDEX:
     open(p, 'w').write(s)
     p = T + '/src/PrefixTable.cpp'
     s = open(p).read()
-    s = sub1(s, '#include "PrefixTable.h"', '#include "PrefixTable.h"\n#include <vector>\n#include <stdlib.h>\n#include <stdint.h>\n#include "cvx_align.h"', 'PrefixTable.cpp includes')
+    s = sub1(s, '#include "PrefixTable.h"', '#include "PrefixTable.h"\n#include <vector>\n#include <stdlib.h>\n#include <string.h>\n#include <stdint.h>\n#include "cvx_align.h"', 'PrefixTable.cpp includes')
     s = sub1(s, 'void CompactPrefixTable::CreateTable(uint const length) {\n', 'void CompactPrefixTable::CreateTable(uint const length) {\n#include "index_build_binding.inc"\n', 'CompactPrefixTable::CreateTable')
     open(p, 'w').write(s)
 if SEARCH:
