@@ -404,10 +404,14 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
  * which of those it keeps on the two sampled k-mers before -- so it runs a window per thread: sampled windows compacted in
  * walk order, the drop rule against the neighbours in that list, a histogram, row starts by a scan, and the rows by a stable
  * radix sort of (k-mer, position) (scan and sort: rocPRIM).  512 Mbp: 3.8-4.1 s on eight host threads -> 0.30-0.35 s including the
- * copies in and out (1.3 GB); CVX_ERR_NO_DEVICE without a device (the host builder above is the alternative, not a silent substitute). */
+ * copies in and out (1.3 GB); CVX_ERR_NO_DEVICE without a device (the host builder above is the alternative, not a silent substitute).
+ * flags: CVX_INDEX_KEEP_RESIDENT leaves the table on the device in the form the search reads; the next cvx_index_upload of these
+ * very arrays (same pointers, same count) on that device takes it over instead of converting 4^k records on the host and copying
+ * a gigabyte back up.  One table waits at a time; a later build, or the process's end, drops it. */
+#define CVX_INDEX_KEEP_RESIDENT 1u
 int cvx_index_build_device(int32_t device_id, const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table, const uint64_t *seq_lengths,
 		int32_t n_seqs, int32_t kmer_len, int32_t ref_skip, int32_t bin_shift, void *ref_table_index, uint32_t *ref_table,
-		uint64_t ref_table_capacity, uint64_t *n_locations);
+		uint64_t ref_table_capacity, uint64_t *n_locations, uint32_t flags);
 int cvx_search_batch(cvx_handle h, cvx_index ix, int32_t n, const char *const *seqs, const int32_t *lens,
 		float sensitivity, float min_kmer_hits, int32_t bin_shift,
 		int32_t *n_candidates, uint64_t *cand_begin, cvx_candidate *cands, uint64_t cand_capacity, uint64_t *cand_used);

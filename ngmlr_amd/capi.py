@@ -196,7 +196,7 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_stage_kernel_ms.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
     lib.cvx_search_last_attempts.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.cvx_index_build_device.argtypes = [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                           C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+                                           C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32]
     lib.cvx_index_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.cvx_runtime_regime.argtypes = [C.c_int, C.POINTER(CvxRegime)]

@@ -236,6 +236,16 @@ ib_keys_kernel(uint32_t *pre, uint32_t *pos, const uint8_t *kept, const uint8_t 
 	if (row && weight[p] == 0) pos[j] = 0u;
 }
 
+/* for a caller that goes on to search this table on the same device: the rows as the search reads them (cvx_index_upload's
+ * records: row start, row length | used << 31; 4^k + 1 of them) */
+__global__ void __launch_bounds__(256)
+ib_rows_kernel(const unsigned long long *row_start, const uint32_t *listed, const uint8_t *weight, unsigned long long n_prefix, uint2 *rows) {
+	const unsigned long long i = (unsigned long long) blockIdx.x * 256ull + threadIdx.x;
+	if (i > n_prefix) return;
+	const bool used = i < n_prefix && weight[i] != 0;
+	rows[i] = make_uint2(used ? (uint32_t) row_start[i] : 0u, used ? (listed[i] | 0x80000000u) : 0u);
+}
+
 struct DevMem {      /* everything this build allocates on the device, released together */
 	std::vector<void *> blocks;
 	template <class T> hipError_t get(T **p, size_t n) {
@@ -245,7 +255,8 @@ struct DevMem {      /* everything this build allocates on the device, released 
 		*p = static_cast<T *>(v);
 		return e;
 	}
-	~DevMem() { for (void *b : blocks) (void) hipFree(b); }
+	void keep(void *p) { for (void *&b : blocks) if (b == p) b = nullptr; }      /* (leaves with the caller) */
+	~DevMem() { for (void *b : blocks) if (b) (void) hipFree(b); }
 };
 
 }  // namespace
@@ -254,8 +265,10 @@ struct DevMem {      /* everything this build allocates on the device, released 
 
 int index_build_device(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table, const uint64_t *seq_lengths, int32_t n_seqs,
 		int32_t kmer_len, int32_t ref_skip, int32_t bin_shift, void *ref_table_index, uint32_t *ref_table, uint64_t ref_table_capacity,
-		uint64_t *n_locations, hipStream_t st, char *err, size_t err_len) {
+		uint64_t *n_locations, hipStream_t st, char *err, size_t err_len, void **resident_rows, uint32_t **resident_locs) {
 	const int k = kmer_len;
+	if (resident_rows) *resident_rows = nullptr;
+	if (resident_locs) *resident_locs = nullptr;
 	const unsigned long long n_prefix = 1ull << (2 * k);
 	/* chunks never straddle sequences */
 	std::vector<SeqDesc> seqs((size_t) n_seqs);
@@ -320,7 +333,7 @@ int index_build_device(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_
 	IB_HIP(hipStreamSynchronize(st));
 	const unsigned long long n_sampled = h_coff[(size_t) n_chunks];
 	/* 3: the sampled windows, compact */
-	uint32_t *d_pos, *d_pre, *d_pos2, *d_pre2, *d_freq, *d_listed;
+	uint32_t *d_pos, *d_pre, *d_pos2 = nullptr, *d_pre2, *d_freq, *d_listed;
 	uint8_t *d_kept, *d_weight, *d_wot, *d_idx;
 	unsigned long long *d_seq_first, *d_row;
 	IB_HIP(mem.get(&d_pos, (size_t) n_sampled)); IB_HIP(mem.get(&d_pre, (size_t) n_sampled)); IB_HIP(mem.get(&d_kept, (size_t) n_sampled));
@@ -363,14 +376,25 @@ int index_build_device(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_
 	if (n_sampled && next) {
 		hipLaunchKernelGGL(ib_keys_kernel, dim3((unsigned) ((n_sampled + 255) / 256)), dim3(256), 0, st, d_pre, d_pos, d_kept, d_weight, d_listed, n_sampled, (uint32_t) n_prefix);
 		IB_HIP(hipGetLastError());
-		IB_HIP(mem.get(&d_pos2, (size_t) n_sampled)); IB_HIP(mem.get(&d_pre2, (size_t) n_sampled));
+		IB_HIP(mem.get(&d_pos2, (size_t) n_sampled + 1)); IB_HIP(mem.get(&d_pre2, (size_t) n_sampled));
 		size_t tmp_bytes = 0;
 		IB_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_pre, d_pre2, d_pos, d_pos2, (size_t) n_sampled, 0, 2 * k + 1, st));
 		void *tmp; IB_HIP(mem.get(reinterpret_cast<uint8_t **>(&tmp), tmp_bytes));
 		IB_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, d_pre, d_pre2, d_pos, d_pos2, (size_t) n_sampled, 0, 2 * k + 1, st));
 		IB_HIP(hipMemcpyAsync(ref_table, d_pos2, 4 * (size_t) next, hipMemcpyDeviceToHost, st));
 	}
+	uint2 *d_rows = nullptr;
+	if (resident_rows && resident_locs) {
+		IB_HIP(mem.get(&d_rows, (size_t) n_prefix + 1));
+		hipLaunchKernelGGL(ib_rows_kernel, dim3((unsigned) ((n_prefix + 1 + 255) / 256)), dim3(256), 0, st, d_row, d_listed, d_weight, n_prefix, d_rows);
+		IB_HIP(hipGetLastError());
+		if (!(n_sampled && next)) IB_HIP(mem.get(&d_pos2, 1));
+	}
 	IB_HIP(hipStreamSynchronize(st));
+	if (d_rows) {
+		mem.keep(d_rows); mem.keep(d_pos2);
+		*resident_rows = d_rows; *resident_locs = d_pos2;
+	}
 	return CVX_OK;
 }
 

@@ -2116,12 +2116,43 @@ struct cvx_index_s {             /* one unit of ngmlr's CompactPrefixTable, resi
 	DevBuf<uint32_t> d_locs;
 };
 
+/* a table cvx_index_build_device(CVX_INDEX_KEEP_RESIDENT) left on its device: the next cvx_index_upload of these very host
+ * arrays on that device takes it over instead of reading 4^k records on the host and copying a gigabyte back up */
+struct ResidentTable {
+	std::mutex mtx;
+	int device = -1;
+	int32_t k = 0;
+	const void *index = nullptr;
+	const uint32_t *locs = nullptr;
+	uint64_t n_locs = 0;
+	void *d_rows = nullptr;
+	uint32_t *d_locs = nullptr;
+	void drop() {      /* (mtx held) */
+		if (device >= 0 && (d_rows || d_locs)) { (void) hipSetDevice(device); if (d_rows) (void) hipFree(d_rows); if (d_locs) (void) hipFree(d_locs); }
+		device = -1; d_rows = nullptr; d_locs = nullptr; index = nullptr; locs = nullptr;
+	}
+} g_resident_table;
+
 int cvx_index_upload(cvx_handle h, int32_t k, const void *index, const uint32_t *locs, uint32_t n_locs, uint64_t unit_offset, cvx_index *out) {
 	ABI_GUARD_BEGIN
 	if (!h || !out || !index || (n_locs > 0 && !locs) || k < 4 || k > 15) { set_err("cvx_index_upload: bad argument (kmer_len 4..15)"); return CVX_ERR_ARG; }
 	*out = nullptr;
 	HIP_TRY(hipSetDevice(h->device));
 	const uint64_t n_index = (1ull << (2 * k)) + 2ull;
+	{
+		std::lock_guard<std::mutex> lk(g_resident_table.mtx);
+		ResidentTable &r = g_resident_table;
+		if (r.device == h->device && r.k == k && r.index == index && r.locs == locs && r.n_locs == n_locs && r.d_rows && r.d_locs) {
+			cvx_index_s *ix = new (std::nothrow) cvx_index_s();
+			if (!ix) return CVX_ERR_OOM;
+			ix->device = h->device; ix->k = k; ix->n_index = n_index; ix->unit_offset = unit_offset; ix->n_locs = n_locs;
+			ix->d_rows.p = static_cast<uint2 *>(r.d_rows); ix->d_rows.cap = (size_t) n_index - 1;
+			ix->d_locs.p = r.d_locs; ix->d_locs.cap = (size_t) n_locs + 1;
+			r.device = -1; r.d_rows = nullptr; r.d_locs = nullptr; r.index = nullptr; r.locs = nullptr;
+			*out = ix;
+			return CVX_OK;
+		}
+	}
 	/* the 5-byte Index records (uint m_TabIndex; char m_RevCompIndex, #pragma pack(1): src/PrefixTable.h:15-31) as one 8-byte
 	 * record per prefix: where GetRefEntry's row starts (m_TabIndex - 1), how long it is (the next record's m_TabIndex - this
 	 * one's, PrefixTable.cpp:476-532) and Index::used() */
@@ -2160,7 +2191,7 @@ int cvx_index_upload(cvx_handle h, int32_t k, const void *index, const uint32_t 
 
 int cvx_index_build_device(int32_t device_id, const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *start_table, const uint64_t *seq_lengths, int32_t n_seqs,
 		int32_t kmer_len, int32_t ref_skip, int32_t bin_shift, void *ref_table_index, uint32_t *ref_table, uint64_t ref_table_capacity,
-		uint64_t *n_locations) {
+		uint64_t *n_locations, uint32_t flags) {
 	ABI_GUARD_BEGIN
 	if (!bin_ref || !start_table || !seq_lengths || n_seqs <= 0 || kmer_len < 4 || kmer_len > 15 || ref_skip < 0 || bin_shift < 0 || bin_shift > 30 ||
 			!ref_table_index || !n_locations) { set_err("cvx_index_build_device: bad argument (kmer_len 4..15, bin_shift 0..30)"); return CVX_ERR_ARG; }
@@ -2176,11 +2207,22 @@ int cvx_index_build_device(int32_t device_id, const uint8_t *bin_ref, uint64_t n
 	HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 	char err[320];
 	err[0] = 0;
+	const bool keep = (flags & CVX_INDEX_KEEP_RESIDENT) != 0u;
+	void *d_rows = nullptr;
+	uint32_t *d_locs = nullptr;
 	const int rc = index_build_device(bin_ref, n_nibbles, start_table, seq_lengths, n_seqs, kmer_len, ref_skip, bin_shift, ref_table_index, ref_table,
-			ref_table_capacity, n_locations, st, err, sizeof(err));
+			ref_table_capacity, n_locations, st, err, sizeof(err), keep ? &d_rows : nullptr, keep ? &d_locs : nullptr);
 	(void) hipStreamSynchronize(st);
 	(void) hipStreamDestroy(st);
 	if (rc != CVX_OK) set_err("cvx_index_build_device: %s", err);
+	if (keep) {
+		std::lock_guard<std::mutex> lk(g_resident_table.mtx);
+		g_resident_table.drop();                                  /* one table waits at a time */
+		if (rc == CVX_OK && d_rows && d_locs) {
+			g_resident_table.device = device_id; g_resident_table.k = kmer_len; g_resident_table.index = ref_table_index; g_resident_table.locs = ref_table;
+			g_resident_table.n_locs = *n_locations; g_resident_table.d_rows = d_rows; g_resident_table.d_locs = d_locs;
+		}
+	}
 	return rc;
 	ABI_GUARD_END
 }

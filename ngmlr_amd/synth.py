@@ -512,10 +512,11 @@ def big_reference(total_bases: int = 512 << 20, n_contigs: int = 8, seed: int = 
     return contigs
 
 
-def kmer_table(lib, contigs: Sequence[np.ndarray], k: int = 13, skip: int = 2, bin_shift: int = 4, device: int = None):
+def kmer_table(lib, contigs: Sequence[np.ndarray], k: int = 13, skip: int = 2, bin_shift: int = 4, device: int = None, keep: bool = False):
     """-> (index bytes [(4^k + 2) * 5], locations uint32[], start table uint64[]) for `contigs`: cvx_genome_encode + cvx_index_build,
     i.e. what ngmlr's SequenceProvider and CompactPrefixTable build from the same sequences (host only); device = a device
-    number: the table by cvx_index_build_device instead (same bytes)."""
+    number: the table by cvx_index_build_device instead (same bytes); keep: CVX_INDEX_KEEP_RESIDENT -- a KmerIndex made from exactly
+    the returned arrays on that device then takes the device's copy over."""
     import ctypes as C
     from . import capi
     n = len(contigs)
@@ -539,7 +540,7 @@ def kmer_table(lib, contigs: Sequence[np.ndarray], k: int = 13, skip: int = 2, b
                                        idx.ctypes.data, locs.ctypes.data, cap, C.byref(nl)))
     else:
         capi.check(lib.cvx_index_build_device(device, binref.ctypes.data, nn.value, starts.ctypes.data, kept.ctypes.data, len(kept), k, skip, bin_shift,
-                                              idx.ctypes.data, locs.ctypes.data, cap, C.byref(nl)))
+                                              idx.ctypes.data, locs.ctypes.data, cap, C.byref(nl), 1 if keep else 0))
     return idx, locs[:nl.value], starts[:ns.value]
 
 

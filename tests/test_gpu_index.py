@@ -121,6 +121,44 @@ def test_device_builder_at_genome_scale(hip_aligner):
     assert hashlib.sha256(locs.tobytes()).hexdigest() == str(z["locs_sha256"])
 
 
+def test_resident_table_is_taken_over_by_the_upload(hip_aligner):
+    """CVX_INDEX_KEEP_RESIDENT: the table stays on the device in the search's own form and cvx_index_upload of the very arrays the
+    build filled adopts it (no conversion of 4^13 records on the host, no copy back up) -- the search over it returns what it
+    returns over a table uploaded the usual way; other arrays are uploaded the usual way."""
+    import time
+    from ngmlr_amd.aligner import KmerIndex
+    lib = hip_aligner.lib
+    contigs = synth.big_reference(8 << 20, n_contigs=2, seed=11)
+    reads = synth.sample_subreads(contigs, 1500)
+    idx, locs, _ = synth.kmer_table(lib, contigs, device=0, keep=True)
+    dt = np.dtype([("tab", "<u4"), ("rc", "i1")])
+    t0 = time.perf_counter()
+    ix = KmerIndex(hip_aligner, 13, idx.view(dt), locs, 0)
+    t_adopt = time.perf_counter() - t0
+    try:
+        got = ix.search(reads)
+    finally:
+        ix.free()
+    idx2, locs2 = idx.copy(), locs.copy()          # other arrays: nothing to adopt
+    t0 = time.perf_counter()
+    ix2 = KmerIndex(hip_aligner, 13, idx2.view(dt), locs2, 0)
+    t_upload = time.perf_counter() - t0
+    try:
+        want = ix2.search(reads)
+        # the resident copy is gone after the first upload: the same arrays again take the usual path and still give the same lists
+        ix3 = KmerIndex(hip_aligner, 13, idx.view(dt), locs, 0)
+        try:
+            again = ix3.search(reads[:200])
+        finally:
+            ix3.free()
+    finally:
+        ix2.free()
+    assert all((g is None and w is None) or (g is not None and w is not None and np.array_equal(g, w)) for g, w in zip(got, want))
+    assert all((g is None and w is None) or np.array_equal(g, w) for g, w in zip(again, want[:200]))
+    assert sum(len(g) for g in got if g is not None) > 1000
+    assert t_adopt < t_upload, (t_adopt, t_upload)
+
+
 def test_device_builder_errors(hip_aligner):
     lib = hip_aligner.lib
     contigs = [_rand(np.random.default_rng(3), 5000)]
@@ -130,7 +168,7 @@ def test_device_builder_errors(hip_aligner):
     st = np.array([0], dtype=np.uint64); ln = np.array([5002], dtype=np.uint64)
     out = np.zeros((4 ** 13 + 2) * 5, dtype=np.uint8)
     # too little room: the need comes back and the index records are complete
-    rc = lib.cvx_index_build_device(0, binref.ctypes.data, 8192, st.ctypes.data, ln.ctypes.data, 1, 13, 2, 4, out.ctypes.data, None, 0, C.byref(nl))
+    rc = lib.cvx_index_build_device(0, binref.ctypes.data, 8192, st.ctypes.data, ln.ctypes.data, 1, 13, 2, 4, out.ctypes.data, None, 0, C.byref(nl), 0)
     assert rc == -6 and nl.value > 0
-    assert lib.cvx_index_build_device(0, binref.ctypes.data, 8192, st.ctypes.data, ln.ctypes.data, 1, 3, 2, 4, out.ctypes.data, None, 0, C.byref(nl)) != 0      # k out of range
-    assert lib.cvx_index_build_device(99, binref.ctypes.data, 8192, st.ctypes.data, ln.ctypes.data, 1, 13, 2, 4, out.ctypes.data, None, 0, C.byref(nl)) != 0     # no such device
+    assert lib.cvx_index_build_device(0, binref.ctypes.data, 8192, st.ctypes.data, ln.ctypes.data, 1, 3, 2, 4, out.ctypes.data, None, 0, C.byref(nl), 0) != 0      # k out of range
+    assert lib.cvx_index_build_device(99, binref.ctypes.data, 8192, st.ctypes.data, ln.ctypes.data, 1, 13, 2, 4, out.ctypes.data, None, 0, C.byref(nl), 0) != 0     # no such device
