@@ -2340,7 +2340,10 @@ static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *cons
 	const char *cls_env = getenv("CVX_TUNE_SEARCH_CLASSIFY"), *log2_env = getenv("CVX_TUNE_SEARCH_LOG2");
 	const int classify_min = cls_env ? atoi(cls_env) : 2048;
 	const int forced_log2 = log2_env ? std::min(kSearchWaveLog2Max, std::max(kSearchWaveLog2Min, atoi(log2_env))) : 0;
-	const bool classify = use_wave && !forced_log2 && n >= classify_min;
+	/* (a table with three locations per k-mer and more -- a genome of 600 Mbp and up at ngmlr's defaults -- gives a 256-base read
+	 * 1 500 votes and more: the one-size map of a small call would not hold it, so its reads are counted and sorted as well) */
+	const bool big_table = (uint64_t) ix->n_locs >= 3ull * (ix->n_index - 2ull);
+	const bool classify = use_wave && !forced_log2 && (n >= classify_min || big_table);
 	bool counted = false;
 	uint64_t total = 0;             /* votes of the reads that took the HBM-table form so far: their rList / candidate regions */
 	std::vector<uint8_t> has_region(n1, 0);

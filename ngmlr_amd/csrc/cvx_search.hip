@@ -374,6 +374,13 @@ struct LdsVotes {
 	__device__ uint64_t bin_of(const int idx) const { return (uint64_t) bin[idx]; }
 	__device__ float2 scores_of(const int idx) const { const uint32_t v = fr[idx]; return make_float2((float) (v & 0xFFFFu), (float) (v >> 16)); }
 	__device__ bool room_for(const int n_new) const { return entries + n_new <= cap; }
+	/* after `done` of `total` windows: at this rate the read ends with 5/4 of what the map holds or more -- give up now instead of
+	 * at the entry that does not fit (a sub-read of a 2 Gbp genome casts 5 000 votes into as many bins: it was cast to 59 % in
+	 * LDS before the map was full, then all over again over the table in HBM).  Only ever a question for the largest map: the
+	 * smaller ones are chosen to hold the read's vote count.  A read given up wrongly is merely slower. */
+	__device__ bool hopeless(const int done, const int total) const {
+		return done * 8 >= total && (long long) entries * total * 4 > (long long) cap * done * 5;
+	}
 };
 
 struct HbmVotes {
@@ -414,6 +421,7 @@ struct HbmVotes {
 	__device__ bool room_for(const int n_new) const { (void) n_new; return true; }
 	__device__ static bool fits(const uint64_t b) { (void) b; return true; }
 	__device__ static bool score_fits(const float s) { (void) s; return true; }
+	__device__ bool hopeless(const int done, const int total) const { (void) done; (void) total; return false; }
 };
 
 /* the running state of a read's vote (CS::RunRead's locals, CS.cpp:324-398) */
@@ -620,6 +628,7 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		const Kmers kn = lookup(q0 + 64);      /* (behind the last chunk: no lane with a k-mer) */
 		cast_chunk(kc, q0);
 		kc = kn;
+		if (tb.hopeless(q0 + 64, n_win)) S.too_many = true;
 	}
 
 	if (S.too_many) { if (lane == 0) a.n_cand[i] = kSearchNeedsHbm; return; }      /* redone over a table in HBM: nothing of this attempt counts */
