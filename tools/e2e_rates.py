@@ -18,7 +18,7 @@
 
 Environment: E2E_POOL="[all@]t:K:target:hold_us[:ENV=v...],..." (pool binaries: CS threads, contexts, batch target / hold, extra environment),
 E2E_ONLY=binary (no reference run), E2E_QUICK / E2E_SKIP_OLD (fewer runs), E2E_VERBOSE (timeline and trace lines of the run's stderr),
-and for --synthetic: E2E_READ_LEN=lo:hi, E2E_REF_LEN=bases, E2E_CONTIGS=n (reference as n sequences, a fifth of the reads flush with a contig end).
+E2E_BIG_MBP (--synthetic-big: reference size, 512), and for --synthetic: E2E_READ_LEN=lo:hi, E2E_REF_LEN=bases, E2E_CONTIGS=n (reference as n sequences, a fifth of the reads flush with a contig end).
 
 Wall clock includes ngmlr's start-up (reference encoding + index); `map` is the wall clock minus the
 index construction time ngmlr reports (thread start-up + mapping + exit).  Says how the drop-in behaves inside the real pipeline, not how fast the kernels are."""
@@ -197,7 +197,8 @@ def write_big_workload(fa, fq, n_reads, seed=31):
     24 repeat families, 600 microsatellites; the reference of bench.py's candidate_search_big) -- and PacBio-like 10 kb reads drawn
     uniformly from it (15 % error 6:3:1, half of them reverse-complemented).  -> read bases"""
     from ngmlr_amd import synth
-    contigs = synth.big_reference(512 << 20, n_contigs=8)
+    mbp = int(os.environ.get("E2E_BIG_MBP", "512"))      # (2048: a 3.2 GB table, 5 000 votes per sub-read -- every search through the table in HBM)
+    contigs = synth.big_reference(mbp << 20, n_contigs=8)
     with open(fa, "wb") as f:
         for i, c in enumerate(contigs):
             f.write(b">big%d\n" % i)
@@ -412,9 +413,9 @@ def synthetic(n_reads, threads, sv=False, rep=False, big=False):
         bases = write_sv_workload(fa, fq, n_reads, L=L)
         print("SV workload (ONT-like 8-30 kb reads, 20 % error, a third with an inversion / deletion / insertion; -x ont):")
     elif big:
-        L = 512 << 20
+        L = int(os.environ.get("E2E_BIG_MBP", "512")) << 20
         bases = write_big_workload(fa, fq, n_reads)
-        print("genome-sized reference (512 Mbp in 8 contigs, repeat families, microsatellites: the k-mer table is 1 GB and leaves every cache):")
+        print("genome-sized reference (%d Mbp in 8 contigs, repeat families, microsatellites: the k-mer table is %.1f GB and leaves every cache):" % (L >> 20, (L >> 20) / 512.0))
     elif rep:
         L = 3_000_000
         bases = write_repeat_workload(fa, fq, n_reads, L=L)
