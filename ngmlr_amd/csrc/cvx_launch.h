@@ -49,6 +49,7 @@ struct SearchArgs {
 	unsigned long long *events;      /* votes it will cast (search_count_kernel) */
 	const uint64_t *list_off;        /* exclusive prefix sum of events: rList region; candidates at twice that */
 	uint32_t *rlist;
+	uint32_t *undo;                  /* search_wave_hbm_kernel: the table slots a read opened, same regions as rlist */
 	SearchCandidate *cand;
 	int32_t *n_cand;                 /* -1: the probe budget ran out at this table size */
 	float *max_hit;
@@ -81,7 +82,9 @@ hipError_t launch_search_count(const SearchArgs &a, hipStream_t st);
 hipError_t launch_search(const SearchArgs &a, hipStream_t st);
 /* seq_cap: bytes of LDS for the read, >= the launch's longest read + 65, a multiple of 4 */
 hipError_t launch_search_wave(const SearchArgs &a, int log2s, int seq_cap, hipStream_t st);
-hipError_t launch_search_wave_hbm(const SearchArgs &a, hipStream_t st);      /* a wave per read over the real table in HBM */
+/* a wave per read over the real table in HBM: n_tables tables of 2^bits 16-byte entries at a.keys, every one empty when the
+ * launch starts and when it ends; *ticket = 0 */
+hipError_t launch_search_wave_hbm(const SearchArgs &a, int n_tables, unsigned int *ticket, hipStream_t st);
 /* dense[dst_begin[i] ...) = the n_cand[i] candidates of read i, which lie at sparse + src_off[i] */
 hipError_t launch_search_compact(const SearchCandidate *sparse, const uint64_t *src_off, const int32_t *n_cand, const uint64_t *dst_begin,
 		SearchCandidate *dense, int n, hipStream_t st);

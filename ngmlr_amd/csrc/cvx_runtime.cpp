@@ -354,7 +354,9 @@ struct cvx_search_state {
 	DevBuf<int32_t> d_len, d_ncand, d_work, d_miss;
 	DevBuf<unsigned long long> d_events;
 	DevBuf<float> d_maxhit, d_scores;
-	DevBuf<uint32_t> d_rlist;
+	DevBuf<uint32_t> d_rlist, d_undo;
+	DevBuf<unsigned int> d_ticket;
+	size_t tables_clean_words = 0;     /* this much of d_keys is known to hold nothing but empty slots (search_wave_hbm_kernel's tables) */
 	DevBuf<SearchCandidate> d_cand, d_dense;
 	DevBuf<uint64_t> d_keys;
 	hipEvent_t done = nullptr;
@@ -373,7 +375,7 @@ struct cvx_search_state {
 		kev.clear(); kev_used = 0;
 		h_seq.release(); h_meta.release(); h_out.release();
 		d_seq.release(); d_off.release(); d_listoff.release(); d_begin.release(); d_srcoff.release(); h_srcoff.release(); d_len.release(); d_ncand.release(); d_work.release(); d_miss.release();
-		d_events.release(); d_maxhit.release(); d_scores.release(); d_rlist.release(); d_cand.release(); d_dense.release(); d_keys.release();
+		d_events.release(); d_maxhit.release(); d_scores.release(); d_rlist.release(); d_undo.release(); d_ticket.release(); d_cand.release(); d_dense.release(); d_keys.release();
 		if (done) { (void) hipEventDestroy(done); done = nullptr; }
 	}
 };
@@ -2455,11 +2457,36 @@ static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *cons
 			RC_TRY(give_regions(hbm_now));
 			for (int32_t i : hbm_now) h_srcoff[i] = fixed_total + 2 * h_listoff[i];
 			const size_t per_read = (size_t) 1 << bits;
-			const size_t chunk = std::max<size_t>(1, std::min<size_t>(hbm_now.size(), ((size_t) 8 << 30) / (per_read * 16)));     /* <= 8 GB of tables, and no more tables than reads */
+			a.rlist = ss->d_rlist.p; a.cand = ss->d_cand.p + fixed_total;
+			if (!lane_serial) {
+				/* the wave kernel's tables belong to the waves: as many as can be resident (or as 8 GB hold), each 2^bits entries of 16
+				 * bytes, empty between launches -- a wave frees the slots a read opened when the read is done -- so they are cleared
+				 * when they are allocated, when the table size changes and after a launch that failed, not per read */
+				RC_TRY(ss->d_undo.ensure((size_t) total + 64));
+				a.undo = ss->d_undo.p;
+				const size_t n_tables = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hbm_now.size(), 8192), ((size_t) 8 << 30) / (per_read * 16)));
+				const size_t need_words = n_tables * per_read * 2;
+				if (ss->d_keys.cap < need_words) { RC_TRY(ss->d_keys.ensure(need_words)); ss->tables_clean_words = 0; }
+				if (ss->tables_clean_words < need_words) {
+					HIP_TRY(hipMemsetAsync(ss->d_keys.p, 0xFF, ss->d_keys.cap * 8, st));      /* (scores of a free slot are never read) */
+					ss->tables_clean_words = ss->d_keys.cap;
+				}
+				RC_TRY(ss->d_ticket.ensure(16));
+				HIP_TRY(hipMemsetAsync(ss->d_ticket.p, 0, 4, st));
+				a.keys = ss->d_keys.p;
+				memcpy(h_work, hbm_now.data(), hbm_now.size() * 4);
+				HIP_TRY(hipMemcpyAsync(ss->d_work.p, h_work, hbm_now.size() * 4, hipMemcpyHostToDevice, st));
+				a.n_work = (int32_t) hbm_now.size();
+				ss->tables_clean_words = 0;                     /* until the launch is known to have ended */
+				RC_TRY(ss->kmark(st));
+				HIP_TRY(launch_search_wave_hbm(a, (int) n_tables, ss->d_ticket.p, st));
+				RC_TRY(ss->kmark(st));
+			} else {
+			const size_t chunk = std::max<size_t>(1, std::min<size_t>(hbm_now.size(), ((size_t) 8 << 30) / (per_read * 16)));
+			ss->tables_clean_words = 0;                         /* the lane-per-read kernel leaves its tables as they are */
 			RC_TRY(ss->d_keys.ensure(chunk * per_read));
 			RC_TRY(ss->d_scores.ensure(chunk * per_read * 2));
 			a.keys = ss->d_keys.p; a.scores = ss->d_scores.p;
-			a.rlist = ss->d_rlist.p; a.cand = ss->d_cand.p + fixed_total;
 			for (size_t w0 = 0; w0 < hbm_now.size(); w0 += chunk) {
 				const size_t m = std::min(chunk, hbm_now.size() - w0);
 				memcpy(h_work, hbm_now.data() + w0, m * 4);
@@ -2467,12 +2494,14 @@ static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *cons
 				HIP_TRY(hipMemsetAsync(ss->d_keys.p, 0xFF, m * per_read * 8, st));          /* every slot empty */
 				a.n_work = (int32_t) m;
 				RC_TRY(ss->kmark(st));
-				HIP_TRY(lane_serial ? launch_search(a, st) : launch_search_wave_hbm(a, st));
+				HIP_TRY(launch_search(a, st));
 				RC_TRY(ss->kmark(st));
 				if (w0 + chunk < hbm_now.size()) RC_TRY(search_wait(ss, st));      /* (the work list is reused by the next chunk) */
 			}
+			}
 			HIP_TRY(hipMemcpyAsync(h_ncand, ss->d_ncand.p, n1 * 4, hipMemcpyDeviceToHost, st));
 			RC_TRY(search_wait(ss, st));
+			if (!lane_serial) ss->tables_clean_words = ss->d_keys.cap;      /* the launch ended: every wave left its table empty */
 			for (int32_t i : hbm_now) if (h_ncand[i] < 0) next_hbm.push_back(i);
 			if (trace) { char b[160]; snprintf(b, sizeof(b), " [bits %d hbm %zu (%llu votes in the call) -> %zu retry, at %.2f ms]", bits, hbm_now.size(), (unsigned long long) total, next_hbm.size(), tr_ms()); tr += b; }
 		}

@@ -374,6 +374,7 @@ struct LdsVotes {
 	__device__ uint64_t bin_of(const int idx) const { return (uint64_t) bin[idx]; }
 	__device__ float2 scores_of(const int idx) const { const uint32_t v = fr[idx]; return make_float2((float) (v & 0xFFFFu), (float) (v >> 16)); }
 	__device__ bool room_for(const int n_new) const { return entries + n_new <= cap; }
+	__device__ void remember(const int at, const uint32_t e) { (void) at; (void) e; }
 	/* after `done` of `total` windows: at this rate the read ends with 5/4 of what the map holds or more -- give up now instead of
 	 * at the entry that does not fit (a sub-read of a 2 Gbp genome casts 5 000 votes into as many bins: it was cast to 59 % in
 	 * LDS before the map was full, then all over again over the table in HBM).  Only ever a question for the largest map: the
@@ -385,43 +386,65 @@ struct LdsVotes {
 
 struct HbmVotes {
 	static const bool kLds = false;
-	uint64_t *keys;          /* 2^bits: bin | kListed, kEmptyKey = free (search_kernel's layout) */
-	float *fr;               /* 2 floats per slot */
+	/* The reference's table itself, 2^bits entries of 16 bytes: { bin | kListed (kEmptyKey: free), forward score, reverse score }
+	 * -- key and scores in ONE 64-byte sector (round 6; two arrays until then: over a 2 Gbp genome, where every sub-read casts
+	 * 5 000 votes into 5 000 bins and none fits an LDS map, the kernel ran at the device's random-access rate, and half of its
+	 * sectors were the second array and the 1 MB memset per read).  The table belongs to the wave, not to the read: the wave takes
+	 * reads off a ticket counter, remembers the slots it opens (undo[]) and frees exactly those when the read is done. */
+	unsigned long long *tab;  /* entry e at tab[2 e], tab[2 e + 1] = (forward bits) | (reverse bits) << 32 */
 	uint32_t *rlist;
+	uint32_t *undo;
 	const uint8_t *gseq;     /* the read, seq_bytes of it readable (its NUL included) */
 	int seq_bytes;
 	int entries;
-	/* lanes of one wave share these through L2: every access is an agent-scope atomic (no stale L1 lines), so ordering them
+	unsigned long long last_sc;      /* scores of the entry this lane's last find() matched */
+	/* lanes of one wave share the table through L2: every access is an agent-scope atomic (no stale L1 lines), so ordering them
 	 * needs no more than the wave's own memory operations completing -- a workgroup fence; an agent-scope one would write L2 back */
 	__device__ void fence() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 	__device__ int char_at(const int p) const { return p < seq_bytes ? gseq[p] : 0; }
-	__device__ int find(const uint32_t e, const uint64_t bin, int &idx, bool &listed) const {
-		const uint64_t key = __hip_atomic_load(&keys[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (key == kEmptyKey) return kProbeFree;
-		if ((key & ~kListed) == bin) { idx = (int) e; listed = (key & kListed) != 0ull; return kProbeMatch; }
+	__device__ int find(const uint32_t e, const uint64_t bin, int &idx, bool &listed) {
+		/* (both halves of the entry in flight at once: one sector) */
+		const uint64_t key = __hip_atomic_load(&tab[2 * (size_t) e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint64_t sc = __hip_atomic_load(&tab[2 * (size_t) e + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (key == kEmptyKey) { last_sc = 0ull; return kProbeFree; }      /* (whoever opens it starts from 0 / 0) */
+		if ((key & ~kListed) == bin) { idx = (int) e; listed = (key & kListed) != 0ull; last_sc = sc; return kProbeMatch; }
 		return kProbeOther;
 	}
 	__device__ void claim(const uint32_t e, const uint64_t bin, int &idx, bool &creator, bool &hazard) {
 		unsigned long long expected = kEmptyKey;
-		const bool won = __hip_atomic_compare_exchange_strong((unsigned long long *) &keys[e], &expected, (unsigned long long) bin, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const bool won = __hip_atomic_compare_exchange_strong(&tab[2 * (size_t) e], &expected, (unsigned long long) bin, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		idx = (int) e;
 		creator = won;
 		hazard = !won && (expected & ~kListed) != bin;
-		if (won) { __hip_atomic_store(&fr[2 * (size_t) e], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&fr[2 * (size_t) e + 1], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		if (won) __hip_atomic_store(&tab[2 * (size_t) e + 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	__device__ bool verify(const int idx, const uint64_t bin) const { (void) idx; (void) bin; return true; }
-	__device__ void unclaim(const int idx, const uint32_t e) { (void) idx; __hip_atomic_store(&keys[e], kEmptyKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-	__device__ float score(const int idx, const bool rev) const { return __hip_atomic_load(&fr[2 * (size_t) (uint32_t) idx + (rev ? 1 : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-	__device__ void set_score(const int idx, const bool rev, const float s) { __hip_atomic_store(&fr[2 * (size_t) (uint32_t) idx + (rev ? 1 : 0)], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-	__device__ void set_listed(const int idx, const uint32_t e) { (void) e; __hip_atomic_fetch_or((unsigned long long *) &keys[(uint32_t) idx], (unsigned long long) kListed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	__device__ void unclaim(const int idx, const uint32_t e) { (void) idx; __hip_atomic_store(&tab[2 * (size_t) e], (unsigned long long) kEmptyKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	__device__ void remember(const int at, const uint32_t e) { undo[at] = e; }
+	/* the score the lane's last find() saw (0 for a slot that was free then: opened in this very batch) */
+	__device__ float score(const int idx, const bool rev) const { (void) idx; return __uint_as_float((uint32_t) (rev ? last_sc >> 32 : last_sc)); }
+	__device__ void set_score(const int idx, const bool rev, const float s) {
+		__hip_atomic_store(reinterpret_cast<uint32_t *>(&tab[2 * (size_t) (uint32_t) idx + 1]) + (rev ? 1 : 0), __float_as_uint(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	__device__ void set_listed(const int idx, const uint32_t e) { (void) e; __hip_atomic_fetch_or(&tab[2 * (size_t) (uint32_t) idx], (unsigned long long) kListed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 	__device__ void list_put(const int pos, const int idx) { rlist[pos] = (uint32_t) idx; }
 	__device__ int list_at(const int pos) const { return (int) __hip_atomic_load(&rlist[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-	__device__ uint64_t bin_of(const int idx) const { return __hip_atomic_load(&keys[(uint32_t) idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~kListed; }
-	__device__ float2 scores_of(const int idx) const { return make_float2(score(idx, false), score(idx, true)); }
+	__device__ uint64_t bin_of(const int idx) const { return __hip_atomic_load(&tab[2 * (size_t) (uint32_t) idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~kListed; }
+	__device__ float2 scores_of(const int idx) const {
+		const unsigned long long sc = __hip_atomic_load(&tab[2 * (size_t) (uint32_t) idx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return make_float2(__uint_as_float((uint32_t) sc), __uint_as_float((uint32_t) (sc >> 32)));
+	}
 	__device__ bool room_for(const int n_new) const { (void) n_new; return true; }
 	__device__ static bool fits(const uint64_t b) { (void) b; return true; }
 	__device__ static bool score_fits(const float s) { (void) s; return true; }
 	__device__ bool hopeless(const int done, const int total) const { (void) done; (void) total; return false; }
+	/* the read is done (or its attempt ran out of budget): the slots it opened are free again */
+	__device__ void cleanup(const int lane) {
+		fence();
+		for (int j = lane; j < entries; j += 64) __hip_atomic_store(&tab[2 * (size_t) undo[j]], (unsigned long long) kEmptyKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		fence();
+		entries = 0;
+	}
 };
 
 /* the running state of a read's vote (CS::RunRead's locals, CS.cpp:324-398) */
@@ -459,7 +482,7 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		if (st == kProbeFree) {
 			if (!tb.room_for(1)) { S.too_many = true; return; }
 			bool creator = false, hazard = false;
-			if (lane == 0) tb.claim(e, bin, idx, creator, hazard);
+			if (lane == 0) { tb.claim(e, bin, idx, creator, hazard); tb.remember(tb.entries, e); }
 			tb.fence();
 			idx = lane_of(idx, 0);
 			tb.entries += 1;
@@ -517,7 +540,9 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 			return;
 		}
 		S.hpoc -= (long long) total_steps;
-		tb.entries += __popcll(__ballot(creator));
+		const uint64_t created = __ballot(creator);
+		if (creator) tb.remember(tb.entries + __popcll(created & lt), e);
+		tb.entries += __popcll(created);
 		/* votes of the batch for the same entry: ranked in lane order per orientation, listed once */
 		uint64_t grp_h = 1ull << lane, grp_hr = 1ull << lane;
 		if (active) C.scr[(uint32_t) idx & 1023u] = (uint8_t) lane;      /* (1 024 buckets: 64 lanes over 256 met by chance eight times a batch, each a trip of the loop below) */
@@ -680,23 +705,29 @@ search_wave_kernel(const SearchArgs a, const int log2s, const int seq_cap) {
 	search_vote_read(a, tb, C, i, lane, a.cand + a.cand_off[i]);
 }
 
-/* the same over the real table in HBM (table q of the launch: keys / scores as search_kernel lays them out, emptied by the host) */
+/* the same over the real table in HBM: block b owns table b of the launch (clean when the launch starts, clean when it ends)
+ * and takes reads off the ticket counter until none is left */
 __global__ void __launch_bounds__(64)
-search_wave_hbm_kernel(const SearchArgs a) {
+search_wave_hbm_kernel(const SearchArgs a, unsigned int *ticket) {
 	__shared__ ChunkRows C;
-	const int q = blockIdx.x;
-	if (q >= a.n_work) return;
 	const int lane = threadIdx.x;
-	const int i = a.work ? a.work[q] : q;
 	const size_t size = (size_t) 1 << a.bits;
 	HbmVotes tb;
-	tb.seq_bytes = a.seq_len[i] + 1;
-	tb.keys = a.keys + (size_t) q * size;
-	tb.fr = a.scores + 2 * (size_t) q * size;
-	tb.rlist = a.rlist + a.list_off[i];
-	tb.gseq = a.seq + a.seq_off[i];
-	tb.entries = 0;
-	search_vote_read(a, tb, C, i, lane, a.cand + 2ull * a.list_off[i]);
+	tb.tab = reinterpret_cast<unsigned long long *>(a.keys) + 2 * (size_t) blockIdx.x * size;
+	tb.entries = 0; tb.last_sc = 0ull;
+	for (;;) {
+		unsigned int q = 0;
+		if (lane == 0) q = atomicAdd(ticket, 1u);
+		q = (unsigned int) lane_of((int) q, 0);
+		if (q >= (unsigned int) a.n_work) break;
+		const int i = a.work ? a.work[q] : (int) q;
+		tb.seq_bytes = a.seq_len[i] + 1;
+		tb.rlist = a.rlist + a.list_off[i];
+		tb.undo = a.undo + a.list_off[i];
+		tb.gseq = a.seq + a.seq_off[i];
+		search_vote_read(a, tb, C, i, lane, a.cand + 2ull * a.list_off[i]);
+		tb.cleanup(lane);
+	}
 }
 
 /* dense[dst_begin[i] ...) = the n_cand[i] candidates of read i, which lie at sparse + src_off[i] */
@@ -727,9 +758,10 @@ hipError_t launch_search_wave(const SearchArgs &a, const int log2s, const int se
 	return hipGetLastError();
 }
 
-hipError_t launch_search_wave_hbm(const SearchArgs &a, hipStream_t st) {
+hipError_t launch_search_wave_hbm(const SearchArgs &a, int n_tables, unsigned int *ticket, hipStream_t st) {
 	if (a.n_work <= 0) return hipSuccess;
-	hipLaunchKernelGGL(search_wave_hbm_kernel, dim3(a.n_work), dim3(64), 0, st, a);
+	if (n_tables <= 0 || !ticket) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(search_wave_hbm_kernel, dim3(a.n_work < n_tables ? a.n_work : n_tables), dim3(64), 0, st, a, ticket);
 	return hipGetLastError();
 }
 
