@@ -30,6 +30,8 @@ for W in ont c5; do
 	timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/${TAG}_${W}_sq -o p -- python $R/tools/ab_knobs.py $W -- "" > $OUT/${TAG}_${W}_sq.log 2>&1
 done
 timeout -s KILL 300 python $R/tools/search_rates.py --big 512 100000 > $OUT/${TAG}_search_big.json 2> $OUT/${TAG}_search_big.err
+# round 6: the same over a 2 Gbp reference (3.2 GB table, 5 000 votes per sub-read: no LDS map holds one, every read goes through the table in HBM)
+CVX_SEARCH_TRACE=1 timeout -s KILL 400 python $R/tools/search_rates.py --big 2048 20000 > $OUT/${TAG}_search_2gbp.json 2> $OUT/${TAG}_search_2gbp.err
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_search_stats -o p -- python $R/tools/search_rates.py --big 512 100000 > $OUT/${TAG}_search_stats.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_search_fetch -o p -- python $R/tools/search_rates.py --big 512 100000 > $OUT/${TAG}_search_fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_search_write -o p -- python $R/tools/search_rates.py --big 512 100000 > $OUT/${TAG}_search_write.log 2>&1
