@@ -1,5 +1,6 @@
 /* align_pool.cpp -- see align_pool.h.  Compiled only inside ngmlr's tree (tools/build_ngmlr_hip.sh). */
 #include "align_pool.h"
+#include "cvx_pcsample.h"
 
 #include <chrono>
 #include <condition_variable>
@@ -186,7 +187,7 @@ struct FiberContexts {
 		delete it;
 	}
 	static void destroySlot(void *, void * slot) { delete (AlignmentBuffer *) slot; }      /* ~SAMWriter flushes this context's records */
-	static void carrierStart(void *, int) { pthread_setname_np(pthread_self(), "cvx-context"); }
+	static void carrierStart(void *, int) { pthread_setname_np(pthread_self(), "cvx-context"); pcsample::arm_this_thread(1); }
 	static void lastItemTaken(void *) { SharedAligner::SetFeedActive(false); }
 
 	FiberContexts() : pool(0), failed(0), maxContexts(4096), carriers(16), queueLimit(0), born(std::chrono::steady_clock::now()) {
@@ -283,6 +284,7 @@ AnyPool * poolForSubmit() {
 
 void AlignPool::Attach() {
 	pthread_setname_np(pthread_self(), "ngm-cs");      /* the calling CS thread */
+	pcsample::arm_this_thread(2);
 	std::lock_guard<std::mutex> g(g_poolMtx);
 	/* the aligner fronts built from now on (the CS threads' own, the contexts') register with their dispatcher per
 	 * read (ThreadBegin / ThreadEnd), not for their lifetime */

@@ -1,5 +1,6 @@
 /* batching_aligner.cpp -- see batching_aligner.h */
 #include "batching_aligner.h"
+#include "cvx_pcsample.h"
 #include "service_device.h"
 
 #include <algorithm>
@@ -146,6 +147,7 @@ bool BatchingAligner::shouldCut(bool deviceIdle) const {
 /* The one thread that owns the device handle.  Up to maxFlight (two) launches in flight: the upload and corridor analysis
  * of the younger run under the kernels of the older; requests that arrive meanwhile form the launch after that. */
 void BatchingAligner::dispatchLoop() {
+	pcsample::arm_this_thread(3);
 	pthread_setname_np(pthread_self(), "cvx-dispatch");      /* (thread names: tools/e2e_rates.py splits the process's CPU time by them) */
 	std::unique_lock<std::mutex> lk(mtx);
 	for (;;) {
