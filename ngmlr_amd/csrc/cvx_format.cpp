@@ -7,6 +7,7 @@
  * Written against the forward-ordered op list the device backtrack emits instead of
  * the reference's back-filled binaryCigar buffer.  Pure host code; no HIP, no oracle.
  */
+#include <emmintrin.h>
 #include <cstdint>
 #include <cstring>
 
@@ -62,7 +63,19 @@ struct NmSink {
 			const int room = cap - n;
 			const int m = count - j0 < room ? count - j0 : (room > 0 ? room : 0);
 			int a = posInRef + j0 - 16, b = posInRead + j0 - 16;
-			for (int j = 0; j < m; ++j) { o[0] = a++; o[1] = b++; o[2] = yi; o += 3; }
+			int j = 0;
+			/* four (ref, read, yi) triples = three 16-byte stores (SSE2: every x86-64 has it) */
+			__m128i v0 = _mm_set_epi32(a + 1, yi, b, a), v1 = _mm_set_epi32(b + 2, a + 2, yi, b + 1), v2 = _mm_set_epi32(yi, b + 3, a + 3, yi);
+			const __m128i s0 = _mm_set_epi32(4, 0, 4, 4), s1 = _mm_set_epi32(4, 4, 0, 4), s2 = _mm_set_epi32(0, 4, 4, 0);
+			for (; j + 4 <= m; j += 4) {
+				_mm_storeu_si128(reinterpret_cast<__m128i *>(o), v0);
+				_mm_storeu_si128(reinterpret_cast<__m128i *>(o + 4), v1);
+				_mm_storeu_si128(reinterpret_cast<__m128i *>(o + 8), v2);
+				v0 = _mm_add_epi32(v0, s0); v1 = _mm_add_epi32(v1, s1); v2 = _mm_add_epi32(v2, s2);
+				o += 12;
+			}
+			a += j; b += j;
+			for (; j < m; ++j) { o[0] = a++; o[1] = b++; o[2] = yi; o += 3; }
 		}
 		n += count - j0;
 	}
