@@ -172,3 +172,32 @@ def test_device_builder_errors(hip_aligner):
     assert rc == -6 and nl.value > 0
     assert lib.cvx_index_build_device(0, binref.ctypes.data, 8192, st.ctypes.data, ln.ctypes.data, 1, 3, 2, 4, out.ctypes.data, None, 0, C.byref(nl), 0) != 0      # k out of range
     assert lib.cvx_index_build_device(99, binref.ctypes.data, 8192, st.ctypes.data, ln.ctypes.data, 1, 13, 2, 4, out.ctypes.data, None, 0, C.byref(nl), 0) != 0     # no such device
+
+
+def test_device_builder_on_the_quirk_reference(hip_aligner):
+    """The reference of tests/test_index_cpu.py -- odd lengths, N runs at every place, a homopolymer, tandem repeats beyond the
+    frequency cutoff, a period equal to the sampling stride, a second copy, lower case, 995 copies of a unit (slots reserved,
+    weight 0) -- through both builders."""
+    from tests.test_index_cpu import _reference
+    seqs = _reference(np.random.default_rng(31))
+    contigs = [s for _, s in seqs]
+    a, b = _both(hip_aligner.lib, contigs)
+    _same(a, b, "quirk reference")
+    assert len(a[1]) > 50000
+
+
+def test_device_builder_bound_inside_ngmlr_writes_the_reference_table(tmp_path):
+    """index_build_binding.inc with a device present: the -ht-13-2.2.ngm file ngmlr_hip_all writes -- header, 4^13 + 1 index
+    records, locations, unit offset -- is the unmodified binary's byte for byte, its log says the device built it, and the read
+    mapped over the table the search adopted from the device gets the reference's SAM record."""
+    from tests.test_index_cpu import REF_BIN, ROOT, _build_with, _reference
+    hip_bin = os.path.join(ROOT, "oracle", "_ref", "ngmlr_hip_all")
+    if not os.path.exists(REF_BIN) or not os.path.exists(hip_bin):
+        pytest.skip("oracle/_ref/ngmlr_ref / ngmlr_hip_all not built")
+    seqs = _reference(np.random.default_rng(31))
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    want_raw, want_sam, _ = _build_with(REF_BIN, tmp_path / "a", seqs)
+    raw, sam, err = _build_with(hip_bin, tmp_path / "b", seqs)
+    assert "cvx_index_build_device" in err, err[-1500:]
+    assert raw.shape == want_raw.shape and np.array_equal(raw, want_raw)
+    assert sam == want_sam and any(not l.startswith("@") for l in sam)
