@@ -77,11 +77,12 @@ static inline int search_wave_log2(const unsigned long long votes) {
 	return kSearchWaveLog2Max;
 }
 static const int kSearchNeedsHbm = -2;
-size_t search_wave_lds_bytes(int log2s, int seq_cap);
+size_t search_wave_lds_bytes(int log2s, int seq_cap, bool slot8);
 hipError_t launch_search_count(const SearchArgs &a, hipStream_t st);
 hipError_t launch_search(const SearchArgs &a, hipStream_t st);
 /* seq_cap: bytes of LDS for the read, >= the launch's longest read + 65, a multiple of 4 */
-hipError_t launch_search_wave(const SearchArgs &a, int log2s, int seq_cap, hipStream_t st);
+/* slot8: the 8-byte map (a.bits <= 16, counts up to 255, rList of a quarter of the slots; not for the largest map) */
+hipError_t launch_search_wave(const SearchArgs &a, int log2s, int seq_cap, bool slot8, hipStream_t st);
 /* a wave per read over the real table in HBM: n_tables tables of 2^bits 16-byte entries at a.keys, every one empty when the
  * launch starts and when it ends; *ticket = 0 */
 hipError_t launch_search_wave_hbm(const SearchArgs &a, int n_tables, unsigned int *ticket, hipStream_t st);

@@ -2339,7 +2339,7 @@ static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *cons
 	const int wave_mode = wave_env ? atoi(wave_env) : 1;
 	const bool use_wave = wave_mode == 1;
 	const bool lane_serial = wave_mode == 0;
-	const char *cls_env = getenv("CVX_TUNE_SEARCH_CLASSIFY"), *log2_env = getenv("CVX_TUNE_SEARCH_LOG2");
+	const char *cls_env = getenv("CVX_TUNE_SEARCH_CLASSIFY"), *log2_env = getenv("CVX_TUNE_SEARCH_LOG2"), *slot8_env = getenv("CVX_TUNE_SEARCH_SLOT8");
 	const int classify_min = cls_env ? atoi(cls_env) : 2048;
 	const int forced_log2 = log2_env ? std::min(kSearchWaveLog2Max, std::max(kSearchWaveLog2Min, atoi(log2_env))) : 0;
 	/* (a table with three locations per k-mer and more -- a genome of 600 Mbp and up at ngmlr's defaults -- gives a 256-base read
@@ -2438,7 +2438,10 @@ static int search_common(cvx_handle h, cvx_index ix, int32_t n, const char *cons
 				a.work = ss->d_work.p + first;
 				a.n_work = (int32_t) (at - first);
 				RC_TRY(ss->kmark(st));
-				HIP_TRY(launch_search_wave(a, l, (longest + 65 + 63) / 64 * 64, st));
+				/* the 8-byte map where it applies: the reference's default table size or below, sub-reads (a count of 255 is out of
+				 * reach of a read's 256 k-mers unless a row repeats inside a bin), not the largest map; CVX_TUNE_SEARCH_SLOT8=0 / 1 */
+				const bool slot8 = slot8_env ? atoi(slot8_env) != 0 && bits <= 16 && l < kSearchWaveLog2Max : (bits <= 16 && l < kSearchWaveLog2Max && longest <= 268);
+				HIP_TRY(launch_search_wave(a, l, (longest + 65 + 63) / 64 * 64, slot8, st));
 				RC_TRY(ss->kmark(st));
 				if (trace) { char b[96]; snprintf(b, sizeof(b), " [2^%d-slot maps: %zu reads]", l, at - first); tr += b; }
 			}

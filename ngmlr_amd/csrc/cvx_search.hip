@@ -326,6 +326,7 @@ struct LdsVotes {
 		seq = reinterpret_cast<uint8_t *>(rlist + cap);
 		entries = 0;
 	}
+	__device__ void clear(const int lane) { for (uint32_t h = (uint32_t) lane; h <= smask; h += 64u) slot[h] = kFreeSlot; }
 	__device__ void fence() const { lds_fence(); }
 	__device__ int char_at(const int p) const { return seq[p]; }
 	/* the map's own probe sequence of key e: double hashing (an odd step walks all 2^log2s slots) -- the lanes of a batch probe at
@@ -374,6 +375,7 @@ struct LdsVotes {
 	__device__ uint64_t bin_of(const int idx) const { return (uint64_t) bin[idx]; }
 	__device__ float2 scores_of(const int idx) const { const uint32_t v = fr[idx]; return make_float2((float) (v & 0xFFFFu), (float) (v >> 16)); }
 	__device__ bool room_for(const int n_new) const { return entries + n_new <= cap; }
+	__device__ bool list_room(const int n_listed) const { (void) n_listed; return true; }      /* (rList holds `cap` positions) */
 	__device__ void remember(const int at, const uint32_t e) { (void) at; (void) e; }
 	/* after `done` of `total` windows: at this rate the read ends with 5/4 of what the map holds or more -- give up now instead of
 	 * at the entry that does not fit (a sub-read of a 2 Gbp genome casts 5 000 votes into as many bins: it was cast to 59 % in
@@ -382,6 +384,87 @@ struct LdsVotes {
 	__device__ bool hopeless(const int done, const int total) const {
 		return done * 8 >= total && (long long) entries * total * 4 > (long long) cap * done * 5;
 	}
+};
+
+/* The same map in 8 bytes per slot, for the case that fills the device at the scale of a genome: a first attempt at the
+ * reference's default table size (virtual slots of 16 bits) on a sub-read of at most 268 bases (a bin can hardly collect more
+ * than 255 votes of one orientation).  { bin (31 bits) | listed << 31; 0xFFFFFFFF: free } { virtual slot | forward count << 16 |
+ * reverse count << 24 }; rList holds a quarter of the slots.  Whatever does not fit -- a bin of 31 bits and more, a count beyond
+ * 255, more listed bins than rList holds -- sends the read to the table in HBM, as with the 12-byte map.  2 048 slots are 16 KB
+ * where the 12-byte form takes 24: eight reads on a CU instead of five. */
+struct LdsVotes8 {
+	static const bool kLds = true;
+	uint2 *sl;
+	uint16_t *rlist;
+	uint8_t *seq;
+	int log2s, cap, list_cap;
+	uint32_t smask;
+	int entries;
+	static __host__ __device__ size_t bytes(const int log2s, const int seq_cap) {
+		const size_t S = (size_t) 1 << log2s;
+		return S * 8 + (S / 4) * 2 + (size_t) seq_cap;
+	}
+	__device__ void carve(uint32_t *base, const int log2s_) {
+		log2s = log2s_;
+		const uint32_t S = 1u << log2s;
+		smask = S - 1u; cap = (int) (S * 3u / 4u); list_cap = (int) (S / 4u);
+		sl = reinterpret_cast<uint2 *>(base);
+		rlist = reinterpret_cast<uint16_t *>(base + 2u * S);
+		seq = reinterpret_cast<uint8_t *>(rlist + list_cap);
+		entries = 0;
+	}
+	__device__ void clear(const int lane) { for (uint32_t h = (uint32_t) lane; h <= smask; h += 64u) sl[h] = make_uint2(kFreeSlot, 0u); }
+	__device__ void fence() const { lds_fence(); }
+	__device__ int char_at(const int p) const { return seq[p]; }
+	__device__ uint32_t first_slot(const uint32_t e) const { return (e * 2654435761u) >> (32 - log2s); }
+	__device__ uint32_t slot_step(const uint32_t e) const { return ((e * 0x85EBCA6Bu) >> (32 - log2s)) | 1u; }
+	__device__ static bool fits(const uint64_t b) { return b < 0x7FFFFFFFull; }
+	__device__ int find(const uint32_t e, const uint64_t b, int &idx, bool &listed) const {
+		uint32_t h = first_slot(e);
+		const uint32_t step = slot_step(e);
+		uint2 v;
+		for (;;) {      /* two slots of the sequence per round trip */
+			const uint32_t h1 = (h + step) & smask;
+			const uint2 v0 = sl[h], v1 = sl[h1];
+			if (v0.x == kFreeSlot || (v0.y & 0xFFFFu) == e) { v = v0; break; }
+			if (v1.x == kFreeSlot || (v1.y & 0xFFFFu) == e) { v = v1; h = h1; break; }
+			h = (h1 + step) & smask;
+		}
+		idx = (int) h;
+		if (v.x == kFreeSlot) return kProbeFree;      /* (where claim() starts) */
+		if ((v.x & 0x7FFFFFFFu) == (uint32_t) b) { listed = (v.x >> 31) != 0u; return kProbeMatch; }
+		return kProbeOther;
+	}
+	/* The claim is ONE 64-bit compare-and-swap of the whole slot, (free, 0) -> (bin, virtual slot): what it returns tells a loser
+	 * whose slot this has become.  (Claiming the bin word alone and naming the virtual slot in a second store leaves the losers
+	 * to read that store -- and nothing keeps the compiler from laying the losers' path out in front of the winners'.) */
+	__device__ void claim(const uint32_t e, const uint64_t b, int &idx, bool &creator, bool &hazard) {
+		uint32_t h = (uint32_t) idx;
+		const uint32_t step = slot_step(e);
+		const unsigned long long free64 = (unsigned long long) kFreeSlot, mine = ((unsigned long long) e << 32) | (unsigned long long) (uint32_t) b;
+		for (;;) {
+			const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&sl[h]), free64, mine);
+			if (old == free64) { creator = true; break; }
+			if ((uint32_t) (old >> 32 & 0xFFFFull) == e) break;
+			h = (h + step) & smask;
+		}
+		idx = (int) h;
+		hazard = false;         /* decided by verify() */
+	}
+	__device__ bool verify(const int idx, const uint64_t b) const { return (sl[idx].x & 0x7FFFFFFFu) == (uint32_t) b; }
+	__device__ void unclaim(const int idx, const uint32_t e) { (void) e; sl[idx] = make_uint2(kFreeSlot, 0u); }      /* (a free slot is (free, 0): the claim compares both words) */
+	__device__ float score(const int idx, const bool rev) const { return (float) reinterpret_cast<const uint8_t *>(&sl[idx])[rev ? 7 : 6]; }
+	__device__ static bool score_fits(const float s) { return s <= 255.0f; }
+	__device__ void set_score(const int idx, const bool rev, const float s) { reinterpret_cast<uint8_t *>(&sl[idx])[rev ? 7 : 6] = (uint8_t) (uint32_t) s; }
+	__device__ void set_listed(const int idx, const uint32_t e) { (void) e; sl[idx].x |= 0x80000000u; }      /* (one lane per entry lists it) */
+	__device__ void list_put(const int pos, const int idx) { rlist[pos] = (uint16_t) idx; }
+	__device__ int list_at(const int pos) const { return rlist[pos]; }
+	__device__ uint64_t bin_of(const int idx) const { return (uint64_t) (sl[idx].x & 0x7FFFFFFFu); }
+	__device__ float2 scores_of(const int idx) const { const uint32_t v = sl[idx].y; return make_float2((float) ((v >> 16) & 0xFFu), (float) (v >> 24)); }
+	__device__ bool room_for(const int n_new) const { return entries + n_new <= cap; }
+	__device__ bool list_room(const int n_listed) const { return n_listed <= list_cap; }
+	__device__ void remember(const int at, const uint32_t e) { (void) at; (void) e; }
+	__device__ bool hopeless(const int done, const int total) const { (void) done; (void) total; return false; }      /* (only ever used below the largest map) */
 };
 
 struct HbmVotes {
@@ -435,6 +518,7 @@ struct HbmVotes {
 		return make_float2(__uint_as_float((uint32_t) sc), __uint_as_float((uint32_t) (sc >> 32)));
 	}
 	__device__ bool room_for(const int n_new) const { (void) n_new; return true; }
+	__device__ bool list_room(const int n_listed) const { (void) n_listed; return true; }
 	__device__ static bool fits(const uint64_t b) { (void) b; return true; }
 	__device__ static bool score_fits(const float s) { (void) s; return true; }
 	__device__ bool hopeless(const int done, const int total) const { (void) done; (void) total; return false; }
@@ -494,6 +578,7 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		if (lane == 0) tb.set_score(idx, reverse, score);
 		if (score > S.max_hit) { S.max_hit = score; S.thresh = S.max_hit * a.sensitivity; }
 		if (!listed && score >= S.thresh) {
+			if (!tb.list_room(S.rlen + 1)) { S.too_many = true; return; }
 			if (lane == 0) { tb.list_put(S.rlen, idx); tb.set_listed(idx, e); }
 			S.rlen += 1;
 		}
@@ -565,6 +650,7 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 		const uint64_t qb = __ballot(qual);
 		const bool lister = qual && !listed && (qb & grp_h & lt) == 0ull;
 		const uint64_t lb = __ballot(lister);
+		if (TABLE::kLds && !tb.list_room(S.rlen + __popcll(lb))) { S.too_many = true; return; }
 		if (lister) { tb.list_put(S.rlen + __popcll(lb & lt), idx); tb.set_listed(idx, e); }
 		S.rlen += __popcll(lb);
 		if (active && (grp_hr & gt) == 0ull) tb.set_score(idx, rev, s);
@@ -686,9 +772,10 @@ __device__ void search_vote_read(const SearchArgs &a, TABLE &tb, ChunkRows &C, c
 }
 }  // namespace
 
+template <class MAP>
 __global__ void __launch_bounds__(64)
 search_wave_kernel(const SearchArgs a, const int log2s, const int seq_cap) {
-	extern __shared__ uint32_t map_lds[];
+	extern __shared__ __attribute__((aligned(16))) uint32_t map_lds[];      /* (the 8-byte map reads its slots as 64-bit words) */
 	__shared__ ChunkRows C;
 	const int q = blockIdx.x;
 	if (q >= a.n_work) return;
@@ -697,9 +784,9 @@ search_wave_kernel(const SearchArgs a, const int log2s, const int seq_cap) {
 	const int read_len = a.seq_len[i];
 	if (read_len + 65 > seq_cap) { if (lane == 0) a.n_cand[i] = kSearchNeedsHbm; return; }      /* (the host sized seq_cap for the launch's longest read: cannot happen) */
 	const uint8_t *gseq = a.seq + a.seq_off[i];
-	LdsVotes tb;
+	MAP tb;
 	tb.carve(map_lds, log2s);
-	for (uint32_t s = (uint32_t) lane; s <= tb.smask; s += 64u) tb.slot[s] = kFreeSlot;
+	tb.clear(lane);
 	for (int s = lane; s < read_len + 64; s += 64) tb.seq[s] = s < read_len ? gseq[s] : (uint8_t) 0;      /* coalesced; NULs behind the read */
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	search_vote_read(a, tb, C, i, lane, a.cand + a.cand_off[i]);
@@ -749,12 +836,17 @@ hipError_t launch_search_compact(const SearchCandidate *sparse, const uint64_t *
 	return hipGetLastError();
 }
 
-size_t search_wave_lds_bytes(const int log2s, const int seq_cap) { return LdsVotes::bytes(log2s, seq_cap); }
+size_t search_wave_lds_bytes(const int log2s, const int seq_cap, const bool slot8) { return slot8 ? LdsVotes8::bytes(log2s, seq_cap) : LdsVotes::bytes(log2s, seq_cap); }
 
-hipError_t launch_search_wave(const SearchArgs &a, const int log2s, const int seq_cap, hipStream_t st) {
+hipError_t launch_search_wave(const SearchArgs &a, const int log2s, const int seq_cap, const bool slot8, hipStream_t st) {
 	if (a.n_work <= 0) return hipSuccess;
 	if (log2s < kSearchWaveLog2Min || log2s > kSearchWaveLog2Max || seq_cap < 65 || seq_cap > kSearchWaveSeq + 64 || (seq_cap & 3)) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(search_wave_kernel, dim3(a.n_work), dim3(64), LdsVotes::bytes(log2s, seq_cap), st, a, log2s, seq_cap);
+	if (slot8) {
+		if (a.bits > 16 || log2s == kSearchWaveLog2Max) return hipErrorInvalidValue;      /* 16-bit virtual slots; the largest map keeps the 12-byte form (its give-up rule) */
+		hipLaunchKernelGGL(search_wave_kernel<LdsVotes8>, dim3(a.n_work), dim3(64), LdsVotes8::bytes(log2s, seq_cap), st, a, log2s, seq_cap);
+	} else {
+		hipLaunchKernelGGL(search_wave_kernel<LdsVotes>, dim3(a.n_work), dim3(64), LdsVotes::bytes(log2s, seq_cap), st, a, log2s, seq_cap);
+	}
 	return hipGetLastError();
 }
 

@@ -19,18 +19,25 @@ def _same(got, loc, sc, rev):
         and np.array_equal(got["reverse"], rev)
 
 
-@pytest.fixture(params=["wave", "wave_sorted", "wave_small", "wave_hbm", "lane"])
+@pytest.fixture(params=["wave", "wave_sorted", "wave_small", "wave_slot12", "wave_slot8", "wave_hbm", "lane"])
 def search_kernel(request, monkeypatch):
     """The device kernels of the vote: one wave per read casting 64 votes at a time, with the vote map in LDS (the default; reads
     it cannot hold fall back per read) or with the real table in HBM (CVX_TUNE_SEARCH_WAVE=2 sends every read there), and one lane
     per read casting its votes one by one over a table in HBM (=0: an independent implementation of the same contract).  The LDS
     form three ways: as a small call takes it (one map size for every read), as a large call does (CVX_TUNE_SEARCH_CLASSIFY=0:
     votes counted first, reads sorted into launches by map size, 2^9 .. 2^12 slots), and with the smallest map forced on every
-    read (CVX_TUNE_SEARCH_LOG2=9: most reads overflow it and are redone over the table in HBM)."""
+    read (CVX_TUNE_SEARCH_LOG2=9: most reads overflow it and are redone over the table in HBM); and with the 12-byte and the
+    8-byte form of the map forced (CVX_TUNE_SEARCH_SLOT8)."""
     if request.param == "wave_sorted":
         monkeypatch.setenv("CVX_TUNE_SEARCH_CLASSIFY", "0")
     if request.param == "wave_small":
         monkeypatch.setenv("CVX_TUNE_SEARCH_LOG2", "9")
+    if request.param == "wave_slot12":      # the 12-byte map everywhere (the default takes the 8-byte one for sub-reads at table sizes up to 2^16)
+        monkeypatch.setenv("CVX_TUNE_SEARCH_SLOT8", "0")
+        monkeypatch.setenv("CVX_TUNE_SEARCH_CLASSIFY", "0")
+    if request.param == "wave_slot8":       # the 8-byte map wherever its 16-bit virtual slots allow, long reads included (counts beyond 255 fall back)
+        monkeypatch.setenv("CVX_TUNE_SEARCH_SLOT8", "1")
+        monkeypatch.setenv("CVX_TUNE_SEARCH_CLASSIFY", "0")
     if request.param == "wave_hbm":
         monkeypatch.setenv("CVX_TUNE_SEARCH_WAVE", "2")
     if request.param == "lane":

@@ -26,8 +26,9 @@ THREADS = 16
 # (name, environment of the search call): the runtime reads these per call
 FORMS = [("wave", {}), ("wave sorted by map size", {"CVX_TUNE_SEARCH_CLASSIFY": "0"}), ("wave sorted by map size", {"CVX_TUNE_SEARCH_CLASSIFY": "0"}),
          ("wave 2^9 maps", {"CVX_TUNE_SEARCH_LOG2": "9"}), ("wave 2^10 maps", {"CVX_TUNE_SEARCH_LOG2": "10"}), ("wave 2^12 maps", {"CVX_TUNE_SEARCH_LOG2": "12"}),
+         ("wave 12-byte maps", {"CVX_TUNE_SEARCH_CLASSIFY": "0", "CVX_TUNE_SEARCH_SLOT8": "0"}), ("wave 8-byte maps", {"CVX_TUNE_SEARCH_CLASSIFY": "0", "CVX_TUNE_SEARCH_SLOT8": "1"}),
          ("wave_hbm", {"CVX_TUNE_SEARCH_WAVE": "2"}), ("lane", {"CVX_TUNE_SEARCH_WAVE": "0"})]
-KNOBS = ("CVX_TUNE_SEARCH_WAVE", "CVX_TUNE_SEARCH_CLASSIFY", "CVX_TUNE_SEARCH_LOG2")
+KNOBS = ("CVX_TUNE_SEARCH_WAVE", "CVX_TUNE_SEARCH_CLASSIFY", "CVX_TUNE_SEARCH_LOG2", "CVX_TUNE_SEARCH_SLOT8")
 
 
 def main():
