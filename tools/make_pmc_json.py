@@ -30,10 +30,10 @@ def all_kernels(path, prefix):
     for line in open(path):
         if not line.startswith(prefix):
             continue
-        m = re.match(r"^(.*?\))\s+(.*)$", line)
-        if not m:
+        # (the summary pads / cuts kernel names to 70 columns; names hold blanks and brackets of their own)
+        name, f = line[:70].rstrip(), line[70:].split()
+        if not f:
             continue
-        name, f = m.group(1), m.group(2).split()
         e = out.setdefault(name, {})
         if len(f) == 5 and re.match(r"^[A-Z_0-9]+$", f[0]):
             e[f[0]] = float(f[4])
