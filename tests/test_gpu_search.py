@@ -182,6 +182,29 @@ def test_device_walk_over_reads_with_N(hip_aligner, search_kernel):
     assert sum(1 for r in reads if b"N" in r) > 500 and sum(w["n"] for w in want) > 500
 
 
+@pytest.mark.parametrize("unit_offset", [1 << 34, (1 << 35) - 4096, 1 << 37])
+def test_bins_beyond_the_lds_maps_words(hip_aligner, search_kernel, unit_offset):
+    """A table unit far into a large genome (TableUnit::Offset): the bins of its votes pass 31 and 32 bits -- more than the 8-byte
+    and the 12-byte LDS map keep per slot, so those reads must come out of the table in HBM with the reference's lists, not
+    truncated ones."""
+    fx, reads = util.synthetic_search_case()
+    fx.unit_offset = unit_offset
+    reads = [r for r in reads if len(r) <= 300][:8] + [reads[0][:200], reads[0][30:]]
+    o = SearchOracle(fx)
+    want = [o.search(r, cap=1 << 16) for r in reads]
+    o.close()
+    idx, locs = fx.index_arrays()
+    ix = KmerIndex(hip_aligner, fx.k, idx, locs, unit_offset)
+    try:
+        got, max_hit, misses = ix.search(reads, extras=True)
+    finally:
+        ix.free()
+    for i, (w, g) in enumerate(zip(want, got)):
+        assert (w["n"] < 0 and g is None) or _same(g, w["loc"], w["score"], w["rev"]), (i, w["n"], None if g is None else len(g))
+    assert [int(m) for m in misses] == [w["kmer_misses"] for w in want]
+    assert max(int(w["loc"].max()) for w in want if w["n"] > 0) >> 4 >= (1 << 30)
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 def test_arena_form_returns_the_recorded_lists(hip_aligner, pinned, search_kernel):
     """cvx_search_batch_arena (ABI 7): the reads back to back in ONE block -- pageable, or page-locked memory from cvx_host_alloc that
