@@ -201,3 +201,21 @@ def test_device_builder_bound_inside_ngmlr_writes_the_reference_table(tmp_path):
     assert "cvx_index_build_device" in err, err[-1500:]
     assert raw.shape == want_raw.shape and np.array_equal(raw, want_raw)
     assert sam == want_sam and any(not l.startswith("@") for l in sam)
+
+
+def test_device_builder_many_short_sequences(hip_aligner):
+    """A reference of thousands of short sequences (an assembly in contigs): every sequence its own chunks, its own start of the
+    drop rule's state, its own last-window test -- against the host builder."""
+    rng = np.random.default_rng(77)
+    contigs = []
+    for _ in range(3000):
+        n = int(rng.choice([11, 12, 13, 14, 15, 25, 100, 700, 2047, 2048, 2049, 3000]))
+        c = _rand(rng, n)
+        if rng.random() < 0.3:
+            c[rng.random(n) < 0.05] = ord("N")
+        if rng.random() < 0.1:
+            c[:] = c[0]                       # a homopolymer: equal k-mers from the first window on
+        contigs.append(c)
+    a, b = _both(hip_aligner.lib, contigs)
+    _same(a, b, "many short sequences")
+    assert len(a[1]) > 100000
