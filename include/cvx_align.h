@@ -405,6 +405,9 @@ int cvx_index_build(const uint8_t *bin_ref, uint64_t n_nibbles, const uint64_t *
  * walk order, the drop rule against the neighbours in that list, a histogram, row starts by a scan, and the rows by a stable
  * radix sort of (k-mer, position) (scan and sort: rocPRIM).  512 Mbp: 3.8-4.1 s on eight host threads -> 0.30-0.35 s including the
  * copies in and out (1.3 GB); CVX_ERR_NO_DEVICE without a device (the host builder above is the alternative, not a silent substitute).
+ * Device memory while it runs: the genome (0.5 B per base), ~17 B per sampled window (position, k-mer, flag, the sort's second
+ * buffers) plus the sort's scratch, ~21 B per possible k-mer (4^k counters, weights, row starts, records): 512 Mbp at k = 13 ~6 GB,
+ * 2 Gbp ~18 GB.
  * flags: CVX_INDEX_KEEP_RESIDENT leaves the table on the device in the form the search reads; the next cvx_index_upload of these
  * very arrays (same pointers, same count) on that device takes it over instead of converting 4^k records on the host and copying
  * a gigabyte back up.  One table waits at a time; a later build, or the process's end, drops it. */
