@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define CVX_ABI_VERSION 8
+#define CVX_ABI_VERSION 9
 
 /* return codes */
 enum {
@@ -512,6 +512,16 @@ int cvx_job_text(cvx_handle h, cvx_job job, const int32_t *ext_qstart, const int
  * several GB for a full batch of long reads.  *kernel_ms (may be NULL): the kernel's own duration. */
 int cvx_job_nm_profile(cvx_handle h, cvx_job job, int32_t first, int32_t count, uint64_t *entry_off,
 		int32_t *triples, uint64_t cap_entries, double *kernel_ms);
+/* ABI 9: the same with the triples left in page-locked memory the job owns (*triples, valid until cvx_job_release): one DMA
+ * at PCIe speed instead of a staged copy into the caller's pageable array -- the profile is 125 kB per 10 kb alignment, and
+ * a dispatcher that runs the text stage per launch (CVX_DEVICE_TEXT=1) spent most of that stage in the copy. */
+int cvx_job_nm_profile_resident(cvx_handle h, cvx_job job, int32_t first, int32_t count, uint64_t *entry_off,
+		const int32_t **triples, double *kernel_ms);
+/* ABI 9: cvx_job_text and cvx_job_nm_profile_resident of the whole job in one call -- two round trips to the device (the sizes
+ * of both, then the strings and triples of both) instead of four.  Outputs as in those two calls; nm_entry_off[n_tiles + 1]. */
+int cvx_job_text_all(cvx_handle h, cvx_job job, const int32_t *ext_qstart, const int32_t *ext_qend,
+		cvx_alignment_text *out, uint64_t *text_off, const char **text, uint64_t *text_bytes,
+		uint64_t *nm_entry_off, const int32_t **triples);
 /* the entry offsets alone (entry_off[0 .. count], as above): what a caller needs to size `triples` -- no profile is
  * computed and nothing is allocated for it */
 int cvx_job_nm_sizes(cvx_handle h, cvx_job job, int32_t first, int32_t count, uint64_t *entry_off);

@@ -238,6 +238,49 @@ class Job:
         capi.check(lib.cvx_job_nm_profile(self.al.h, self.j, first, count, off.ctypes.data, tri.ctypes.data, int(off[count]), C.byref(ms)))
         return off, tri, ms.value
 
+    def text_all(self, ext_qstart=None, ext_qend=None):
+        """cvx_job_text_all (ABI 9): text() and nm_profile_resident() of the whole job in one call.
+        -> (list of dicts as text(), entry offsets uint64[n + 1], triples int32[entries, 3])"""
+        n = self.n
+        out = (capi.CvxAlignmentText * max(n, 1))()
+        off = np.zeros(max(n, 1), dtype=np.uint64)
+        nmoff = np.zeros(n + 1, dtype=np.uint64)
+        nbytes = C.c_uint64()
+        eq = np.ascontiguousarray(ext_qstart, dtype=np.int32) if ext_qstart is not None else None
+        ee = np.ascontiguousarray(ext_qend, dtype=np.int32) if ext_qend is not None else None
+        lib = self.al.lib
+        lib.cvx_job_text_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(capi.CvxAlignmentText),
+                                         C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_void_p)]
+        tp, np_ = C.c_void_p(), C.c_void_p()
+        capi.check(lib.cvx_job_text_all(self.al.h, self.j, eq.ctypes.data if eq is not None else None,
+                                        ee.ctypes.data if ee is not None else None, out, off.ctypes.data,
+                                        C.byref(tp), C.byref(nbytes), nmoff.ctypes.data, C.byref(np_)))
+        raw = (C.c_char * int(nbytes.value)).from_address(tp.value).raw if nbytes.value else b""
+        res = []
+        for i in range(n):
+            t = out[i]
+            d = {f: getattr(t, f) for f, _ in capi.CvxAlignmentText._fields_}
+            d["score_bits"] = int(np.float32(t.score).view(np.uint32))
+            o = int(off[i])
+            d["cigar"] = raw[o:o + t.cigar_len].decode()
+            d["md"] = raw[o + t.cigar_len + 1:o + t.cigar_len + 1 + t.md_len].decode()
+            res.append(d)
+        e = int(nmoff[n])
+        tri = np.ctypeslib.as_array(C.cast(np_, C.POINTER(C.c_int32)), shape=(e * 3,)).reshape(e, 3).copy() if e else np.zeros((0, 3), dtype=np.int32)
+        return res, nmoff, tri
+
+    def nm_profile_resident(self, first: int = 0, count: Optional[int] = None):
+        """cvx_job_nm_profile_resident (ABI 9): the same triples left in the job's page-locked memory (copied out here).
+        -> (entry offsets uint64[count + 1], triples int32[entries, 3], kernel ms)"""
+        count = self.n - first if count is None else count
+        off = np.zeros(count + 1, dtype=np.uint64)
+        ms = C.c_double()
+        ptr = C.c_void_p()
+        capi.check(self.al.lib.cvx_job_nm_profile_resident(self.al.h, self.j, first, count, off.ctypes.data, C.byref(ptr), C.byref(ms)))
+        n = int(off[count])
+        tri = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=(n * 3,)).reshape(n, 3).copy() if n else np.zeros((0, 3), dtype=np.int32)
+        return off, tri, ms.value
+
     def release(self) -> None:
         if self.j:
             self.al.lib.cvx_job_release(self.al.h, self.j)

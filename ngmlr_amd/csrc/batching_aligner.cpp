@@ -63,7 +63,7 @@ namespace Convex {
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
 		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0),
 		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), stop(false), launches(0), requests(0), maxInFlight(0),
-		target(0), holdUs(20000), feedActive(true), textLaunches(0), textNs(0), launchTrace(false), deviceText(false), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000) {
+		target(0), holdUs(20000), feedActive(true), textLaunches(0), textNs(0), launchTrace(false), deviceText(false), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000), textPending(0), textStop(false) {
 	if (const char * e = getenv("CVX_BATCH_TARGET")) target = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_HOLD_US")) holdUs = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_LEAD_US")) leadUs = atoi(e);      /* < 0: the plain timeout rule while a launch runs */
@@ -71,8 +71,10 @@ BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, in
 	 * with 4, and with the runtime's two stream sets) only makes the launches smaller: 20 000 reads 25.1 s against 21.2 s */
 	if (const char * e = getenv("CVX_BATCH_INFLIGHT")) maxFlight = atoi(e) > 0 ? atoi(e) : 1;
 	if (const char * e = getenv("CVX_DEVICE_TEXT")) deviceText = atoi(e) != 0;
+	if (DeviceWindows::Enabled()) deviceText = true;      /* windows decoded on the device: the host has no reference characters to write MD from */
 	if (const char * e = getenv("CVX_LAUNCH_TRACE")) launchTrace = atoi(e) != 0;
 	dispatcher = std::thread([this] { dispatchLoop(); });
+	if (deviceText) textThread = std::thread([this] { textLoop(); });
 }
 
 BatchingAligner::~BatchingAligner() {
@@ -82,6 +84,57 @@ BatchingAligner::~BatchingAligner() {
 	}
 	cvDispatch.notify_all();
 	dispatcher.join();
+	if (textThread.joinable()) {
+		{
+			std::lock_guard<std::mutex> lk(mtx);
+			textStop = true;
+		}
+		cvText.notify_all();
+		textThread.join();
+	}
+}
+
+/* with mtx held */
+void BatchingAligner::completeLaunch(Launch * l) {
+	for (size_t i = 0; i < l->reqs.size(); ++i) {
+		Request * r = l->reqs[i];
+		r->failed = l->failed;
+		r->result = l->failed ? 0 : &l->results[i];
+		r->done = true;
+		/* under the lock: the request lives on its worker's stack until that worker has seen `done` */
+		if (r->fiber) FiberApi::Wake(r->fiber);      /* a read on a user-level context: runnable on its carrier (cvx_fiber.h) */
+		else r->cv.notify_one();
+	}
+}
+
+/* CVX_DEVICE_TEXT=1: CIGAR / MD / profile of finished launches on the device, one launch at a time in the order they finished */
+void BatchingAligner::textLoop() {
+	pthread_setname_np(pthread_self(), "cvx-text");
+	std::unique_lock<std::mutex> lk(mtx);
+	for (;;) {
+		while (textQueue.empty() && !textStop) cvText.wait(lk);
+		if (textQueue.empty()) break;
+		Launch * l = textQueue.front();
+		textQueue.pop_front();
+		lk.unlock();
+		try {
+			std::vector<ConvexAlignHip::Tile const *> tiles(l->reqs.size());
+			for (size_t i = 0; i < tiles.size(); ++i) tiles[i] = &l->reqs[i]->tile;
+			l->text = new ConvexAlignHip::JobText();
+			std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
+			backend->Text(l->job, tiles.data(), (int) tiles.size(), *l->text);
+			long long const ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+			lk.lock();
+			textNs += ns;
+			textLaunches += 1;
+		} catch (...) {
+			lk.lock();
+			l->failed = true;
+		}
+		completeLaunch(l);
+		textPending -= 1;
+		cvDispatch.notify_one();
+	}
 }
 
 void BatchingAligner::WorkerDone() {
@@ -161,7 +214,7 @@ void BatchingAligner::dispatchLoop() {
 			delete l;
 			lk.lock();
 		}
-		if (stop && queue.empty() && inFlight.empty()) break;
+		if (stop && queue.empty() && inFlight.empty() && textPending == 0) break;
 		bool const canSubmit = (int) inFlight.size() < maxFlight;
 		if (canSubmit && shouldCut(inFlight.empty())) {
 			Launch * l = new Launch();
@@ -219,15 +272,6 @@ void BatchingAligner::dispatchLoop() {
 						backend->Trace(l->job, (int) l->reqs.size(), std::chrono::duration<double, std::milli>(t - l->cutAt).count(),
 								std::chrono::duration<double, std::milli>(l->cutAt - l->oldestAt).count());
 					}
-					if (deviceText) {
-						std::vector<ConvexAlignHip::Tile const *> tiles(l->reqs.size());
-						for (size_t i = 0; i < tiles.size(); ++i) tiles[i] = &l->reqs[i]->tile;
-						l->text = new ConvexAlignHip::JobText();
-						std::chrono::steady_clock::time_point const t0 = std::chrono::steady_clock::now();
-						backend->Text(l->job, tiles.data(), (int) tiles.size(), *l->text);
-						textNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();      /* (dispatcher only) */
-						textLaunches += 1;
-					}
 				} catch (...) {
 					l->failed = true;
 				}
@@ -241,14 +285,13 @@ void BatchingAligner::dispatchLoop() {
 				frontSince = t;
 				if (inFlight.empty()) busyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(t - busySince).count();
 			}
-			for (size_t i = 0; i < l->reqs.size(); ++i) {
-				Request * r = l->reqs[i];
-				r->failed = l->failed;
-				r->result = l->failed ? 0 : &l->results[i];
-				r->done = true;
-				/* under the lock: the request lives on its worker's stack until that worker has seen `done` */
-				if (r->fiber) FiberApi::Wake(r->fiber);      /* a read on a user-level context: runnable on its carrier (cvx_fiber.h) */
-				else r->cv.notify_one();
+			if (deviceText && !l->failed) {
+				/* its text stage runs on the text thread, under the kernels of the launches behind it */
+				textQueue.push_back(l);
+				textPending += 1;
+				cvText.notify_one();
+			} else {
+				completeLaunch(l);
 			}
 			continue;
 		}
@@ -423,6 +466,11 @@ SharedAligner::~SharedAligner() {
 			long prepared = 0, closedForm = 0;
 			ConvexAlignHip::CorridorStats(prepared, closedForm);
 			fprintf(stderr, "SharedAligner: %ld of %ld corridors travelled as closed forms (cvx_corridor_fit), the rest as row arrays\n", closedForm, prepared);
+		}
+		{
+			long wl = 0, wt = 0, ml = 0;
+			ConvexAlignHip::WindowStats(wl, wt, ml);
+			if (wl + ml > 0) fprintf(stderr, "SharedAligner: %ld tiles in %ld launches took their reference as windows of the genome in HBM (cvx_submit_windows; CVX_DEVICE_DECODE=1), %ld mixed launches materialised theirs\n", wt, wl, ml);
 		}
 		if (g_lastTextLaunches > 0) fprintf(stderr, "SharedAligner: text stage on the device for %ld launches (cvx_job_text + cvx_job_nm_profile), %.3f s of the dispatchers' time\n", g_lastTextLaunches, g_lastTextSeconds);
 		fprintf(stderr, "SharedAligner: library loaded at 0, first worker joined at %.2f s, last one left at %.2f s\n",

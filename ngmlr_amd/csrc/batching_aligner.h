@@ -144,8 +144,19 @@ private:
 	std::chrono::steady_clock::time_point frontSince;   /* when the oldest launch in flight became the oldest */
 	std::chrono::steady_clock::time_point busySince;
 	std::thread dispatcher;
+	/* The text stage of a finished launch (CVX_DEVICE_TEXT=1) off the dispatcher's critical path: its own thread on the
+	 * handle's text stream, under the kernels of the launches that follow.  cvx_job_text /
+	 * cvx_job_nm_profile touch only the finished job's own buffers and that stream; the dispatcher keeps cutting, submitting
+	 * and waiting meanwhile.  A launch's requests are woken by whichever thread completes it. */
+	std::thread textThread;
+	std::deque<Launch *> textQueue;        /* waited for, text stage not yet run (under mtx) */
+	std::condition_variable cvText;
+	int textPending;                       /* launches in textQueue or in the text thread's hands */
+	bool textStop;
 
 	void dispatchLoop();
+	void textLoop();
+	void completeLaunch(Launch * l);       /* with mtx held: hands every request of the launch its result and wakes it */
 	bool shouldCut(bool deviceIdle) const;
 };
 

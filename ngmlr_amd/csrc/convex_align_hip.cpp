@@ -4,6 +4,7 @@
  * library reports an error the call throws, exactly like a hard error in the reference.
  */
 #include "convex_align_hip.h"
+#include "cvx_fiber.h"
 
 #include <atomic>
 #include <cstdio>
@@ -21,6 +22,59 @@ std::atomic<long> g_prepared(0), g_closedForm(0);
 bool const g_fitCorridors = [] { const char * e = getenv("CVX_CORRIDOR_FIT"); return !(e && atoi(e) == 0); }();
 }
 
+/* ------------------------------------------------------------------ DeviceWindows */
+namespace {
+struct WindowNote { char const * buf; unsigned long long position; long length; };
+thread_local WindowNote tl_window = { 0, 0, 0 };
+void const * g_binRef = 0;
+unsigned long long g_nNibbles = 0;
+std::vector<uint64_t> g_startTable;
+std::atomic<long> g_windowLaunches(0), g_windowTiles(0), g_mixedLaunches(0);
+bool const g_deviceDecode = [] { const char * e = getenv("CVX_DEVICE_DECODE"); return e && atoi(e) != 0; }();
+}
+
+bool DeviceWindows::Enabled() { return g_deviceDecode; }
+bool DeviceWindows::HaveGenome() { return g_binRef != 0; }
+
+void DeviceWindows::SetGenome(void const * binRef, unsigned long long nNibbles, unsigned long long const * startTable, int nStarts) {
+	g_startTable.assign(startTable, startTable + (nStarts > 0 ? nStarts : 0));
+	g_nNibbles = nNibbles;
+	g_binRef = binRef;
+}
+
+void DeviceWindows::Placeholder(char * buf, unsigned long long position, int length) {
+	memset(buf, 'x', (size_t) (length - 1));      /* what the reference's decode starts from (src/SequenceProvider.cpp:501) */
+	buf[length - 1] = '\0';
+	if (Fiber * const f = FiberApi::Current()) {
+		/* slots 1-3 of the read's context (0 is the dispatcher: batching_aligner.cpp) */
+		FiberApi::Local(f, 1) = buf;
+		FiberApi::Local(f, 2) = reinterpret_cast<void *>((uintptr_t) position);
+		FiberApi::Local(f, 3) = reinterpret_cast<void *>((uintptr_t) length);
+	} else {
+		tl_window.buf = buf; tl_window.position = position; tl_window.length = length;
+	}
+}
+
+bool DeviceWindows::Lookup(char const * buf, unsigned long long & position, int & length) {
+	if (buf == 0) return false;
+	if (Fiber * const f = FiberApi::Current()) {
+		if (FiberApi::Local(f, 1) != buf) return false;
+		position = (unsigned long long) reinterpret_cast<uintptr_t>(FiberApi::Local(f, 2));
+		length = (int) reinterpret_cast<uintptr_t>(FiberApi::Local(f, 3));
+		return true;
+	}
+	if (tl_window.buf != buf) return false;
+	position = tl_window.position;
+	length = (int) tl_window.length;
+	return true;
+}
+
+void ConvexAlignHip::WindowStats(long & windowLaunches, long & windowTiles, long & mixedLaunches) {
+	windowLaunches = g_windowLaunches.load();
+	windowTiles = g_windowTiles.load();
+	mixedLaunches = g_mixedLaunches.load();
+}
+
 void ConvexAlignHip::CorridorStats(long & prepared, long & closedForm) {
 	prepared = g_prepared.load();
 	closedForm = g_closedForm.load();
@@ -28,7 +82,7 @@ void ConvexAlignHip::CorridorStats(long & prepared, long & closedForm) {
 
 ConvexAlignHip::ConvexAlignHip(int const stdOutMode, float const match, float const mismatch,
 		float const gapOpen, float const gapExtend, float const gapExtendMin, float const gapDecay,
-		int const deviceId, unsigned long const maxMatrixSizeMB) : handle(0) {
+		int const deviceId, unsigned long const maxMatrixSizeMB) : handle(0), genome(0) {
 	(void) stdOutMode;
 	cvx_params p;
 	p.match = match; p.mismatch = mismatch; p.gap_open = gapOpen;
@@ -45,6 +99,8 @@ ConvexAlignHip::ConvexAlignHip(int const stdOutMode, float const match, float co
 }
 
 ConvexAlignHip::~ConvexAlignHip() {
+	if (genome) cvx_genome_free(handle, genome);
+	genome = 0;
 	cvx_destroy(handle);
 	handle = 0;
 }
@@ -88,7 +144,15 @@ void ConvexAlignHip::Prepare(Tile & t) {
 	a.Score = -1.0f;
 	t.ret = -1;
 	t.failed = false;
-	t.refLen = (int) strlen(t.refSeq);
+	t.window = false;
+	t.refPosition = 0;
+	int windowLength = 0;
+	if (g_deviceDecode && g_binRef != 0 && DeviceWindows::Lookup(t.refSeq, t.refPosition, windowLength)) {
+		t.window = true;                        /* the binding's placeholder: the string DecodeRefSequenceExact leaves has windowLength - 1 characters */
+		t.refLen = windowLength - 1;
+	} else {
+		t.refLen = (int) strlen(t.refSeq);
+	}
 	t.qryLen = (int) strlen(t.qrySeq);
 	if (t.corridorHeight != t.qryLen) {
 		/* every reference caller passes corridorHeight == strlen(qry); anything else
@@ -140,12 +204,56 @@ cvx_job ConvexAlignHip::Submit(Tile const * tiles, int n) {
 		c.corridor_offset = t.corridorOffset; c.corridor_width = t.corridorWidth;
 		c.reserved = 0;
 	}
+	int nWindows = 0;
+	for (int i = 0; i < n; ++i) nWindows += tiles[i].window ? 1 : 0;
 	cvx_job job = 0;
-	if (cvx_submit(handle, n, packed.data(), &job) != CVX_OK) {
+	int rc;
+	if (nWindows > 0 && genome == 0) {
+		if (cvx_genome_upload(handle, (uint8_t const *) g_binRef, g_nNibbles, g_startTable.data(), (int32_t) g_startTable.size(), &genome) != CVX_OK) {
+			fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
+			throw 1;
+		}
+	}
+	if (nWindows == n && n > 0) {
+		/* every reference of the launch is a window of the resident genome: (position, length) per tile, decoded on the device
+		 * straight into the launch's sequence arena (the reference: src/AlignmentBuffer.cpp:199-223 on the worker's core) */
+		positions.resize((size_t) n);
+		for (int i = 0; i < n; ++i) { positions[(size_t) i] = tiles[i].refPosition; packed[(size_t) i].ref = 0; }
+		rc = cvx_submit_windows(handle, genome, n, packed.data(), (uint64_t const *) positions.data(), &job);
+		g_windowLaunches.fetch_add(1, std::memory_order_relaxed);
+		g_windowTiles.fetch_add(n, std::memory_order_relaxed);
+	} else {
+		if (nWindows > 0) materialiseWindows(tiles, n);      /* a launch that mixes both forms (no ngmlr path builds one) */
+		rc = cvx_submit(handle, n, packed.data(), &job);
+	}
+	if (rc != CVX_OK) {
 		fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
 		throw 1;
 	}
 	return job;
+}
+
+/* the windows among the tiles decoded into their callers' placeholder buffers (which extractReferenceSequenceForAlignment
+ * allocated writable, window length + 100 bytes), so that the launch can travel as characters */
+void ConvexAlignHip::materialiseWindows(Tile const * tiles, int n) {
+	std::vector<uint64_t> pos, off;
+	std::vector<int32_t> len;
+	std::vector<int> who;
+	uint64_t total = 0;
+	for (int i = 0; i < n; ++i) if (tiles[i].window) {
+		who.push_back(i);
+		pos.push_back(tiles[i].refPosition);
+		len.push_back(tiles[i].refLen + 1);
+		off.push_back(total);
+		total += (uint64_t) tiles[i].refLen + 1;
+	}
+	std::vector<char> out((size_t) total + 8);
+	if (cvx_genome_decode(handle, genome, (int32_t) who.size(), pos.data(), len.data(), off.data(), out.data()) != CVX_OK) {
+		fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
+		throw 1;
+	}
+	for (size_t k = 0; k < who.size(); ++k) memcpy(const_cast<char *>(tiles[who[k]].refSeq), out.data() + off[k], (size_t) len[k]);
+	g_mixedLaunches.fetch_add(1, std::memory_order_relaxed);
 }
 
 bool ConvexAlignHip::Poll(cvx_job job) {
@@ -193,9 +301,24 @@ void ConvexAlignHip::AlignTiles(Tile * tiles, int n) {
 		Release(job);
 		throw;
 	}
+	bool anyWindow = false;
+	for (int i = 0; i < n; ++i) anyWindow = anyWindow || tiles[i].window;
+	JobText jt;
+	if (anyWindow) {
+		/* no reference characters on the host: CIGAR / MD / profile from the device, where the decoded windows lie */
+		std::vector<Tile const *> ptrs((size_t) n);
+		for (int i = 0; i < n; ++i) ptrs[(size_t) i] = &tiles[i];
+		try {
+			Text(job, ptrs.data(), n, jt);
+		} catch (...) {
+			Release(job);
+			throw;
+		}
+	}
 	for (int i = 0; i < n; ++i) {
 		try {
-			Finish(tiles[i], res[i], ops);
+			if (anyWindow) FinishText(tiles[i], res[i], jt, i);
+			else Finish(tiles[i], res[i], ops);
 		} catch (...) {
 			/* this tile's own hard error: the caller drops this alignment and no other (src/AlignmentBuffer.cpp:454-463) */
 			tiles[i].failed = true;
@@ -292,12 +415,8 @@ void ConvexAlignHip::Text(cvx_job job, Tile const * const * tiles, int n, JobTex
 	std::vector<int32_t> ext(2 * n1);
 	for (size_t i = 0; i < n1; ++i) { ext[i] = tiles[i]->externalQStart; ext[n1 + i] = tiles[i]->externalQEnd; }
 	uint64_t bytes = 0;
-	int rc = cvx_job_text(handle, job, ext.data(), ext.data() + n1, jt.out.data(), jt.textOff.data(), &jt.text, &bytes);
-	if (rc == CVX_OK) rc = cvx_job_nm_sizes(handle, job, 0, n, jt.nmOff.data());
-	if (rc == CVX_OK) {
-		jt.nm.resize((size_t) (3 * jt.nmOff[n1] + 3));
-		rc = cvx_job_nm_profile(handle, job, 0, n, jt.nmOff.data(), jt.nm.data(), jt.nmOff[n1] + 1, 0);
-	}
+	jt.nm = 0;
+	int const rc = cvx_job_text_all(handle, job, ext.data(), ext.data() + n1, jt.out.data(), jt.textOff.data(), &jt.text, &bytes, jt.nmOff.data(), &jt.nm);
 	if (rc != CVX_OK) {
 		fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
 		throw 1;
@@ -337,7 +456,7 @@ void ConvexAlignHip::FinishText(Tile & t, cvx_result const & r, JobText const & 
 		fprintf(stderr, "ConvexAlignHip: nmPerPosition count of the device (%llu) differs from the text stage's (%d)\n", (unsigned long long) (e1 - e0), txt.nm_count);
 		throw 1;
 	}
-	if (e1 > e0) memcpy((void *) a.nmPerPosition, jt.nm.data() + 3 * e0, (size_t) (e1 - e0) * 3 * sizeof(int32_t));
+	if (e1 > e0) memcpy((void *) a.nmPerPosition, jt.nm + 3 * e0, (size_t) (e1 - e0) * 3 * sizeof(int32_t));
 	fillAlign(t, txt);
 }
 

@@ -64,6 +64,10 @@ public:
 		int32_t corridorKind;
 		float corridorK, corridorD, corridorRight;
 		int32_t corridorOffset, corridorWidth;
+		/* filled by Prepare(): refSeq is a placeholder for the window of the resident genome at refPosition (DeviceWindows
+		 * below) -- the launch carries (position, length) and the device decodes; only the device text stage may finish it */
+		bool window;
+		unsigned long long refPosition;
 	};
 	/* n independent corridor alignments in one device launch.  A hard error that belongs to one tile (a corridor no
 	 * kernel covers, a CIGAR that does not fit the caller's buffer) marks that tile `failed` and leaves the others
@@ -96,10 +100,13 @@ public:
 	struct JobText {
 		std::vector<cvx_alignment_text> out;
 		std::vector<uint64_t> textOff, nmOff;
-		std::vector<int32_t> nm;           /* (refPosition, readPosition, nm) triples of all tiles */
+		int32_t const * nm;                /* (refPosition, readPosition, nm) triples of all tiles, in the job's page-locked memory */
 		char const * text;                 /* the job's page-locked text buffer */
 	};
 	void Text(cvx_job job, Tile const * const * tiles, int n, JobText & jt);
+	/* launches that travelled as windows of the resident genome (cvx_submit_windows), and launches that mixed windows with
+	 * decoded references (their windows were materialised with cvx_genome_decode first) */
+	static void WindowStats(long & windowLaunches, long & windowTiles, long & mixedLaunches);
 	/* tiles Prepare() has seen in this process, and how many of them travelled as a closed form */
 	static void CorridorStats(long & prepared, long & closedForm);
 	void FinishText(Tile & t, cvx_result const & r, JobText const & jt, int index) const;
@@ -110,6 +117,33 @@ private:
 	cvx_handle handle;
 	unsigned long maxMatrixMB;
 	std::vector<cvx_tile> packed;
+	cvx_genome genome;                     /* DeviceWindows' genome on this aligner's device (uploaded by the first launch that carries a window) */
+	std::vector<unsigned long long> positions;
+	void materialiseWindows(Tile const * tiles, int n);
+};
+
+/*
+ * Reference windows decoded on the device inside ngmlr's worker flow (decode half).
+ *
+ * ngmlr expands the reference window of every alignment from its 4-bit genome on the worker's core
+ * (extractReferenceSequenceForAlignment -> DecodeRefSequenceExact, reference src/AlignmentBuffer.cpp:199-223,
+ * src/SequenceProvider.cpp:493-565) and hands SingleAlign the characters.  Between that call and SingleAlign the
+ * caller only measures the string (strlen in the corridor builders, :112, :135).  With CVX_DEVICE_DECODE=1 the
+ * binding (window_decode_binding.inc) allocates the same buffer, fills it with a placeholder of the same length and
+ * notes (buffer, position, length) for the calling context; Prepare() recognises the buffer, the launch travels
+ * through cvx_submit_windows, and CIGAR / MD come from the device text stage, which reads the decoded window where
+ * the fill read it.  No reference character crosses PCIe or is produced on the host.  The note travels with the read:
+ * fiber-local under the pool's user-level contexts, thread-local on a plain worker thread.
+ */
+struct DeviceWindows {
+	static bool Enabled();                 /* CVX_DEVICE_DECODE=1 */
+	/* ngmlr's encoded genome as _SequenceProvider::Init leaves it (binRef, binRefIndex nibbles, refStartPos with its upper
+	 * bound): the pointers must stay valid; each aligner uploads it to its own device at its first window launch */
+	static void SetGenome(void const * binRef, unsigned long long nNibbles, unsigned long long const * startTable, int nStarts);
+	static bool HaveGenome();
+	/* buf[0 .. length) stands for DecodeRefSequenceExact(buf, position, length, 0): length - 1 characters and a NUL */
+	static void Placeholder(char * buf, unsigned long long position, int length);
+	static bool Lookup(char const * buf, unsigned long long & position, int & length);
 };
 
 }  // namespace Convex

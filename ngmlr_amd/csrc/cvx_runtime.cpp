@@ -272,6 +272,7 @@ struct cvx_batch_s {
 	DevBuf<unsigned long long> d_nmoff;  /* nmPerPosition: entry counts, offsets, total of the requested tile range */
 	DevBuf<int32_t> d_nm;            /* ... and the triples */
 	PinBuf h_nmoff;
+	PinBuf h_nm;                     /* the triples on the host (cvx_job_nm_profile_resident) */
 	hipEvent_t ev_nm0 = nullptr, ev_nm1 = nullptr;
 	PinBuf h_win;                    /* WindowDesc[n]: reference windows decoded on the device (cvx_submit_windows) */
 	DevBuf<WindowDesc> d_win;
@@ -328,7 +329,7 @@ struct cvx_batch_s {
 		h_win.release(); d_win.release();
 		h_ext.release(); h_trec.release(); h_toff.release(); h_text.release();
 		d_ext.release(); d_trec.release(); d_tlen.release(); d_text.release();
-		d_nmoff.release(); d_nm.release(); h_nmoff.release();
+		d_nmoff.release(); d_nm.release(); h_nmoff.release(); h_nm.release();
 		if (ev_nm0) { (void) hipEventDestroy(ev_nm0); ev_nm0 = nullptr; }
 		if (ev_nm1) { (void) hipEventDestroy(ev_nm1); ev_nm1 = nullptr; }
 		h_chain.release(); d_chain.release(); d_bnd.release(); d_chain_out.release();
@@ -548,6 +549,14 @@ int ensure_streams(cvx_context *c) {
 	hipError_t e = hipSuccess;
 	auto make = [&](hipStream_t *st) { if (e == hipSuccess && *st == nullptr) e = hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
 	make(&c->s_post);
+	/* the text stage of finished jobs runs beside the fills of the jobs behind them: at normal priority its stream shared a
+	 * hardware queue with one of the fill classes and every one of its waits sat out a whole fill kernel (38 ms per launch of
+	 * 500 tiles inside ngmlr, profiles/r06_e2e_device_decode.txt); the high-priority queues carry only uploads and plans
+	 * (CVX_TEXT_STREAM_PRIO=0: as before) */
+	{
+		const char *tp = getenv("CVX_TEXT_STREAM_PRIO");
+		if (e == hipSuccess && c->s_text == nullptr && !(tp && atoi(tp) == 0)) e = hipStreamCreateWithPriority(&c->s_text, hipStreamNonBlocking, prio_hi);
+	}
 	make(&c->s_text);
 	for (int i = 0; i < kAuxStreams; ++i) make(&c->aux[i]);
 	make(&c->s_main2);
@@ -1896,11 +1905,87 @@ int cvx_job_text(cvx_handle h, cvx_job j, const int32_t *ext_qstart, const int32
 }
 
 static int nm_profile_common(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint64_t *entry_off,
-		int32_t *triples, uint64_t cap_entries, double *kernel_ms, bool sizes_only);
+		int32_t *triples, uint64_t cap_entries, double *kernel_ms, bool sizes_only, const int32_t **resident = nullptr);
+
+/* ABI 9: cvx_job_text + cvx_job_nm_profile_resident of the whole job in two round trips to the device instead of four (sizes
+ * of both, then strings and triples of both): what a dispatcher runs per finished launch */
+int cvx_job_text_all(cvx_handle h, cvx_job j, const int32_t *ext_qstart, const int32_t *ext_qend,
+		cvx_alignment_text *out, uint64_t *text_off, const char **text, uint64_t *text_bytes,
+		uint64_t *nm_entry_off, const int32_t **triples) {
+	ABI_GUARD_BEGIN
+	if (!h || !j || j->state < kFinished) { set_err("cvx_job_text_all: job not finished (call cvx_wait first)"); return CVX_ERR_ARG; }
+	const int n = j->n;
+	if (!text || !triples || (n > 0 && (!out || !text_off || !nm_entry_off))) { set_err("cvx_job_text_all: NULL output"); return CVX_ERR_ARG; }
+	if (text_bytes) *text_bytes = 0;
+	*triples = nullptr;
+	if (n == 0) { *text = ""; return CVX_OK; }
+	HIP_TRY(hipSetDevice(h->device));
+	hipStream_t st = h->s_text;
+	const size_t n1 = (size_t) n;
+	TextArgs a;
+	memset(&a, 0, sizeof(a));
+	if (ext_qstart || ext_qend) {
+		RC_TRY(j->h_ext.ensure(2 * n1 * sizeof(int32_t)));
+		RC_TRY(j->d_ext.ensure(2 * n1));
+		int32_t *he = j->h_ext.as<int32_t>();
+		for (int i = 0; i < n; ++i) { he[i] = ext_qstart ? ext_qstart[i] : 0; he[n1 + (size_t) i] = ext_qend ? ext_qend[i] : 0; }
+		HIP_TRY(hipMemcpyAsync(j->d_ext.p, he, 2 * n1 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+		a.ext_qstart = j->d_ext.p;
+		a.ext_qend = j->d_ext.p + n1;
+	}
+	RC_TRY(j->d_trec.ensure(n1));
+	RC_TRY(j->d_tlen.ensure(2 * n1 + 8));
+	RC_TRY(j->h_trec.ensure(n1 * sizeof(TextRec)));
+	RC_TRY(j->h_toff.ensure((n1 + 1) * sizeof(unsigned long long)));
+	RC_TRY(j->d_nmoff.ensure(2 * n1 + 8));
+	RC_TRY(j->h_nmoff.ensure((n1 + 1) * sizeof(unsigned long long)));
+	a.seq = j->d_seq.p; a.tin = j->d_tin.p; a.trun = j->d_trun.p; a.tout = j->d_tout.p; a.ops = j->d_regions.p;
+	a.recs = j->d_trec.p;
+	a.text_len = j->d_tlen.p; a.text_off = j->d_tlen.p + n1; a.text_total = j->d_tlen.p + 2 * n1;
+	a.text = nullptr;
+	a.n_tiles = n;
+	/* round trip 1: lengths, fields and offsets of the strings; entry counts and offsets of the profile */
+	HIP_TRY(launch_text_size(a, st));
+	unsigned long long *d_len = j->d_nmoff.p, *d_off = j->d_nmoff.p + n1;
+	HIP_TRY(launch_nm_offsets(a, 0, n, d_len, d_off, d_off + n1, st));
+	unsigned long long *hoff = j->h_toff.as<unsigned long long>(), *hnm = j->h_nmoff.as<unsigned long long>();
+	HIP_TRY(hipMemcpyAsync(hoff, a.text_off, (n1 + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(hnm, d_off, (n1 + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(j->h_trec.p, j->d_trec.p, n1 * sizeof(TextRec), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const unsigned long long total = hoff[n1], entries = hnm[n1];
+	/* round trip 2: the strings and the triples */
+	RC_TRY(j->d_text.ensure((size_t) total + 64));
+	RC_TRY(j->h_text.ensure((size_t) total + 64));
+	RC_TRY(j->d_nm.ensure(3 * (size_t) entries + 16));
+	RC_TRY(j->h_nm.ensure((3 * (size_t) entries + 16) * sizeof(int32_t)));
+	a.text = j->d_text.p;
+	HIP_TRY(launch_text_write(a, st));
+	HIP_TRY(hipMemcpyAsync(j->h_text.p, j->d_text.p, (size_t) ((total + 255) / 256 * 256 <= j->d_text.cap ? (total + 255) / 256 * 256 : total), hipMemcpyDeviceToHost, st));
+	HIP_TRY(launch_nm_profile(a, 0, n, d_off, j->d_nm.p, st));
+	if (entries > 0) HIP_TRY(hipMemcpyAsync(j->h_nm.p, j->d_nm.p, 3 * (size_t) entries * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	memcpy(out, j->h_trec.p, n1 * sizeof(TextRec));
+	for (int i = 0; i < n; ++i) text_off[i] = hoff[i];
+	for (int i = 0; i <= n; ++i) nm_entry_off[i] = hnm[i];
+	*text = j->h_text.as<char>();
+	*triples = j->h_nm.as<int32_t>();
+	if (text_bytes) *text_bytes = total;
+	j->text_done = true;
+	return CVX_OK;
+	ABI_GUARD_END
+}
 
 int cvx_job_nm_profile(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint64_t *entry_off,
 		int32_t *triples, uint64_t cap_entries, double *kernel_ms) {
 	return nm_profile_common(h, j, first, count, entry_off, triples, cap_entries, kernel_ms, false);
+}
+
+int cvx_job_nm_profile_resident(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint64_t *entry_off,
+		const int32_t **triples, double *kernel_ms) {
+	if (!triples) { set_err("cvx_job_nm_profile_resident: NULL argument"); return CVX_ERR_ARG; }
+	*triples = nullptr;
+	return nm_profile_common(h, j, first, count, entry_off, nullptr, 0, kernel_ms, false, triples);
 }
 
 int cvx_job_nm_sizes(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint64_t *entry_off) {
@@ -1908,7 +1993,7 @@ int cvx_job_nm_sizes(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint
 }
 
 static int nm_profile_common(cvx_handle h, cvx_job j, int32_t first, int32_t count, uint64_t *entry_off,
-		int32_t *triples, uint64_t cap_entries, double *kernel_ms, bool sizes_only) {
+		int32_t *triples, uint64_t cap_entries, double *kernel_ms, bool sizes_only, const int32_t **resident) {
 	ABI_GUARD_BEGIN
 	if (kernel_ms) *kernel_ms = 0.0;
 	if (!h || !j || j->state < kFinished) { set_err("cvx_job_nm_profile: job not finished (call cvx_wait first)"); return CVX_ERR_ARG; }
@@ -1937,6 +2022,11 @@ static int nm_profile_common(cvx_handle h, cvx_job j, int32_t first, int32_t cou
 	if (sizes_only) return CVX_OK;      /* the entry offsets alone: no 12-byte-per-column arena, no profile kernel */
 	if (triples && total > cap_entries) { set_err("cvx_job_nm_profile: %llu entries, room for %llu", total, (unsigned long long) cap_entries); return CVX_ERR_CAPACITY; }
 	RC_TRY(j->d_nm.ensure(3 * (size_t) total + 16));
+	if (resident) {
+		RC_TRY(j->h_nm.ensure((3 * (size_t) total + 16) * sizeof(int32_t)));
+		triples = j->h_nm.as<int32_t>();
+		*resident = triples;
+	}
 	HIP_TRY(hipEventRecord(j->ev_nm0, st));
 	HIP_TRY(launch_nm_profile(a, first, count, d_off, j->d_nm.p, st));
 	HIP_TRY(hipEventRecord(j->ev_nm1, st));

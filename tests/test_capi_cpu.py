@@ -24,7 +24,7 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(capi.EXPORTS)
-    assert lib.cvx_abi_version() == 8
+    assert lib.cvx_abi_version() == 9
 
 
 def test_library_carries_gfx950_code_object(built):

@@ -213,6 +213,63 @@ def test_text_stage_on_the_device_in_the_pipeline(built, tmp_path):
     assert re.search(r"text stage on the device for [1-9]\d* launches", err), err[-1500:]
 
 
+def test_reference_windows_decoded_on_the_device_in_the_pipeline(built, tmp_path):
+    """CVX_DEVICE_DECODE=1 -- extractReferenceSequenceForAlignment (reference src/AlignmentBuffer.cpp:199-223)
+    hands computeAlignment a placeholder of the window's length instead of running DecodeRefSequenceExact on the worker's core
+    (window_decode_binding.inc); every launch of the dispatcher travels through cvx_submit_windows (the device decodes the window
+    from ngmlr's own 4-bit genome, uploaded once per device) and CIGAR / MD / nmPerPosition come from the device text stage, which
+    runs on its own thread under the kernels of the next launch.  test_2 (short reads: windows at chromosome edges), test_4,
+    test_3 (-t 16, 256 contexts), the split-read workload (reverse-strand windows, realignment windows) and the repeat-rich
+    one: every SAM record identical to the unmodified reference's, and no tile took its reference as characters."""
+    import re
+    import sys
+    env = {"CVX_POOL_CONTEXTS": "256", "CVX_DEVICE_DECODE": "1"}
+
+    def windows(err, alignments=None):
+        m = re.search(r"SharedAligner: (\d+) tiles in (\d+) launches took their reference as windows of the genome in HBM .*, (\d+) mixed", err)
+        k = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", err)
+        assert m and k, err[-2500:]
+        assert int(m.group(1)) == int(k.group(1)) and int(m.group(2)) == int(k.group(2)) and int(m.group(3)) == 0, (m.groups(), k.groups())
+        if alignments is not None:
+            assert int(k.group(1)) == alignments
+        t = re.search(r"text stage on the device for (\d+) launches", err)
+        assert t and int(t.group(1)) == int(k.group(2)), err[-2500:]
+
+    got, err = _run(["-t", "1", "-r", os.path.join(E2E, "ref_chr21_20kb.fa"), "-q", os.path.join(E2E, "reads_100_2200bp.fa")], tmp_path, binary=BIN_ALL, env=env)
+    assert sorted(got) == sorted(_records(open(os.path.join(ROOT, "tests", "golden", "test_2.sam")).read())) and len(got) == 12
+    windows(err)
+    got, err = _run(["-x", "pacbio", "-t", "1", "-r", os.path.join(E2E, "test_4_reference.fasta.gz"),
+                     "-q", os.path.join(E2E, "test_4_read.fa.gz")], tmp_path, binary=BIN_ALL, env=env)
+    assert got == _records(open(os.path.join(ROOT, "tests", "golden", "test_4.sam")).read()) and len(got) == 1
+    windows(err)
+    got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_ALL, env=env)
+    assert sorted(got) == _test_3_want()
+    windows(err, 985)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ngmlr_ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/ngmlr_ref not built")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_rates
+    fa, fq = str(tmp_path / "sv_ref.fa"), str(tmp_path / "sv_reads.fq")
+    e2e_rates.write_sv_workload(fa, fq, 120, seed=79)
+    args = ["-x", "ont", "-R", "0.01", "--no-progress", "-r", fa, "-q", fq]
+    want, _ = _run(["-t", "16"] + args, tmp_path, binary=ref_bin)
+    got, err = _run(["-t", "8"] + args, tmp_path, binary=BIN_ALL, env=dict(env, CVX_POOL_CONTEXTS="128"))
+    assert sorted(got) == sorted(want)
+    windows(err)
+    fa, fq = str(tmp_path / "rep_ref.fa"), str(tmp_path / "rep_reads.fq")
+    e2e_rates.write_repeat_workload(fa, fq, 160, seed=92)
+    args = ["-x", "pacbio", "-R", "0.01", "--no-progress", "-r", fa, "-q", fq]
+    want, _ = _run(["-t", "16"] + args, tmp_path, binary=ref_bin)
+    got, err = _run(["-t", "8"] + args, tmp_path, binary=BIN_ALL, env=dict(env, CVX_POOL_CONTEXTS="128"))
+    assert sorted(got) == sorted(want)
+    windows(err)
+    # plain worker threads instead of user-level contexts: the note of a window is thread-local there
+    got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_ALL, env=dict(env, CVX_POOL_FIBERS="0"))
+    assert sorted(got) == _test_3_want()
+    windows(err, 985)
+
+
 def test_repeat_rich_reference(built, tmp_path):
     """What a k-mer vote sees on a real genome: repeat families of 8-20 diverged copies and microsatellites, so that sub-reads cast
     10^4..10^5 votes, overflow the wave kernel's LDS map (forced to its smallest size here: the HBM-table form runs) and reads get several close candidates (MAPQ

@@ -134,11 +134,19 @@ def _device_profiles(al, tiles, ranges=None):
     for first, count in (ranges or [(0, len(tiles))]):
         off, tri, ms = job.nm_profile(first, count)
         assert ms >= 0.0 and off[0] == 0 and int(off[count]) == len(tri)
+        off2, tri2, _ = job.nm_profile_resident(first, count)      # ABI 9: the triples in the job's page-locked memory
+        assert np.array_equal(off, off2) and np.array_equal(tri, tri2)
         for i in range(count):
             d = dev[first + i]
             n = int(off[i + 1] - off[i])
             assert n == (d["nm_count"] if d["ret"] >= 0 else 0), (tiles[first + i].tag, n, d["nm_count"])
             out[first + i] = tri[int(off[i]):int(off[i + 1])]
+    if not ranges:
+        # ABI 9: both stages of the whole job in one call (what the pipeline's dispatcher runs per finished launch)
+        dev3, off3, tri3 = job.text_all(eqs, eqe)
+        assert dev3 == dev
+        for i in range(len(tiles)):
+            assert np.array_equal(tri3[int(off3[i]):int(off3[i + 1])], out[i]), tiles[i].tag
     job.release()
     return out, dev
 

@@ -58,6 +58,21 @@ if INDEX:
     s = sub1(s, '#include "PrefixTable.h"', '#include "PrefixTable.h"\n#include <vector>\n#include <stdlib.h>\n#include <string.h>\n#include <stdint.h>\n#include "cvx_align.h"', 'PrefixTable.cpp includes')
     s = sub1(s, 'void CompactPrefixTable::CreateTable(uint const length) {\n', 'void CompactPrefixTable::CreateTable(uint const length) {\n#include "index_build_binding.inc"\n', 'CompactPrefixTable::CreateTable')
     open(p, 'w').write(s)
+if INDEX and POOL:
+    # the reference window of an alignment decoded on the device (CVX_DEVICE_DECODE=1; ngmlr_amd/csrc/window_decode_binding.inc,
+    # Convex::DeviceWindows in convex_align_hip.h): the encoded genome is announced where _SequenceProvider::Init has finished it
+    p = T + '/src/SequenceProvider.cpp'
+    s = open(p).read()
+    s = sub1(s, '#include "SequenceProvider.h"', '#include "SequenceProvider.h"\n#include "convex_align_hip.h"', 'SequenceProvider.cpp include')
+    s = sub1(s, '\trefStartPos[j] = refStartPos[j - 1] + SequenceProvider.GetRefLen(refCount - 1) + 1000;\n',
+             '\trefStartPos[j] = refStartPos[j - 1] + SequenceProvider.GetRefLen(refCount - 1) + 1000;\n'
+             '\tConvex::DeviceWindows::SetGenome(binRef, (unsigned long long) binRefIndex, refStartPos, j + 1);\n', 'SequenceProvider::Init genome')
+    open(p, 'w').write(s)
+    p = T + '/src/AlignmentBuffer.cpp'
+    s = open(p).read()
+    s = sub1(s, 'char const * const AlignmentBuffer::extractReferenceSequenceForAlignment(Interval const*& interval, int & refSeqLength) {\n',
+             'char const * const AlignmentBuffer::extractReferenceSequenceForAlignment(Interval const*& interval, int & refSeqLength) {\n#include "window_decode_binding.inc"\n', 'extractReferenceSequenceForAlignment')
+    open(p, 'w').write(s)
 if SEARCH:
     # the k-mer vote of a CS thread's batch on the device (ngmlr_amd/csrc/candidate_search_hip.h, cs_search_binding.inc)
     p = T + '/src/PrefixTable.h'
