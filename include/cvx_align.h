@@ -37,6 +37,9 @@
  * cvx_score_batch             StrippedSW::BatchScore/SingleScore  src/StrippedSW.cpp:118-203 (next-row f2)
  * cvx_genome_* / cvx_submit_windows  SequenceProvider's 4-bit genome + DecodeRefSequenceExact
  *                             src/SequenceProvider.cpp:333-386,475-565 (next-row f4, decode half)
+ * cvx_job_window_refs         the windows cvx_submit_windows decoded, back on the host for a text stage there
+ *                             (replaces extractReferenceSequenceForAlignment's decode, src/AlignmentBuffer.cpp:199-223)
+ * cvx_job_text_all / cvx_job_nm_profile_resident  cvx_job_text + cvx_job_nm_profile per finished launch, profile in page-locked memory
  * cvx_index_upload / cvx_search_batch  CS::RunRead's k-mer vote over the CompactPrefixTable
  *                             src/CS.cpp:57-149,219-268,324-398, src/CSstatic.cpp:23-73, src/PrefixTable.cpp:476-532 (f4, search half)
  *
@@ -351,6 +354,11 @@ int cvx_genome_decode(cvx_handle h, cvx_genome g, int32_t n, const uint64_t *pos
 		const uint64_t *out_offset, char *out);
 int cvx_submit_windows(cvx_handle h, cvx_genome g, int32_t n_tiles, const cvx_tile *tiles,
 		const uint64_t *ref_position, cvx_job *out);
+/* ABI 9: the windows a job of cvx_submit_windows decoded, back on the host: refs[i] = the ref_len characters of tile i's
+ * reference (page-locked memory of the job, valid after cvx_wait until cvx_job_release; not NUL-terminated).  They come
+ * back with the job's other results at one byte per base; a caller that writes MD on the host (cvx_format_alignment)
+ * reads the reference bases of mismatches and deletions there and never decodes a window itself. */
+int cvx_job_window_refs(cvx_handle h, cvx_job job, const char **refs);
 
 /* Candidate search (search half): the k-mer vote of CS::RunRead (src/CS.cpp:324-398: PrefixIteration
  * src/CSstatic.cpp:23-73, PrefixSearch / AddLocationStd src/CS.cpp:57-149, CollectResultsStd :219-268) for a batch of

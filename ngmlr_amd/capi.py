@@ -27,7 +27,7 @@ EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_
            "cvx_genome_encoded_bytes", "cvx_genome_encode", "cvx_genome_upload", "cvx_genome_free",
            "cvx_genome_decode", "cvx_submit_windows", "cvx_job_text",
            "cvx_host_alloc", "cvx_host_free", "cvx_corridor_rows", "cvx_pack_probe", "cvx_build_id", "cvx_job_poll", "cvx_score_kernel_ms",
-           "cvx_index_upload", "cvx_index_free", "cvx_search_batch", "cvx_search_batch_ex", "cvx_job_nm_profile", "cvx_job_nm_profile_resident", "cvx_job_text_all", "cvx_job_nm_sizes", "cvx_nm_profile_ops",
+           "cvx_index_upload", "cvx_index_free", "cvx_search_batch", "cvx_search_batch_ex", "cvx_job_nm_profile", "cvx_job_nm_profile_resident", "cvx_job_text_all", "cvx_job_window_refs", "cvx_job_nm_sizes", "cvx_nm_profile_ops",
            "cvx_sam_record_text", "cvx_sam_unmapped_text", "cvx_sam_batch", "cvx_stage_kernel_ms", "cvx_search_last_attempts", "cvx_index_build", "cvx_index_build_device",
            "cvx_corridor_fit", "cvx_corridor_fit_batch", "cvx_create_ex", "cvx_runtime_regime", "cvx_search_batch_arena")
 
@@ -175,6 +175,7 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_job_nm_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
     lib.cvx_job_nm_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.cvx_job_nm_profile_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
+    lib.cvx_job_window_refs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cvx_job_text_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CvxAlignmentText), C.c_void_p,
                                      C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_void_p)]
     lib.cvx_nm_profile_ops.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]

@@ -63,7 +63,7 @@ namespace Convex {
 BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, int tmoUs) :
 		backend(be), workers(nWorkers >= 0 ? nWorkers : 1), parked(0),
 		maxBatch(maxB > 0 ? maxB : 1), timeoutUs(tmoUs), stop(false), launches(0), requests(0), maxInFlight(0),
-		target(0), holdUs(20000), feedActive(true), textLaunches(0), textNs(0), launchTrace(false), deviceText(false), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000), textPending(0), textStop(false) {
+		target(0), holdUs(20000), feedActive(true), textLaunches(0), textNs(0), launchTrace(false), deviceText(false), parkedNs(0), finishNs(0), busyNs(0), maxFlight(2), emaServiceUs(0.0), leadUs(3000), textPending(0), textStop(false), maxTextAhead(4) {
 	if (const char * e = getenv("CVX_BATCH_TARGET")) target = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_HOLD_US")) holdUs = atoi(e) > 0 ? atoi(e) : 0;
 	if (const char * e = getenv("CVX_BATCH_LEAD_US")) leadUs = atoi(e);      /* < 0: the plain timeout rule while a launch runs */
@@ -71,8 +71,8 @@ BatchingAligner::BatchingAligner(ConvexAlignHip * be, int nWorkers, int maxB, in
 	 * with 4, and with the runtime's two stream sets) only makes the launches smaller: 20 000 reads 25.1 s against 21.2 s */
 	if (const char * e = getenv("CVX_BATCH_INFLIGHT")) maxFlight = atoi(e) > 0 ? atoi(e) : 1;
 	if (const char * e = getenv("CVX_DEVICE_TEXT")) deviceText = atoi(e) != 0;
-	if (DeviceWindows::Enabled()) deviceText = true;      /* windows decoded on the device: the host has no reference characters to write MD from */
 	if (const char * e = getenv("CVX_LAUNCH_TRACE")) launchTrace = atoi(e) != 0;
+	if (const char * e = getenv("CVX_TEXT_AHEAD")) maxTextAhead = atoi(e) > 0 ? atoi(e) : 1;
 	dispatcher = std::thread([this] { dispatchLoop(); });
 	if (deviceText) textThread = std::thread([this] { textLoop(); });
 }
@@ -127,6 +127,7 @@ void BatchingAligner::textLoop() {
 			lk.lock();
 			textNs += ns;
 			textLaunches += 1;
+			if (launchTrace) fprintf(stderr, "cvx text stage: %d tiles in %.2f ms, %d launches behind it\n", (int) l->reqs.size(), (double) ns * 1e-6, (int) textQueue.size());
 		} catch (...) {
 			lk.lock();
 			l->failed = true;
@@ -215,7 +216,10 @@ void BatchingAligner::dispatchLoop() {
 			lk.lock();
 		}
 		if (stop && queue.empty() && inFlight.empty() && textPending == 0) break;
-		bool const canSubmit = (int) inFlight.size() < maxFlight;
+		/* (with the text stage on its own thread a launch stays alive until that stage has run: the dispatcher does not cut
+		 * further ahead than four launches whose text is still to be written -- their job slots hold the launch's arenas; two
+		 * left the device idle whenever a text stage had to grow its buffers: a launch in flight 61 % of the time) */
+		bool const canSubmit = (int) inFlight.size() < maxFlight && textPending < maxTextAhead;
 		if (canSubmit && shouldCut(inFlight.empty())) {
 			Launch * l = new Launch();
 			l->job = 0; l->results = 0; l->ops = 0; l->failed = false; l->text = 0; l->submitMs = l->waitMs = 0.0;
@@ -284,6 +288,15 @@ void BatchingAligner::dispatchLoop() {
 				if (!l->failed) emaServiceUs = emaServiceUs > 0.0 ? 0.7 * emaServiceUs + 0.3 * us : us;
 				frontSince = t;
 				if (inFlight.empty()) busyNs += std::chrono::duration_cast<std::chrono::nanoseconds>(t - busySince).count();
+			}
+			if (!deviceText && !l->failed) {
+				/* a launch of windows decoded on the device (window_decode_binding.inc): its workers' host text stage reads the
+				 * characters that came back with the results (they are parked: nobody else touches their tiles) */
+				std::vector<ConvexAlignHip::Tile *> tp(l->reqs.size());
+				for (size_t i = 0; i < tp.size(); ++i) tp[i] = &l->reqs[i]->tile;
+				lk.unlock();
+				(void) backend->WindowRefs(l->job, tp.data(), (int) tp.size());
+				lk.lock();
 			}
 			if (deviceText && !l->failed) {
 				/* its text stage runs on the text thread, under the kernels of the launches behind it */
@@ -470,7 +483,7 @@ SharedAligner::~SharedAligner() {
 		{
 			long wl = 0, wt = 0, ml = 0;
 			ConvexAlignHip::WindowStats(wl, wt, ml);
-			if (wl + ml > 0) fprintf(stderr, "SharedAligner: %ld tiles in %ld launches took their reference as windows of the genome in HBM (cvx_submit_windows; CVX_DEVICE_DECODE=1), %ld mixed launches materialised theirs\n", wt, wl, ml);
+			if (wl + ml > 0) fprintf(stderr, "SharedAligner: %ld tiles in %ld launches took their reference as windows of the genome in HBM (cvx_submit_windows; CVX_DEVICE_DECODE=0 turns that off), %ld mixed launches materialised theirs\n", wt, wl, ml);
 		}
 		if (g_lastTextLaunches > 0) fprintf(stderr, "SharedAligner: text stage on the device for %ld launches (cvx_job_text + cvx_job_nm_profile), %.3f s of the dispatchers' time\n", g_lastTextLaunches, g_lastTextSeconds);
 		fprintf(stderr, "SharedAligner: library loaded at 0, first worker joined at %.2f s, last one left at %.2f s\n",

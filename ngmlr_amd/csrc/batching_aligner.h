@@ -153,6 +153,7 @@ private:
 	std::condition_variable cvText;
 	int textPending;                       /* launches in textQueue or in the text thread's hands */
 	bool textStop;
+	int maxTextAhead;                      /* CVX_TEXT_AHEAD (4): launches the dispatcher may have handed to the text thread before it stops cutting new ones */
 
 	void dispatchLoop();
 	void textLoop();

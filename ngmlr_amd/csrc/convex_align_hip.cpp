@@ -30,7 +30,9 @@ void const * g_binRef = 0;
 unsigned long long g_nNibbles = 0;
 std::vector<uint64_t> g_startTable;
 std::atomic<long> g_windowLaunches(0), g_windowTiles(0), g_mixedLaunches(0);
-bool const g_deviceDecode = [] { const char * e = getenv("CVX_DEVICE_DECODE"); return e && atoi(e) != 0; }();
+/* on wherever the binding announced a genome (DeviceWindows::SetGenome: only oracle/_ref/ngmlr_hip_all carries it); CVX_DEVICE_DECODE=0 keeps
+ * the reference's decode on the worker's core */
+bool const g_deviceDecode = [] { const char * e = getenv("CVX_DEVICE_DECODE"); return !(e && atoi(e) == 0); }();
 }
 
 bool DeviceWindows::Enabled() { return g_deviceDecode; }
@@ -270,6 +272,16 @@ void ConvexAlignHip::Wait(cvx_job job, cvx_result const ** results, uint32_t con
 	}
 }
 
+bool ConvexAlignHip::WindowRefs(cvx_job job, Tile * const * tiles, int n) {
+	bool any = false;
+	for (int i = 0; i < n && !any; ++i) any = tiles[i]->window;
+	if (!any || n <= 0) return false;
+	std::vector<char const *> refs((size_t) n);
+	if (cvx_job_window_refs(handle, job, refs.data()) != CVX_OK) return false;      /* a mixed launch: its windows were materialised in the callers' buffers */
+	for (int i = 0; i < n; ++i) tiles[i]->refSeq = refs[(size_t) i];
+	return true;
+}
+
 void ConvexAlignHip::Trace(cvx_job job, int nTiles, double serviceMs, double waitedMs) const {
 	cvx_timing t;
 	if (cvx_job_timing(job, &t) != CVX_OK) return;
@@ -301,24 +313,14 @@ void ConvexAlignHip::AlignTiles(Tile * tiles, int n) {
 		Release(job);
 		throw;
 	}
-	bool anyWindow = false;
-	for (int i = 0; i < n; ++i) anyWindow = anyWindow || tiles[i].window;
-	JobText jt;
-	if (anyWindow) {
-		/* no reference characters on the host: CIGAR / MD / profile from the device, where the decoded windows lie */
-		std::vector<Tile const *> ptrs((size_t) n);
-		for (int i = 0; i < n; ++i) ptrs[(size_t) i] = &tiles[i];
-		try {
-			Text(job, ptrs.data(), n, jt);
-		} catch (...) {
-			Release(job);
-			throw;
-		}
-	}
+	/* windows decoded on the device: the host text stage reads the characters that came back with the results */
+	std::vector<char const *> callers((size_t) n);
+	std::vector<Tile *> ptrs((size_t) n);
+	for (int i = 0; i < n; ++i) { callers[(size_t) i] = tiles[i].refSeq; ptrs[(size_t) i] = &tiles[i]; }
+	(void) WindowRefs(job, ptrs.data(), n);
 	for (int i = 0; i < n; ++i) {
 		try {
-			if (anyWindow) FinishText(tiles[i], res[i], jt, i);
-			else Finish(tiles[i], res[i], ops);
+			Finish(tiles[i], res[i], ops);
 		} catch (...) {
 			/* this tile's own hard error: the caller drops this alignment and no other (src/AlignmentBuffer.cpp:454-463) */
 			tiles[i].failed = true;
@@ -326,6 +328,7 @@ void ConvexAlignHip::AlignTiles(Tile * tiles, int n) {
 			tiles[i].result->Score = -1.0f;
 		}
 	}
+	for (int i = 0; i < n; ++i) tiles[i].refSeq = callers[(size_t) i];
 	Release(job);
 }
 

@@ -65,7 +65,7 @@ public:
 		float corridorK, corridorD, corridorRight;
 		int32_t corridorOffset, corridorWidth;
 		/* filled by Prepare(): refSeq is a placeholder for the window of the resident genome at refPosition (DeviceWindows
-		 * below) -- the launch carries (position, length) and the device decodes; only the device text stage may finish it */
+		 * below) -- the launch carries (position, length) and the device decodes; Finish needs WindowRefs() first */
 		bool window;
 		unsigned long long refPosition;
 	};
@@ -104,6 +104,10 @@ public:
 		char const * text;                 /* the job's page-locked text buffer */
 	};
 	void Text(cvx_job job, Tile const * const * tiles, int n, JobText & jt);
+	/* after Wait, for a launch that travelled through cvx_submit_windows: tiles[i]->refSeq is redirected to the characters
+	 * the device decoded (cvx_job_window_refs: the job's page-locked memory, valid until Release), so that Finish -- the host
+	 * text stage, which reads the reference base of every mismatch and deletion -- works on them.  false: not a window launch */
+	bool WindowRefs(cvx_job job, Tile * const * tiles, int n);
 	/* launches that travelled as windows of the resident genome (cvx_submit_windows), and launches that mixed windows with
 	 * decoded references (their windows were materialised with cvx_genome_decode first) */
 	static void WindowStats(long & windowLaunches, long & windowTiles, long & mixedLaunches);
@@ -119,6 +123,7 @@ private:
 	std::vector<cvx_tile> packed;
 	cvx_genome genome;                     /* DeviceWindows' genome on this aligner's device (uploaded by the first launch that carries a window) */
 	std::vector<unsigned long long> positions;
+	std::vector<char const *> refPtrs;
 	void materialiseWindows(Tile const * tiles, int n);
 };
 
@@ -128,15 +133,16 @@ private:
  * ngmlr expands the reference window of every alignment from its 4-bit genome on the worker's core
  * (extractReferenceSequenceForAlignment -> DecodeRefSequenceExact, reference src/AlignmentBuffer.cpp:199-223,
  * src/SequenceProvider.cpp:493-565) and hands SingleAlign the characters.  Between that call and SingleAlign the
- * caller only measures the string (strlen in the corridor builders, :112, :135).  With CVX_DEVICE_DECODE=1 the
+ * caller only measures the string (strlen in the corridor builders, :112, :135).  Unless CVX_DEVICE_DECODE=0, the
  * binding (window_decode_binding.inc) allocates the same buffer, fills it with a placeholder of the same length and
  * notes (buffer, position, length) for the calling context; Prepare() recognises the buffer, the launch travels
- * through cvx_submit_windows, and CIGAR / MD come from the device text stage, which reads the decoded window where
- * the fill read it.  No reference character crosses PCIe or is produced on the host.  The note travels with the read:
+ * through cvx_submit_windows, and the text stage -- on the host (default) or on the device (CVX_DEVICE_TEXT=1) -- reads
+ * what the device decoded: the windows come back with the launch's results (cvx_job_window_refs, one byte per base) resp.
+ * are read where the fill read them.  No core expands a window.  The note travels with the read:
  * fiber-local under the pool's user-level contexts, thread-local on a plain worker thread.
  */
 struct DeviceWindows {
-	static bool Enabled();                 /* CVX_DEVICE_DECODE=1 */
+	static bool Enabled();                 /* unless CVX_DEVICE_DECODE=0 */
 	/* ngmlr's encoded genome as _SequenceProvider::Init leaves it (binRef, binRefIndex nibbles, refStartPos with its upper
 	 * bound): the pointers must stay valid; each aligner uploads it to its own device at its first window launch */
 	static void SetGenome(void const * binRef, unsigned long long nNibbles, unsigned long long const * startTable, int nStarts);

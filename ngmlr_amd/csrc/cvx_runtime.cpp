@@ -215,7 +215,7 @@ bool in_pinned_block(const void *p, uint64_t bytes) {
  * measured: with seven streams the 18-tile M = 4 launch ran alone for 11 ms in front of the
  * 24 558-tile M = 3 launch instead of beside it. */
 static const int kAuxStreams = 2;      /* (round 5: a batch has up to four fill classes -- chained, gangs, M = 4, M = 3 -- and each wants a stream of its own) */
-static const size_t kPoolBatches = 4;
+static const size_t kPoolBatches = 8;      /* (4 until the text stage of a finished job got its own thread: a launch in the fill, one uploading, two in the text stage and those the workers still copy from) */
 
 enum BatchState { kFailed = -1, kEmpty = 0, kUploaded = 1, kPlanned = 2, kComputed = 3, kFinished = 4 };
 
@@ -275,6 +275,9 @@ struct cvx_batch_s {
 	PinBuf h_nm;                     /* the triples on the host (cvx_job_nm_profile_resident) */
 	hipEvent_t ev_nm0 = nullptr, ev_nm1 = nullptr;
 	PinBuf h_win;                    /* WindowDesc[n]: reference windows decoded on the device (cvx_submit_windows) */
+	PinBuf h_refs;                   /* ... and the decoded windows back on the host (cvx_job_window_refs): the reference part of d_seq */
+	uint64_t refs_base = 0;          /* offset of that part in the sequence arena */
+	bool have_refs = false;
 	DevBuf<WindowDesc> d_win;
 	PinBuf h_chain;                  /* ChainTask[] of all chain classes, ChainBlk[], tile lists */
 	DevBuf<uint8_t> d_chain;
@@ -306,7 +309,10 @@ struct cvx_batch_s {
 		d_plan.hwm = &marks[k++]; d_trun.hwm = &marks[k++]; d_tout.hwm = &marks[k++]; d_dirs.hwm = &marks[k++]; d_regions.hwm = &marks[k++];
 		d_lists.hwm = &marks[k++]; d_dstoff.hwm = &marks[k++]; d_dense.hwm = &marks[k++]; d_res.hwm = &marks[k++];
 		d_chain.hwm = &marks[k++]; d_bnd.hwm = &marks[k++]; d_chain_out.hwm = &marks[k++];
-		static_assert(11 + 17 <= kSharedMarks, "marks");
+		/* the big buffers of the text stage (strings, profile triples: 125 kB per 10 kb alignment); written by the one thread that
+		 * runs a handle's text stages -- never the thread that submits, and these entries are nobody else's */
+		h_text.hwm = &marks[k++]; h_nm.hwm = &marks[k++]; d_text.hwm = &marks[k++]; d_nm.hwm = &marks[k++];
+		static_assert(11 + 17 + 4 <= kSharedMarks, "marks");
 	}
 	int make_events() {
 		if (!ev_in) HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
@@ -326,7 +332,7 @@ struct cvx_batch_s {
 		d_tout.release(); d_dirs.release(); d_regions.release(); d_lists.release();
 		d_counters.release(); d_dstoff.release(); d_dense.release(); d_res.release();
 		d_gscratch.release(); d_gscratch_off.release();
-		h_win.release(); d_win.release();
+		h_win.release(); d_win.release(); h_refs.release();
 		h_ext.release(); h_trec.release(); h_toff.release(); h_text.release();
 		d_ext.release(); d_trec.release(); d_tlen.release(); d_text.release();
 		d_nmoff.release(); d_nm.release(); h_nmoff.release(); h_nm.release();
@@ -492,6 +498,7 @@ void recycle_batch(cvx_context *h, cvx_batch_s *b) {
 	b->state = kEmpty;
 	b->in_flight = false;
 	b->have_ops = false;
+	b->have_refs = false;
 	b->text_done = false;
 	b->fail_rc = CVX_OK;
 	b->fail_msg.clear();
@@ -583,6 +590,7 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 	b->n = n;
 	b->state = kEmpty;
 	b->have_ops = false;
+	b->have_refs = false;
 	b->text_done = false;
 	b->ops_total = 0;
 	b->seq_total = L.seq_total;
@@ -755,6 +763,13 @@ int stage_upload(cvx_context *h, cvx_batch_s *b, int32_t n, const cvx_tile *tile
 		HIP_TRY(hipMemcpyAsync(b->d_win.p, hw, (size_t) n * sizeof(WindowDesc), hipMemcpyHostToDevice, st));
 		HIP_TRY(hipMemsetAsync(b->d_seq.p + L.ref_base + L.ref_bytes, 0, (size_t) (L.seq_total - L.ref_base - L.ref_bytes), st));
 		HIP_TRY(launch_decode_windows(genome->d_bin.p, genome->d_starts.p, genome->n_starts, b->d_win.p, n, b->d_seq.p, st));
+		/* the decoded characters back to the host, 1 byte per reference base under everything that follows: a caller whose
+		 * text stage runs on the host (MD needs the reference base of every mismatch and deletion) reads them there
+		 * (cvx_job_window_refs) instead of decoding the window a second time on a core */
+		RC_TRY(b->h_refs.ensure((size_t) L.ref_bytes + 64));
+		HIP_TRY(hipMemcpyAsync(b->h_refs.p, b->d_seq.p + L.ref_base, (size_t) L.ref_bytes, hipMemcpyDeviceToHost, st));
+		b->refs_base = L.ref_base;
+		b->have_refs = true;
 	}
 	b->state = kUploaded;
 	return CVX_OK;
@@ -1686,6 +1701,17 @@ int cvx_wait(cvx_handle h, cvx_job j, const cvx_result **results, const uint32_t
 	if (results) *results = reinterpret_cast<const cvx_result *>(j->res());
 	if (ops) *ops = j->h_ops.as<uint32_t>();
 	if (n_ops) *n_ops = j->ops_total;
+	return CVX_OK;
+	ABI_GUARD_END
+}
+
+int cvx_job_window_refs(cvx_handle h, cvx_job j, const char **refs) {
+	ABI_GUARD_BEGIN
+	if (!h || !j || !refs || j->state < kFinished) { set_err("cvx_job_window_refs: job not finished (call cvx_wait first)"); return CVX_ERR_ARG; }
+	if (!j->have_refs) { set_err("cvx_job_window_refs: not a job of cvx_submit_windows"); return CVX_ERR_ARG; }
+	const char *base = j->h_refs.as<char>();
+	const TileIn *tin = j->tin();
+	for (int i = 0; i < j->n; ++i) refs[i] = base + (tin[i].ref_off - j->refs_base);
 	return CVX_OK;
 	ABI_GUARD_END
 }

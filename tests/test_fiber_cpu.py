@@ -29,3 +29,16 @@ def test_fibers_park_and_resume(args):
     _build()
     res = subprocess.run([BINARY] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.startswith("ok:"), res.stdout[-1000:]
+
+
+def test_window_note_travels_with_the_read():
+    """Convex::DeviceWindows (convex_align_hip.h): the (buffer, position, length) note window_decode_binding.inc leaves for
+    ConvexAlignHip::Prepare is fiber-local under the pool's user-level contexts -- it survives parks while other reads note
+    their own windows on the same carrier -- and thread-local on plain worker threads; a foreign buffer is never recognised
+    (tests/cpp/windows_test.cpp, linked against libcvxalign.so; no device call)."""
+    binary = os.path.join(ROOT, "ngmlr_amd", "windows_test")
+    res = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "ngmlr_amd", "csrc"), binary], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout[-2000:]
+    for args in (["4", "256", "20000"], ["1", "8", "2000"], ["8", "2048", "30000"]):
+        res = subprocess.run([binary] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert res.returncode == 0 and res.stdout.startswith("ok:"), res.stdout[-1000:]

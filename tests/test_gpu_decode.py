@@ -101,8 +101,17 @@ def test_alignments_from_resident_genome_windows(hip_aligner, port_oracle):
     for i, t in enumerate(tiles):
         r = capi.CvxResult.from_buffer_copy(res[i].tobytes())
         got.append(format_alignment(hip_aligner.lib, r, ops, t))
+    # ABI 9: the decoded windows came back with the results (what a host text stage reads instead of decoding itself)
+    ptrs = (C.c_void_p * len(tiles))()
+    capi.check(hip_aligner.lib.cvx_job_window_refs(hip_aligner.h, job.j, ptrs))
+    for t, p in zip(tiles, ptrs):
+        assert C.string_at(p, len(t.ref)) == t.ref, t.tag
     job.release()
     g.free()
+    plain = hip_aligner.submit(tiles[:3])
+    plain.wait()
+    assert hip_aligner.lib.cvx_job_window_refs(hip_aligner.h, plain.j, ptrs) == -3      # not a job of cvx_submit_windows
+    plain.release()
     ref_run = hip_aligner.batch_align(tiles)
     n_valid = 0
     for t, a, b in zip(tiles, got, ref_run):

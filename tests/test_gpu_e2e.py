@@ -214,18 +214,19 @@ def test_text_stage_on_the_device_in_the_pipeline(built, tmp_path):
 
 
 def test_reference_windows_decoded_on_the_device_in_the_pipeline(built, tmp_path):
-    """CVX_DEVICE_DECODE=1 -- extractReferenceSequenceForAlignment (reference src/AlignmentBuffer.cpp:199-223)
+    """VERDICT r4 / r5 item 4 (the default of ngmlr_hip_all; CVX_DEVICE_DECODE=0 turns it off): extractReferenceSequenceForAlignment (reference src/AlignmentBuffer.cpp:199-223)
     hands computeAlignment a placeholder of the window's length instead of running DecodeRefSequenceExact on the worker's core
     (window_decode_binding.inc); every launch of the dispatcher travels through cvx_submit_windows (the device decodes the window
-    from ngmlr's own 4-bit genome, uploaded once per device) and CIGAR / MD / nmPerPosition come from the device text stage, which
-    runs on its own thread under the kernels of the next launch.  test_2 (short reads: windows at chromosome edges), test_4,
+    from ngmlr's own 4-bit genome, uploaded once per device); the workers' host text stage reads the decoded characters that came
+    back with the launch's results (cvx_job_window_refs) -- or, with CVX_DEVICE_TEXT=1, CIGAR / MD / nmPerPosition come from the
+    device text stage, which runs on its own thread under the kernels of the next launch.  test_2 (short reads: windows at chromosome edges), test_4,
     test_3 (-t 16, 256 contexts), the split-read workload (reverse-strand windows, realignment windows) and the repeat-rich
     one: every SAM record identical to the unmodified reference's, and no tile took its reference as characters."""
     import re
     import sys
-    env = {"CVX_POOL_CONTEXTS": "256", "CVX_DEVICE_DECODE": "1"}
+    env = {"CVX_POOL_CONTEXTS": "256"}
 
-    def windows(err, alignments=None):
+    def windows(err, alignments=None, device_text=False):
         m = re.search(r"SharedAligner: (\d+) tiles in (\d+) launches took their reference as windows of the genome in HBM .*, (\d+) mixed", err)
         k = re.search(r"SharedAligner: (\d+) alignments in (\d+) device launches", err)
         assert m and k, err[-2500:]
@@ -233,7 +234,10 @@ def test_reference_windows_decoded_on_the_device_in_the_pipeline(built, tmp_path
         if alignments is not None:
             assert int(k.group(1)) == alignments
         t = re.search(r"text stage on the device for (\d+) launches", err)
-        assert t and int(t.group(1)) == int(k.group(2)), err[-2500:]
+        if device_text:
+            assert t and int(t.group(1)) == int(k.group(2)), err[-2500:]
+        else:
+            assert t is None
 
     got, err = _run(["-t", "1", "-r", os.path.join(E2E, "ref_chr21_20kb.fa"), "-q", os.path.join(E2E, "reads_100_2200bp.fa")], tmp_path, binary=BIN_ALL, env=env)
     assert sorted(got) == sorted(_records(open(os.path.join(ROOT, "tests", "golden", "test_2.sam")).read())) and len(got) == 12
@@ -268,6 +272,17 @@ def test_reference_windows_decoded_on_the_device_in_the_pipeline(built, tmp_path
     got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_ALL, env=dict(env, CVX_POOL_FIBERS="0"))
     assert sorted(got) == _test_3_want()
     windows(err, 985)
+    # off: the reference's decode on the workers' cores, no launch carries a window
+    got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_ALL, env=dict(env, CVX_DEVICE_DECODE="0"))
+    assert sorted(got) == _test_3_want()
+    assert "windows of the genome" not in err and re.search(r"SharedAligner: 985 alignments", err)
+    # the text stage on the device as well (its own thread, under the next launch's kernels): nothing of the window returns
+    got, err = _run(_test_3_args(tmp_path, 16), tmp_path, binary=BIN_ALL, env=dict(env, CVX_DEVICE_TEXT="1"))
+    assert sorted(got) == _test_3_want()
+    windows(err, 985, device_text=True)
+    got, err = _run(["-t", "8"] + args, tmp_path, binary=BIN_ALL, env=dict(env, CVX_POOL_CONTEXTS="128", CVX_DEVICE_TEXT="1"))
+    assert sorted(got) == sorted(want)
+    windows(err, device_text=True)
 
 
 def test_repeat_rich_reference(built, tmp_path):

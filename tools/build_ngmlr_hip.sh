@@ -59,7 +59,7 @@ if INDEX:
     s = sub1(s, 'void CompactPrefixTable::CreateTable(uint const length) {\n', 'void CompactPrefixTable::CreateTable(uint const length) {\n#include "index_build_binding.inc"\n', 'CompactPrefixTable::CreateTable')
     open(p, 'w').write(s)
 if INDEX and POOL:
-    # the reference window of an alignment decoded on the device (CVX_DEVICE_DECODE=1; ngmlr_amd/csrc/window_decode_binding.inc,
+    # the reference window of an alignment decoded on the device (CVX_DEVICE_DECODE=0 turns it off; ngmlr_amd/csrc/window_decode_binding.inc,
     # Convex::DeviceWindows in convex_align_hip.h): the encoded genome is announced where _SequenceProvider::Init has finished it
     p = T + '/src/SequenceProvider.cpp'
     s = open(p).read()

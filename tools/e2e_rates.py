@@ -343,8 +343,10 @@ def run(name, t, ref, fq, extra_env=None):
     po = re.search(r"AlignPool: \d+ reads on.*", res.stderr)
     il = re.search(r"AlignPool: ngmlr's input lock.*", res.stderr)
     cf = re.search(r"SharedAligner: (\d+) of (\d+) corridors travelled as closed forms", res.stderr)
+    tx = re.search(r"SharedAligner: text stage on the device.*", res.stderr)
+    wn = re.search(r"SharedAligner: \d+ tiles in \d+ launches took their reference as windows.*", res.stderr)
     cpu_by_class = {k: round(c, 2) for k, (c, n) in by.items()}
-    return {"peak_rss_mb": peak_rss_kb / 1024.0, "cpu_by_class": cpu_by_class, "cpu_total_s": sum(c for c, _ in by.values()), "wall": dt, "search_stats": se.group(0) if se else None, "cpu_note": cpu_note, "pool_stats": po.group(0) if po else None, "input_lock": il.group(0) if il else None,
+    return {"peak_rss_mb": peak_rss_kb / 1024.0, "cpu_by_class": cpu_by_class, "cpu_total_s": sum(c for c, _ in by.values()), "wall": dt, "search_stats": se.group(0) if se else None, "cpu_note": cpu_note, "pool_stats": po.group(0) if po else None, "input_lock": il.group(0) if il else None, "text_stats": tx.group(0) if tx else None, "window_stats": wn.group(0) if wn else None,
             "closed_forms": (int(cf.group(1)), int(cf.group(2))) if cf else None, "rc": res.returncode, "recs": recs, "launch": (int(m.group(1)), int(m.group(2))) if m else None, "stats": st.group(0) if st else None, "score_stats": sc.group(0) if sc else None,
             "map_s": dt - float(mp.group(1)) if mp else None, "err": res.stderr[-400:], "full_err": res.stderr}
 
@@ -368,9 +370,12 @@ def line(name, t, r, same):
         print("    " + r["input_lock"], flush=True)
     if r.get("closed_forms"):
         print("    corridors sent as closed forms: %d of %d" % r["closed_forms"], flush=True)
+    for k in ("text_stats", "window_stats"):
+        if r.get(k):
+            print("    " + r[k], flush=True)
     if os.environ.get("E2E_VERBOSE"):
         for l in r["full_err"].splitlines():
-            if "library loaded" in l or "time" in l.lower() or "Done" in l or l.startswith("cvx_search_batch:") or l.startswith("cvx timeline") or l.startswith("cvx launch") or l.startswith("cvx dispatcher") or l.startswith("cvx_submit:"):
+            if "library loaded" in l or "time" in l.lower() or "Done" in l or l.startswith("cvx_search_batch:") or l.startswith("cvx timeline") or l.startswith("cvx launch") or l.startswith("cvx text stage") or l.startswith("cvx dispatcher") or l.startswith("cvx_submit:"):
                 print("      | " + l[:460], flush=True)
 
 
