@@ -526,7 +526,10 @@ int cvx_job_nm_profile(cvx_handle h, cvx_job job, int32_t first, int32_t count, 
 int cvx_job_nm_profile_resident(cvx_handle h, cvx_job job, int32_t first, int32_t count, uint64_t *entry_off,
 		const int32_t **triples, double *kernel_ms);
 /* ABI 9: cvx_job_text and cvx_job_nm_profile_resident of the whole job in one call -- two round trips to the device (the sizes
- * of both, then the strings and triples of both) instead of four.  Outputs as in those two calls; nm_entry_off[n_tiles + 1]. */
+ * of both, then the strings and triples of both) instead of four.  Outputs as in those two calls; nm_entry_off[n_tiles + 1].
+ * Threads: the text-stage calls (cvx_job_text, cvx_job_nm_profile*, this one) touch only the finished job they are given and
+ * the handle's text stream, so ONE other thread may run them while the handle's own thread submits and waits for other jobs
+ * (BatchingAligner's text thread does); two text-stage calls on one handle at a time are not supported. */
 int cvx_job_text_all(cvx_handle h, cvx_job job, const int32_t *ext_qstart, const int32_t *ext_qend,
 		cvx_alignment_text *out, uint64_t *text_off, const char **text, uint64_t *text_bytes,
 		uint64_t *nm_entry_off, const int32_t **triples);
