@@ -285,6 +285,36 @@ def test_reference_windows_decoded_on_the_device_in_the_pipeline(built, tmp_path
     windows(err, device_text=True)
 
 
+def test_reads_at_contig_ends_of_a_multi_contig_reference(built, tmp_path, monkeypatch):
+    """A reference of six contigs, a fifth of the reads flush with a contig's first or last base: their alignment windows reach
+    into the 1000-N spacers ngmlr puts between sequences and beyond the chromosome the read lies on -- the branches of
+    DecodeRefSequenceExact (reference src/SequenceProvider.cpp:493-565: start in a spacer, end past the chromosome, 'x' fill)
+    that the windows decoded on the device inside the pipeline must reproduce.  Unmodified reference against ngmlr_hip_all with
+    the device decode (default) and without: every SAM record identical."""
+    import re
+    import sys
+    import numpy as np
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ngmlr_ref")
+    if not os.path.exists(ref_bin) or not os.path.exists(BIN_ALL):
+        pytest.skip("oracle/_ref/ngmlr_ref / ngmlr_hip_all not built")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_rates
+    monkeypatch.setenv("E2E_CONTIGS", "6")
+    monkeypatch.setenv("E2E_READ_LEN", "3000:6000")
+    fa, fq = str(tmp_path / "ctg_ref.fa"), str(tmp_path / "ctg_reads.fq")
+    e2e_rates.write_plain_workload(fa, fq, 400, np.random.default_rng(606), 600000)
+    args = ["-x", "pacbio", "-R", "0.01", "--no-progress", "-r", fa, "-q", fq]
+    want, _ = _run(["-t", "16"] + args, tmp_path, binary=ref_bin)
+    assert len({l.split("\t")[2] for l in want}) == 6, "reads must map to every contig"
+    got, err = _run(["-t", "8"] + args, tmp_path, binary=BIN_ALL, env={"CVX_POOL_CONTEXTS": "128"})
+    assert sorted(got) == sorted(want)
+    m = re.search(r"SharedAligner: (\d+) tiles in (\d+) launches took their reference as windows", err)
+    k = re.search(r"SharedAligner: (\d+) alignments in", err)
+    assert m and k and m.group(1) == k.group(1) and int(k.group(1)) >= 400, err[-2000:]
+    got, err = _run(["-t", "8"] + args, tmp_path, binary=BIN_ALL, env={"CVX_POOL_CONTEXTS": "128", "CVX_DEVICE_DECODE": "0"})
+    assert sorted(got) == sorted(want) and "windows of the genome" not in err
+
+
 def test_repeat_rich_reference(built, tmp_path):
     """What a k-mer vote sees on a real genome: repeat families of 8-20 diverged copies and microsatellites, so that sub-reads cast
     10^4..10^5 votes, overflow the wave kernel's LDS map (forced to its smallest size here: the HBM-table form runs) and reads get several close candidates (MAPQ
