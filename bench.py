@@ -402,9 +402,11 @@ def index_stage_rates(al):
             for pm_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
                 pm = json.load(open(pm_path))
                 ent = pm.get("candidate_search_big")
-                if pm.get("build_id") == bid and ent:
+                same_search = pm.get("source_ids", {}).get("search") == al.lib.cvx_source_id(b"search").decode()      # cvx_search.hip unchanged since that collection
+                if (pm.get("build_id") == bid or same_search) and ent:
                     bpv = ent["hbm_bytes_per_vote"]
-                    bpv_src = "%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/search_rates.py --big on build %s)" % (os.path.relpath(pm_path, ROOT), bid)
+                    bpv_src = "%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/search_rates.py --big on build %s%s)" % (
+                        os.path.relpath(pm_path, ROOT), pm.get("build_id"), "" if pm.get("build_id") == bid else "; this build is %s, the search kernels' sources (cvx_source_id \"search\" %s) are the same" % (bid, pm["source_ids"]["search"]))
                     break
         except Exception as e:
             bpv_src = "unavailable: %s" % e
@@ -997,14 +999,18 @@ def main() -> int:
             build_id = lib.cvx_build_id().decode()
             for pm_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
                 pm = json.load(open(pm_path))
-                if pm.get("build_id") != build_id:
-                    continue                                   # counters of another build of the kernels: not this launch's traffic
+                lib.cvx_source_id.restype = C_char_p
+                fill_id = lib.cvx_source_id(b"fill").decode()
+                if pm.get("build_id") != build_id and pm.get("source_ids", {}).get("fill") != fill_id:
+                    continue                                   # counters of another build of the fill kernels: not this launch's traffic
                 ent = pm.get("fill_ring_kernel<M=%d,NW=%d,wrap16=%d>" % dom)
                 if ent:
                     traffic = ent["hbm_bytes"] * (meta["alg_bytes"] / ent["alg_bytes"])
                     traffic_src = ("not measured in this run: %s (separate rocprofv3 --pmc FETCH_SIZE x2 / --pmc WRITE_SIZE passes of the same bench "
-                                   "command on the same build %s, %d tiles in the launch) x algorithmic-byte ratio %.3f" % (
-                                       os.path.relpath(pm_path, ROOT), build_id, ent.get("tiles", 0), meta["alg_bytes"] / ent["alg_bytes"]))
+                                   "command on %s, %d tiles in the launch) x algorithmic-byte ratio %.3f" % (
+                                       os.path.relpath(pm_path, ROOT), ("the same build %s" % build_id) if pm.get("build_id") == build_id else
+                                       "build %s -- this build is %s, the fill kernels' sources (cvx_source_id \"fill\" %s) are the same" % (pm.get("build_id"), build_id, fill_id),
+                                       ent.get("tiles", 0), meta["alg_bytes"] / ent["alg_bytes"]))
                     break
             if traffic is None:
                 traffic_src = "no profiles/r*_pmc.json was collected on this build of the kernels (%s): null rather than a stale number" % build_id

@@ -215,6 +215,9 @@ int cvx_device_count(void);
 /* identifies the build of the device kernels (a hash of their source): profiles/ records it with the counters it
  * collects, and bench.py reports counter-derived figures only for the build they were collected on */
 const char *cvx_build_id(void);
+/* the same for one kernel family's sources alone -- "fill" (cvx_kernels.hip), "search" (cvx_search.hip), each with the shared
+ * headers; anything else: cvx_build_id().  Counters collected for a kernel (profiles/r*_pmc.json) stay valid while its own id does. */
+const char *cvx_source_id(const char *family);
 /* Blocks until everything queued on `device_id` (by any handle of this process) has finished:
  * hipDeviceSynchronize behind the C ABI, for callers that bracket a timed region. */
 int cvx_device_synchronize(int device_id);

@@ -19,7 +19,7 @@ ERR_NAMES = {0: "CVX_OK", -1: "CVX_ERR_NO_DEVICE", -2: "CVX_ERR_PARAMS", -3: "CV
 TILE_STATUS = {0: "ok", 1: "invalid-row0", 2: "invalid-edge", 3: "invalid-length", 4: "too-large",
                5: "empty", -1: "unsupported"}
 
-EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_device_count", "cvx_device_synchronize", "cvx_create", "cvx_destroy",
+EXPORTS = ("cvx_last_error", "cvx_abi_version", "cvx_source_id", "cvx_device_count", "cvx_device_synchronize", "cvx_create", "cvx_destroy",
            "cvx_align_batch", "cvx_batch_upload", "cvx_batch_run", "cvx_batch_timing",
            "cvx_batch_ops_total", "cvx_batch_launch_info", "cvx_batch_download", "cvx_batch_free",
            "cvx_submit", "cvx_wait", "cvx_job_timing", "cvx_job_launch_info", "cvx_job_release",
@@ -135,6 +135,8 @@ def load(path: str = None) -> C.CDLL:
     lib.cvx_last_error.restype = C.c_char_p
     lib.cvx_abi_version.restype = C.c_int
     lib.cvx_build_id.restype = C.c_char_p
+    lib.cvx_source_id.restype = C.c_char_p
+    lib.cvx_source_id.argtypes = [C.c_char_p]
     lib.cvx_device_count.restype = C.c_int
     lib.cvx_device_synchronize.argtypes = [C.c_int]
     lib.cvx_create.argtypes = [C.c_int, C.POINTER(CvxParams), C.c_uint64, C.POINTER(C.c_void_p)]

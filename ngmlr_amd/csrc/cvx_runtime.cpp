@@ -1326,6 +1326,17 @@ int cvx_abi_version(void) { return CVX_ABI_VERSION; }
 #define CVX_BUILD_ID "unknown"
 #endif
 const char *cvx_build_id(void) { return CVX_BUILD_ID; }
+#ifndef CVX_FILL_ID
+#define CVX_FILL_ID "unknown"
+#endif
+#ifndef CVX_SEARCH_ID
+#define CVX_SEARCH_ID "unknown"
+#endif
+const char *cvx_source_id(const char *family) {
+	if (family && strcmp(family, "fill") == 0) return CVX_FILL_ID;
+	if (family && strcmp(family, "search") == 0) return CVX_SEARCH_ID;
+	return CVX_BUILD_ID;
+}
 
 int cvx_device_count(void) {
 	int n = 0;

@@ -94,7 +94,8 @@ def main():
     sys.path.insert(0, ROOT)
     from ngmlr_amd import capi
     build_id = capi.load().cvx_build_id().decode()      # the library the passes ran on (same snapshot)
-    d = {"build_id": build_id, "_comment": "rocprofv3 --pmc passes of tools/collect_profiles.sh %s (separate runs, --kernel-trace only); largest dispatch of "
+    lib_ = capi.load()
+    d = {"build_id": build_id, "source_ids": {"fill": lib_.cvx_source_id(b"fill").decode(), "search": lib_.cvx_source_id(b"search").decode()}, "_comment": "rocprofv3 --pmc passes of tools/collect_profiles.sh %s (separate runs, --kernel-trace only); largest dispatch of "
                      "the dominant fill kernel; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); hbm_bytes = 2*FETCH + WRITE. "
                      "bench.py scales hbm_bytes to its own launch by algorithmic bytes and says so." % tag,
          "fill_ring_kernel<M=3,NW=1,wrap16=0>": {"tiles": tiles, "alg_bytes": alg, "fetch_size_kib": fetch["FETCH_SIZE"],
