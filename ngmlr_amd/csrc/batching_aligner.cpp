@@ -295,8 +295,14 @@ void BatchingAligner::dispatchLoop() {
 				std::vector<ConvexAlignHip::Tile *> tp(l->reqs.size());
 				for (size_t i = 0; i < tp.size(); ++i) tp[i] = &l->reqs[i]->tile;
 				lk.unlock();
-				(void) backend->WindowRefs(l->job, tp.data(), (int) tp.size());
+				bool refsFailed = false;
+				try {
+					(void) backend->WindowRefs(l->job, tp.data(), (int) tp.size());
+				} catch (...) {
+					refsFailed = true;
+				}
 				lk.lock();
+				if (refsFailed) l->failed = true;
 			}
 			if (deviceText && !l->failed) {
 				/* its text stage runs on the text thread, under the kernels of the launches behind it */

@@ -273,11 +273,16 @@ void ConvexAlignHip::Wait(cvx_job job, cvx_result const ** results, uint32_t con
 }
 
 bool ConvexAlignHip::WindowRefs(cvx_job job, Tile * const * tiles, int n) {
-	bool any = false;
-	for (int i = 0; i < n && !any; ++i) any = tiles[i]->window;
-	if (!any || n <= 0) return false;
+	int nWindows = 0;
+	for (int i = 0; i < n; ++i) nWindows += tiles[i]->window ? 1 : 0;
+	if (nWindows == 0 || n <= 0) return false;
+	if (nWindows < n) return false;      /* a mixed launch travelled as characters: its windows were materialised in the callers' buffers (Submit) */
 	std::vector<char const *> refs((size_t) n);
-	if (cvx_job_window_refs(handle, job, refs.data()) != CVX_OK) return false;      /* a mixed launch: its windows were materialised in the callers' buffers */
+	if (cvx_job_window_refs(handle, job, refs.data()) != CVX_OK) {
+		/* the placeholders must never reach the text stage: fail the launch like any other error of it */
+		fprintf(stderr, "ConvexAlignHip: %s\n", cvx_last_error());
+		throw 1;
+	}
 	for (int i = 0; i < n; ++i) tiles[i]->refSeq = refs[(size_t) i];
 	return true;
 }
@@ -317,7 +322,12 @@ void ConvexAlignHip::AlignTiles(Tile * tiles, int n) {
 	std::vector<char const *> callers((size_t) n);
 	std::vector<Tile *> ptrs((size_t) n);
 	for (int i = 0; i < n; ++i) { callers[(size_t) i] = tiles[i].refSeq; ptrs[(size_t) i] = &tiles[i]; }
-	(void) WindowRefs(job, ptrs.data(), n);
+	try {
+		(void) WindowRefs(job, ptrs.data(), n);
+	} catch (...) {
+		Release(job);
+		throw;
+	}
 	for (int i = 0; i < n; ++i) {
 		try {
 			Finish(tiles[i], res[i], ops);

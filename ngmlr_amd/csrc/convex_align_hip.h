@@ -106,7 +106,7 @@ public:
 	void Text(cvx_job job, Tile const * const * tiles, int n, JobText & jt);
 	/* after Wait, for a launch that travelled through cvx_submit_windows: tiles[i]->refSeq is redirected to the characters
 	 * the device decoded (cvx_job_window_refs: the job's page-locked memory, valid until Release), so that Finish -- the host
-	 * text stage, which reads the reference base of every mismatch and deletion -- works on them.  false: not a window launch */
+	 * text stage, which reads the reference base of every mismatch and deletion -- works on them.  false: not a window launch; throws 1 when a window launch cannot hand its characters back */
 	bool WindowRefs(cvx_job job, Tile * const * tiles, int n);
 	/* launches that travelled as windows of the resident genome (cvx_submit_windows), and launches that mixed windows with
 	 * decoded references (their windows were materialised with cvx_genome_decode first) */
