@@ -39,13 +39,7 @@ struct KernelClass {
  * Gbp/h when everything above M = 4 goes to 64-row blocks). */
 /* Round 5: rings of 384 and 576 slots as GANGS of two / three M = 3 waves in one workgroup (the lane boundary between the
  * waves goes through LDS, cvx_kernels.hip): the retry loop's doubled corridors (257-576 live rows) are whole tiles again. */
-/* Late round 6, behind CVX_TUNE_LATENCY_GANGS: {1, 3} and {2, 2} -- the SAME 192 / 256 slots as {3, 1} / {4, 1} on three / two waves.
- * At full occupancy that only adds hand-overs (gangs lose there, history 3); in a launch that leaves the device a tenth full --
- * ngmlr's own pipeline: 440 tiles on 1 024 SIMDs, a launch as long as its longest tile -- a tile's step is a third / half as
- * long.  Never picked by the first-fit loop (they come after the single-wave classes of their ring sizes): host_plan_rows routes
- * to them by name. */
-static const KernelClass kClasses[] = { {1, 1}, {2, 1}, {3, 1}, {4, 1}, {3, 2}, {3, 3}, {1, 3}, {2, 2} };
-static const int kClassGang192 = 6, kClassGang256 = 7;
+static const KernelClass kClasses[] = { {1, 1}, {2, 1}, {3, 1}, {4, 1}, {3, 2}, {3, 3} };
 static const int kNumClasses = (int) (sizeof(kClasses) / sizeof(kClasses[0]));
 
 /* Corridors with more live rows than the widest single-wave ring are cut into row blocks that run
@@ -541,7 +535,6 @@ struct PlanTuning {
 	int small_batch = 0;   /* > 0: replaces kSmallBatchTiles */
 	int long_need = 0;     /* > 0: replaces the 128 live rows from which a very long tile of a small batch is chained */
 	int no_gangs = 0;      /* != 0: no gang classes (corridors with more than 256 live rows are chained, as before round 5) */
-	int latency_gangs = 0; /* != 0: in a small batch, whole tiles of 129-192 / 193-256 live rows run as gangs of three M = 1 / two M = 2 waves (CVX_TUNE_LATENCY_GANGS) */
 };
 
 /* rows_of(i, tmp) -> the (offset, length) rows of tile i (may fill and return tmp), or an empty function /
@@ -591,11 +584,6 @@ inline void host_plan_rows(int n, const TilePlan *plan, const TileIn *tin, RowsO
 				if (kClasses[c].ring() >= p.need && kClasses[c].m >= tune_min_slots &&
 						(tune.max_slots <= 0 || kClasses[c].m <= tune.max_slots) &&
 						(kClasses[c].gang == 1 || (!wrap && !tune.no_gangs))) { k = c; break; }
-			/* a launch that cannot fill the device: the tile's ring on several waves (same slots, a shorter step) */
-			if (tune.latency_gangs && small_batch && !wrap && k >= 0 && kClasses[k].gang == 1 && tune_min_slots == 0 && tune.max_slots <= 0) {
-				if (kClasses[k].m == 3) k = kClassGang192;
-				else if (kClasses[k].m == 4) k = kClassGang256;
-			}
 		}
 		r.skip = 0;
 		r.chain_blk0 = -1;

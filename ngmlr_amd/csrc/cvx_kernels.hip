@@ -1702,11 +1702,11 @@ chain_reduce_kernel(const int32_t *tiles, int n_tiles, const TileRun *trun, cons
 
 /* gangs: G waves per tile on one ring of 64 * 3 * G slots (two-phase with the penalty table when the scoring allows, else
  * arithmetic; and the exact pass) */
-template <int G, int M = 3>
+template <int G>
 static hipError_t launch_fill_gang(const FillArgs &a, int mode, hipStream_t st) {
-	if (mode == kFillExact) hipLaunchKernelGGL((fill_ring_kernel<M, false, kFillExact, false, G>), dim3(a.list_n), dim3(64 * G), 0, st, a);
-	else if (a.pen_table) hipLaunchKernelGGL((fill_ring_kernel<M, false, kFillTwoPhase, true, G>), dim3(a.list_n), dim3(64 * G), 0, st, a);
-	else hipLaunchKernelGGL((fill_ring_kernel<M, false, kFillTwoPhase, false, G>), dim3(a.list_n), dim3(64 * G), 0, st, a);
+	if (mode == kFillExact) hipLaunchKernelGGL((fill_ring_kernel<3, false, kFillExact, false, G>), dim3(a.list_n), dim3(64 * G), 0, st, a);
+	else if (a.pen_table) hipLaunchKernelGGL((fill_ring_kernel<3, false, kFillTwoPhase, true, G>), dim3(a.list_n), dim3(64 * G), 0, st, a);
+	else hipLaunchKernelGGL((fill_ring_kernel<3, false, kFillTwoPhase, false, G>), dim3(a.list_n), dim3(64 * G), 0, st, a);
 	return hipGetLastError();
 }
 
@@ -1731,10 +1731,7 @@ static hipError_t launch_fill_w(const FillArgs &a, bool wrap, int mode, size_t p
 hipError_t launch_fill(int m, int gang, bool wrap, int mode, const FillArgs &a, size_t pad_lds, hipStream_t st) {
 	if (a.list_n <= 0) return hipSuccess;
 	if (gang > 1) {
-		if (wrap || mode == kFillChain) return hipErrorInvalidValue;
-		if (m == 1 && gang == 3) return launch_fill_gang<3, 1>(a, mode, st);      /* 192 slots on three waves (CVX_TUNE_LATENCY_GANGS) */
-		if (m == 2 && gang == 2) return launch_fill_gang<2, 2>(a, mode, st);      /* 256 slots on two */
-		if (m != 3) return hipErrorInvalidValue;
+		if (m != 3 || wrap || mode == kFillChain) return hipErrorInvalidValue;
 		return gang == 2 ? launch_fill_gang<2>(a, mode, st) : gang == 3 ? launch_fill_gang<3>(a, mode, st) : hipErrorInvalidValue;
 	}
 	switch (m) {

@@ -430,8 +430,6 @@ struct cvx_context {
 	int tune_max_slots = 0;   /* tuning knob (env CVX_TUNE_MAX_M): largest whole-tile ring class; wider tiles are chained */
 	int tune_long_need = 0;   /* tuning knob (env CVX_TUNE_LONG_NEED): see PlanTuning */
 	int tune_gang_prio = 0;   /* tuning knob (env CVX_TUNE_GANG_PRIO = 0 / 1): gang tiles at raised wave priority (measured: 26.9 against 24.0 ms, a loss) */
-	int tune_latency_gangs = 0;      /* tuning knob (env CVX_TUNE_LATENCY_GANGS = 0 / 1): in a batch too small to fill the device, whole tiles of the M = 3 / M = 4 classes run
-	                                 * on three M = 1 / two M = 2 waves (cvx_host_logic.h, kClasses) */
 	int tune_gangs = 0;       /* tuning knob (env CVX_TUNE_GANGS = 0 / 1): rings of 384 / 576 slots as gangs of two / three waves instead of chained row
 	                           * blocks.  Off: measured, the gangs lose -- the ONT mix's retry tiles alone 24.0 ms against 21.4 ms chained, the whole mix
 	                           * equal within noise (profiles/r05_gang_ab.txt): short tiles leave a 576-slot ring idle through its ramps (60 % slot use
@@ -827,7 +825,6 @@ int stage_compute(cvx_context *h, cvx_batch_s *b, bool streaming = false) {
 	tune.force_generic = h->sse_variant ? 1 : 0;
 	tune.long_steps = h->tune_long_steps; tune.small_batch = h->tune_small_batch; tune.long_need = h->tune_long_need;
 	tune.no_gangs = h->tune_gangs ? 0 : 1;
-	tune.latency_gangs = h->tune_latency_gangs;
 	/* (a tile that gets chained needs its rows on the host: rebuilt from the step stream the batch still owns) */
 	const RowSrc *rsrc = b->h_rsrc.as<RowSrc>();
 	host_plan_rows(n, b->plan(), b->tin(), [&](int i, std::vector<RowDesc> &tmp) -> const RowDesc * {
@@ -1475,7 +1472,6 @@ int cvx_create_ex(int device_id, const cvx_params *p, uint64_t max_matrix_mb, ui
 	if (const char *e = getenv("CVX_TUNE_SMALL_BATCH")) c->tune_small_batch = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_LONG_NEED")) c->tune_long_need = atoi(e);
 	if (const char *e = getenv("CVX_TUNE_GANGS")) c->tune_gangs = atoi(e) != 0;
-	if (const char *e = getenv("CVX_TUNE_LATENCY_GANGS")) c->tune_latency_gangs = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_GANG_PRIO")) c->tune_gang_prio = atoi(e) != 0;
 	if (const char *e = getenv("CVX_TUNE_LATE_MIN")) c->tune_late_min = std::max(1, atoi(e));
 	if (const char *e = getenv("CVX_TUNE_LATE_SHIFT")) c->tune_late_shift = std::min(16, std::max(0, atoi(e)));
