@@ -109,3 +109,25 @@ def test_runtime_regime_without_a_device(built):
     assert r.hw_queues_env >= 1 and r.blocking_sync == -1 and r.service_streams == 4 and r.runtime_up_at_load == 0
     assert r.hw_queues_set_by_library == (0 if os.environ.get("CVX_TEST_HWQ_PRESET") else 1) or r.hw_queues_env != 16
     assert lib.cvx_runtime_regime(0, None) != 0
+
+
+def test_source_ids_and_the_committed_counters(built):
+    """cvx_source_id: twelve hex digits per kernel family, the whole-library id for anything else.  bench.py takes HBM traffic and
+    bytes per vote from a profiles/r*_pmc.json only while the id of that kernel family is the one the counters were collected on
+    (null otherwise, never a stale number); when the newest committed file belongs to the kernels of this tree, say so -- when it
+    does not, that is a fact about the profiles, not a failure of the library."""
+    import glob
+    import json
+    from ngmlr_amd import capi
+    lib = capi.load()
+    ids = {f: lib.cvx_source_id(f.encode()).decode() for f in ("fill", "search", "anything else")}
+    assert all(re.fullmatch(r"[0-9a-f]{12}", v) for v in ids.values()), ids
+    assert ids["anything else"] == lib.cvx_build_id().decode() and len(set(ids.values())) == 3
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc.json")), reverse=True)
+    assert files, "no counters committed"
+    pm = json.load(open(files[0]))
+    src = pm.get("source_ids", {})
+    if pm.get("build_id") != ids["anything else"] and (src.get("fill") != ids["fill"] or src.get("search") != ids["search"]):
+        pytest.skip("%s was collected on other fill / search kernels (%s) than this tree's (%s): bench.py reports null traffic until the passes are repeated"
+                    % (os.path.basename(files[0]), src or pm.get("build_id"), ids))
