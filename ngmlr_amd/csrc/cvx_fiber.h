@@ -76,7 +76,8 @@ struct FiberApi {
 	 * first makes the next Park return at once. */
 	static void Park();
 	static void Wake(Fiber * f);                /* any thread */
-	/* fiber-local storage: kSlots pointers per fiber, 0-initialised (a thread_local that travels with the read) */
+	/* fiber-local storage: kSlots pointers per fiber, 0-initialised (a thread_local that travels with the read).  In use: slot 0 the
+	 * read's dispatcher (batching_aligner.cpp), slots 1-3 the note of its placeholder window (DeviceWindows, convex_align_hip.cpp) */
 	enum { kSlots = 4 };
 	static void *& Local(Fiber * f, int slot);
 };
